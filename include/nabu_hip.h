@@ -1,0 +1,149 @@
+/* nabu_hip.h — C ABI of libnabu_hip.so: the MI355X (gfx950) kernels behind the
+ * Nabu training hot path.
+ *
+ * The reference (vrenkens/nabu) has no FFI: its numerical backend is the
+ * TensorFlow-1.8 op library, called from Python.  Each entry point below names
+ * the reference call site (path relative to the reference root, file:line) whose
+ * TF ops it replaces.  INTEGRATION.md shows the ctypes binding a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *    the caller owns all memory, the library never allocates;
+ *  - tensors are contiguous, batch-major, float32; lengths/labels are int32;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *  - return value: 0 = ok, < 0 = NABU_E* argument error, > 0 = hipError_t;
+ *    nabu_last_error() returns a thread-local message;
+ *  - no C++ exceptions cross the boundary, no global mutable state.
+ */
+#ifndef NABU_HIP_H
+#define NABU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NABU_ABI_VERSION 1
+
+#define NABU_EINVAL   (-1)  /* bad argument (shape, null pointer, alignment) */
+#define NABU_EUNSUP   (-2)  /* shape not supported by the requested kernel   */
+#define NABU_EWS      (-3)  /* workspace too small                           */
+
+typedef void *nabu_stream_t; /* hipStream_t */
+
+int nabu_version(void);
+const char *nabu_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Dense fp32 GEMM on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32):
+ *   C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C + bias[N]
+ * row-major; op(X) = X or X^T (trans* != 0 means the matrix is STORED
+ * transposed, i.e. A is [K,M] / B is [N,K]).  bias may be NULL.
+ * Segmented K (kseg > 0): the reduction index k runs over K = nseg*kseg rows
+ * that are stored as nseg segments of kseg consecutive rows, segment s of A
+ * starting a_seg_stride elements after segment s-1 (same for B); used for the
+ * per-utterance shifted h_{t-1}^T·dz products.  Only valid with transA=1,
+ * transB=0.  kseg = 0 means one contiguous segment.
+ * Replaces: tf MatMul/BiasAdd inside LayerNormBasicLSTMCell._linear
+ * (nabu/neuralnetworks/components/layer.py:35-47), tf.contrib.layers.linear
+ * (models/ed_decoders/dnn_decoder.py:53-57), Dense layers of the attention
+ * (components/attention.py:163-175) and their autodiff (trainers/trainer.py:556).
+ * ws: split-K partial sums; query the size with nabu_gemm_ws_bytes. */
+size_t nabu_gemm_ws_bytes(int M, int N, int K);
+int nabu_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
+                  const float *A, int lda, const float *B, int ldb, float beta,
+                  float *C, int ldc, const float *bias, int kseg,
+                  long long a_seg_stride, long long b_seg_stride, void *ws,
+                  size_t ws_bytes, nabu_stream_t stream);
+
+/* out[n] = beta*out[n] + sum_m A[m*lda + n]  (bias gradients; deterministic
+ * two-stage tree).  ws >= nabu_colsum_ws_bytes(M,N). */
+size_t nabu_colsum_ws_bytes(int M, int N);
+int nabu_colsum_f32(int M, int N, const float *A, int lda, float beta, float *out,
+                    void *ws, size_t ws_bytes, nabu_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * One bidirectional LSTM layer — layer.blstm
+ * (nabu/neuralnetworks/components/layer.py:8-51): two
+ * tf.contrib.rnn.LayerNormBasicLSTMCell(layer_norm=False) driven by
+ * bidirectional_dynamic_rnn(sequence_length=len) and concatenated on the
+ * feature axis.  Gate order i,j,f,o; forget bias +1 at run time; rows t >= len
+ * produce 0 and freeze (c,h); the backward direction starts at each sequence's
+ * own last frame.
+ *   x [B,T,D], len [B], kernel_* [(D+H),4H], bias_* [4H], out [B,T,2H].
+ * reserve (nabu_blstm_reserve_bytes) keeps the gate activations and cell states
+ * for the backward pass; ws (nabu_blstm_ws_bytes) is scratch.
+ * mode: NABU_LSTM_AUTO picks the persistent whole-sequence kernel when the
+ * shape is supported, else one launch per timestep. */
+#define NABU_LSTM_AUTO       0
+#define NABU_LSTM_STEPWISE   1
+#define NABU_LSTM_PERSISTENT 2
+
+typedef struct {
+  uint32_t size;      /* sizeof(nabu_blstm_desc), ABI versioning */
+  int32_t B, T, D, H;
+  int32_t max_len;    /* max(len) if known on the host, else T */
+  int32_t mode;       /* NABU_LSTM_* */
+} nabu_blstm_desc;
+
+size_t nabu_blstm_reserve_bytes(const nabu_blstm_desc *d);
+size_t nabu_blstm_ws_bytes(const nabu_blstm_desc *d);
+int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const int32_t *len,
+                   const float *kernel_fw, const float *bias_fw,
+                   const float *kernel_bw, const float *bias_bw, float *out,
+                   void *reserve, void *ws, size_t ws_bytes, nabu_stream_t stream);
+/* Gradient of nabu_blstm_fwd (autodiff of layer.blstm, trainers/trainer.py:556-558).
+ * d_out [B,T,2H]; d_x [B,T,D] is overwritten (may be NULL for the first layer);
+ * dkernel_*, dbias_* are overwritten.  reserve is consumed (overwritten). */
+int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const int32_t *len,
+                   const float *kernel_fw, const float *kernel_bw, const float *out,
+                   const float *d_out, void *reserve, float *d_x, float *dkernel_fw,
+                   float *dbias_fw, float *dkernel_bw, float *dbias_bw, void *ws,
+                   size_t ws_bytes, nabu_stream_t stream);
+
+/* ops.pyramid_stack (nabu/neuralnetworks/components/ops.py:6-60) when T is not
+ * a multiple of numsteps: y [B,Tp,F] = x [B,T,F] zero-padded in time (for T a
+ * multiple the stack is a free view on the batch-major buffer).  The inverse
+ * (gradient) drops the padded frames. */
+int nabu_pad_time_f32(int B, int T, int Tp, int F, const float *x, float *y,
+                      nabu_stream_t stream);
+int nabu_unpad_time_f32(int B, int T, int Tp, int F, const float *y, float *x,
+                        nabu_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * CTC loss and gradient — loss_functions.CTC
+ * (nabu/neuralnetworks/trainers/loss_functions.py:180-214): tf.nn.ctc_loss on
+ * batch-major logits with blank = C-1, softmax inside, frames >= logit_len
+ * ignored.  labels [B,Lmax] zero padded, label_len [B].
+ *   nll [B]                     per-utterance -log p(labels | logits)
+ *   dlogits [B,T,C]             grad_scale * d nll[b] / d logits  (0 past len)
+ *   status [1] int32 (device)   set to 1+b if utterance b has no valid
+ *                               alignment (TF raises in that case)
+ * ws >= nabu_ctc_ws_bytes(B,T,Lmax). */
+size_t nabu_ctc_ws_bytes(int B, int T, int Lmax);
+int nabu_ctc_loss_grad(int B, int T, int C, int Lmax, const float *logits,
+                       const int32_t *logit_len, const int32_t *labels,
+                       const int32_t *label_len, float grad_scale, float *nll,
+                       float *dlogits, int32_t *status, void *ws, size_t ws_bytes,
+                       nabu_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Fused per-element gradient clip + TF-style Adam on flat buffers —
+ * Trainer._update (nabu/neuralnetworks/trainers/trainer.py:525,560-569):
+ *   g = clamp(grad_scale*grad, -clip, clip); m = b1 m + (1-b1) g;
+ *   v = b2 v + (1-b2) g^2; param -= lr_t * m / (sqrt(v) + eps)
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller. */
+int nabu_adam_clip_step(size_t n, float *param, const float *grad, float *m,
+                        float *v, float lr_t, float b1, float b2, float eps,
+                        float clip, float grad_scale, nabu_stream_t stream);
+/* g = clamp(g, -clip, clip) in place (data-parallel mode clips per replica
+ * BEFORE the all-reduce, trainer.py:556-569). */
+int nabu_clip_f32(size_t n, float *g, float clip, nabu_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NABU_HIP_H */

@@ -1,0 +1,102 @@
+"""ctypes binding of libnabu_hip.so (the C ABI declared in include/nabu_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a tensor is
+not on the GPU, the call raises.  PyTorch is used only to own device memory and
+to name the HIP stream the kernels are enqueued on."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libnabu_hip.so')
+
+_c = ctypes
+_vp, _i, _f, _sz, _ll = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t, _c.c_longlong
+
+
+class BlstmDesc(_c.Structure):
+    _fields_ = [('size', _c.c_uint32), ('B', _c.c_int32), ('T', _c.c_int32), ('D', _c.c_int32),
+                ('H', _c.c_int32), ('max_len', _c.c_int32), ('mode', _c.c_int32)]
+
+
+# name -> (restype, argtypes); must list every symbol of include/nabu_hip.h
+SIGNATURES = {
+    'nabu_version': (_i, []),
+    'nabu_last_error': (_c.c_char_p, []),
+    'nabu_gemm_ws_bytes': (_sz, [_i, _i, _i]),
+    'nabu_gemm_f32': (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i, _vp, _i, _ll, _ll,
+                           _vp, _sz, _vp]),
+    'nabu_colsum_ws_bytes': (_sz, [_i, _i]),
+    'nabu_colsum_f32': (_i, [_i, _i, _vp, _i, _f, _vp, _vp, _sz, _vp]),
+    'nabu_blstm_reserve_bytes': (_sz, [_c.POINTER(BlstmDesc)]),
+    'nabu_blstm_ws_bytes': (_sz, [_c.POINTER(BlstmDesc)]),
+    'nabu_blstm_fwd': (_i, [_c.POINTER(BlstmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'nabu_blstm_bwd': (_i, [_c.POINTER(BlstmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                            _vp, _vp, _vp, _sz, _vp]),
+    'nabu_pad_time_f32': (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
+    'nabu_unpad_time_f32': (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
+    'nabu_ctc_ws_bytes': (_sz, [_i, _i, _i]),
+    'nabu_ctc_loss_grad': (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'nabu_adam_clip_step': (_i, [_sz, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _vp]),
+    'nabu_clip_f32': (_i, [_sz, _vp, _f, _vp]),
+}
+
+_lib = None
+
+
+class NabuHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libnabu_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NabuHipError(
+                'libnabu_hip.so is missing (%s): run `python -m nabu_amd.build` or '
+                '__graft_entry__.build(); there is no CPU fallback' % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().nabu_last_error().decode(errors='replace')
+        raise NabuHipError('%s failed (%d): %s' % (what, code, msg))
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NabuHipError('tensor is not on the GPU (device=%s): the HIP path has no CPU fallback'
+                           % t.device)
+    if not t.is_contiguous():
+        raise NabuHipError('tensor must be contiguous')
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Workspace(object):
+    """Grow-only scratch buffers, one per (device, tag)."""
+    _bufs = {}
+
+    @classmethod
+    def get(cls, nbytes, device, tag='ws'):
+        key = (str(device), tag)
+        buf = cls._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            cls._bufs[key] = buf
+        return buf

@@ -1,0 +1,42 @@
+// common.h — shared helpers of libnabu_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/nabu_hip.h"
+
+namespace nabu {
+
+// thread-local last-error text returned by nabu_last_error()
+char *err_buf();
+int fail(int code, const char *fmt, ...);
+
+#define NABU_CHECK_ARG(cond, ...)                          \
+  do {                                                     \
+    if (!(cond)) return ::nabu::fail(NABU_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+#define NABU_HIP(call)                                                        \
+  do {                                                                        \
+    hipError_t e_ = (call);                                                   \
+    if (e_ != hipSuccess)                                                     \
+      return ::nabu::fail((int)e_, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+#define NABU_LAUNCH_CHECK()                                                   \
+  do {                                                                        \
+    hipError_t e_ = hipGetLastError();                                        \
+    if (e_ != hipSuccess)                                                     \
+      return ::nabu::fail((int)e_, "kernel launch failed (%s:%d): %s", __FILE__, \
+                          __LINE__, hipGetErrorString(e_));                   \
+  } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// tanh through one exp: 2*sigmoid(2x)-1 (abs error ~1e-7)
+__device__ __forceinline__ float tanhf_(float x) { return 2.0f / (1.0f + __expf(-2.0f * x)) - 1.0f; }
+
+}  // namespace nabu

@@ -1,0 +1,268 @@
+// gemm.hip — fp32 GEMM on the gfx950 f32 matrix pipe (v_mfma_f32_32x32x2_f32).
+//
+// C[M,N] = alpha * op(A) * op(B) + beta * C + bias, row-major, exact f32
+// (the f32-input MFMA is bitwise a k-ordered fmaf chain).  Used for the
+// time-batched input projections X·Wx of every (B)LSTM layer, their gradients
+// dX = dZ·Wx^T, dWx = X^T·dZ, dWh = H_{t-1}^T·dZ (segmented K), the DNNDecoder
+// output layer and the attention Dense layers.
+//
+// Tiling: 128x128x16 block tile, 256 threads = 4 wave64 in a 2x2 grid, each
+// wave owns 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs).  Operands are staged
+// k-major in LDS (As[k][m], Bs[k][n]) so that the 32 lanes of an MFMA operand
+// read 32 consecutive floats (conflict-free ds_read_b32); the next k-tile is
+// prefetched into registers while the current one is multiplied.
+// Small-MN / long-K products (weight gradients) use deterministic split-K:
+// partial tiles go to a workspace and are summed in fixed order by a second
+// kernel (no float atomics).
+#include "common.h"
+
+namespace nabu {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;
+
+struct GemmArgs {
+  const float *A, *B, *bias;
+  float *C;
+  float *partial;
+  int M, N, K, lda, ldb, ldc;
+  float alpha, beta;
+  int kseg;
+  long long a_seg, b_seg;
+  int ksplit;  // k-range per z-slice (multiple of BK)
+  int nsplit;
+  int vecA, vecB;  // 16-byte vector loads allowed
+};
+
+// ---- "k-contiguous" operand: element (r,k) at base[r*ld + k] ----------------
+__device__ __forceinline__ void load_kc(float4 (&v)[2], const float *base, int ld, int r0,
+                                        int rmax, int k0, int kend, int vec, int tid) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int idx = tid + 256 * j;
+    int r = r0 + (idx >> 2), k = k0 + 4 * (idx & 3);
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rmax) {
+      const float *p = base + (size_t)r * ld + k;
+      if (vec && k + 3 < kend) {
+        x = *reinterpret_cast<const float4 *>(p);
+      } else {
+        if (k < kend) x.x = p[0];
+        if (k + 1 < kend) x.y = p[1];
+        if (k + 2 < kend) x.z = p[2];
+        if (k + 3 < kend) x.w = p[3];
+      }
+    }
+    v[j] = x;
+  }
+}
+__device__ __forceinline__ void store_kc(float (*S)[LDT], const float4 (&v)[2], int tid) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int idx = tid + 256 * j;
+    int r = idx >> 2, k = 4 * (idx & 3);
+    S[k + 0][r] = v[j].x;
+    S[k + 1][r] = v[j].y;
+    S[k + 2][r] = v[j].z;
+    S[k + 3][r] = v[j].w;
+  }
+}
+// ---- "r-contiguous" operand: element (r,k) at base[row(k) + r] ---------------
+__device__ __forceinline__ void load_rc(float4 (&v)[2], const float *base, int ld, int kseg,
+                                        long long seg, int r0, int rmax, int k0, int kend,
+                                        int vec, int tid) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int idx = tid + 256 * j;
+    int k = k0 + (idx >> 5), r = r0 + 4 * (idx & 31);
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < kend) {
+      size_t off = kseg > 0 ? (size_t)(k / kseg) * (size_t)seg + (size_t)(k % kseg) * ld
+                            : (size_t)k * ld;
+      const float *p = base + off + r;
+      if (vec && r + 3 < rmax) {
+        x = *reinterpret_cast<const float4 *>(p);
+      } else {
+        if (r < rmax) x.x = p[0];
+        if (r + 1 < rmax) x.y = p[1];
+        if (r + 2 < rmax) x.z = p[2];
+        if (r + 3 < rmax) x.w = p[3];
+      }
+    }
+    v[j] = x;
+  }
+}
+__device__ __forceinline__ void store_rc(float (*S)[LDT], const float4 (&v)[2], int tid) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int idx = tid + 256 * j;
+    *reinterpret_cast<float4 *>(&S[idx >> 5][4 * (idx & 31)]) = v[j];
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[BK][LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * a.ksplit;
+  const int kend = min(a.K, kbeg + a.ksplit);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[2], rb[2];
+  auto gload = [&](int k0) {
+    if (TA) load_rc(ra, a.A, a.lda, a.kseg, a.a_seg, m0, a.M, k0, kend, a.vecA, tid);
+    else    load_kc(ra, a.A, a.lda, m0, a.M, k0, kend, a.vecA, tid);
+    if (TB) load_kc(rb, a.B, a.ldb, n0, a.N, k0, kend, a.vecB, tid);
+    else    load_rc(rb, a.B, a.ldb, a.kseg, a.b_seg, n0, a.N, k0, kend, a.vecB, tid);
+  };
+  auto sstore = [&]() {
+    if (TA) store_rc(As, ra, tid); else store_kc(As, ra, tid);
+    if (TB) store_kc(Bs, rb, tid); else store_rc(Bs, rb, tid);
+  };
+
+  if (kbeg < kend) {
+    gload(kbeg);
+    sstore();
+    __syncthreads();
+    const int li = lane & 31, lk = lane >> 5;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      const bool more = k0 + BK < kend;
+      if (more) gload(k0 + BK);
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        float a0 = As[kk + lk][wm * 64 + li];
+        float a1 = As[kk + lk][wm * 64 + 32 + li];
+        float b0 = Bs[kk + lk][wn * 64 + li];
+        float b1 = Bs[kk + lk][wn * 64 + 32 + li];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+      __syncthreads();
+      if (more) {
+        sstore();
+        __syncthreads();
+      }
+    }
+  }
+
+  // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int col = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = n0 + wn * 64 + ni * 32 + col;
+      if (n >= a.N) continue;
+      const float bv = (a.nsplit == 1 && a.bias) ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+        if (m >= a.M) continue;
+        if (a.nsplit == 1) {
+          float *c = a.C + (size_t)m * a.ldc + n;
+          float v = a.alpha * acc[mi][ni][r] + bv;
+          if (a.beta != 0.f) v += a.beta * *c;
+          *c = v;
+        } else {
+          a.partial[((size_t)blockIdx.z * a.M + m) * a.N + n] = acc[mi][ni][r];
+        }
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs a) {
+  const size_t total = (size_t)a.M * a.N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int m = (int)(i / a.N), n = (int)(i % a.N);
+    float s = 0.f;
+    for (int z = 0; z < a.nsplit; ++z) s += a.partial[(size_t)z * total + i];
+    float v = a.alpha * s + (a.bias ? a.bias[n] : 0.f);
+    float *c = a.C + (size_t)m * a.ldc + n;
+    if (a.beta != 0.f) v += a.beta * *c;
+    *c = v;
+  }
+}
+
+// split-K policy: only for products with few output tiles and a long reduction.
+static int choose_split(int M, int N, int K, int *ksplit) {
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  int ns = 1;
+  if (tiles < 192 && K >= 2048) {
+    ns = (512 + tiles - 1) / tiles;
+    const int maxs = K / 512;
+    if (ns > maxs) ns = maxs;
+    if (ns < 1) ns = 1;
+  }
+  int ks = (K + ns - 1) / ns;
+  ks = (ks + BK - 1) / BK * BK;
+  ns = (K + ks - 1) / ks;
+  *ksplit = ks;
+  return ns;
+}
+
+}  // namespace nabu
+
+using namespace nabu;
+
+extern "C" size_t nabu_gemm_ws_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int ks;
+  const int ns = choose_split(M, N, K, &ks);
+  return ns > 1 ? (size_t)ns * M * N * sizeof(float) : 0;
+}
+
+extern "C" int nabu_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
+                             const float *A, int lda, const float *B, int ldb, float beta,
+                             float *C, int ldc, const float *bias, int kseg,
+                             long long a_seg_stride, long long b_seg_stride, void *ws,
+                             size_t ws_bytes, nabu_stream_t stream) {
+  NABU_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "gemm: negative dimension");
+  if (M == 0 || N == 0) return 0;
+  NABU_CHECK_ARG(A && B && C, "gemm: null pointer");
+  NABU_CHECK_ARG(kseg == 0 || (transA && !transB && K % kseg == 0),
+                 "gemm: segmented K needs transA=1, transB=0 and K %% kseg == 0");
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.bias = bias;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.alpha = alpha; a.beta = beta;
+  a.kseg = kseg; a.a_seg = a_seg_stride; a.b_seg = b_seg_stride;
+  a.nsplit = K > 0 ? choose_split(M, N, K, &a.ksplit) : 1;
+  if (K == 0) a.ksplit = BK;
+  a.partial = nullptr;
+  if (a.nsplit > 1) {
+    const size_t need = (size_t)a.nsplit * M * N * sizeof(float);
+    if (!ws || ws_bytes < need) return fail(NABU_EWS, "gemm: workspace %zu < %zu", ws_bytes, need);
+    a.partial = static_cast<float *>(ws);
+  }
+  auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  a.vecA = al16(A) && lda % 4 == 0 && (a_seg_stride % 4 == 0);
+  a.vecB = al16(B) && ldb % 4 == 0 && (b_seg_stride % 4 == 0);
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, a.nsplit), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, a);
+  else if (transA) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, a);
+  else if (transB) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, a);
+  NABU_LAUNCH_CHECK();
+  if (a.nsplit > 1) {
+    const size_t total = (size_t)M * N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), block, 0, s, a);
+    NABU_LAUNCH_CHECK();
+  }
+  return 0;
+}

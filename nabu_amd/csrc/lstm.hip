@@ -1,0 +1,366 @@
+// lstm.hip — one bidirectional LSTM layer (layer.blstm of the reference):
+// orchestration of the input-projection GEMMs, the recurrent kernels and the
+// weight-gradient GEMMs, plus the one-launch-per-timestep recurrent kernels.
+//
+// Data layout in HBM (all fp32, batch-major):
+//   x      [B,T,D]        layer input
+//   out    [B,T,2H]       fw | bw hidden states, 0 for t >= len
+//   reserve = gates_fw [B,T,4H] | gates_bw [B,T,4H] | cs_fw [B,T,H] | cs_bw [B,T,H]
+//     gates_* first holds x·Wx+b (GEMM output), is overwritten in place by the
+//     activations (i,g,f,o) in the forward recurrence and again in place by the
+//     pre-activation gradients dz in the backward recurrence.
+// The TF kernel [(D+H),4H] is used as stored: rows [0,D) = Wx, rows [D,D+H) = Wh.
+#include "common.h"
+#include "lstm_persist.h"
+
+namespace nabu {
+
+struct StepArgs {
+  int B, T, D, H, max_len;
+  const int32_t *len;
+  const float *kernel[2];  // per direction
+  float *gates[2];
+  float *cs[2];
+  float *out;          // fwd: written; bwd: unused
+  const float *dout;   // bwd
+  float *hstate;       // [2 pingpong][2 dir][B][H]
+  float *cstate;       // fwd: c state [2][B][H]; bwd: dc carry [2][B][H]
+};
+
+constexpr int SB = 16;  // batch rows per block
+constexpr int SU = 16;  // hidden units per block
+
+// ---------------------------------------------------------------------------
+// forward, one timestep, both directions.  grid (H/16, B/16, 2), 256 threads.
+__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgs p, int s) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = p.H, B = p.B, T = p.T;
+  float *hs = smem;               // [SB][H]
+  float *zs = smem + SB * H;      // [SB][4][SU]
+  const int dir = blockIdx.z, u0 = blockIdx.x * SU, b0 = blockIdx.y * SB;
+  const int tid = threadIdx.x;
+  const float *hprev = p.hstate + ((size_t)((s & 1) * 2 + dir) * B) * H;
+  float *hnext = p.hstate + ((size_t)(((s & 1) ^ 1) * 2 + dir) * B) * H;
+
+  // stage h_{s-1} of this block's batch rows
+  for (int i = tid; i < SB * H / 4; i += 256) {
+    const int bl = i / (H / 4), k4 = i % (H / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b0 + bl < B) v = reinterpret_cast<const float4 *>(hprev + (size_t)(b0 + bl) * H)[k4];
+    reinterpret_cast<float4 *>(hs + bl * H)[k4] = v;
+  }
+  __syncthreads();
+
+  {  // recurrent product: thread = (batch row bl, gate g, unit quad q)
+    const int q = tid & 3, g = (tid >> 2) & 3, bl = tid >> 4;
+    const int ucol = u0 + 4 * q;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ucol < H) {
+      const float *W = p.kernel[dir] + (size_t)p.D * 4 * H + (size_t)g * H + ucol;
+      const float *hrow = hs + bl * H;
+#pragma unroll 4
+      for (int k = 0; k < H; ++k) {
+        const float4 w = *reinterpret_cast<const float4 *>(W + (size_t)k * 4 * H);
+        const float hv = hrow[k];
+        acc.x = fmaf(hv, w.x, acc.x);
+        acc.y = fmaf(hv, w.y, acc.y);
+        acc.z = fmaf(hv, w.z, acc.z);
+        acc.w = fmaf(hv, w.w, acc.w);
+      }
+    }
+    *reinterpret_cast<float4 *>(zs + (bl * 4 + g) * SU + 4 * q) = acc;
+  }
+  __syncthreads();
+
+  {  // gates + state update: thread = (batch row bl, unit u)
+    const int u = tid & 15, bl = tid >> 4;
+    const int b = b0 + bl, hu = u0 + u;
+    if (b < B && hu < H) {
+      const int n = p.len[b];
+      const size_t sidx = (size_t)b * H + hu;
+      if (s < n) {
+        const int t = dir ? n - 1 - s : s;
+        float *gp = p.gates[dir] + ((size_t)b * T + t) * 4 * H + hu;
+        const float zi = gp[0] + zs[(bl * 4 + 0) * SU + u];
+        const float zj = gp[H] + zs[(bl * 4 + 1) * SU + u];
+        const float zf = gp[2 * H] + zs[(bl * 4 + 2) * SU + u];
+        const float zo = gp[3 * H] + zs[(bl * 4 + 3) * SU + u];
+        const float i = sigmoidf_(zi), g = tanhf_(zj), f = sigmoidf_(zf + 1.0f), o = sigmoidf_(zo);
+        float *cst = p.cstate + (size_t)dir * B * H + sidx;
+        const float c = *cst * f + i * g;
+        const float h = tanhf_(c) * o;
+        gp[0] = i; gp[H] = g; gp[2 * H] = f; gp[3 * H] = o;
+        p.cs[dir][((size_t)b * T + t) * H + hu] = c;
+        p.out[((size_t)b * T + t) * 2 * H + (size_t)dir * H + hu] = h;
+        *cst = c;
+        hnext[sidx] = h;
+      } else {
+        // finished sequence: state frozen, output row s is zero (t >= len)
+        hnext[sidx] = hs[bl * H + hu];
+        p.out[((size_t)b * T + s) * 2 * H + (size_t)dir * H + hu] = 0.f;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// backward, one timestep (s descending), both directions.
+//   dh_carry[b,u] = sum_col dz_{s+1}[b,col] * Wh[u,col]      (block-local)
+//   dz_s from saved activations, written in place over the activations.
+constexpr int DZC = 512;  // dz columns staged per LDS chunk
+
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgs p, int s) {
+  __shared__ __attribute__((aligned(16))) float dzs[SB][DZC];
+  const int H = p.H, B = p.B, T = p.T;
+  const int dir = blockIdx.z, u0 = blockIdx.x * SU, b0 = blockIdx.y * SB;
+  const int tid = threadIdx.x;
+  const int u = tid & 15, bl = tid >> 4;
+  const int b = b0 + bl, hu = u0 + u;
+  const bool valid = b < B && hu < H;
+  const int n = b < B ? p.len[b] : 0;
+
+  float dh = 0.f;
+  if (s + 1 < p.max_len) {
+    const float *Wrow = p.kernel[dir] + (size_t)(p.D + (hu < H ? hu : 0)) * 4 * H;
+    for (int c0 = 0; c0 < 4 * H; c0 += DZC) {
+      const int cw = min(DZC, 4 * H - c0);
+      __syncthreads();
+      for (int i = tid; i < SB * (DZC / 4); i += 256) {
+        const int r = i / (DZC / 4), c4 = i % (DZC / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int bb = b0 + r;
+        if (bb < B && 4 * c4 < cw) {
+          const int nn = p.len[bb];
+          if (s + 1 < nn) {
+            const int t1 = dir ? nn - 2 - s : s + 1;
+            v = *reinterpret_cast<const float4 *>(p.gates[dir] + ((size_t)bb * T + t1) * 4 * H + c0 + 4 * c4);
+          }
+        }
+        *reinterpret_cast<float4 *>(&dzs[r][4 * c4]) = v;
+      }
+      __syncthreads();
+      if (valid) {
+#pragma unroll 4
+        for (int c = 0; c < cw; c += 4) {
+          const float4 w = *reinterpret_cast<const float4 *>(Wrow + c0 + c);
+          const float4 d = *reinterpret_cast<const float4 *>(&dzs[bl][c]);
+          dh = fmaf(d.x, w.x, dh);
+          dh = fmaf(d.y, w.y, dh);
+          dh = fmaf(d.z, w.z, dh);
+          dh = fmaf(d.w, w.w, dh);
+        }
+      }
+    }
+  }
+  if (!valid) return;
+  if (s < n) {
+    const int t = dir ? n - 1 - s : s;
+    float *gp = p.gates[dir] + ((size_t)b * T + t) * 4 * H + hu;
+    const float i = gp[0], g = gp[H], f = gp[2 * H], o = gp[3 * H];
+    const float c = p.cs[dir][((size_t)b * T + t) * H + hu];
+    float cprev = 0.f;
+    if (s > 0) cprev = p.cs[dir][((size_t)b * T + (dir ? t + 1 : t - 1)) * H + hu];
+    float *dcp = p.cstate + (size_t)dir * B * H + (size_t)b * H + hu;
+    const float tc = tanhf_(c);
+    const float dht = p.dout[((size_t)b * T + t) * 2 * H + (size_t)dir * H + hu] + dh;
+    const float dct = *dcp + dht * o * (1.f - tc * tc);
+    gp[0] = dct * g * i * (1.f - i);
+    gp[H] = dct * i * (1.f - g * g);
+    gp[2 * H] = dct * cprev * f * (1.f - f);
+    gp[3 * H] = dht * tc * o * (1.f - o);
+    *dcp = dct * f;
+  } else {
+    // padded frame s >= len: dz must be 0 for the weight-gradient GEMMs
+    float *gp = p.gates[dir] + ((size_t)b * T + s) * 4 * H + hu;
+    gp[0] = 0.f; gp[H] = 0.f; gp[2 * H] = 0.f; gp[3 * H] = 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------
+struct Layout {
+  size_t gates_elems, cs_elems;
+  size_t reserve_bytes;
+  // workspace carve
+  size_t hstate_off, cstate_off, gemm_off, gemm_bytes, persist_off, persist_bytes, total;
+};
+
+static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+
+static Layout make_layout(const nabu_blstm_desc *d) {
+  Layout L;
+  const size_t B = d->B, T = d->T, D = d->D, H = d->H;
+  L.gates_elems = B * T * 4 * H;
+  L.cs_elems = B * T * H;
+  L.reserve_bytes = (2 * L.gates_elems + 2 * L.cs_elems) * sizeof(float);
+  size_t off = 0;
+  L.hstate_off = off; off += align_up(4 * B * H * sizeof(float), 256);
+  L.cstate_off = off; off += align_up(2 * B * H * sizeof(float), 256);
+  size_t g = 0;
+  const int M = (int)(B * T);
+  g = max_sz(g, nabu_gemm_ws_bytes(M, (int)(4 * H), (int)D));            // x·Wx
+  g = max_sz(g, nabu_gemm_ws_bytes(M, (int)D, (int)(4 * H)));            // dz·Wx^T
+  g = max_sz(g, nabu_gemm_ws_bytes((int)D, (int)(4 * H), M));            // x^T·dz
+  if (T > 1) g = max_sz(g, nabu_gemm_ws_bytes((int)H, (int)(4 * H), (int)(B * (T - 1))));
+  g = max_sz(g, nabu_colsum_ws_bytes(M, (int)(4 * H)));
+  L.gemm_off = off; L.gemm_bytes = align_up(g, 256); off += L.gemm_bytes;
+  L.persist_bytes = align_up(lstm_persist_ws_bytes(d->B, d->T, d->H), 256);
+  L.persist_off = off; off += L.persist_bytes;
+  L.total = off;
+  return L;
+}
+
+static int check_desc(const nabu_blstm_desc *d) {
+  if (!d || d->size != sizeof(nabu_blstm_desc)) return fail(NABU_EINVAL, "blstm: bad descriptor size");
+  if (d->B <= 0 || d->T <= 0 || d->D <= 0 || d->H <= 0) return fail(NABU_EINVAL, "blstm: non-positive dimension");
+  if (d->H % 4 != 0) return fail(NABU_EUNSUP, "blstm: num_units must be a multiple of 4 (got %d)", d->H);
+  if (d->max_len < 0 || d->max_len > d->T) return fail(NABU_EINVAL, "blstm: max_len out of range");
+  return 0;
+}
+
+static bool use_persistent(const nabu_blstm_desc *d) {
+  if (d->mode == NABU_LSTM_STEPWISE) return false;
+  return lstm_persist_supported(d->B, d->T, d->H);
+}
+
+}  // namespace nabu
+
+using namespace nabu;
+
+extern "C" size_t nabu_blstm_reserve_bytes(const nabu_blstm_desc *d) {
+  if (check_desc(d)) return 0;
+  return make_layout(d).reserve_bytes;
+}
+extern "C" size_t nabu_blstm_ws_bytes(const nabu_blstm_desc *d) {
+  if (check_desc(d)) return 0;
+  return make_layout(d).total;
+}
+
+extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const int32_t *len,
+                              const float *kernel_fw, const float *bias_fw,
+                              const float *kernel_bw, const float *bias_bw, float *out,
+                              void *reserve, void *ws, size_t ws_bytes, nabu_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  NABU_CHECK_ARG(x && len && kernel_fw && bias_fw && kernel_bw && bias_bw && out && reserve && ws,
+                 "blstm_fwd: null pointer");
+  const Layout L = make_layout(d);
+  if (ws_bytes < L.total) return fail(NABU_EWS, "blstm_fwd: workspace %zu < %zu", ws_bytes, L.total);
+  if (d->mode == NABU_LSTM_PERSISTENT && !lstm_persist_supported(d->B, d->T, d->H))
+    return fail(NABU_EUNSUP, "blstm_fwd: persistent kernel does not support B=%d H=%d", d->B, d->H);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int B = d->B, T = d->T, D = d->D, H = d->H;
+  const int max_len = d->max_len > 0 ? d->max_len : T;
+  float *r = static_cast<float *>(reserve);
+  float *gates[2] = {r, r + L.gates_elems};
+  float *cs[2] = {r + 2 * L.gates_elems, r + 2 * L.gates_elems + L.cs_elems};
+  char *w = static_cast<char *>(ws);
+  const float *kern[2] = {kernel_fw, kernel_bw};
+  const float *bias[2] = {bias_fw, bias_bw};
+
+  // time-batched input projections (MFMA): gates_d = x·Wx_d + b_d
+  for (int dir = 0; dir < 2; ++dir) {
+    int e = nabu_gemm_f32(0, 0, B * T, 4 * H, D, 1.f, x, D, kern[dir], 4 * H, 0.f, gates[dir],
+                          4 * H, bias[dir], 0, 0, 0, w + L.gemm_off, L.gemm_bytes, stream);
+    if (e) return e;
+  }
+  // frames t in [max_len, T) are never visited by the recurrence
+  if (max_len < T)
+    NABU_HIP(hipMemset2DAsync(out + (size_t)max_len * 2 * H, (size_t)T * 2 * H * sizeof(float), 0,
+                              (size_t)(T - max_len) * 2 * H * sizeof(float), B, s));
+
+  if (use_persistent(d)) {
+    return lstm_persist_fwd(B, T, D, H, max_len, len, kern, gates, cs, out, w + L.persist_off,
+                            L.persist_bytes, s);
+  }
+  StepArgs p;
+  p.B = B; p.T = T; p.D = D; p.H = H; p.max_len = max_len; p.len = len;
+  for (int i = 0; i < 2; ++i) { p.kernel[i] = kern[i]; p.gates[i] = gates[i]; p.cs[i] = cs[i]; }
+  p.out = out; p.dout = nullptr;
+  p.hstate = reinterpret_cast<float *>(w + L.hstate_off);
+  p.cstate = reinterpret_cast<float *>(w + L.cstate_off);
+  NABU_HIP(hipMemsetAsync(p.hstate, 0, 4 * (size_t)B * H * sizeof(float), s));
+  NABU_HIP(hipMemsetAsync(p.cstate, 0, 2 * (size_t)B * H * sizeof(float), s));
+  const dim3 grid((H + SU - 1) / SU, (B + SB - 1) / SB, 2);
+  const size_t shm = ((size_t)SB * H + SB * 4 * SU) * sizeof(float);
+  if (shm > 64 * 1024)
+    NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_step_fwd_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  for (int t = 0; t < max_len; ++t) {
+    hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(256), shm, s, p, t);
+  }
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const int32_t *len,
+                              const float *kernel_fw, const float *kernel_bw, const float *out,
+                              const float *d_out, void *reserve, float *d_x, float *dkernel_fw,
+                              float *dbias_fw, float *dkernel_bw, float *dbias_bw, void *ws,
+                              size_t ws_bytes, nabu_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  NABU_CHECK_ARG(x && len && kernel_fw && kernel_bw && out && d_out && reserve && dkernel_fw &&
+                     dbias_fw && dkernel_bw && dbias_bw && ws, "blstm_bwd: null pointer");
+  const Layout L = make_layout(d);
+  if (ws_bytes < L.total) return fail(NABU_EWS, "blstm_bwd: workspace %zu < %zu", ws_bytes, L.total);
+  if (d->mode == NABU_LSTM_PERSISTENT && !lstm_persist_supported(d->B, d->T, d->H))
+    return fail(NABU_EUNSUP, "blstm_bwd: persistent kernel does not support B=%d H=%d", d->B, d->H);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int B = d->B, T = d->T, D = d->D, H = d->H;
+  const int max_len = d->max_len > 0 ? d->max_len : T;
+  float *r = static_cast<float *>(reserve);
+  float *gates[2] = {r, r + L.gates_elems};
+  float *cs[2] = {r + 2 * L.gates_elems, r + 2 * L.gates_elems + L.cs_elems};
+  char *w = static_cast<char *>(ws);
+  const float *kern[2] = {kernel_fw, kernel_bw};
+  float *dkern[2] = {dkernel_fw, dkernel_bw};
+  float *dbias[2] = {dbias_fw, dbias_bw};
+
+  // dz rows of frames never visited by the recurrence must be zero
+  if (max_len < T)
+    for (int dir = 0; dir < 2; ++dir)
+      NABU_HIP(hipMemset2DAsync(gates[dir] + (size_t)max_len * 4 * H, (size_t)T * 4 * H * sizeof(float),
+                                0, (size_t)(T - max_len) * 4 * H * sizeof(float), B, s));
+
+  if (use_persistent(d)) {
+    int e = lstm_persist_bwd(B, T, D, H, max_len, len, kern, gates, cs, d_out, w + L.persist_off,
+                             L.persist_bytes, s);
+    if (e) return e;
+  } else {
+    StepArgs p;
+    p.B = B; p.T = T; p.D = D; p.H = H; p.max_len = max_len; p.len = len;
+    for (int i = 0; i < 2; ++i) { p.kernel[i] = kern[i]; p.gates[i] = gates[i]; p.cs[i] = cs[i]; }
+    p.out = nullptr; p.dout = d_out;
+    p.hstate = nullptr;
+    p.cstate = reinterpret_cast<float *>(w + L.cstate_off);  // dc carry
+    NABU_HIP(hipMemsetAsync(p.cstate, 0, 2 * (size_t)B * H * sizeof(float), s));
+    const dim3 grid((H + SU - 1) / SU, (B + SB - 1) / SB, 2);
+    for (int t = max_len - 1; t >= 0; --t)
+      hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, dim3(256), 0, s, p, t);
+    NABU_LAUNCH_CHECK();
+  }
+
+  // weight / input gradients from dz (now stored in gates[])
+  const int M = B * T;
+  for (int dir = 0; dir < 2; ++dir) {
+    int e;
+    // dWx = x^T · dz
+    e = nabu_gemm_f32(1, 0, D, 4 * H, M, 1.f, x, D, gates[dir], 4 * H, 0.f, dkern[dir], 4 * H,
+                      nullptr, 0, 0, 0, w + L.gemm_off, L.gemm_bytes, stream);
+    if (e) return e;
+    // dWh = h_{prev}^T · dz : fw pairs (out[b,t-1,:H], dz[b,t]); bw pairs (out[b,t+1,H:], dz[b,t])
+    const float *A = dir == 0 ? out : out + H + (size_t)2 * H;
+    const float *Bm = dir == 0 ? gates[0] + (size_t)4 * H : gates[1];
+    e = nabu_gemm_f32(1, 0, H, 4 * H, B * (T - 1), 1.f, A, 2 * H, Bm, 4 * H, 0.f,
+                      dkern[dir] + (size_t)D * 4 * H, 4 * H, nullptr, T > 1 ? T - 1 : 0,
+                      (long long)T * 2 * H, (long long)T * 4 * H, w + L.gemm_off, L.gemm_bytes, stream);
+    if (e) return e;
+    e = nabu_colsum_f32(M, 4 * H, gates[dir], 4 * H, 0.f, dbias[dir], w + L.gemm_off, L.gemm_bytes, stream);
+    if (e) return e;
+    // dx (+)= dz · Wx^T
+    if (d_x) {
+      e = nabu_gemm_f32(0, 1, M, D, 4 * H, 1.f, gates[dir], 4 * H, kern[dir], 4 * H,
+                        dir == 0 ? 0.f : 1.f, d_x, D, nullptr, 0, 0, 0, w + L.gemm_off, L.gemm_bytes, stream);
+      if (e) return e;
+    }
+  }
+  return 0;
+}

@@ -1,0 +1,118 @@
+"""Typed Python wrappers over the C ABI (one function per entry point of
+include/nabu_hip.h).  Tensors are torch CUDA tensors used as device-memory
+handles; all arithmetic happens inside libnabu_hip.so."""
+import ctypes
+
+import torch
+
+from . import _hip
+from ._hip import ptr, stream, check, Workspace
+
+LSTM_AUTO, LSTM_STEPWISE, LSTM_PERSISTENT = 0, 1, 2
+
+
+def _f32(t, name):
+    if t.dtype != torch.float32:
+        raise _hip.NabuHipError('%s must be float32, got %s' % (name, t.dtype))
+    return t
+
+
+def gemm(a, b, c, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None,
+         M=None, N=None, K=None, lda=None, ldb=None, ldc=None,
+         kseg=0, a_seg=0, b_seg=0):
+    """c = alpha*op(a)@op(b) + beta*c + bias on 2-D row-major tensors (or raw
+    views when M/N/K/ld* are given explicitly)."""
+    L = _hip.lib()
+    if M is None:
+        M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+        N = b.shape[0] if trans_b else b.shape[1]
+        lda, ldb, ldc = a.stride(0), b.stride(0), c.stride(0)
+    ws_bytes = L.nabu_gemm_ws_bytes(M, N, K)
+    ws = Workspace.get(ws_bytes, c.device, 'gemm') if ws_bytes else None
+    check(L.nabu_gemm_f32(int(trans_a), int(trans_b), M, N, K, alpha, a.data_ptr(), lda,
+                          b.data_ptr(), ldb, beta, c.data_ptr(), ldc,
+                          bias.data_ptr() if bias is not None else None, kseg, a_seg, b_seg,
+                          ptr(ws), ws_bytes, stream()), 'nabu_gemm_f32')
+    return c
+
+
+def colsum(a, out, beta=0.0):
+    """out[n] = beta*out[n] + sum_m a[m,n] for a 2-D row-major tensor."""
+    L = _hip.lib()
+    M, N = a.shape
+    ws_bytes = L.nabu_colsum_ws_bytes(M, N)
+    ws = Workspace.get(ws_bytes, a.device, 'gemm')
+    check(L.nabu_colsum_f32(M, N, ptr(a), a.stride(0), beta, ptr(out), ptr(ws), ws_bytes, stream()),
+          'nabu_colsum_f32')
+    return out
+
+
+class BlstmPlan(object):
+    """Shape descriptor + buffers of one BLSTM layer call."""
+
+    def __init__(self, B, T, D, H, max_len, mode=LSTM_AUTO):
+        self.desc = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), B, T, D, H, int(max_len), mode)
+        L = _hip.lib()
+        self.reserve_bytes = L.nabu_blstm_reserve_bytes(ctypes.byref(self.desc))
+        self.ws_bytes = L.nabu_blstm_ws_bytes(ctypes.byref(self.desc))
+        if self.reserve_bytes == 0:
+            raise _hip.NabuHipError('blstm: unsupported shape B=%d T=%d D=%d H=%d: %s' % (
+                B, T, D, H, L.nabu_last_error().decode()))
+
+
+def blstm_fwd(plan, x, lens_dev, k_fw, b_fw, k_bw, b_bw, out, reserve):
+    L = _hip.lib()
+    ws = Workspace.get(plan.ws_bytes, x.device, 'blstm')
+    check(L.nabu_blstm_fwd(ctypes.byref(plan.desc), ptr(_f32(x, 'x')), ptr(lens_dev), ptr(k_fw), ptr(b_fw),
+                           ptr(k_bw), ptr(b_bw), ptr(out), ptr(reserve), ptr(ws), plan.ws_bytes,
+                           stream()), 'nabu_blstm_fwd')
+    return out
+
+
+def blstm_bwd(plan, x, lens_dev, k_fw, k_bw, out, d_out, reserve, d_x, dk_fw, db_fw, dk_bw, db_bw):
+    L = _hip.lib()
+    ws = Workspace.get(plan.ws_bytes, x.device, 'blstm')
+    check(L.nabu_blstm_bwd(ctypes.byref(plan.desc), ptr(x), ptr(lens_dev), ptr(k_fw), ptr(k_bw), ptr(out),
+                           ptr(d_out), ptr(reserve), ptr(d_x), ptr(dk_fw), ptr(db_fw), ptr(dk_bw),
+                           ptr(db_bw), ptr(ws), plan.ws_bytes, stream()), 'nabu_blstm_bwd')
+    return d_x
+
+
+def pad_time(x, Tp):
+    B, T, F = x.shape
+    y = torch.empty((B, Tp, F), dtype=x.dtype, device=x.device)
+    check(_hip.lib().nabu_pad_time_f32(B, T, Tp, F, ptr(x), ptr(y), stream()), 'nabu_pad_time_f32')
+    return y
+
+
+def unpad_time(y, T):
+    B, Tp, F = y.shape
+    x = torch.empty((B, T, F), dtype=y.dtype, device=y.device)
+    check(_hip.lib().nabu_unpad_time_f32(B, T, Tp, F, ptr(y), ptr(x), stream()), 'nabu_unpad_time_f32')
+    return x
+
+
+def ctc_loss_grad(logits, logit_len_dev, labels_dev, label_len_dev, grad_scale):
+    """Returns (nll [B], dlogits [B,T,C], status [1] int32) — all on device."""
+    L = _hip.lib()
+    B, T, C = logits.shape
+    Lmax = labels_dev.shape[1]
+    nll = torch.empty(B, dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    status = torch.empty(1, dtype=torch.int32, device=logits.device)
+    ws_bytes = L.nabu_ctc_ws_bytes(B, T, Lmax)
+    ws = Workspace.get(ws_bytes, logits.device, 'ctc')
+    check(L.nabu_ctc_loss_grad(B, T, C, Lmax, ptr(_f32(logits, 'logits')), ptr(logit_len_dev),
+                               ptr(labels_dev), ptr(label_len_dev), grad_scale, ptr(nll), ptr(dlogits),
+                               ptr(status), ptr(ws), ws_bytes, stream()), 'nabu_ctc_loss_grad')
+    return nll, dlogits, status
+
+
+def adam_clip_step(param, grad, m, v, lr_t, b1=0.9, b2=0.999, eps=1e-8, clip=1.0, grad_scale=1.0):
+    check(_hip.lib().nabu_adam_clip_step(param.numel(), ptr(param), ptr(grad), ptr(m), ptr(v), lr_t, b1, b2,
+                                         eps, clip, grad_scale, stream()), 'nabu_adam_clip_step')
+
+
+def clip_(g, clip=1.0):
+    check(_hip.lib().nabu_clip_f32(g.numel(), ptr(g), clip, stream()), 'nabu_clip_f32')
+    return g

@@ -1,0 +1,62 @@
+"""CPU tests of the drop-in boundary: libnabu_hip.so loads and exports every
+symbol that include/nabu_hip.h declares, with ctypes signatures for each."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'nabu_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(nabu_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from nabu_amd import build, _hip
+    build.build(verbose=False)
+    lib = _hip.lib()
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), 'libnabu_hip.so does not export %s' % n
+        assert n in _hip.SIGNATURES, 'no ctypes signature for %s' % n
+    for n in _hip.SIGNATURES:
+        assert n in names, '%s bound in _hip.py but not declared in nabu_hip.h' % n
+    assert lib.nabu_version() == 1
+
+
+def test_host_side_queries_and_argument_errors():
+    """No GPU needed: size queries and argument validation run on the host."""
+    import ctypes
+    from nabu_amd import _hip
+    lib = _hip.lib()
+    d = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), 32, 1000, 40, 512, 1000, 0)
+    res = lib.nabu_blstm_reserve_bytes(ctypes.byref(d))
+    assert res == (2 * 32 * 1000 * 2048 + 2 * 32 * 1000 * 512) * 4
+    assert lib.nabu_blstm_ws_bytes(ctypes.byref(d)) > 0
+    bad = _hip.BlstmDesc(4, 32, 1000, 40, 512, 1000, 0)
+    assert lib.nabu_blstm_reserve_bytes(ctypes.byref(bad)) == 0
+    odd = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), 2, 3, 4, 6, 3, 0)       # H % 4 != 0
+    assert lib.nabu_blstm_reserve_bytes(ctypes.byref(odd)) == 0
+    assert b'multiple of 4' in lib.nabu_last_error()
+    assert lib.nabu_ctc_ws_bytes(32, 125, 60) == 32 * 125 * 121 * 4
+    # null pointers are rejected before any launch
+    assert lib.nabu_gemm_f32(0, 0, 4, 4, 4, 1.0, None, 4, None, 4, 0.0, None, 4, None, 0, 0, 0,
+                             None, 0, None) == -1
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    from nabu_amd import _hip
+    with pytest.raises(_hip.NabuHipError):
+        _hip.ptr(torch.zeros(4))
+    # the package never imports the oracle
+    pkg = os.path.join(ROOT, 'nabu_amd')
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith('.py'):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', txt, flags=re.M), f

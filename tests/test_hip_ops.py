@@ -1,0 +1,222 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI
+(nabu_amd.ops -> libnabu_hip.so), against the NumPy float64 oracle on the same
+seeded inputs.  Tolerances are stated per test (fp32 kernels vs float64 oracle).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nabu_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def rel_err(a, b):
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize('ta,tb', [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 16), (200, 136, 40), (37, 40, 1024), (1, 5, 3),
+                                   (40, 256, 4100), (300, 40, 48)])
+def test_gemm_matches_float64(ta, tb, M, N, K):
+    from nabu_amd import ops
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    a = rng.normal(size=(K, M) if ta else (M, K))
+    b = rng.normal(size=(N, K) if tb else (K, N))       # asymmetric operands
+    c0 = rng.normal(size=(M, N))
+    bias = rng.normal(size=N)
+    ref = 0.5 * (a.T if ta else a) @ (b.T if tb else b) + 2.0 * c0 + bias
+    c = dev(c0)
+    ops.gemm(dev(a), dev(b), c, ta, tb, alpha=0.5, beta=2.0, bias=dev(bias))
+    # fp32 fma chain over K terms: error ~ 1e-7 * sqrt(K) * |a||b|
+    assert rel_err(host(c), ref) < 2e-6 * max(1.0, np.sqrt(K) / 4)
+
+
+def test_gemm_beta0_ignores_garbage_and_unaligned_ld():
+    from nabu_amd import ops
+    rng = np.random.default_rng(3)
+    a = rng.normal(size=(50, 23)); b = rng.normal(size=(23, 31))       # ld not multiple of 4
+    c = torch.full((50, 31), float('nan'), device='cuda')
+    ops.gemm(dev(a), dev(b), c)
+    assert rel_err(host(c), a @ b) < 2e-6
+
+
+def test_gemm_segmented_k_shifted_product():
+    """dWh = sum_b out[b, :-1]^T dz[b, 1:] without materialising the shift."""
+    from nabu_amd import ops
+    rng = np.random.default_rng(4)
+    B, T, H = 5, 9, 8
+    out = rng.normal(size=(B, T, 2 * H)); dz = rng.normal(size=(B, T, 4 * H))
+    ref_fw = np.einsum('bth,btg->hg', out[:, :-1, :H], dz[:, 1:])
+    ref_bw = np.einsum('bth,btg->hg', out[:, 1:, H:], dz[:, :-1])
+    o, d = dev(out), dev(dz)
+    c = torch.empty((H, 4 * H), device='cuda')
+    ops.gemm(o, d.view(-1)[4 * H:], c, True, False, M=H, N=4 * H, K=B * (T - 1), lda=2 * H, ldb=4 * H,
+             ldc=4 * H, kseg=T - 1, a_seg=T * 2 * H, b_seg=T * 4 * H)
+    assert rel_err(host(c), ref_fw) < 2e-6
+    ops.gemm(o.view(-1)[H + 2 * H:], d, c, True, False, M=H, N=4 * H, K=B * (T - 1), lda=2 * H,
+             ldb=4 * H, ldc=4 * H, kseg=T - 1, a_seg=T * 2 * H, b_seg=T * 4 * H)
+    assert rel_err(host(c), ref_bw) < 2e-6
+
+
+def test_colsum():
+    from nabu_amd import ops
+    rng = np.random.default_rng(5)
+    a = rng.normal(size=(1500, 200))
+    out = dev(np.ones(200))
+    ops.colsum(dev(a), out, beta=0.5)
+    assert rel_err(host(out), a.sum(0) + 0.5) < 1e-5
+    out2 = dev(np.ones(200)); out3 = dev(np.ones(200))
+    ops.colsum(dev(a), out2); ops.colsum(dev(a), out3)
+    assert torch.equal(out2, out3)                      # deterministic reduction
+
+
+# ------------------------------------------------------------------ BLSTM
+def _blstm_params(rng, D, H, scale=0.2):
+    return dict(fw_kernel=rng.normal(0, scale, (D + H, 4 * H)), fw_bias=rng.normal(0, scale, 4 * H),
+                bw_kernel=rng.normal(0, scale, (D + H, 4 * H)), bw_bias=rng.normal(0, scale, 4 * H))
+
+
+def _run_blstm(B, T, D, H, lens, mode, seed=0, need_dx=True):
+    from nabu_amd import ops
+    rng = np.random.default_rng(seed)
+    x = rng.normal(size=(B, T, D)).astype(np.float32).astype(np.float64)
+    for b in range(B):
+        x[b, lens[b]:] = 0
+    p = {k: v.astype(np.float32).astype(np.float64) for k, v in _blstm_params(rng, D, H).items()}
+    dout = rng.normal(size=(B, T, 2 * H)).astype(np.float32).astype(np.float64)
+    ref_out, cache = O.blstm_fwd(x, np.asarray(lens), p)
+    ref_dx, ref_g = O.blstm_bwd(dout, cache)
+
+    plan = ops.BlstmPlan(B, T, D, H, int(max(lens)), mode)
+    xd, ld = dev(x), dev(np.asarray(lens), torch.int32)
+    pd = {k: dev(v) for k, v in p.items()}
+    out = torch.full((B, T, 2 * H), float('nan'), device='cuda')
+    reserve = torch.empty(plan.reserve_bytes, dtype=torch.uint8, device='cuda')
+    ops.blstm_fwd(plan, xd, ld, pd['fw_kernel'], pd['fw_bias'], pd['bw_kernel'], pd['bw_bias'], out, reserve)
+    got_out = host(out)
+    dx = torch.full((B, T, D), float('nan'), device='cuda') if need_dx else None
+    g = {k: torch.full(v.shape, float('nan'), device='cuda') for k, v in pd.items()}
+    ops.blstm_bwd(plan, xd, ld, pd['fw_kernel'], pd['bw_kernel'], out, dev(dout), reserve, dx,
+                  g['fw_kernel'], g['fw_bias'], g['bw_kernel'], g['bw_bias'])
+    torch.cuda.synchronize()
+    return got_out, ref_out, (host(dx) if need_dx else None), ref_dx, {k: host(v) for k, v in g.items()}, ref_g
+
+
+@pytest.mark.parametrize('B,T,D,H,lens', [
+    (3, 7, 8, 16, [7, 4, 1]),          # ragged, tiny
+    (8, 40, 40, 64, None),             # all full length
+    (5, 33, 12, 32, [33, 20, 33, 2, 17]),
+    (17, 12, 20, 48, None),            # B not a multiple of the block tile, H % 16 == 0
+    (2, 9, 4, 20, [9, 5]),             # H not a multiple of 16
+    (4, 10, 8, 16, [6, 4, 6, 3]),      # max(len) < T (padded tail never visited)
+])
+def test_blstm_stepwise_matches_oracle(B, T, D, H, lens):
+    from nabu_amd import ops
+    lens = lens or [T] * B
+    out, rout, dx, rdx, g, rg = _run_blstm(B, T, D, H, lens, ops.LSTM_STEPWISE, seed=B * T)
+    assert np.isfinite(out).all()
+    assert np.abs(out - rout).max() < 2e-5              # fp32 recurrence vs float64
+    for b, n in enumerate(lens):
+        assert np.all(out[b, n:] == 0)                   # TF zero-output past len: exact
+    assert rel_err(dx, rdx) < 2e-4
+    for k in rg:
+        assert rel_err(g[k], rg[k]) < 2e-4, k
+
+
+def test_blstm_T1_and_first_layer_without_dx():
+    from nabu_amd import ops
+    out, rout, dx, rdx, g, rg = _run_blstm(3, 1, 8, 16, [1, 1, 1], ops.LSTM_STEPWISE, need_dx=False)
+    assert np.abs(out - rout).max() < 2e-5
+    for k in rg:
+        assert np.abs(g[k] - rg[k]).max() < 1e-5, k
+    assert np.all(g['fw_kernel'][8:] == 0)               # no recurrent contribution with T=1
+
+
+# ------------------------------------------------------------------ CTC
+def _ctc_case(rng, B, T, C, Lmax, full=False):
+    logits = rng.normal(0, 2, (B, T, C)).astype(np.float32).astype(np.float64)
+    tl = np.full(B, T) if full else rng.integers(max(2 * Lmax + 1, T // 2), T + 1, B)
+    tl[0] = T
+    ll = rng.integers(0, Lmax + 1, B)
+    ll[-1] = Lmax
+    labels = rng.integers(0, C - 1, (B, Lmax))
+    if Lmax >= 2:
+        labels[0, 1] = labels[0, 0]                      # adjacent repeat
+    return logits, tl, labels, ll
+
+
+@pytest.mark.parametrize('B,T,C,Lmax', [(4, 30, 6, 5), (32, 125, 40, 60), (8, 200, 40, 40), (3, 5, 3, 2),
+                                        (2, 300, 40, 140)])
+def test_ctc_matches_oracle(B, T, C, Lmax):
+    from nabu_amd import ops
+    rng = np.random.default_rng(B + T)
+    logits, tl, labels, ll = _ctc_case(rng, B, T, C, Lmax)
+    rn, rg = O.ctc_loss(logits, tl, labels, ll)
+    nll, dl, status = ops.ctc_loss_grad(dev(logits), dev(tl, torch.int32), dev(labels, torch.int32),
+                                        dev(ll, torch.int32), 1.0 / B)
+    assert int(status.item()) == 0
+    assert np.abs(host(nll) - rn).max() / np.abs(rn).max() < 1e-5      # fp32 log-space
+    # float32 log-space: alpha, beta ~ -3T, so gamma carries ~1e-7*3T*few relative error
+    assert np.abs(host(dl) * B - rg).max() < 1e-6 * T * 4 + 1e-5
+    for b in range(B):
+        assert np.all(host(dl)[b, tl[b]:] == 0)
+
+
+def test_ctc_edge_cases():
+    from nabu_amd import ops
+    C = 5
+    # empty label, T=1, and an infeasible utterance (repeat needs a blank)
+    logits = np.random.default_rng(1).normal(size=(3, 4, C))
+    tl = np.array([4, 1, 2]); ll = np.array([0, 1, 2]); labels = np.array([[0, 0], [2, 0], [1, 1]])
+    nll, dl, status = ops.ctc_loss_grad(dev(logits), dev(tl, torch.int32), dev(labels, torch.int32),
+                                        dev(ll, torch.int32), 1.0)
+    rn, rg = O.ctc_loss(logits[:2], tl[:2], labels[:2], ll[:2])
+    assert np.abs(host(nll)[:2] - rn).max() < 1e-5
+    assert np.abs(host(dl)[:2] - rg).max() < 1e-5
+    assert int(status.item()) == 3 and np.isinf(host(nll)[2])           # TF raises for this one
+    assert np.all(host(dl)[2] == 0)
+
+
+def test_ctc_is_deterministic():
+    from nabu_amd import ops
+    rng = np.random.default_rng(9)
+    logits, tl, labels, ll = _ctc_case(rng, 8, 60, 40, 20)
+    args = (dev(logits), dev(tl, torch.int32), dev(labels, torch.int32), dev(ll, torch.int32), 1.0)
+    a = ops.ctc_loss_grad(*args); b = ops.ctc_loss_grad(*args)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+# ------------------------------------------------------------------ Adam
+def test_adam_clip_matches_oracle_over_steps():
+    from nabu_amd import ops
+    rng = np.random.default_rng(11)
+    n = 10007                                            # not a multiple of 4
+    th = rng.normal(size=n); m = np.zeros(n); v = np.zeros(n)
+    p, md, vd = dev(th), dev(m), dev(v)
+    for t in range(1, 6):
+        g = rng.normal(0, 1.5, n).astype(np.float32).astype(np.float64)
+        th, m, v = O.clip_adam_update(th, g, m, v, t, 1e-3)
+        lr_t = 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        ops.adam_clip_step(p, dev(g), md, vd, lr_t)
+    assert np.abs(host(p) - th).max() < 1e-6
+    assert np.abs(host(md) - m).max() < 1e-6
+    g = dev(rng.normal(0, 3, n)); ops.clip_(g, 1.0)
+    assert float(g.abs().max()) <= 1.0
+
+
+def test_pad_unpad_time():
+    from nabu_amd import ops
+    x = torch.randn(3, 7, 8, device='cuda')
+    y = ops.pad_time(x, 8)
+    assert torch.equal(y[:, :7], x) and torch.all(y[:, 7] == 0)
+    assert torch.equal(ops.unpad_time(y, 7), x)
