@@ -130,6 +130,17 @@ int nabu_ctc_loss_grad(int B, int T, int C, int Lmax, const float *logits,
                        float *dlogits, int32_t *status, void *ws, size_t ws_bytes,
                        nabu_stream_t stream);
 
+/* Masked sparse softmax cross-entropy averaged over the target length —
+ * loss_functions.average_cross_entropy / cross_entropy
+ * (nabu/neuralnetworks/trainers/loss_functions.py:78-109,155-165):
+ *   loss[b]    = sum_{t<logit_len[b]} xent(logits[b,t], targets[b,t]) / target_len[b]
+ *   dlogits    = grad_scale * d loss[b] / d logits   (0 for t >= logit_len[b])
+ * logits [B,L,C]; targets [B,ldt] int32 with ldt >= L. */
+int nabu_xent_loss_grad(int B, int L, int C, int ldt, const float *logits,
+                        const int32_t *targets, const int32_t *logit_len,
+                        const int32_t *target_len, float grad_scale, float *loss,
+                        float *dlogits, nabu_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Fused per-element gradient clip + TF-style Adam on flat buffers —
  * Trainer._update (nabu/neuralnetworks/trainers/trainer.py:525,560-569):
@@ -142,6 +153,28 @@ int nabu_adam_clip_step(size_t n, float *param, const float *grad, float *m,
 /* g = clamp(g, -clip, clip) in place (data-parallel mode clips per replica
  * BEFORE the all-reduce, trainer.py:556-569). */
 int nabu_clip_f32(size_t n, float *g, float clip, nabu_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Regularisation noise (Philox4x32-10, counter = element index, key = seed):
+ *   dropout: y = x * mask / keep_prob, mask ~ Bernoulli(keep_prob) —
+ *     tf.nn.dropout(x, keep_prob) in Listener/DBLSTM/Speller
+ *     (models/ed_encoders/listener.py:57-59,67-69; dblstm.py:52-54).  The
+ *     same (seed, offset) regenerates the mask, so the gradient is the same
+ *     call applied to dy.
+ *   gaussian noise: y = x + stddev * N(0,1) — input_noise
+ *     (listener.py:40-45, dblstm.py:37-42). */
+int nabu_dropout_f32(size_t n, const float *x, float *y, float keep_prob,
+                     unsigned long long seed, unsigned long long offset,
+                     nabu_stream_t stream);
+int nabu_gaussian_noise_f32(size_t n, const float *x, float *y, float stddev,
+                            unsigned long long seed, unsigned long long offset,
+                            nabu_stream_t stream);
+
+/* out[0] = scale * sum(x) (deterministic single-block tree): tf.reduce_mean of
+ * the per-utterance losses (trainers/loss_functions.py:161,206-212). */
+int nabu_sum_f32(size_t n, const float *x, float scale, float *out, nabu_stream_t stream);
+/* y += a*x : gradient accumulation where a tensor has several consumers. */
+int nabu_axpy_f32(size_t n, float a, const float *x, float *y, nabu_stream_t stream);
 
 #ifdef __cplusplus
 }

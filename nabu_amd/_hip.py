@@ -38,8 +38,13 @@ SIGNATURES = {
     'nabu_unpad_time_f32': (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     'nabu_ctc_ws_bytes': (_sz, [_i, _i, _i]),
     'nabu_ctc_loss_grad': (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'nabu_xent_loss_grad': (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     'nabu_adam_clip_step': (_i, [_sz, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _vp]),
     'nabu_clip_f32': (_i, [_sz, _vp, _f, _vp]),
+    'nabu_dropout_f32': (_i, [_sz, _vp, _vp, _f, _c.c_ulonglong, _c.c_ulonglong, _vp]),
+    'nabu_gaussian_noise_f32': (_i, [_sz, _vp, _vp, _f, _c.c_ulonglong, _c.c_ulonglong, _vp]),
+    'nabu_sum_f32': (_i, [_sz, _vp, _f, _vp, _vp]),
+    'nabu_axpy_f32': (_i, [_sz, _f, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,115 @@
+"""A minimal reverse-mode tape — the stand-in for ``optimizer.compute_gradients``
+(nabu/neuralnetworks/trainers/trainer.py:556-558).
+
+Every hot-path op is a HIP kernel with a hand-written gradient kernel; the tape
+only remembers which backward closure to call, in reverse order, and routes the
+gradient tensors between them.  No arithmetic happens here except the rare
+accumulation of a tensor consumed twice (one axpy kernel)."""
+import torch
+
+from . import ops as hip_ops
+
+
+class _Op(object):
+    __slots__ = ('inputs', 'outputs', 'backward')
+
+    def __init__(self, inputs, outputs, backward):
+        self.inputs, self.outputs, self.backward = inputs, outputs, backward
+
+
+class Tape(object):
+    current = None
+
+    def __init__(self):
+        self.ops = []
+        self.produced = set()
+        self._prev = None
+
+    def __enter__(self):
+        self._prev = Tape.current
+        Tape.current = self
+        return self
+
+    def __exit__(self, *exc):
+        Tape.current = self._prev
+        return False
+
+    def requires_grad(self, tensor):
+        """True if ``tensor`` was produced by a recorded op (i.e. it depends on a
+        parameter); raw input features do not need an input gradient."""
+        return id(tensor) in self.produced
+
+    def backward(self, root):
+        """Run the recorded backward closures from ``root`` (the scalar loss)."""
+        grads = {id(root): None}
+        seen = {id(root)}
+        for op in reversed(self.ops):
+            if not any(id(o) in seen for o in op.outputs):
+                continue
+            gouts = [grads.get(id(o)) for o in op.outputs]
+            gins = op.backward(*gouts)
+            if gins is None:
+                continue
+            for inp, g in zip(op.inputs, gins):
+                if g is None:
+                    continue
+                key = id(inp)
+                if key in seen and grads.get(key) is not None:
+                    hip_ops.axpy_(grads[key], g)
+                else:
+                    grads[key] = g
+                    seen.add(key)
+        self.ops = []
+        self.produced = set()
+
+
+def record(inputs, outputs, backward):
+    """Register ``backward(*grad_outputs) -> grad_inputs`` on the active tape (no-op
+    outside a tape, e.g. in validation)."""
+    tape = Tape.current
+    if tape is None:
+        return
+    tape.ops.append(_Op(list(inputs), list(outputs), backward))
+    for o in outputs:
+        tape.produced.add(id(o))
+
+
+def requires_grad(tensor):
+    tape = Tape.current
+    return tape is not None and tape.requires_grad(tensor)
+
+
+class SeqLen(object):
+    """Sequence lengths: a host copy (loop bounds, ceil-div) next to the device copy
+    the kernels read.  Behaves like the [batch_size] int32 vector of the reference."""
+
+    def __init__(self, host, device=None, dev_tensor=None):
+        import numpy as np
+        self.host = np.ascontiguousarray(np.asarray(host, dtype=np.int32))
+        if dev_tensor is None:
+            if device is None:
+                device = torch.device('cuda', torch.cuda.current_device())
+            dev_tensor = torch.from_numpy(self.host).to(device)
+        self.dev = dev_tensor
+
+    @classmethod
+    def wrap(cls, x, device=None):
+        if isinstance(x, SeqLen):
+            return x
+        if isinstance(x, torch.Tensor):
+            if x.is_cuda:
+                return cls(x.detach().cpu().numpy(), dev_tensor=x.to(torch.int32).contiguous())
+            return cls(x.numpy(), device)
+        return cls(x, device)
+
+    def max(self):
+        return int(self.host.max()) if self.host.size else 0
+
+    def __len__(self):
+        return len(self.host)
+
+    def numpy(self):
+        return self.host
+
+    def __repr__(self):
+        return 'SeqLen(%s)' % self.host

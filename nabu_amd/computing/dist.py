@@ -1,0 +1,50 @@
+"""Data-parallel process group — replaces nabu/computing/create_server.py
+(tf.train.Server over gRPC, parameter servers, ssh tunnels) on one MI355X node.
+
+One process per GPU (launched by torch.distributed.run); gradients are exchanged
+with ONE all-reduce of the flat fp32 gradient buffer per training step over
+RCCL/xGMI (backend "nccl" is RCCL on ROCm).  ``gloo`` is accepted for the CPU
+tests of the host-side protocol."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class ProcessGroup(object):
+    """Handle passed to Trainer(server=...)."""
+
+    def __init__(self, rank, world_size, backend):
+        self.rank, self.world_size, self.backend = rank, world_size, backend
+
+    def all_reduce_sum_(self, tensor):
+        if self.world_size > 1:
+            dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+        return tensor
+
+    def broadcast_(self, tensor, src=0):
+        if self.world_size > 1:
+            dist.broadcast(tensor, src)
+        return tensor
+
+    def barrier(self):
+        if self.world_size > 1:
+            dist.barrier()
+
+
+def create_server(backend=None):
+    """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR /
+    MASTER_PORT (set by torch.distributed.run).  Single-process when unset —
+    the analogue of create_local_server() (create_server.py:23-25)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world == 1:
+        return ProcessGroup(0, 1, None)
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return ProcessGroup(rank, world, backend)

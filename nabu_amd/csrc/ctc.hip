@@ -214,3 +214,61 @@ extern "C" int nabu_ctc_loss_grad(int B, int T, int C, int Lmax, const float *lo
   NABU_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------
+// Masked sparse softmax cross-entropy averaged over the target length
+// (loss_functions.average_cross_entropy / cross_entropy of the reference):
+//   loss[b] = sum_{t < logit_len[b]} -log softmax(logits[b,t])[targets[b,t]] / target_len[b]
+//   dlogits[b,t,:] = grad_scale * (softmax - onehot) / target_len[b]   (0 for t >= logit_len[b])
+// One workgroup per utterance, one thread per frame, fixed-order block reduction.
+namespace nabu {
+__global__ __launch_bounds__(256) void xent_kernel(int B, int L, int C, int ldt,
+                                                   const float *__restrict__ logits,
+                                                   const int32_t *__restrict__ targets,
+                                                   const int32_t *__restrict__ logit_len,
+                                                   const int32_t *__restrict__ target_len,
+                                                   float grad_scale, float *__restrict__ loss,
+                                                   float *__restrict__ dlogits) {
+  __shared__ float red[256];
+  const int b = blockIdx.x;
+  const int n = min(max(logit_len[b], 0), L);
+  const float inv = 1.0f / (float)target_len[b];
+  float acc = 0.f;
+  for (int t = threadIdx.x; t < L; t += 256) {
+    const float *x = logits + ((size_t)b * L + t) * C;
+    float *d = dlogits + ((size_t)b * L + t) * C;
+    if (t >= n) {
+      for (int c = 0; c < C; ++c) d[c] = 0.f;
+      continue;
+    }
+    float m = x[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+    float z = 0.f;
+    for (int c = 0; c < C; ++c) z += expf(x[c] - m);
+    const float lz = m + logf(z);
+    const int y = targets[(size_t)b * ldt + t];
+    acc += lz - x[y];
+    const float s = grad_scale * inv;
+    for (int c = 0; c < C; ++c) d[c] = s * (expf(x[c] - lz) - (c == y ? 1.f : 0.f));
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[b] = red[0] * inv;
+}
+}  // namespace nabu
+
+extern "C" int nabu_xent_loss_grad(int B, int L, int C, int ldt, const float *logits,
+                                   const int32_t *targets, const int32_t *logit_len,
+                                   const int32_t *target_len, float grad_scale, float *loss,
+                                   float *dlogits, nabu_stream_t stream) {
+  NABU_CHECK_ARG(B > 0 && L > 0 && C > 0 && ldt >= L, "xent: bad dimensions");
+  NABU_CHECK_ARG(logits && targets && logit_len && target_len && loss && dlogits, "xent: null pointer");
+  hipLaunchKernelGGL(nabu::xent_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), B, L, C,
+                     ldt, logits, targets, logit_len, target_len, grad_scale, loss, dlogits);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}

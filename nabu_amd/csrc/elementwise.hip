@@ -112,6 +112,88 @@ __global__ __launch_bounds__(256) void pad_time_kernel(int B, int T, int Tp, int
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// counter-based RNG (Philox4x32-10) for dropout masks and Gaussian input noise:
+// element i uses counter (i/4, offset) and key seed, so the backward pass
+// regenerates the forward mask instead of storing it.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+  const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+    const unsigned hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u;
+    k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+__device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+__global__ __launch_bounds__(256) void dropout_kernel(size_t n, const float *__restrict__ x,
+                                                      float *__restrict__ y, float keep,
+                                                      unsigned long long seed, unsigned long long offset) {
+  const size_t n4 = (n + 3) / 4;
+  const float inv = 1.0f / keep;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const uint4 r = philox4x32_10(make_uint4((unsigned)i, (unsigned)(i >> 32), (unsigned)offset,
+                                             (unsigned)(offset >> 32)),
+                                  make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+    const unsigned rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t e = 4 * i + j;
+      if (e < n) y[e] = u01(rr[j]) < keep ? x[e] * inv : 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gaussian_noise_kernel(size_t n, const float *__restrict__ x,
+                                                             float *__restrict__ y, float stddev,
+                                                             unsigned long long seed,
+                                                             unsigned long long offset) {
+  const size_t n4 = (n + 3) / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const uint4 r = philox4x32_10(make_uint4((unsigned)i, (unsigned)(i >> 32), (unsigned)offset,
+                                             (unsigned)(offset >> 32)),
+                                  make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+    // Box-Muller on (0,1] uniforms
+    const float u1 = 1.0f - u01(r.x), u2 = u01(r.y), u3 = 1.0f - u01(r.z), u4 = u01(r.w);
+    const float ra = sqrtf(-2.0f * logf(u1)), rb = sqrtf(-2.0f * logf(u3));
+    float sa, ca, sb, cb;
+    sincosf(6.283185307179586f * u2, &sa, &ca);
+    sincosf(6.283185307179586f * u4, &sb, &cb);
+    const float z[4] = {ra * ca, ra * sa, rb * cb, rb * sb};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t e = 4 * i + j;
+      if (e < n) y[e] = x[e] + stddev * z[j];
+    }
+  }
+}
+
+// out[0] = scale * sum(x[0..n)) — one block, fixed tree (deterministic).
+__global__ __launch_bounds__(256) void sum_kernel(size_t n, const float *__restrict__ x, float scale,
+                                                  float *__restrict__ out) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 256) s += x[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = scale * red[0];
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(size_t n, float a, const float *__restrict__ x,
+                                                   float *__restrict__ y) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    y[i] = fmaf(a, x[i], y[i]);
+}
+
 static int grid_for(size_t work_items) {
   size_t b = (work_items + 255) / 256;
   if (b > 2048) b = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
@@ -183,6 +265,43 @@ extern "C" int nabu_unpad_time_f32(int B, int T, int Tp, int F, const float *y, 
   NABU_CHECK_ARG(B > 0 && T > 0 && Tp >= T && F > 0 && F % 4 == 0 && x && y, "unpad_time: bad argument");
   hipLaunchKernelGGL(pad_time_kernel, dim3(grid_for((size_t)B * T * (F / 4))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), B, T, Tp, F, y, x, 1);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_dropout_f32(size_t n, const float *x, float *y, float keep_prob,
+                                unsigned long long seed, unsigned long long offset,
+                                nabu_stream_t stream) {
+  if (n == 0) return 0;
+  NABU_CHECK_ARG(x && y && keep_prob > 0.f && keep_prob <= 1.f, "dropout: bad argument");
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), n, x, y, keep_prob, seed, offset);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_gaussian_noise_f32(size_t n, const float *x, float *y, float stddev,
+                                       unsigned long long seed, unsigned long long offset,
+                                       nabu_stream_t stream) {
+  if (n == 0) return 0;
+  NABU_CHECK_ARG(x && y && stddev >= 0.f, "gaussian_noise: bad argument");
+  hipLaunchKernelGGL(gaussian_noise_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), n, x, y, stddev, seed, offset);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_sum_f32(size_t n, const float *x, float scale, float *out, nabu_stream_t stream) {
+  NABU_CHECK_ARG(out && (n == 0 || x), "sum: null pointer");
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), n, x, scale, out);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_axpy_f32(size_t n, float a, const float *x, float *y, nabu_stream_t stream) {
+  if (n == 0) return 0;
+  NABU_CHECK_ARG(x && y, "axpy: null pointer");
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), n, a, x, y);
   NABU_LAUNCH_CHECK();
   return 0;
 }

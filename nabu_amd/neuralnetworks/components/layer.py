@@ -1,0 +1,61 @@
+"""Neural network layers (reference: nabu/neuralnetworks/components/layer.py).
+
+Same functions, same variable names; the body of ``blstm`` is ONE call into the
+C ABI (nabu_blstm_fwd) instead of two tf.while_loops of ~15 small ops per step."""
+import torch
+
+from nabu_amd import ops as hip
+from nabu_amd import variables as vs
+from nabu_amd.autodiff import record, requires_grad, SeqLen
+from nabu_amd.neuralnetworks.components import ops
+
+# cell scope of tf.contrib.rnn.LayerNormBasicLSTMCell under bidirectional_dynamic_rnn
+_CELL = 'bidirectional_rnn/%s/layer_norm_basic_lstm_cell'
+LSTM_MODE = [hip.LSTM_AUTO]      # tests flip this to compare the two recurrent paths
+
+
+def blstm(inputs, sequence_length, num_units, layer_norm=False, scope=None):
+    """A BLSTM layer (reference layer.py:8-51).
+
+    inputs [B,T,D] fp32 contiguous on the GPU; sequence_length [B];
+    returns [B,T,2*num_units] = concat(fw, bw).  Variables (TF layout):
+    <scope>/bidirectional_rnn/{fw,bw}/layer_norm_basic_lstm_cell/{kernel [(D+H),4H], bias [4H]},
+    gate order i,j,f,o; both use the scope-default glorot-uniform initialiser."""
+    if layer_norm:
+        raise NotImplementedError('layer_norm=True is not on the hot path (the reference '
+                                  'always calls blstm with layer_norm=False)')
+    lens = SeqLen.wrap(sequence_length, inputs.device)
+    B, T, D = inputs.shape
+    H = int(num_units)
+    with vs.variable_scope(scope or 'BLSTM'):
+        kf = vs.get_variable((_CELL % 'fw') + '/kernel', [D + H, 4 * H])
+        bf = vs.get_variable((_CELL % 'fw') + '/bias', [4 * H])
+        kb = vs.get_variable((_CELL % 'bw') + '/kernel', [D + H, 4 * H])
+        bb = vs.get_variable((_CELL % 'bw') + '/bias', [4 * H])
+    plan = hip.BlstmPlan(B, T, D, H, min(lens.max(), T), LSTM_MODE[0])
+    x = inputs if inputs.is_contiguous() else inputs.contiguous()
+    out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
+    reserve = torch.empty(plan.reserve_bytes, dtype=torch.uint8, device=x.device)
+    hip.blstm_fwd(plan, x, lens.dev, kf.data, bf.data, kb.data, bb.data, out, reserve)
+    need_dx = requires_grad(inputs)
+
+    def backward(dout):
+        for v in (kf, bf, kb, bb):
+            if v.grad is None:
+                v.grad = torch.zeros_like(v.data)
+        dx = torch.empty_like(x) if need_dx else None
+        hip.blstm_bwd(plan, x, lens.dev, kf.data, kb.data, out, dout.contiguous(), reserve, dx,
+                      kf.grad, bf.grad, kb.grad, bb.grad)
+        return [dx]
+    record([inputs], [out], backward)
+    return out
+
+
+def pblstm(inputs, sequence_length, num_units, num_steps=2, layer_norm=False, scope=None):
+    """A pyramidal BLSTM layer (reference layer.py:53-94): blstm, then stack
+    ``num_steps`` consecutive output frames.  Returns (outputs, new lengths)."""
+    with vs.variable_scope(scope or 'PBLSTM'):
+        outputs = blstm(inputs=inputs, sequence_length=sequence_length, num_units=num_units,
+                        layer_norm=layer_norm)
+        outputs, output_seq_lengths = ops.pyramid_stack(outputs, sequence_length, num_steps)
+    return outputs, output_seq_lengths

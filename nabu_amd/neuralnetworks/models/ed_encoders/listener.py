@@ -1,0 +1,37 @@
+"""The Listener: pyramidal deep BLSTM encoder
+(reference: models/ed_encoders/listener.py:14-74)."""
+from nabu_amd import variables as vs
+from nabu_amd.neuralnetworks.components import layer, ops
+from nabu_amd.neuralnetworks.models.ed_encoders import ed_encoder
+
+
+class Listener(ed_encoder.EDEncoder):
+    '''transforms input features into a high level representation'''
+
+    def encode(self, inputs, input_seq_length, is_training):
+        encoded, encoded_seq_length = {}, {}
+        keep = float(self.conf['dropout'])
+        for inp in inputs:
+            with vs.variable_scope(inp):
+                std_input_noise = float(self.conf['input_noise'])
+                if is_training and std_input_noise > 0:          # listener.py:40-45
+                    outputs = ops.input_noise(inputs[inp], std_input_noise, ops.global_rng())
+                else:
+                    outputs = inputs[inp]
+                output_seq_lengths = input_seq_length[inp]
+                for l in range(int(self.conf['num_layers'])):    # listener.py:49-59
+                    outputs, output_seq_lengths = layer.pblstm(
+                        inputs=outputs, sequence_length=output_seq_lengths,
+                        num_units=int(self.conf['num_units']),
+                        num_steps=int(self.conf['pyramid_steps']), scope='layer%d' % l)
+                    if keep < 1 and is_training:
+                        outputs = ops.seq_dropout(outputs, keep, ops.global_rng())
+                outputs = layer.blstm(                           # listener.py:61-65
+                    inputs=outputs, sequence_length=output_seq_lengths,
+                    num_units=int(self.conf['num_units']),
+                    scope='layer%d' % int(self.conf['num_layers']))
+                if keep < 1 and is_training:
+                    outputs = ops.seq_dropout(outputs, keep, ops.global_rng())
+                encoded[inp] = outputs
+                encoded_seq_length[inp] = output_seq_lengths
+        return encoded, encoded_seq_length

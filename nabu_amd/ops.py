@@ -116,3 +116,40 @@ def adam_clip_step(param, grad, m, v, lr_t, b1=0.9, b2=0.999, eps=1e-8, clip=1.0
 def clip_(g, clip=1.0):
     check(_hip.lib().nabu_clip_f32(g.numel(), ptr(g), clip, stream()), 'nabu_clip_f32')
     return g
+
+
+def dropout(x, keep_prob, seed, offset):
+    y = torch.empty_like(x)
+    check(_hip.lib().nabu_dropout_f32(x.numel(), ptr(x), ptr(y), keep_prob, seed, offset, stream()),
+          'nabu_dropout_f32')
+    return y
+
+
+def gaussian_noise(x, stddev, seed, offset):
+    y = torch.empty_like(x)
+    check(_hip.lib().nabu_gaussian_noise_f32(x.numel(), ptr(x), ptr(y), stddev, seed, offset, stream()),
+          'nabu_gaussian_noise_f32')
+    return y
+
+
+def sum_(x, scale=1.0):
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    check(_hip.lib().nabu_sum_f32(x.numel(), ptr(x), scale, ptr(out), stream()), 'nabu_sum_f32')
+    return out
+
+
+def axpy_(y, x, a=1.0):
+    check(_hip.lib().nabu_axpy_f32(x.numel(), a, ptr(x), ptr(y), stream()), 'nabu_axpy_f32')
+    return y
+
+
+def xent_loss_grad(logits, targets_dev, logit_len_dev, target_len_dev, grad_scale):
+    """Returns (loss [B], dlogits [B,L,C])."""
+    B, L, C = logits.shape
+    loss = torch.empty(B, dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    check(_hip.lib().nabu_xent_loss_grad(B, L, C, targets_dev.shape[1], ptr(_f32(logits, 'logits')),
+                                         ptr(targets_dev), ptr(logit_len_dev), ptr(target_len_dev),
+                                         grad_scale, ptr(loss), ptr(dlogits), stream()),
+          'nabu_xent_loss_grad')
+    return loss, dlogits
