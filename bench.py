@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""bench.py — utterances/sec of the Nabu training step on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+          --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]/[3], "cfg2"): 4-layer Listener-512 (3 pyramidal
+BLSTM layers + 1 BLSTM) + DNNDecoder + CTC, batch 32 x 1000 frames x 40 fbank per
+GPU, fp32, synthetic seeded data, random-init weights.  One step = forward + CTC
+loss/gradient + backward + per-element clip + Adam (+ RCCL all-reduce of the
+clipped gradients when N > 1, weak scaling: every rank has its own batch of 32).
+Inputs are resident in HBM before the timed region.
+
+One JSON line is printed by rank 0.  Extra objects:
+  roofline     — the dominant kernel (the recurrent LSTM step), ALGORITHMIC bytes
+                 (per timestep per direction W_h + x-projection +
+                 gate activations + h/c state) / duration measured with HIP events
+                 recorded by the library around the recurrent launches, inside the
+                 timed region, on the launch stream.
+  cpu_baseline — the oracle (NumPy float32 restatement of the reference graph at
+                 TF op granularity, "port") timed on the host cores on a bounded
+                 sample.  The reference's own TF-1.8 trainer cannot run here.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+B, T, D, H, C = 32, 1000, 40, 512, 40
+LAYER_T = (1000, 500, 250, 125)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def step_bytes(batch, hidden):
+    """algorithmic bytes of ONE recurrent timestep of ONE direction"""
+    return 4 * (hidden * 4 * hidden + batch * 4 * hidden + batch * 4 * hidden + 4 * batch * hidden)
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """Time the oracle (float32) for one full training step of the cfg2 model on a
+    bounded sample: all 32 utterances, the first T_s frames (cost is linear in T)."""
+    import numpy as np
+    from oracle import nabu_oracle as O
+    from nabu_amd.processing.synthetic import SyntheticData
+    Ts = 200
+    rng = np.random.default_rng(99)
+    dims = [D, 4 * H, 4 * H, 4 * H]
+    layers = [{k: O.glorot_uniform(rng, (d + H, 4 * H)) if 'kernel' in k else O.glorot_uniform(rng, (4 * H,))
+               for k in ('fw_kernel', 'fw_bias', 'bw_kernel', 'bw_bias')} for d in dims]
+    W = O.glorot_uniform(rng, (2 * H, C)); bo = np.zeros(C, np.float32)
+    data = SyntheticData(B, Ts, D, min_frames=Ts, min_labels=4, max_labels=12, time_reduction=8, seed=2234)
+    batch = data.batch(0)
+    x = batch['inputs']['features']
+
+    def one_step():
+        enc, el, caches = O.listener_fwd(x, batch['input_seq_length']['features'], layers)
+        lg = O.linear_fwd(enc, W, bo)
+        nll, dlg = O.ctc_loss(lg, el, batch['targets']['text'], batch['target_seq_length']['text'])
+        de, dW, db = O.linear_bwd((dlg / B).astype(np.float32), enc, W)
+        _, grads = O.listener_bwd(de, caches)
+        for l, g in zip(layers, grads):
+            for k in l:
+                l[k], _, _ = O.clip_adam_update(l[k], g[k], np.zeros_like(l[k]), np.zeros_like(l[k]), 1, 1e-3)
+        return float(nll.mean())
+    t0 = time.time()
+    one_step()
+    dt = time.time() - t0
+    reps = 1
+    if dt * 3 < seconds_budget:          # a second repetition if it is cheap
+        t0 = time.time()
+        one_step()
+        dt = min(dt, time.time() - t0)
+        reps = 2
+    utt_s = B / (dt * (T / float(Ts)))
+    return {'value': round(utt_s, 3), 'unit': 'utterances/sec', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': '%d step(s) of the cfg2 model, 32 utterances x first %d of 1000 frames, NumPy float32 '
+                      'oracle at TF op granularity (one [B,in+H]x[in+H,4H] matmul per timestep per '
+                      'direction), BLAS threads = all host cores; utt/s scaled by %d/1000 (cost linear in T); '
+                      'the reference TF-1.8 trainer itself cannot run here' % (reps, Ts, Ts)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--mode', default='auto', choices=['auto', 'stepwise', 'persistent'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    from nabu_amd import recipes, ops, _hip
+    from nabu_amd.computing import dist
+    from nabu_amd.neuralnetworks.components import layer
+    from nabu_amd.neuralnetworks.trainers import trainer_factory, loss_functions
+    from nabu_amd.processing.synthetic import SyntheticData
+
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    server = dist.create_server()
+    rank, world = server.rank, server.world_size
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if world == 1:
+        torch.cuda.set_device(0)
+    _hip.lib()
+    layer.LSTM_MODE[0] = {'auto': ops.LSTM_AUTO, 'stepwise': ops.LSTM_STEPWISE,
+                          'persistent': ops.LSTM_PERSISTENT}[args.mode]
+
+    mc, tc, ec = recipes.load_recipe('cfg2_listener_ctc')
+    data = SyntheticData(B, T, D, min_frames=T, min_labels=20, max_labels=60, time_reduction=8,
+                         seed=4234 + rank)
+    tr = trainer_factory.factory('standard')(conf=tc, dataconf=data, modelconf=mc, evaluatorconf=ec,
+                                             expdir=None, server=server, task_index=rank)
+    batches = [tr.to_device(data.batch(i)) for i in range(2)]      # resident in HBM
+    for i in range(args.warmup):
+        tr.step(batches[i % 2])
+    loss_functions.check_status()
+    torch.cuda.synchronize()
+    server.barrier()
+    prof = ops.enable_profiler()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = tr.step(batches[i % 2])
+    torch.cuda.synchronize()
+    server.barrier()
+    dt = time.perf_counter() - t0
+    prof.enabled = False
+    recs = prof.collect()
+    final_loss = float(loss.item())
+    loss_functions.check_status()
+    tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank != 0:
+        return
+
+    # roofline of the dominant kernel: recurrent step(s), per launch
+    import ctypes
+    desc = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), B, T, D, H, T, layer.LSTM_MODE[0])
+    persistent = bool(_hip.lib().nabu_blstm_uses_persistent(ctypes.byref(desc)))
+    tot_ms = sum(r[4] for r in recs)
+    tot_steps = sum(r[2] for r in recs)                   # timesteps covered (both directions each)
+    tot_bytes = sum(2 * r[2] * step_bytes(r[1], r[3]) for r in recs)
+    launches = len(recs) if persistent else tot_steps
+    per_launch_bytes = tot_bytes / max(launches, 1)
+    per_launch_s = tot_ms * 1e-3 / max(launches, 1)
+    achieved = per_launch_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
+    roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                'kernel': 'lstm_persist_{fwd,bwd}' if persistent else 'lstm_step_{fwd,bwd}_kernel',
+                'bytes_per_launch': int(per_launch_bytes), 'us_per_launch': round(per_launch_s * 1e6, 3),
+                'launches_timed': launches,
+                'recurrent_ms_per_step': round(tot_ms / args.steps, 3),
+                'note': 'algorithmic bytes (W_h streamed per timestep model, SURVEY.md 8(d)); '
+                        'events recorded by the library around the recurrent launches'}
+    step_bytes_total = 2 * 2 * sum(LAYER_T) * step_bytes(B, H)
+    out = {
+        'metric': 'utterances/sec training step, 4x512 Listener+CTC, batch 32x1000x40 fbank',
+        'value': round(world * B * args.steps / dt, 2), 'unit': 'utterances/sec', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': 'cfg2: Listener 3 pyramidal + 1 BLSTM x512, DNNDecoder, CTC, Adam+clip; '
+                               '32 utt x 1000 frames x 40 fbank per GPU',
+                   'global_batch': world * B, 'frames': T, 'parallelism': 'dp%d' % world,
+                   'recurrent_path': 'persistent' if persistent else 'stepwise'},
+        'roofline': roofline,
+        'hbm_roofline_frac_whole_step': round(step_bytes_total / (dt / args.steps) / (HBM_PEAK_GBS * 1e9), 4),
+        'final_loss': round(final_loss, 4),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline()
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -104,6 +104,14 @@ int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const int32_t *len,
                    float *dbias_fw, float *dkernel_bw, float *dbias_bw, void *ws,
                    size_t ws_bytes, nabu_stream_t stream);
 
+/* 1 if nabu_blstm_fwd/bwd will run the persistent whole-sequence kernel for d. */
+int nabu_blstm_uses_persistent(const nabu_blstm_desc *d);
+/* Profiling hook (thread-local): when non-NULL, nabu_blstm_fwd/bwd record the
+ * caller-owned hipEvent_t ev_begin right before and ev_end right after the
+ * recurrent kernel(s) on the call's stream, so that bench.py can time the
+ * dominant kernel live inside the timed region.  Pass NULLs to switch it off. */
+int nabu_blstm_set_profile_events(void *ev_begin, void *ev_end);
+
 /* ops.pyramid_stack (nabu/neuralnetworks/components/ops.py:6-60) when T is not
  * a multiple of numsteps: y [B,Tp,F] = x [B,T,F] zero-padded in time (for T a
  * multiple the stack is a free view on the batch-major buffer).  The inverse

@@ -34,6 +34,8 @@ SIGNATURES = {
     'nabu_blstm_fwd': (_i, [_c.POINTER(BlstmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nabu_blstm_bwd': (_i, [_c.POINTER(BlstmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp, _vp, _vp, _sz, _vp]),
+    'nabu_blstm_uses_persistent': (_i, [_c.POINTER(BlstmDesc)]),
+    'nabu_blstm_set_profile_events': (_i, [_vp, _vp]),
     'nabu_pad_time_f32': (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     'nabu_unpad_time_f32': (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     'nabu_ctc_ws_bytes': (_sz, [_i, _i, _i]),

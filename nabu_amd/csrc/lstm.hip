@@ -217,6 +217,10 @@ static int check_desc(const nabu_blstm_desc *d) {
   return 0;
 }
 
+// optional profiling hook: caller-owned events recorded around the recurrent kernels
+static thread_local hipEvent_t g_ev_begin = nullptr, g_ev_end = nullptr;
+#define NABU_PROFILE_MARK(ev, s) do { if (ev) NABU_HIP(hipEventRecord(ev, s)); } while (0)
+
 static bool use_persistent(const nabu_blstm_desc *d) {
   if (d->mode == NABU_LSTM_STEPWISE) return false;
   return lstm_persist_supported(d->B, d->T, d->H);
@@ -225,6 +229,16 @@ static bool use_persistent(const nabu_blstm_desc *d) {
 }  // namespace nabu
 
 using namespace nabu;
+
+extern "C" int nabu_blstm_set_profile_events(void *ev_begin, void *ev_end) {
+  g_ev_begin = static_cast<hipEvent_t>(ev_begin);
+  g_ev_end = static_cast<hipEvent_t>(ev_end);
+  return 0;
+}
+extern "C" int nabu_blstm_uses_persistent(const nabu_blstm_desc *d) {
+  if (check_desc(d)) return 0;
+  return use_persistent(d) ? 1 : 0;
+}
 
 extern "C" size_t nabu_blstm_reserve_bytes(const nabu_blstm_desc *d) {
   if (check_desc(d)) return 0;
@@ -268,8 +282,12 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const in
                               (size_t)(T - max_len) * 2 * H * sizeof(float), B, s));
 
   if (use_persistent(d)) {
-    return lstm_persist_fwd(B, T, D, H, max_len, len, kern, gates, cs, out, w + L.persist_off,
-                            L.persist_bytes, s);
+    NABU_PROFILE_MARK(g_ev_begin, s);
+    int e = lstm_persist_fwd(B, T, D, H, max_len, len, kern, gates, cs, out, w + L.persist_off,
+                             L.persist_bytes, s);
+    if (e) return e;
+    NABU_PROFILE_MARK(g_ev_end, s);
+    return 0;
   }
   StepArgs p;
   p.B = B; p.T = T; p.D = D; p.H = H; p.max_len = max_len; p.len = len;
@@ -284,10 +302,12 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const in
   if (shm > 64 * 1024)
     NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_step_fwd_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  NABU_PROFILE_MARK(g_ev_begin, s);
   for (int t = 0; t < max_len; ++t) {
     hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(256), shm, s, p, t);
   }
   NABU_LAUNCH_CHECK();
+  NABU_PROFILE_MARK(g_ev_end, s);
   return 0;
 }
 
@@ -320,6 +340,7 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
       NABU_HIP(hipMemset2DAsync(gates[dir] + (size_t)max_len * 4 * H, (size_t)T * 4 * H * sizeof(float),
                                 0, (size_t)(T - max_len) * 4 * H * sizeof(float), B, s));
 
+  NABU_PROFILE_MARK(g_ev_begin, s);
   if (use_persistent(d)) {
     int e = lstm_persist_bwd(B, T, D, H, max_len, len, kern, gates, cs, d_out, w + L.persist_off,
                              L.persist_bytes, s);
@@ -337,6 +358,7 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
       hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, dim3(256), 0, s, p, t);
     NABU_LAUNCH_CHECK();
   }
+  NABU_PROFILE_MARK(g_ev_end, s);
 
   // weight / input gradients from dz (now stored in gates[])
   const int M = B * T;

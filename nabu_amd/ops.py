@@ -63,18 +63,26 @@ class BlstmPlan(object):
 def blstm_fwd(plan, x, lens_dev, k_fw, b_fw, k_bw, b_bw, out, reserve):
     L = _hip.lib()
     ws = Workspace.get(plan.ws_bytes, x.device, 'blstm')
+    if PROFILER is not None:
+        PROFILER.arm('fwd', plan)
     check(L.nabu_blstm_fwd(ctypes.byref(plan.desc), ptr(_f32(x, 'x')), ptr(lens_dev), ptr(k_fw), ptr(b_fw),
                            ptr(k_bw), ptr(b_bw), ptr(out), ptr(reserve), ptr(ws), plan.ws_bytes,
                            stream()), 'nabu_blstm_fwd')
+    if PROFILER is not None:
+        PROFILER.disarm()
     return out
 
 
 def blstm_bwd(plan, x, lens_dev, k_fw, k_bw, out, d_out, reserve, d_x, dk_fw, db_fw, dk_bw, db_bw):
     L = _hip.lib()
     ws = Workspace.get(plan.ws_bytes, x.device, 'blstm')
+    if PROFILER is not None:
+        PROFILER.arm('bwd', plan)
     check(L.nabu_blstm_bwd(ctypes.byref(plan.desc), ptr(x), ptr(lens_dev), ptr(k_fw), ptr(k_bw), ptr(out),
                            ptr(d_out), ptr(reserve), ptr(d_x), ptr(dk_fw), ptr(db_fw), ptr(dk_bw),
                            ptr(db_bw), ptr(ws), plan.ws_bytes, stream()), 'nabu_blstm_bwd')
+    if PROFILER is not None:
+        PROFILER.disarm()
     return d_x
 
 
@@ -153,3 +161,58 @@ def xent_loss_grad(logits, targets_dev, logit_len_dev, target_len_dev, grad_scal
                                          grad_scale, ptr(loss), ptr(dlogits), stream()),
           'nabu_xent_loss_grad')
     return loss, dlogits
+
+
+class RecurrentProfiler(object):
+    """Times the recurrent kernel(s) of every BLSTM call with HIP events recorded by
+    the library on the launch stream (nabu_blstm_set_profile_events).  Used by
+    bench.py for the live roofline figure; off by default."""
+
+    def __init__(self):
+        self.hip = ctypes.CDLL('libamdhip64.so')
+        self.records = []          # (kind, B, T_steps, H, ev_begin, ev_end)
+        self.enabled = False
+
+    def _event(self):
+        ev = ctypes.c_void_p()
+        err = self.hip.hipEventCreate(ctypes.byref(ev))
+        if err:
+            raise _hip.NabuHipError('hipEventCreate failed: %d' % err)
+        return ev
+
+    def arm(self, kind, plan):
+        if not self.enabled:
+            return
+        b, e = self._event(), self._event()
+        _hip.lib().nabu_blstm_set_profile_events(b, e)
+        d = plan.desc
+        self.records.append((kind, d.B, d.max_len if d.max_len > 0 else d.T, d.H, b, e))
+
+    def disarm(self):
+        if self.enabled:
+            _hip.lib().nabu_blstm_set_profile_events(None, None)
+
+    def collect(self):
+        """[(kind, B, steps, H, milliseconds)] — call after a device synchronize."""
+        out = []
+        for kind, B, steps, H, b, e in self.records:
+            ms = ctypes.c_float()
+            err = self.hip.hipEventElapsedTime(ctypes.byref(ms), b, e)
+            if err:
+                raise _hip.NabuHipError('hipEventElapsedTime failed: %d' % err)
+            out.append((kind, B, steps, H, ms.value))
+            self.hip.hipEventDestroy(b)
+            self.hip.hipEventDestroy(e)
+        self.records = []
+        return out
+
+
+PROFILER = None
+
+
+def enable_profiler():
+    global PROFILER
+    if PROFILER is None:
+        PROFILER = RecurrentProfiler()
+    PROFILER.enabled = True
+    return PROFILER

@@ -11,7 +11,7 @@ import torch
 from oracle import nabu_oracle as O
 from tests import torch_ref as R
 
-torch.set_default_dtype(torch.float64)
+F64 = torch.float64
 
 
 def _rng(seed):
@@ -66,7 +66,7 @@ def test_blstm_matches_torch_nn_lstm():
     lens = np.array([7, 5, 2])
     p = _blstm_params(rng, D, H)
     out, _ = O.blstm_fwd(x, lens, p)
-    lstm = torch.nn.LSTM(D, H, batch_first=True, bidirectional=True)
+    lstm = torch.nn.LSTM(D, H, batch_first=True, bidirectional=True).double()
 
     def conv(kern, bias, sfx):
         ki, kj, kf, ko = np.split(kern, 4, 1)
@@ -76,7 +76,7 @@ def test_blstm_matches_torch_nn_lstm():
         getattr(lstm, 'weight_ih_l0' + sfx).data = torch.tensor(w[:D].T.copy())
         getattr(lstm, 'weight_hh_l0' + sfx).data = torch.tensor(w[D:].T.copy())
         getattr(lstm, 'bias_ih_l0' + sfx).data = torch.tensor(bb)
-        getattr(lstm, 'bias_hh_l0' + sfx).data = torch.zeros(4 * H)
+        getattr(lstm, 'bias_hh_l0' + sfx).data = torch.zeros(4 * H, dtype=F64)
     conv(p['fw_kernel'], p['fw_bias'], '')
     conv(p['bw_kernel'], p['bw_bias'], '_reverse')
     pk = torch.nn.utils.rnn.pack_padded_sequence(torch.tensor(x), torch.tensor(lens),
