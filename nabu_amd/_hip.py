@@ -104,6 +104,8 @@ class Workspace(object):
         key = (str(device), tag)
         buf = cls._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            # zero-filled: the first word of the 'blstm' workspace is the persistent
+            # kernels' status word (0 = ok)
+            buf = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=device)
             cls._bufs[key] = buf
         return buf

@@ -192,7 +192,7 @@ static Layout make_layout(const nabu_blstm_desc *d) {
   L.gates_elems = B * T * 4 * H;
   L.cs_elems = B * T * H;
   L.reserve_bytes = (2 * L.gates_elems + 2 * L.cs_elems) * sizeof(float);
-  size_t off = 0;
+  size_t off = 256;   // ws[0..4) is the persistent kernels' status word (0 = ok), zeroed by the caller once
   L.hstate_off = off; off += align_up(4 * B * H * sizeof(float), 256);
   L.cstate_off = off; off += align_up(2 * B * H * sizeof(float), 256);
   size_t g = 0;
@@ -283,7 +283,7 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const in
 
   if (use_persistent(d)) {
     NABU_PROFILE_MARK(g_ev_begin, s);
-    int e = lstm_persist_fwd(B, T, D, H, max_len, len, kern, gates, cs, out, w + L.persist_off,
+    int e = lstm_persist_fwd(B, T, D, H, max_len, len, kern, gates, cs, out, reinterpret_cast<int *>(w), w + L.persist_off,
                              L.persist_bytes, s);
     if (e) return e;
     NABU_PROFILE_MARK(g_ev_end, s);
@@ -342,7 +342,7 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
 
   NABU_PROFILE_MARK(g_ev_begin, s);
   if (use_persistent(d)) {
-    int e = lstm_persist_bwd(B, T, D, H, max_len, len, kern, gates, cs, d_out, w + L.persist_off,
+    int e = lstm_persist_bwd(B, T, D, H, max_len, len, kern, gates, cs, d_out, reinterpret_cast<int *>(w), w + L.persist_off,
                              L.persist_bytes, s);
     if (e) return e;
   } else {

@@ -7,8 +7,8 @@ bool lstm_persist_supported(int B, int T, int H);
 size_t lstm_persist_ws_bytes(int B, int T, int H);
 int lstm_persist_fwd(int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2],
-                     float *out, void *ws, size_t ws_bytes, hipStream_t stream);
+                     float *out, int *status, void *ws, size_t ws_bytes, hipStream_t stream);
 int lstm_persist_bwd(int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2],
-                     const float *dout, void *ws, size_t ws_bytes, hipStream_t stream);
+                     const float *dout, int *status, void *ws, size_t ws_bytes, hipStream_t stream);
 }  // namespace nabu

@@ -216,3 +216,18 @@ def enable_profiler():
         PROFILER = RecurrentProfiler()
     PROFILER.enabled = True
     return PROFILER
+
+
+def check_persist_status(device=None):
+    """Raise if a persistent recurrent kernel gave up (bounded-spin timeout); the
+    status word is the first int32 of the 'blstm' workspace.  Synchronises."""
+    for (dev, tag), buf in list(Workspace._bufs.items()):
+        if tag != 'blstm':
+            continue
+        code = int(buf[:4].view(torch.int32).item())
+        if code:
+            buf[:4].zero_()
+            raise _hip.NabuHipError(
+                'persistent LSTM kernel timed out waiting for a peer workgroup (code %d: block %d, %s '
+                'pass); results of this step are invalid' % (code, (code - 1) // 2,
+                                                             'forward' if code % 2 else 'backward'))
