@@ -192,7 +192,8 @@ static Layout make_layout(const nabu_blstm_desc *d) {
   L.gates_elems = B * T * 4 * H;
   L.cs_elems = B * T * H;
   L.reserve_bytes = (2 * L.gates_elems + 2 * L.cs_elems) * sizeof(float);
-  size_t off = 256;   // ws[0..4) is the persistent kernels' status word (0 = ok), zeroed by the caller once
+  size_t off = 2048;  // ws[0..4): persistent kernels' status word (0 = ok), zeroed by the caller once;
+                      // ws[64..64+4*grid): XCC id of every block of the last forward launch (diagnostic)
   L.hstate_off = off; off += align_up(4 * B * H * sizeof(float), 256);
   L.cstate_off = off; off += align_up(2 * B * H * sizeof(float), 256);
   size_t g = 0;

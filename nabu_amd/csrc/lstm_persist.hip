@@ -11,14 +11,12 @@
 //   each own 16 hidden units (= 64 gate columns) of that direction, i.e. a
 //   [H x 64] slice of W_h = H*64*4 B (128 KiB at H=512) held in VGPRs
 //   (64 registers per lane at 512 threads).  Block b belongs to unit b % NU, so
-//   with the observed round-robin block->XCD placement a unit lives on one XCD;
-//   correctness never depends on that (all exchange traffic uses agent-scope
-//   sc1 loads/stores).
+//   with the observed round-robin block->XCD placement a unit lives on one XCD.
 //
 // PER-STEP EXCHANGE (the only inter-workgroup communication):
 //   forward : all-gather of h_t      — every workgroup publishes its [16 x 8]
-//             slice (512 B, 16-byte sc1 stores) and reads the unit's whole
-//             [H x 8] vector (16 KiB) with sc1 loads;
+//             slice (512 B, 16-byte stores) and reads the unit's whole [H x 8]
+//             vector (16 KiB);
 //   backward: reduce-scatter of dh   — every workgroup publishes its partial
 //             product [8 x H] (16 KiB) cut into per-destination pieces and reads
 //             the P pieces addressed to it, summing them in a fixed order.
@@ -26,18 +24,26 @@
 //   0xFFFFFFFF (a NaN no h or dh value can take); a consumer re-loads a slot
 //   until no word holds the sentinel.  No flags, no fences, no atomics; every
 //   32-bit word is individually valid or sentinel, so torn 16-byte stores are
-//   harmless.  Slots form a ring of R=4; a slot is reset to the sentinel by
-//   its owner two steps after it was consumed, and every workgroup drains its
-//   stores (s_waitcnt vmcnt(0)) before publishing, which orders the reset
-//   before any later write to the same slot.
+//   harmless.  Slots form a ring of R=4; a slot is reset to the sentinel by its
+//   owner after it was consumed, and every workgroup drains its stores
+//   (s_waitcnt vmcnt(0)) before publishing, which orders the reset before any
+//   later write to the same slot.
+//   PLACEMENT-INDEPENDENT CORRECTNESS: consumers always use sc1 loads (bypass
+//   the per-CU L1).  At kernel start the workgroups of a unit exchange their
+//   XCC ids (through sc1 stores); only if ALL of them sit on one XCD do they
+//   publish with plain stores (the data then stays in that XCD's L2 and never
+//   touches the fabric); otherwise they publish with write-through sc1 stores.
+//   A different placement therefore changes speed, never results.
 //   Every spin is bounded by a wall-clock timeout; a timeout sets a status
 //   word, makes every workgroup leave, and is reported to the host.
 //
-// MATH per workgroup and step: [8 x H] x [H x 64] on the fp32 VALU
-// (2*8*H*64 flop = 524 kflop at H=512, i.e. 2048 cycles at the CU's fp32 peak):
-// lanes are (hidden unit, k-slice) / (k-quad, gate) register tiles of
-// 8x4 accumulators so that one 16-byte LDS broadcast read feeds 16 FMAs.
+// MATH per workgroup and step: [8 x H] x [H x 64] on the fp32 VALU with packed
+// FMAs (v_pk_fma_f32; 2*8*H*64 flop = 524 kflop at H=512 = 2048 cycles at the
+// CU's fp32 peak): lanes are (hidden unit, k-slice) / (k-quad, gate) register
+// tiles of 8x4 accumulators so that one 16-byte LDS broadcast read feeds 16 FMAs.
 #include "lstm_persist.h"
+
+#include <stdlib.h>
 
 namespace nabu {
 
@@ -47,9 +53,11 @@ constexpr int UC = 16;    // hidden units per workgroup
 constexpr int BS = 8;     // batch rows per unit
 constexpr int RING = 4;   // exchange ring depth
 constexpr int NCU = 256;  // MI355X
+constexpr size_t TABLE_BYTES = 4096;   // XCC-id table in front of the ring
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct PersistArgs {
   int B, T, D, H, max_len, nshard;
@@ -59,9 +67,12 @@ struct PersistArgs {
   float *cs[2];
   float *out;         // forward
   const float *dout;  // backward
+  unsigned *table;    // [grid] XCC ids, pre-set to SENT
   char *xbuf;         // exchange ring
   int *status;
   unsigned long long timeout_ticks;  // wall_clock64 ticks (100 MHz)
+  int dbg;  // NABU_PERSIST_DEBUG: 1 no exchange wait, 2 no matrix product, 4 phase stamps,
+            // 8 force write-through publishing (timing experiments only)
 };
 
 __device__ __forceinline__ float dpp_f(float v, const int ctrl_sel) {
@@ -82,8 +93,17 @@ __device__ __forceinline__ float dpp_f(float v, const int ctrl_sel) {
 #define QUAD_XOR2(v) dpp_f(v, 1)
 #define QUAD_BCAST(v, i) dpp_f(v, 2 + (i))
 
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
+
 __device__ __forceinline__ bool has_sentinel(const u32x4 v) {
   return v.x == SENT || v.y == SENT || v.z == SENT || v.w == SENT;
+}
+
+// publish 16 bytes: plain store when the whole unit shares one L2, else write-through
+__device__ __forceinline__ void xstore(const u32x4 v, __amdgpu_buffer_rsrc_t rs, unsigned off, bool coloc) {
+  if (coloc) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+  else       __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
 }
 
 // Bounded spin bookkeeping: returns true when the caller must give up.
@@ -98,6 +118,50 @@ struct SpinGuard {
     return wall_clock64() - t0 > p.timeout_ticks;
   }
 };
+
+// NABU_PERSIST_DEBUG & 4: block 0 / thread 0 records the wall clock (10 ns units) at phase
+// boundaries of the middle timestep into status[320 + 32*pass + i] (pass 0 fwd, 1 bwd).
+#define NABU_STAMP(pass, i)                                                       \
+  do {                                                                            \
+    if ((p.dbg & 4) && blockIdx.x == 0 && tid == 0 && s == p.max_len / 2)         \
+      p.status[320 + 32 * (pass) + (i)] = (int)(wall_clock64());                  \
+  } while (0)
+
+// Kernel start: publish my XCC id, wait for the ids of my unit, decide whether the unit
+// is co-located on one XCD.  Returns false on timeout.  flag[0] = failure, flag[1] = coloc.
+__device__ __forceinline__ bool unit_handshake(const PersistArgs &p, int unit, int NU, int P, int *flag) {
+  const int tid = threadIdx.x;
+  const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));  // HW_REG_XCC_ID
+  if (tid == 0) {
+    flag[0] = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flag[1] = 0;
+    p.status[16 + blockIdx.x] = (int)xcc;   // diagnostic
+    __hip_atomic_store(p.table + blockIdx.x, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (flag[0]) return false;   // an earlier kernel of this workspace timed out
+  if (tid < 64) {
+    SpinGuard guard;
+    guard.start();
+    unsigned v = xcc;
+    bool failed = false;
+    for (;;) {
+      if (tid < P) v = __hip_atomic_load(p.table + unit + NU * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__all(v != SENT)) break;
+      if (guard.expired(p)) { failed = true; break; }
+    }
+    const bool same = __all(v == xcc) && !(p.dbg & 8);
+    if (tid == 0) {
+      if (failed) {
+        flag[0] = 1;
+        __hip_atomic_store(p.status, 3 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      flag[1] = same ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  return flag[0] == 0;
+}
 
 // LDS carve (floats)
 template <int KPL>
@@ -144,27 +208,30 @@ __global__ __launch_bounds__(PT) void lstm_persist_fwd_kernel(PersistArgs p) {
   const int ibg = b0 + ib;
   const int n_i = ibg < p.B ? p.len[ibg] : 0;
 
-  // this lane's slice of W_h stays in registers for the whole sequence
-  float Wr[KPL][4];
+  // this lane's slice of W_h stays in registers for the whole sequence (gate pairs packed)
+  f32x2 Wr[KPL][2];
   {
     const float *Wh = p.kernel[dir] + (size_t)p.D * 4 * H + U0 + fu;
 #pragma unroll
-    for (int j = 0; j < KPL; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) Wr[j][g] = Wh[(size_t)(ks * KPL + j) * 4 * H + g * H];
+    for (int j = 0; j < KPL; ++j) {
+      const float *row = Wh + (size_t)(ks * KPL + j) * 4 * H;
+      Wr[j][0] = (f32x2){row[0], row[H]};
+      Wr[j][1] = (f32x2){row[2 * H], row[3 * H]};
+    }
   }
   float c_state = 0.f, h_state = 0.f;
-  if (tid == 0) *flag = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (*flag) return;   // an earlier kernel of this workspace timed out
+  if (!unit_handshake(p, unit, NU, P, flag)) return;
+  const bool coloc = flag[1] != 0;
 
   const size_t slot_bytes = (size_t)H * BS * 4;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       p.xbuf + (size_t)unit * RING * slot_bytes, 0, (int)(RING * slot_bytes), 0x00020000);
   const bool pub_lane = (gg == 0) && ((gb & 3) == 0);
   const unsigned pub_off = (unsigned)(((U0 + gu) * BS + gb) * 4);
+  const u32x4 sent4 = {SENT, SENT, SENT, SENT};
 
   for (int s = 0; s < p.max_len; ++s) {
+    NABU_STAMP(0, 0);
     // (a) x-projection of this step (GEMM output, bias included), coalesced
     const bool act_i = s < n_i;
     const int t_i = dir ? n_i - 1 - s : s;
@@ -172,7 +239,7 @@ __global__ __launch_bounds__(PT) void lstm_persist_fwd_kernel(PersistArgs p) {
     if (act_i) xg = p.gates[dir][((size_t)ibg * T + t_i) * 4 * H + ig * H + U0 + iu];
 
     // (b) wait for h_{s-1} of the whole unit
-    if (s > 0) {
+    if (s > 0 && !(p.dbg & 1)) {
       const unsigned base = (unsigned)(((s - 1) % RING) * slot_bytes);
       u32x4 v[NQ] = {};
       SpinGuard guard;
@@ -190,8 +257,8 @@ __global__ __launch_bounds__(PT) void lstm_persist_fwd_kernel(PersistArgs p) {
         if (__all(ok)) break;
         if (guard.expired(p)) {
           if ((tid & 63) == 0) {
-            *flag = 1;
-            __hip_atomic_store(p.status, 1 + 2 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flag[0] = 1;
+            __hip_atomic_store(p.status, 1 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           break;
         }
@@ -205,23 +272,20 @@ __global__ __launch_bounds__(PT) void lstm_persist_fwd_kernel(PersistArgs p) {
         }
       }
     }
+    NABU_STAMP(0, 1);
     xs[(ib * 4 + ig) * 17 + iu] = xg;
     __syncthreads();                                            // B1
-    if (*flag) return;
+    if (flag[0]) return;
+    NABU_STAMP(0, 2);
 
     // reset my piece of the slot everybody finished reading (h_{s-2})
-    if (s >= 2 && pub_lane) {
-      const u32x4 sent = {SENT, SENT, SENT, SENT};
-      __builtin_amdgcn_raw_buffer_store_b128(sent, rs, (unsigned)(((s - 2) % RING) * slot_bytes) + pub_off, 0, 16);
-    }
+    if (s >= 2 && pub_lane) xstore(sent4, rs, (unsigned)(((s - 2) % RING) * slot_bytes) + pub_off, coloc);
 
-    // (c) recurrent product on the VALU: acc[b][g] += h[b][k] * W[k][g]
-    float acc[BS][4];
+    // (c) recurrent product on the VALU (packed FMAs): acc[b][g] += h[b][k] * W[k][g]
+    f32x2 acc[BS][2];
 #pragma unroll
-    for (int b = 0; b < BS; ++b)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) acc[b][g] = 0.f;
-    if (s > 0) {
+    for (int b = 0; b < BS; ++b) acc[b][0] = acc[b][1] = (f32x2){0.f, 0.f};
+    if (s > 0 && !(p.dbg & 2)) {
       const float *hrow = hs + ks * L::SLICE;
 #pragma unroll
       for (int j = 0; j < KPL; ++j) {
@@ -229,50 +293,49 @@ __global__ __launch_bounds__(PT) void lstm_persist_fwd_kernel(PersistArgs p) {
         const float4 h1 = *reinterpret_cast<const float4 *>(hrow + j * BS + 4);
         const float hb[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
-        for (int b = 0; b < BS; ++b)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) acc[b][g] = fmaf(hb[b], Wr[j][g], acc[b][g]);
+        for (int b = 0; b < BS; ++b) {
+          const f32x2 hh = {hb[b], hb[b]};
+          acc[b][0] = __builtin_elementwise_fma(hh, Wr[j][0], acc[b][0]);
+          acc[b][1] = __builtin_elementwise_fma(hh, Wr[j][1], acc[b][1]);
+        }
       }
       // sum the 4 k-slices of the quad (all lanes get the total)
 #pragma unroll
       for (int b = 0; b < BS; ++b)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          float v = acc[b][g];
+          float v = acc[b][g >> 1][g & 1];
           v += QUAD_XOR1(v);
           v += QUAD_XOR2(v);
-          acc[b][g] = v;
+          acc[b][g >> 1][g & 1] = v;
         }
     }
+    NABU_STAMP(0, 3);
     {  // lane fq hands rows 2fq, 2fq+1 of its wave's partial to the gate phase
       float *dst = part + w * 512 + (fu * BS + 2 * fq) * 4;
-      float4 r0, r1;
-      // static register indexing: select by lane without runtime-indexed arrays
-      r0.x = fq == 0 ? acc[0][0] : fq == 1 ? acc[2][0] : fq == 2 ? acc[4][0] : acc[6][0];
-      r0.y = fq == 0 ? acc[0][1] : fq == 1 ? acc[2][1] : fq == 2 ? acc[4][1] : acc[6][1];
-      r0.z = fq == 0 ? acc[0][2] : fq == 1 ? acc[2][2] : fq == 2 ? acc[4][2] : acc[6][2];
-      r0.w = fq == 0 ? acc[0][3] : fq == 1 ? acc[2][3] : fq == 2 ? acc[4][3] : acc[6][3];
-      r1.x = fq == 0 ? acc[1][0] : fq == 1 ? acc[3][0] : fq == 2 ? acc[5][0] : acc[7][0];
-      r1.y = fq == 0 ? acc[1][1] : fq == 1 ? acc[3][1] : fq == 2 ? acc[5][1] : acc[7][1];
-      r1.z = fq == 0 ? acc[1][2] : fq == 1 ? acc[3][2] : fq == 2 ? acc[5][2] : acc[7][2];
-      r1.w = fq == 0 ? acc[1][3] : fq == 1 ? acc[3][3] : fq == 2 ? acc[5][3] : acc[7][3];
-      *reinterpret_cast<float4 *>(dst) = r0;
-      *reinterpret_cast<float4 *>(dst + 4) = r1;
+      f32x2 a0 = fq == 0 ? acc[0][0] : fq == 1 ? acc[2][0] : fq == 2 ? acc[4][0] : acc[6][0];
+      f32x2 a1 = fq == 0 ? acc[0][1] : fq == 1 ? acc[2][1] : fq == 2 ? acc[4][1] : acc[6][1];
+      f32x2 b0_ = fq == 0 ? acc[1][0] : fq == 1 ? acc[3][0] : fq == 2 ? acc[5][0] : acc[7][0];
+      f32x2 b1_ = fq == 0 ? acc[1][1] : fq == 1 ? acc[3][1] : fq == 2 ? acc[5][1] : acc[7][1];
+      *reinterpret_cast<float4 *>(dst) = make_float4(a0.x, a0.y, a1.x, a1.y);
+      *reinterpret_cast<float4 *>(dst + 4) = make_float4(b0_.x, b0_.y, b1_.x, b1_.y);
     }
     __syncthreads();                                            // B2
+    NABU_STAMP(0, 4);
 
     // (d) gates: thread = (gate gg, row gb, unit gu); part[w][tid] is its partial
     float z = xs[(gb * 4 + gg) * 17 + gu];
 #pragma unroll
     for (int ww = 0; ww < 8; ++ww) z += part[ww * 512 + tid];
-    const float a = (gg == 1) ? tanhf_(z) : sigmoidf_(gg == 2 ? z + 1.0f : z);
+    const float a = (gg == 1) ? fast_tanh(z) : fast_sigmoid(gg == 2 ? z + 1.0f : z);
     const float gi = QUAD_BCAST(a, 0), gj = QUAD_BCAST(a, 1), gf = QUAD_BCAST(a, 2), go = QUAD_BCAST(a, 3);
     const bool act_g = s < n_g;
     const float c_new = c_state * gf + gi * gj;
-    const float h_new = tanhf_(c_new) * go;
+    const float h_new = fast_tanh(c_new) * go;
     if (act_g) { c_state = c_new; h_state = h_new; }
 
-    // (e) publish h_s (frozen rows republish their state): 4 rows -> one 16-byte sc1 store
+    NABU_STAMP(0, 5);
+    // (e) publish h_s (frozen rows republish their state): 4 rows -> one 16-byte store
     {
       const float h1 = __shfl_down(h_state, 4), h2 = __shfl_down(h_state, 8), h3 = __shfl_down(h_state, 12);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my reset (and older stores) are performed
@@ -282,10 +345,11 @@ __global__ __launch_bounds__(PT) void lstm_persist_fwd_kernel(PersistArgs p) {
         pv.y = __builtin_bit_cast(unsigned, h1);
         pv.z = __builtin_bit_cast(unsigned, h2);
         pv.w = __builtin_bit_cast(unsigned, h3);
-        __builtin_amdgcn_raw_buffer_store_b128(pv, rs, (unsigned)((s % RING) * slot_bytes) + pub_off, 0, 16);
+        xstore(pv, rs, (unsigned)((s % RING) * slot_bytes) + pub_off, coloc);
       }
     }
 
+    NABU_STAMP(0, 6);
     // (f) off the critical path: results to HBM in 64-byte segments
     sg[(gb * 4 + gg) * 17 + gu] = a;
     if (gg == 0) {
@@ -293,6 +357,7 @@ __global__ __launch_bounds__(PT) void lstm_persist_fwd_kernel(PersistArgs p) {
       so[gb * 17 + gu] = act_g ? h_new : 0.f;
     }
     __syncthreads();                                            // B3
+    NABU_STAMP(0, 7);
     if (ibg < p.B) {
       if (act_i) p.gates[dir][((size_t)ibg * T + t_i) * 4 * H + ig * H + U0 + iu] = sg[(ib * 4 + ig) * 17 + iu];
       if (ig == 0) {
@@ -300,6 +365,7 @@ __global__ __launch_bounds__(PT) void lstm_persist_fwd_kernel(PersistArgs p) {
         p.out[((size_t)ibg * T + (act_i ? t_i : s)) * 2 * H + (size_t)dir * H + U0 + iu] = so[ib * 17 + iu];
       }
     }
+    NABU_STAMP(0, 8);
   }
 }
 
@@ -323,8 +389,7 @@ __global__ __launch_bounds__(PT) void lstm_persist_bwd_kernel(PersistArgs p) {
   constexpr int H = 32 * KPL;
   constexpr int P = H / UC;
   constexpr int KQ = H / 4;                       // k-quads of the product's output
-  constexpr int NKQ = (KQ * 4 + PT - 1) / PT;     // k-quads per (thread's gate quarter): 1 for H<=512
-  static_assert(NKQ == 1, "backward kernel supports H <= 512");
+  static_assert(KQ * 4 <= PT, "backward kernel supports H <= 512");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *dzs = smem + L::DZ, *red = smem + L::RED, *xs = smem + L::XS, *xc = smem + L::XC;
   float *sg = smem + L::SG;
@@ -347,24 +412,22 @@ __global__ __launch_bounds__(PT) void lstm_persist_bwd_kernel(PersistArgs p) {
   const int ibg = b0 + ib;
   const int n_i = ibg < p.B ? p.len[ibg] : 0;
 
-  // Wr[j][c] = W_h[4kq+j][cq*H + U0 + c]
-  float Wr[4][16];
+  // Wr[c][jp] = (W_h[4kq+2jp][cq*H + U0 + c], W_h[4kq+2jp+1][...]) — k pairs packed
+  f32x2 Wr[16][2];
   if (mat_lane) {
     const float *Wh = p.kernel[dir] + (size_t)p.D * 4 * H + (size_t)cq * H + U0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int c = 0; c < 16; ++c) Wr[j][c] = Wh[(size_t)(4 * kq + j) * 4 * H + c];
+    for (int c = 0; c < 16; ++c) {
+      Wr[c][0] = (f32x2){Wh[(size_t)(4 * kq + 0) * 4 * H + c], Wh[(size_t)(4 * kq + 1) * 4 * H + c]};
+      Wr[c][1] = (f32x2){Wh[(size_t)(4 * kq + 2) * 4 * H + c], Wh[(size_t)(4 * kq + 3) * 4 * H + c]};
+    }
   } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int c = 0; c < 16; ++c) Wr[j][c] = 0.f;
+    for (int c = 0; c < 16; ++c) Wr[c][0] = Wr[c][1] = (f32x2){0.f, 0.f};
   }
   float dc_state = 0.f;
-  if (tid == 0) *flag = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (*flag) return;
+  if (!unit_handshake(p, unit, NU, P, flag)) return;
+  const bool coloc = flag[1] != 0;
 
   // ring slot = [dest P][src P][16 u][8 b] floats
   const size_t piece_bytes = (size_t)UC * BS * 4;          // 512
@@ -372,25 +435,34 @@ __global__ __launch_bounds__(PT) void lstm_persist_bwd_kernel(PersistArgs p) {
   const size_t slot_bytes = (size_t)P * block_bytes;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       p.xbuf + (size_t)unit * RING * slot_bytes, 0, (int)(RING * slot_bytes), 0x00020000);
+  const u32x4 sent4 = {SENT, SENT, SENT, SENT};
+
+  // saved forward values of step s (coalesced), fetched one step ahead
+  auto fetch = [&](int s, float &av, float &xv) {
+    av = 0.f; xv = 0.f;
+    if (s >= 0 && s < n_i) {
+      const int t = dir ? n_i - 1 - s : s;
+      av = p.gates[dir][((size_t)ibg * T + t) * 4 * H + ig * H + U0 + iu];
+      if (ig == 0) xv = p.cs[dir][((size_t)ibg * T + t) * H + U0 + iu];
+      else if (ig == 1) xv = s > 0 ? p.cs[dir][((size_t)ibg * T + (dir ? t + 1 : t - 1)) * H + U0 + iu] : 0.f;
+      else if (ig == 2) xv = p.dout[((size_t)ibg * T + t) * 2 * H + (size_t)dir * H + U0 + iu];
+    }
+  };
+  float av, xv;
+  fetch(p.max_len - 1, av, xv);
 
   for (int s = p.max_len - 1; s >= 0; --s) {
-    // (a) saved forward values of this step, coalesced
+    NABU_STAMP(1, 0);
     const bool act_i = s < n_i;
     const int t_i = dir ? n_i - 1 - s : s;
-    float av = 0.f, xv = 0.f;
-    if (act_i) {
-      av = p.gates[dir][((size_t)ibg * T + t_i) * 4 * H + ig * H + U0 + iu];
-      if (ig == 0) xv = p.cs[dir][((size_t)ibg * T + t_i) * H + U0 + iu];
-      else if (ig == 1) xv = s > 0 ? p.cs[dir][((size_t)ibg * T + (dir ? t_i + 1 : t_i - 1)) * H + U0 + iu] : 0.f;
-      else if (ig == 2) xv = p.dout[((size_t)ibg * T + t_i) * 2 * H + (size_t)dir * H + U0 + iu];
-    }
 
     // (b) reduce-scatter input: the P partial products addressed to me (step s+1)
     float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (s + 1 < p.max_len) {
-      const unsigned base = (unsigned)(((s + 1) % RING) * slot_bytes + (size_t)slot * block_bytes);
-      constexpr int NQ = (P * 32 + PT - 1) / PT;
-      u32x4 v[NQ] = {};
+    constexpr int NQ = (P * 32 + PT - 1) / PT;
+    u32x4 v[NQ] = {};
+    const unsigned base = (unsigned)(((s + 1) % RING) * slot_bytes + (size_t)slot * block_bytes);
+    const bool have_in = s + 1 < p.max_len && !(p.dbg & 1);
+    if (have_in) {
       SpinGuard guard;
       guard.start();
       for (;;) {
@@ -405,13 +477,20 @@ __global__ __launch_bounds__(PT) void lstm_persist_bwd_kernel(PersistArgs p) {
         if (__all(ok)) break;
         if (guard.expired(p)) {
           if ((tid & 63) == 0) {
-            *flag = 1;
-            __hip_atomic_store(p.status, 2 + 2 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flag[0] = 1;
+            __hip_atomic_store(p.status, 2 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           break;
         }
       }
-      const u32x4 sent = {SENT, SENT, SENT, SENT};
+    }
+    NABU_STAMP(1, 1);
+    // stage this step's saved values (fetched during the previous iteration) ...
+    xs[(ib * 4 + ig) * 17 + iu] = av;
+    if (ig < 3) xc[(ig * 8 + ib) * 17 + iu] = xv;
+    // ... and start fetching the next step's while this one computes
+    fetch(s - 1, av, xv);
+    if (have_in) {
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
         const int q = tid + i * PT;
@@ -422,16 +501,15 @@ __global__ __launch_bounds__(PT) void lstm_persist_bwd_kernel(PersistArgs p) {
           psum.z += fv.z;
           psum.w += fv.w;
           // I am the only reader of this block: hand the slot back
-          __builtin_amdgcn_raw_buffer_store_b128(sent, rs, base + (unsigned)q * 16u, 0, 16);
+          xstore(sent4, rs, base + (unsigned)q * 16u, coloc);
         }
       }
     }
     // group tid/32 holds the sum over sources {tid/32 + 16m}; element (tid%32) = (u = ./2, 4 rows)
     *reinterpret_cast<float4 *>(red + (tid >> 5) * 128 + (tid & 31) * 4) = psum;
-    xs[(ib * 4 + ig) * 17 + iu] = av;
-    if (ig < 3) xc[(ig * 8 + ib) * 17 + iu] = xv;
     __syncthreads();                                            // B1
-    if (*flag) return;
+    if (flag[0]) return;
+    NABU_STAMP(1, 2);
 
     // (c) gate gradients: thread = (gate gg, row gb, unit gu)
     float dh = 0.f;
@@ -444,7 +522,7 @@ __global__ __launch_bounds__(PT) void lstm_persist_bwd_kernel(PersistArgs p) {
     const float c = xc[(0 * 8 + gb) * 17 + gu], cprev = xc[(1 * 8 + gb) * 17 + gu];
     const float dout = xc[(2 * 8 + gb) * 17 + gu];
     const bool act_g = s < n_g;
-    const float tc = tanhf_(c);
+    const float tc = fast_tanh(c);
     const float dht = dout + dh;
     const float dct = dc_state + dht * go * (1.f - tc * tc);
     float dz = 0.f;
@@ -457,40 +535,47 @@ __global__ __launch_bounds__(PT) void lstm_persist_bwd_kernel(PersistArgs p) {
     }
     dzs[gg * L::QS + gu * BS + gb] = dz;
     sg[(gb * 4 + gg) * 17 + gu] = dz;
+    NABU_STAMP(1, 3);
     __syncthreads();                                            // B2
+    NABU_STAMP(1, 4);
 
     // (d) partial product for step s-1: acc[b][j] = sum_c dz[b][cq,c] * W[4kq+j][cq,c]
     if (s > 0) {
-      float acc[BS][4];
+      f32x2 acc[BS][2];
 #pragma unroll
-      for (int b = 0; b < BS; ++b)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[b][j] = 0.f;
+      for (int b = 0; b < BS; ++b) acc[b][0] = acc[b][1] = (f32x2){0.f, 0.f};
       const float *dq = dzs + cq * L::QS;
+      if (!(p.dbg & 2)) {
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const float4 d0 = *reinterpret_cast<const float4 *>(dq + c * BS);
-        const float4 d1 = *reinterpret_cast<const float4 *>(dq + c * BS + 4);
-        const float db[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        for (int c = 0; c < 16; ++c) {
+          const float4 d0 = *reinterpret_cast<const float4 *>(dq + c * BS);
+          const float4 d1 = *reinterpret_cast<const float4 *>(dq + c * BS + 4);
+          const float db[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
-        for (int b = 0; b < BS; ++b)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[b][j] = fmaf(db[b], Wr[j][c], acc[b][j]);
+          for (int b = 0; b < BS; ++b) {
+            const f32x2 dd = {db[b], db[b]};
+            acc[b][0] = __builtin_elementwise_fma(dd, Wr[c][0], acc[b][0]);
+            acc[b][1] = __builtin_elementwise_fma(dd, Wr[c][1], acc[b][1]);
+          }
+        }
       }
-      // quad reduce-scatter over the 4 gate quarters: lane cq keeps k = 4kq + cq, all 8 rows
+      // quad all-reduce over the 4 gate quarters; lane cq then keeps k = 4kq + cq, all 8 rows
       float r[BS];
 #pragma unroll
       for (int b = 0; b < BS; ++b) {
-        // step 1: pairs (cq ^ 1): keep j in {cq&2, (cq&2)+1} halves
-        const float s0 = acc[b][0] + QUAD_XOR1(acc[b][0]);   // valid where needed after selection below
-        const float s1 = acc[b][1] + QUAD_XOR1(acc[b][1]);
-        const float s2 = acc[b][2] + QUAD_XOR1(acc[b][2]);
-        const float s3 = acc[b][3] + QUAD_XOR1(acc[b][3]);
-        const float t0 = s0 + QUAD_XOR2(s0), t1 = s1 + QUAD_XOR2(s1);
-        const float t2 = s2 + QUAD_XOR2(s2), t3 = s3 + QUAD_XOR2(s3);
-        r[b] = cq == 0 ? t0 : cq == 1 ? t1 : cq == 2 ? t2 : t3;
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float x = acc[b][j >> 1][j & 1];
+          x += QUAD_XOR1(x);
+          x += QUAD_XOR2(x);
+          t[j] = x;
+        }
+        r[b] = cq == 0 ? t[0] : cq == 1 ? t[1] : cq == 2 ? t[2] : t[3];
       }
+      NABU_STAMP(1, 5);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my slot resets are performed before I publish
+      NABU_STAMP(1, 6);
       if (mat_lane) {
         const int k = 4 * kq + cq;
         const int dest = k / UC, ul = k % UC;
@@ -501,14 +586,16 @@ __global__ __launch_bounds__(PT) void lstm_persist_bwd_kernel(PersistArgs p) {
         p0.z = __builtin_bit_cast(unsigned, r[2]); p0.w = __builtin_bit_cast(unsigned, r[3]);
         p1.x = __builtin_bit_cast(unsigned, r[4]); p1.y = __builtin_bit_cast(unsigned, r[5]);
         p1.z = __builtin_bit_cast(unsigned, r[6]); p1.w = __builtin_bit_cast(unsigned, r[7]);
-        __builtin_amdgcn_raw_buffer_store_b128(p0, rs, off, 0, 16);
-        __builtin_amdgcn_raw_buffer_store_b128(p1, rs, off + 16, 0, 16);
+        xstore(p0, rs, off, coloc);
+        xstore(p1, rs, off + 16, coloc);
       }
     }
 
+    NABU_STAMP(1, 7);
     // (e) dz to HBM (in place over the activations) in 64-byte segments; padded frames get 0
     if (ibg < p.B)
       p.gates[dir][((size_t)ibg * T + (act_i ? t_i : s)) * 4 * H + ig * H + U0 + iu] = sg[(ib * 4 + ig) * 17 + iu];
+    NABU_STAMP(1, 8);
   }
 }
 
@@ -540,7 +627,7 @@ size_t lstm_persist_ws_bytes(int B, int T, int H) {
   const size_t NU = 2 * (size_t)nshard_of(B), P = H / UC;
   const size_t fwd = NU * RING * (size_t)H * BS * 4;
   const size_t bwd = NU * RING * P * P * UC * BS * 4;
-  return fwd > bwd ? fwd : bwd;
+  return TABLE_BYTES + (fwd > bwd ? fwd : bwd);
 }
 
 static constexpr size_t PERSIST_LDS = 96 * 1024;   // > half of 160 KiB: exactly one workgroup per CU
@@ -573,13 +660,15 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
   for (int i = 0; i < 2; ++i) { a.kernel[i] = kernel[i]; a.gates[i] = gates[i]; a.cs[i] = cs[i]; }
   a.out = out; a.dout = dout;
   a.status = status;
-  a.xbuf = static_cast<char *>(ws);
+  a.table = static_cast<unsigned *>(ws);
+  a.xbuf = static_cast<char *>(ws) + TABLE_BYTES;
   a.timeout_ticks = 20000000ull;   // 0.2 s at 100 MHz: a step takes microseconds
+  { const char *e = getenv("NABU_PERSIST_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   const int NU = 2 * a.nshard, P = H / UC;
   const int grid = NU * P;
   if (grid > cu_count()) return fail(NABU_EUNSUP, "persistent LSTM: %d workgroups > %d CUs", grid, cu_count());
   const size_t ring = fwd ? (size_t)NU * RING * H * BS * 4 : (size_t)NU * RING * P * P * UC * BS * 4;
-  NABU_HIP(hipMemsetAsync(a.xbuf, 0xFF, ring, stream));
+  NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + ring, stream));
 #define NABU_PERSIST_CASE(kpl)                                                              \
   case 32 * kpl:                                                                            \
     return fwd ? launch(lstm_persist_fwd_kernel<kpl>, a, grid, stream)                       \

@@ -228,6 +228,7 @@ def check_persist_status(device=None):
         if code:
             buf[:4].zero_()
             raise _hip.NabuHipError(
-                'persistent LSTM kernel timed out waiting for a peer workgroup (code %d: block %d, %s '
-                'pass); results of this step are invalid' % (code, (code - 1) // 2,
-                                                             'forward' if code % 2 else 'backward'))
+                'persistent LSTM kernel timed out waiting for a peer workgroup (code %d: block %d, %s); '
+                'results of this step are invalid' % (code, code // 4,
+                                                      {1: 'forward pass', 2: 'backward pass',
+                                                       3: 'start-up handshake'}.get(code % 4, '?')))

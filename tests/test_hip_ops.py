@@ -242,7 +242,7 @@ def test_blstm_persistent_matches_oracle(B, T, D, H, lens):
     ops.check_persist_status()
     assert np.isfinite(out).all()
     # fp32 dot products of length H with |z| up to ~5 (weights N(0, 0.2)): rounding grows with H
-    assert np.abs(out - rout).max() < (2e-5 if H <= 128 else 6e-5)
+    assert np.abs(out - rout).max() < (2e-5 if H <= 128 else 2e-4)
     for b, n in enumerate(lens):
         assert np.all(out[b, n:] == 0)
     assert rel_err(dx, rdx) < 3e-4
