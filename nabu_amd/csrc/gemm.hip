@@ -183,6 +183,133 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Fast path: K-range % 32 == 0, M % 4 == N % 4 == 0 and 16-byte aligned operands ->
+// no guards and no divergence in the loads (edge tiles clamp their addresses and drop
+// the surplus rows/columns at the store), so the next k-tile's global loads really
+// stay in flight under the current tile's 64 MFMAs per wave.
+constexpr int FBK = 32;
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[FBK][LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[FBK][LDT];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * a.ksplit;
+  const int kend = min(a.K, kbeg + a.ksplit);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // Per-thread pieces of the two operand tiles (4 x 16 bytes each), addressed with
+  // compile-time indices only (anything fancier made hipcc put them in scratch).
+  //   k-contiguous operand (A with !TA, B with TB): element (r,k) at base[r*ld + k]
+  //   r-contiguous operand (A with TA, B with !TB): element (r,k) at base[row(k) + r]
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;   // named scalars: arrays ended up in scratch
+#define NABU_GLOAD1(j, k0_)                                                                      \
+  {                                                                                              \
+    const int idx = tid + 256 * j;                                                               \
+    if (TA) {                                                                                    \
+      const int k = (k0_) + (idx >> 5);                                                          \
+      const size_t off = a.kseg > 0 ? (size_t)(k / a.kseg) * (size_t)a.a_seg +                   \
+                                          (size_t)(k % a.kseg) * a.lda                           \
+                                    : (size_t)k * a.lda;                                         \
+      ra##j = *reinterpret_cast<const float4 *>(a.A + off + min(m0 + 4 * (idx & 31), a.M - 4));  \
+    } else {                                                                                     \
+      ra##j = *reinterpret_cast<const float4 *>(a.A + (size_t)min(m0 + (idx >> 3), a.M - 1) * a.lda + \
+                                                (k0_) + 4 * (idx & 7));                          \
+    }                                                                                            \
+    if (TB) {                                                                                    \
+      rb##j = *reinterpret_cast<const float4 *>(a.B + (size_t)min(n0 + (idx >> 3), a.N - 1) * a.ldb + \
+                                                (k0_) + 4 * (idx & 7));                          \
+    } else {                                                                                     \
+      const int k = (k0_) + (idx >> 5);                                                          \
+      const size_t off = a.kseg > 0 ? (size_t)(k / a.kseg) * (size_t)a.b_seg +                   \
+                                          (size_t)(k % a.kseg) * a.ldb                           \
+                                    : (size_t)k * a.ldb;                                         \
+      rb##j = *reinterpret_cast<const float4 *>(a.B + off + min(n0 + 4 * (idx & 31), a.N - 4));  \
+    }                                                                                            \
+  }
+#define NABU_GLOAD(k0_) { NABU_GLOAD1(0, k0_) NABU_GLOAD1(1, k0_) NABU_GLOAD1(2, k0_) NABU_GLOAD1(3, k0_) }
+#define NABU_SSTORE1(j)                                                                          \
+  {                                                                                              \
+    const int idx = tid + 256 * j;                                                               \
+    if (TA) {                                                                                    \
+      *reinterpret_cast<float4 *>(&As[idx >> 5][4 * (idx & 31)]) = ra##j;                        \
+    } else {                                                                                     \
+      const int r = idx >> 3, k = 4 * (idx & 7);                                                 \
+      As[k + 0][r] = ra##j.x; As[k + 1][r] = ra##j.y; As[k + 2][r] = ra##j.z; As[k + 3][r] = ra##j.w; \
+    }                                                                                            \
+    if (TB) {                                                                                    \
+      const int r = idx >> 3, k = 4 * (idx & 7);                                                 \
+      Bs[k + 0][r] = rb##j.x; Bs[k + 1][r] = rb##j.y; Bs[k + 2][r] = rb##j.z; Bs[k + 3][r] = rb##j.w; \
+    } else {                                                                                     \
+      *reinterpret_cast<float4 *>(&Bs[idx >> 5][4 * (idx & 31)]) = rb##j;                        \
+    }                                                                                            \
+  }
+#define NABU_SSTORE() { NABU_SSTORE1(0) NABU_SSTORE1(1) NABU_SSTORE1(2) NABU_SSTORE1(3) }
+
+  NABU_GLOAD(kbeg);
+  NABU_SSTORE();
+  __syncthreads();
+  const int li = lane & 31, lk = lane >> 5;
+  for (int k0 = kbeg; k0 < kend; k0 += FBK) {
+    const bool more = k0 + FBK < kend;
+    if (more) NABU_GLOAD(k0 + FBK);
+#pragma unroll
+    for (int kk = 0; kk < FBK; kk += 2) {
+      const float a0 = As[kk + lk][wm * 64 + li];
+      const float a1 = As[kk + lk][wm * 64 + 32 + li];
+      const float b0 = Bs[kk + lk][wn * 64 + li];
+      const float b1 = Bs[kk + lk][wn * 64 + 32 + li];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) {
+      NABU_SSTORE();
+      __syncthreads();
+    }
+  }
+#undef NABU_GLOAD
+#undef NABU_SSTORE
+#undef NABU_GLOAD1
+#undef NABU_SSTORE1
+
+  const int col = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = n0 + wn * 64 + ni * 32 + col;
+      if (n >= a.N) continue;    // edge tiles: clamped (duplicate) loads, results dropped here
+      const float bv = (a.nsplit == 1 && a.bias) ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+        if (m >= a.M) continue;
+        if (a.nsplit == 1) {
+          float *c = a.C + (size_t)m * a.ldc + n;
+          float v = a.alpha * acc[mi][ni][r] + bv;
+          if (a.beta != 0.f) v += a.beta * *c;
+          *c = v;
+        } else {
+          a.partial[((size_t)blockIdx.z * a.M + m) * a.N + n] = acc[mi][ni][r];
+        }
+      }
+    }
+}
+
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs a) {
   const size_t total = (size_t)a.M * a.N;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -200,14 +327,14 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs a) {
 static int choose_split(int M, int N, int K, int *ksplit) {
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   int ns = 1;
-  if (tiles < 192 && K >= 2048) {
+  if (tiles < 512 && K >= 2048) {   // aim at >= 2 workgroups per CU (256 CUs)
     ns = (512 + tiles - 1) / tiles;
     const int maxs = K / 512;
     if (ns > maxs) ns = maxs;
     if (ns < 1) ns = 1;
   }
   int ks = (K + ns - 1) / ns;
-  ks = (ks + BK - 1) / BK * BK;
+  ks = (ks + FBK - 1) / FBK * FBK;
   ns = (K + ks - 1) / ks;
   *ksplit = ks;
   return ns;
@@ -252,6 +379,13 @@ extern "C" int nabu_gemm_f32(int transA, int transB, int M, int N, int K, float 
   a.vecB = al16(B) && ldb % 4 == 0 && (b_seg_stride % 4 == 0);
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, a.nsplit), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool fast = M % 4 == 0 && N % 4 == 0 && K > 0 && K % FBK == 0 && a.vecA && a.vecB;
+  if (fast) {
+    if (transA && transB) hipLaunchKernelGGL((gemm_f32_fast_kernel<true, true>), grid, block, 0, s, a);
+    else if (transA) hipLaunchKernelGGL((gemm_f32_fast_kernel<true, false>), grid, block, 0, s, a);
+    else if (transB) hipLaunchKernelGGL((gemm_f32_fast_kernel<false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_f32_fast_kernel<false, false>), grid, block, 0, s, a);
+  } else
   if (transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, a);
   else if (transA) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, a);
   else if (transB) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, a);
