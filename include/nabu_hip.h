@@ -150,6 +150,71 @@ int nabu_xent_loss_grad(int B, int L, int C, int ldt, const float *logits,
                         float *dlogits, nabu_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Speller decoder step kernels — RNNDecoder._decode / Speller.create_cell
+ * (nabu/neuralnetworks/models/ed_decoders/rnn_decoder.py:13-82, speller.py:13-69):
+ * tf.contrib.rnn.LSTMCell inside tf.contrib.seq2seq.AttentionWrapper driven by
+ * dynamic_decode(impute_finished=True).  The dense products of a step run on
+ * nabu_gemm_f32; these are the fused non-GEMM parts.
+ *
+ * nabu_lstm_cell_fwd: z [B,4U] = (dense part of) [inputs, h]·kernel; adds bias [4U]
+ *   and, when emb_rows != NULL, row ids[b] of emb_rows [C,4U] (the one-hot input
+ *   times the kernel is a row gather); gate order i,j,f,o, forget bias +1;
+ *   acts [B,4U] keeps (i,g,f,o) for the gradient; rows with step >= seq_len[b] are
+ *   finished: state copied through, acts = 0.
+ * nabu_lstm_cell_bwd: dz [B,4U] from dh (+ dh2 if not NULL), dc_in and the saved
+ *   acts / cell states; dc_out is the cell gradient handed to step-1. */
+int nabu_lstm_cell_fwd(int B, int U, int step, const int32_t *seq_len, const float *z,
+                       const float *bias, const float *emb_rows, const int32_t *ids,
+                       const float *c_prev, const float *h_prev, float *acts,
+                       float *c_new, float *h_new, nabu_stream_t stream);
+int nabu_lstm_cell_bwd(int B, int U, int step, const int32_t *seq_len, const float *acts,
+                       const float *c_new, const float *c_prev, const float *dh,
+                       const float *dh2, const float *dc_in, float *dz, float *dc_out,
+                       nabu_stream_t stream);
+
+/* Fused attention step — attention.factory 'vanilla' (tf BahdanauAttention) and
+ * 'location_aware' (nabu/neuralnetworks/components/attention.py:6-39,90-240):
+ *   score[b,t] = sum_u v[u] * tanh(keys[b,t,u] + q[b,u] (+ f[b,t,u]))
+ *   f = conv1d(align_prev, conv_kernel [K,F], 'same') · conv_proj [F,U]   (location)
+ *   align = softmax over t < enc_len[b] (score mask -inf), ctx = align^T · values
+ * keys [B,Te,U] (= values·memory_kernel, one GEMM per batch), values [B,Te,E]
+ * (rows >= enc_len are zero), q [B,U] (= h·query_kernel).  Rows with
+ * step >= dec_len[b] are finished: align/ctx copy align_prev/ctx_prev.
+ * The backward kernel recomputes tanh, ACCUMULATES into dkeys [B,Te,U] and into the
+ * per-utterance partials dv_part [B,U], dconv_proj_part [B,F,U], dconv_kernel_part
+ * [B,K,F] (the caller zeroes them before the first step and column-sums them
+ * afterwards), writes dq [B,U] and dalign_out [B,Te] (gradient w.r.t. align_prev;
+ * location only).  dalign_in (may be NULL) is the gradient that reaches this
+ * step's alignments through the next step's location features. */
+typedef struct {
+  uint32_t size;       /* sizeof(nabu_attn_desc) */
+  int32_t B, Te, E, U;
+  int32_t kind;        /* 0 = vanilla (Bahdanau), 1 = location_aware */
+  int32_t K, F;        /* filtersize, numfilt (location_aware) */
+} nabu_attn_desc;
+int nabu_attn_fwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
+                  const int32_t *enc_len, const float *keys, const float *values,
+                  const float *q, const float *v, const float *conv_kernel,
+                  const float *conv_proj, const float *align_prev, const float *ctx_prev,
+                  float *align, float *ctx, nabu_stream_t stream);
+int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
+                  const int32_t *enc_len, const float *keys, const float *values,
+                  const float *q, const float *v, const float *conv_kernel,
+                  const float *conv_proj, const float *align_prev, const float *align,
+                  const float *dctx, const float *dalign_in, float *dq, float *dkeys,
+                  float *dv_part, float *dconv_proj_part, float *dconv_kernel_part,
+                  float *dalign_out, nabu_stream_t stream);
+
+/* x[b,t,:] = 0 for t >= len[b] (dynamic_decode zeroes the outputs of finished rows). */
+int nabu_mask_time_f32(int B, int L, int F, float *x, const int32_t *len, nabu_stream_t stream);
+/* y[b,l,:] = x[l,b,:] (time-major per-step buffers <-> the batch-major API). */
+int nabu_swap01_f32(int L, int B, int F, const float *x, float *y, nabu_stream_t stream);
+/* dK[c,:] = sum_{i: ids[i]==c} dz[i,:]  (gradient of the kernel rows gathered by the
+ * one-hot decoder inputs), ids [N], dz [N,W], dK [C,W]; deterministic. */
+int nabu_scatter_rows_f32(int C, int N, int W, const int32_t *ids, const float *dz, float *dK,
+                          nabu_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Fused per-element gradient clip + TF-style Adam on flat buffers —
  * Trainer._update (nabu/neuralnetworks/trainers/trainer.py:525,560-569):
  *   g = clamp(grad_scale*grad, -clip, clip); m = b1 m + (1-b1) g;

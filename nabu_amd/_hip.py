@@ -41,6 +41,13 @@ SIGNATURES = {
     'nabu_ctc_ws_bytes': (_sz, [_i, _i, _i]),
     'nabu_ctc_loss_grad': (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nabu_xent_loss_grad': (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    'nabu_lstm_cell_fwd': (_i, [_i, _i, _i] + [_vp] * 10 + [_vp]),
+    'nabu_lstm_cell_bwd': (_i, [_i, _i, _i] + [_vp] * 9 + [_vp]),
+    'nabu_attn_fwd': (_i, [_vp, _i] + [_vp] * 12 + [_vp]),
+    'nabu_attn_bwd': (_i, [_vp, _i] + [_vp] * 18 + [_vp]),
+    'nabu_mask_time_f32': (_i, [_i, _i, _i, _vp, _vp, _vp]),
+    'nabu_swap01_f32': (_i, [_i, _i, _i, _vp, _vp, _vp]),
+    'nabu_scatter_rows_f32': (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     'nabu_adam_clip_step': (_i, [_sz, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _vp]),
     'nabu_clip_f32': (_i, [_sz, _vp, _f, _vp]),
     'nabu_dropout_f32': (_i, [_sz, _vp, _vp, _f, _c.c_ulonglong, _c.c_ulonglong, _vp]),
@@ -109,3 +116,8 @@ class Workspace(object):
             buf = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=device)
             cls._bufs[key] = buf
         return buf
+
+
+class AttnDesc(_c.Structure):
+    _fields_ = [('size', _c.c_uint32), ('B', _c.c_int32), ('Te', _c.c_int32), ('E', _c.c_int32),
+                ('U', _c.c_int32), ('kind', _c.c_int32), ('K', _c.c_int32), ('F', _c.c_int32)]

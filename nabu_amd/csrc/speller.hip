@@ -1,0 +1,505 @@
+// speller.hip — per-step kernels of the Speller decoder (RNNDecoder + tf LSTMCell +
+// AttentionWrapper with Bahdanau / location-aware attention + projection wrapper).
+//
+// The dense products of a step ([ctx,h]·K, h·Wq, [h,ctx]·Wout and their gradients)
+// run on nabu_gemm_f32; this file holds what is not a GEMM:
+//   lstm_cell_fwd/bwd : gate nonlinearities, state update, one-hot input as a row
+//                       gather of the kernel, finished-row freezing;
+//   attn_fwd          : score + mask + softmax + context fused over the encoder
+//                       length, one workgroup per utterance: keys/values rows are
+//                       read once per step in 2-4 KiB coalesced rows, the location
+//                       features are computed from the previous alignment in LDS;
+//   attn_bwd          : the matching gradient (tanh recomputed, not stored).
+// Layouts: keys [B,Te,U], values [B,Te,E] batch-major; per-step state time-major.
+#include "common.h"
+
+namespace nabu {
+
+constexpr int AT = 512;   // threads per attention workgroup (8 wave64)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// LSTM cell (tf.contrib.rnn.LSTMCell: gate order i,j,f,o, forget_bias 1)
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(
+    int B, int U, int step, const int32_t *__restrict__ seq_len, const float *__restrict__ z,
+    const float *__restrict__ bias, const float *__restrict__ emb, const int32_t *__restrict__ ids,
+    const float *__restrict__ c_prev, const float *__restrict__ h_prev, float *__restrict__ acts,
+    float *__restrict__ c_new, float *__restrict__ h_new) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * U) return;
+  const int b = idx / U, u = idx % U;
+  const size_t zo = (size_t)b * 4 * U + u;
+  if (step >= seq_len[b]) {   // finished row: dynamic_decode(impute_finished) freezes the state
+    c_new[idx] = c_prev[idx];
+    h_new[idx] = h_prev[idx];
+    acts[zo] = acts[zo + U] = acts[zo + 2 * U] = acts[zo + 3 * U] = 0.f;
+    return;
+  }
+  float zi = z[zo] + bias[u], zj = z[zo + U] + bias[U + u];
+  float zf = z[zo + 2 * U] + bias[2 * U + u], zq = z[zo + 3 * U] + bias[3 * U + u];
+  if (emb) {   // one-hot input times kernel == one row of the kernel
+    const float *e = emb + (size_t)ids[b] * 4 * U + u;
+    zi += e[0]; zj += e[U]; zf += e[2 * U]; zq += e[3 * U];
+  }
+  const float i = sigmoidf_(zi), g = tanhf_(zj), f = sigmoidf_(zf + 1.0f), o = sigmoidf_(zq);
+  const float c = c_prev[idx] * f + i * g;
+  acts[zo] = i; acts[zo + U] = g; acts[zo + 2 * U] = f; acts[zo + 3 * U] = o;
+  c_new[idx] = c;
+  h_new[idx] = tanhf_(c) * o;
+}
+
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
+    int B, int U, int step, const int32_t *__restrict__ seq_len, const float *__restrict__ acts,
+    const float *__restrict__ c_new, const float *__restrict__ c_prev, const float *__restrict__ dh,
+    const float *__restrict__ dh2, const float *__restrict__ dc_in, float *__restrict__ dz,
+    float *__restrict__ dc_out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * U) return;
+  const int b = idx / U, u = idx % U;
+  const size_t zo = (size_t)b * 4 * U + u;
+  if (step >= seq_len[b]) {
+    dz[zo] = dz[zo + U] = dz[zo + 2 * U] = dz[zo + 3 * U] = 0.f;
+    dc_out[idx] = dc_in[idx];
+    return;
+  }
+  const float i = acts[zo], g = acts[zo + U], f = acts[zo + 2 * U], o = acts[zo + 3 * U];
+  const float tc = tanhf_(c_new[idx]);
+  const float dht = dh[idx] + (dh2 ? dh2[idx] : 0.f);
+  const float dct = dc_in[idx] + dht * o * (1.f - tc * tc);
+  dz[zo] = dct * g * i * (1.f - i);
+  dz[zo + U] = dct * i * (1.f - g * g);
+  dz[zo + 2 * U] = dct * c_prev[idx] * f * (1.f - f);
+  dz[zo + 3 * U] = dht * tc * o * (1.f - o);
+  dc_out[idx] = dct * f;
+}
+
+// ---------------------------------------------------------------------------
+struct AttnArgs {
+  int B, Te, E, U, kind, K, F, step;
+  const int32_t *dec_len, *enc_len;
+  const float *keys, *values, *q, *v, *ck, *wf, *align_prev;
+  // forward
+  const float *ctx_prev;
+  float *align, *ctx;
+  // backward
+  const float *dctx, *dalign_in;
+  float *dq, *dkeys, *dv_part, *dwf_part, *dck_part, *dalign_out;
+};
+
+// LDS carve for the attention kernels (floats): al[Te] prev alignment (padded conv input),
+// sc[Te] scores / alignments, cf[Te*F] location features, red[...] reductions
+__device__ __forceinline__ void conv_features(const AttnArgs &p, const float *al_prev, float *cf, int n) {
+  // cf[t,f] = sum_d a[t + d - pb] ck[d,f], 'same' padding, pb = (K-1)/2 (tf.layers.conv1d)
+  const int pb = (p.K - 1) / 2;
+  for (int i = threadIdx.x; i < p.Te * p.F; i += AT) {
+    const int t = i / p.F, f = i % p.F;
+    float s = 0.f;
+    const int d0 = max(0, pb - t), d1 = min(p.K, p.Te + pb - t);
+    for (int d = d0; d < d1; ++d) s = fmaf(al_prev[t + d - pb], p.ck[d * p.F + f], s);
+    cf[i] = s;
+  }
+}
+
+__global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int Te = p.Te, U = p.U, E = p.E;
+  float *alp = smem, *sc = alp + Te, *cf = sc + Te, *red = cf + (p.kind ? Te * p.F : 0);
+  float *align = p.align + (size_t)b * Te;
+  float *ctx = p.ctx + (size_t)b * E;
+  if (p.step >= p.dec_len[b]) {   // finished row: state frozen
+    for (int t = tid; t < Te; t += AT) align[t] = p.align_prev[(size_t)b * Te + t];
+    for (int e = tid; e < E; e += AT) ctx[e] = p.ctx_prev[(size_t)b * E + e];
+    return;
+  }
+  const int n = min(max(p.enc_len[b], 0), Te);
+  const float *keys = p.keys + (size_t)b * Te * U;
+  const float *vals = p.values + (size_t)b * Te * E;
+  const float *q = p.q + (size_t)b * U;
+  if (p.kind) {
+    for (int t = tid; t < Te; t += AT) alp[t] = p.align_prev[(size_t)b * Te + t];
+    __syncthreads();
+    conv_features(p, alp, cf, n);
+    __syncthreads();
+  }
+  // scores: one wave per encoder frame, lanes over units
+  for (int t = w; t < n; t += AT / 64) {
+    float s = 0.f;
+    for (int u = lane; u < U; u += 64) {
+      float x = keys[(size_t)t * U + u] + q[u];
+      if (p.kind)
+        for (int f = 0; f < p.F; ++f) x = fmaf(cf[t * p.F + f], p.wf[f * U + u], x);
+      s = fmaf(p.v[u], tanhf_(x), s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) sc[t] = s;
+  }
+  __syncthreads();
+  // softmax over the valid frames (score_mask_value = -inf past the length)
+  float m = -3.0e38f;
+  for (int t = tid; t < n; t += AT) m = fmaxf(m, sc[t]);
+  m = fmaxf(m, __shfl_xor(m, 32)); m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 8));
+  m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 1));
+  if (lane == 0) red[w] = m;
+  __syncthreads();
+  m = red[0];
+  for (int i = 1; i < AT / 64; ++i) m = fmaxf(m, red[i]);
+  __syncthreads();
+  float z = 0.f;
+  for (int t = tid; t < n; t += AT) {
+    const float e = expf(sc[t] - m);
+    sc[t] = e;
+    z += e;
+  }
+  z = wave_sum(z);
+  if (lane == 0) red[w] = z;
+  __syncthreads();
+  z = 0.f;
+  for (int i = 0; i < AT / 64; ++i) z += red[i];
+  const float inv = 1.0f / z;
+  for (int t = tid; t < Te; t += AT) {
+    const float a = t < n ? sc[t] * inv : 0.f;
+    sc[t] = a;
+    align[t] = a;
+  }
+  __syncthreads();
+  // context = alignments^T · values : threads over the encoder dimension, coalesced rows
+  for (int e = tid; e < E; e += AT) {
+    float c = 0.f;
+    for (int t = 0; t < n; ++t) c = fmaf(sc[t], vals[(size_t)t * E + e], c);
+    ctx[e] = c;
+  }
+}
+
+__global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int Te = p.Te, U = p.U, E = p.E, F = p.F;
+  constexpr int NW = AT / 64;
+  float *alp = smem;                       // [Te] previous alignment
+  float *ds = alp + Te;                    // [Te] d score
+  float *cf = ds + Te;                     // [Te*F]
+  float *dcf = cf + (p.kind ? Te * F : 0); // [Te*F]
+  float *red = dcf + (p.kind ? Te * F : 0);  // [NW * U] cross-wave partials (dq / dv), also scalars
+  float *dq = p.dq + (size_t)b * U;
+  float *dal_out = p.dalign_out ? p.dalign_out + (size_t)b * Te : nullptr;
+  if (p.step >= p.dec_len[b]) {
+    for (int u = tid; u < U; u += AT) dq[u] = 0.f;
+    if (dal_out)
+      for (int t = tid; t < Te; t += AT) dal_out[t] = p.dalign_in ? p.dalign_in[(size_t)b * Te + t] : 0.f;
+    return;
+  }
+  const int n = min(max(p.enc_len[b], 0), Te);
+  const float *keys = p.keys + (size_t)b * Te * U;
+  const float *vals = p.values + (size_t)b * Te * E;
+  const float *q = p.q + (size_t)b * U;
+  const float *al = p.align + (size_t)b * Te;       // this step's alignments
+  const float *dctx = p.dctx + (size_t)b * E;
+  float *dkeys = p.dkeys + (size_t)b * Te * U;
+  if (p.kind) {
+    for (int t = tid; t < Te; t += AT) alp[t] = p.align_prev[(size_t)b * Te + t];
+    __syncthreads();
+    conv_features(p, alp, cf, n);
+  }
+  // d alignment[t] = dctx · values[t] (+ the gradient arriving through next step's location features)
+  for (int t = w; t < n; t += NW) {
+    float s = 0.f;
+    for (int e = lane; e < E; e += 64) s = fmaf(dctx[e], vals[(size_t)t * E + e], s);
+    s = wave_sum(s);
+    if (lane == 0) ds[t] = s + (p.dalign_in ? p.dalign_in[(size_t)b * Te + t] : 0.f);
+  }
+  __syncthreads();
+  // softmax backward: dscore = a * (da - sum a*da)
+  float r = 0.f;
+  for (int t = tid; t < n; t += AT) r = fmaf(al[t], ds[t], r);
+  r = wave_sum(r);
+  if (lane == 0) red[w] = r;
+  __syncthreads();
+  r = 0.f;
+  for (int i = 0; i < NW; ++i) r += red[i];
+  __syncthreads();
+  for (int t = tid; t < Te; t += AT) ds[t] = t < n ? al[t] * (ds[t] - r) : 0.f;
+  __syncthreads();
+  // through v·tanh(keys + q + f): lanes own units (u = lane + 64 j), waves split the frames
+  constexpr int MAXJ = 16;                 // U <= 1024
+  float dq_l[MAXJ], dv_l[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) dq_l[j] = dv_l[j] = 0.f;
+  for (int t = w; t < n; t += NW) {
+    const float g = ds[t];
+    float dcf_l[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) dcf_l[f] = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int u = lane + 64 * j;
+      if (u < U) {
+        float x = keys[(size_t)t * U + u] + q[u];
+        if (p.kind)
+          for (int f = 0; f < F; ++f) x = fmaf(cf[t * F + f], p.wf[f * U + u], x);
+        const float th = tanhf_(x);
+        dv_l[j] = fmaf(g, th, dv_l[j]);
+        const float d = g * p.v[u] * (1.f - th * th);
+        dq_l[j] += d;
+        dkeys[(size_t)t * U + u] += d;
+        if (p.kind) {
+#pragma unroll
+          for (int f = 0; f < 16; ++f)
+            if (f < F) dcf_l[f] = fmaf(d, p.wf[f * U + u], dcf_l[f]);
+        }
+      }
+    }
+    if (p.kind) {
+#pragma unroll
+      for (int f = 0; f < 16; ++f)
+        if (f < F) {
+          const float s = wave_sum(dcf_l[f]);
+          if (lane == 0) dcf[t * F + f] = s;
+        }
+    }
+  }
+  // cross-wave sums of dq and dv (fixed order)
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int u = lane + 64 * j;
+    if (u < U) red[w * U + u] = dq_l[j];
+  }
+  __syncthreads();
+  for (int u = tid; u < U; u += AT) {
+    float s = 0.f;
+    for (int i = 0; i < NW; ++i) s += red[i * U + u];
+    dq[u] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int u = lane + 64 * j;
+    if (u < U) red[w * U + u] = dv_l[j];
+  }
+  __syncthreads();
+  for (int u = tid; u < U; u += AT) {
+    float s = 0.f;
+    for (int i = 0; i < NW; ++i) s += red[i * U + u];
+    p.dv_part[(size_t)b * U + u] += s;
+  }
+  if (p.kind) {
+    __syncthreads();
+    // frames past the length (and frames no wave visited) carry no gradient
+    for (int i = tid + n * F; i < Te * F; i += AT) dcf[i] = 0.f;
+    __syncthreads();
+    const int pb = (p.K - 1) / 2;
+    // d conv_proj[f,u] += sum_t cf[t,f] * dsu[t,u]  — recompute dsu per (f,u) would repeat the tanh;
+    // instead accumulate through dkeys' increment d = dscore*v*(1-th^2) is not stored, so this
+    // term is produced from cf and a second pass over the frames:
+    for (int u = tid; u < U; u += AT) {
+      float acc[16];
+#pragma unroll
+      for (int f = 0; f < 16; ++f) acc[f] = 0.f;
+      for (int t = 0; t < n; ++t) {
+        float x = keys[(size_t)t * U + u] + q[u];
+        for (int f = 0; f < F; ++f) x = fmaf(cf[t * F + f], p.wf[f * U + u], x);
+        const float th = tanhf_(x);
+        const float d = ds[t] * p.v[u] * (1.f - th * th);
+#pragma unroll
+        for (int f = 0; f < 16; ++f)
+          if (f < F) acc[f] = fmaf(cf[t * F + f], d, acc[f]);
+      }
+#pragma unroll
+      for (int f = 0; f < 16; ++f)
+        if (f < F) p.dwf_part[((size_t)b * F + f) * U + u] += acc[f];
+    }
+    // d previous alignment and d conv kernel
+    for (int t = tid; t < Te; t += AT) {
+      float s = 0.f;
+      // out frame to = t - d + pb receives a[t] * ck[d,f]
+      for (int d = 0; d < p.K; ++d) {
+        const int to = t - d + pb;
+        if (to >= 0 && to < n)
+          for (int f = 0; f < F; ++f) s = fmaf(dcf[to * F + f], p.ck[d * F + f], s);
+      }
+      dal_out[t] = s;
+    }
+    for (int i = tid; i < p.K * F; i += AT) {
+      const int d = i / F, f = i % F;
+      float s = 0.f;
+      for (int to = 0; to < n; ++to) {
+        const int t = to + d - pb;
+        if (t >= 0 && t < Te) s = fmaf(alp[t], dcf[to * F + f], s);
+      }
+      p.dck_part[(size_t)b * p.K * F + i] += s;
+    }
+  } else if (dal_out) {
+    for (int t = tid; t < Te; t += AT) dal_out[t] = 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// helpers
+__global__ __launch_bounds__(256) void mask_time_kernel(int B, int L, int F, float *__restrict__ x,
+                                                        const int32_t *__restrict__ len) {
+  const size_t total = (size_t)B * L * F;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t bt = i / F;
+    const int b = (int)(bt / L), t = (int)(bt % L);
+    if (t >= len[b]) x[i] = 0.f;
+  }
+}
+
+// y[b,l,f] = x[l,b,f]  (time-major <-> batch-major)
+__global__ __launch_bounds__(256) void swap01_kernel(int L, int B, int F, const float *__restrict__ x,
+                                                     float *__restrict__ y) {
+  const size_t total = (size_t)B * L * F;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t f = i % F, bl = i / F;
+    const size_t l = bl % L, b = bl / L;
+    y[i] = x[(l * B + b) * F + f];
+  }
+}
+
+// dK[c,:] = sum over (l,b) with ids[l,b] == c of dz[l,b,:]  (gradient of the one-hot rows)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(int C, int N, int W, const int32_t *__restrict__ ids,
+                                                           const float *__restrict__ dz, float *__restrict__ dK) {
+  const int c = blockIdx.y;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= W) return;
+  float s = 0.f;
+  for (int i = 0; i < N; ++i)
+    if (ids[i] == c) s += dz[(size_t)i * W + col];
+  dK[(size_t)c * W + col] = s;
+}
+
+static int grid1(size_t n) {
+  size_t b = (n + 255) / 256;
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+static size_t attn_lds(const nabu_attn_desc *d, bool bwd) {
+  size_t f = 2 * (size_t)d->Te + (d->kind ? (size_t)d->Te * d->F * (bwd ? 2 : 1) : 0);
+  f += bwd ? (size_t)(AT / 64) * d->U : 64;
+  return f * sizeof(float);
+}
+
+static int check_attn(const nabu_attn_desc *d) {
+  if (!d || d->size != sizeof(nabu_attn_desc)) return fail(NABU_EINVAL, "attention: bad descriptor size");
+  if (d->B <= 0 || d->Te <= 0 || d->E <= 0 || d->U <= 0) return fail(NABU_EINVAL, "attention: bad dimensions");
+  if (d->U > 1024) return fail(NABU_EUNSUP, "attention: num_units > 1024");
+  if (d->kind != 0 && d->kind != 1) return fail(NABU_EINVAL, "attention: unknown kind");
+  if (d->kind && (d->K <= 0 || d->F <= 0 || d->F > 16)) return fail(NABU_EUNSUP, "attention: numfilt must be 1..16");
+  if (attn_lds(d, true) > 150 * 1024) return fail(NABU_EUNSUP, "attention: encoder length too large for LDS");
+  return 0;
+}
+
+}  // namespace nabu
+
+using namespace nabu;
+
+extern "C" int nabu_lstm_cell_fwd(int B, int U, int step, const int32_t *seq_len, const float *z,
+                                  const float *bias, const float *emb_rows, const int32_t *ids,
+                                  const float *c_prev, const float *h_prev, float *acts, float *c_new,
+                                  float *h_new, nabu_stream_t stream) {
+  NABU_CHECK_ARG(B > 0 && U > 0 && seq_len && z && bias && c_prev && h_prev && acts && c_new && h_new,
+                 "lstm_cell_fwd: bad argument");
+  NABU_CHECK_ARG((emb_rows == nullptr) == (ids == nullptr), "lstm_cell_fwd: emb_rows and ids go together");
+  hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3((B * U + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), B, U, step, seq_len, z, bias, emb_rows, ids, c_prev,
+                     h_prev, acts, c_new, h_new);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_lstm_cell_bwd(int B, int U, int step, const int32_t *seq_len, const float *acts,
+                                  const float *c_new, const float *c_prev, const float *dh,
+                                  const float *dh2, const float *dc_in, float *dz, float *dc_out,
+                                  nabu_stream_t stream) {
+  NABU_CHECK_ARG(B > 0 && U > 0 && seq_len && acts && c_new && c_prev && dh && dc_in && dz && dc_out,
+                 "lstm_cell_bwd: bad argument");
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((B * U + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), B, U, step, seq_len, acts, c_new, c_prev, dh, dh2,
+                     dc_in, dz, dc_out);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_attn_fwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
+                             const int32_t *enc_len, const float *keys, const float *values,
+                             const float *q, const float *v, const float *conv_kernel,
+                             const float *conv_proj, const float *align_prev, const float *ctx_prev,
+                             float *align, float *ctx, nabu_stream_t stream) {
+  if (int e = check_attn(d)) return e;
+  NABU_CHECK_ARG(dec_len && enc_len && keys && values && q && v && align_prev && ctx_prev && align && ctx,
+                 "attn_fwd: null pointer");
+  NABU_CHECK_ARG(!d->kind || (conv_kernel && conv_proj), "attn_fwd: location-aware attention needs its kernels");
+  AttnArgs p = {};
+  p.B = d->B; p.Te = d->Te; p.E = d->E; p.U = d->U; p.kind = d->kind; p.K = d->K; p.F = d->F; p.step = step;
+  p.dec_len = dec_len; p.enc_len = enc_len; p.keys = keys; p.values = values; p.q = q; p.v = v;
+  p.ck = conv_kernel; p.wf = conv_proj; p.align_prev = align_prev; p.ctx_prev = ctx_prev;
+  p.align = align; p.ctx = ctx;
+  const size_t shm = attn_lds(d, false);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (shm > 64 * 1024)
+    NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(d->B), dim3(AT), shm, s, p);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
+                             const int32_t *enc_len, const float *keys, const float *values,
+                             const float *q, const float *v, const float *conv_kernel,
+                             const float *conv_proj, const float *align_prev, const float *align,
+                             const float *dctx, const float *dalign_in, float *dq, float *dkeys,
+                             float *dv_part, float *dconv_proj_part, float *dconv_kernel_part,
+                             float *dalign_out, nabu_stream_t stream) {
+  if (int e = check_attn(d)) return e;
+  NABU_CHECK_ARG(dec_len && enc_len && keys && values && q && v && align && dctx && dq && dkeys && dv_part,
+                 "attn_bwd: null pointer");
+  NABU_CHECK_ARG(!d->kind || (conv_kernel && conv_proj && align_prev && dconv_proj_part &&
+                              dconv_kernel_part && dalign_out),
+                 "attn_bwd: location-aware attention needs its kernels and gradient buffers");
+  AttnArgs p = {};
+  p.B = d->B; p.Te = d->Te; p.E = d->E; p.U = d->U; p.kind = d->kind; p.K = d->K; p.F = d->F; p.step = step;
+  p.dec_len = dec_len; p.enc_len = enc_len; p.keys = keys; p.values = values; p.q = q; p.v = v;
+  p.ck = conv_kernel; p.wf = conv_proj; p.align_prev = align_prev;
+  p.align = const_cast<float *>(align);
+  p.dctx = dctx; p.dalign_in = dalign_in; p.dq = dq; p.dkeys = dkeys; p.dv_part = dv_part;
+  p.dwf_part = dconv_proj_part; p.dck_part = dconv_kernel_part; p.dalign_out = dalign_out;
+  const size_t shm = attn_lds(d, true);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (shm > 64 * 1024)
+    NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(d->B), dim3(AT), shm, s, p);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_mask_time_f32(int B, int L, int F, float *x, const int32_t *len, nabu_stream_t stream) {
+  NABU_CHECK_ARG(B > 0 && L > 0 && F > 0 && x && len, "mask_time: bad argument");
+  hipLaunchKernelGGL(mask_time_kernel, dim3(grid1((size_t)B * L * F)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), B, L, F, x, len);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_swap01_f32(int L, int B, int F, const float *x, float *y, nabu_stream_t stream) {
+  NABU_CHECK_ARG(B > 0 && L > 0 && F > 0 && x && y, "swap01: bad argument");
+  hipLaunchKernelGGL(swap01_kernel, dim3(grid1((size_t)B * L * F)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), L, B, F, x, y);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_scatter_rows_f32(int C, int N, int W, const int32_t *ids, const float *dz, float *dK,
+                                     nabu_stream_t stream) {
+  NABU_CHECK_ARG(C > 0 && N > 0 && W > 0 && ids && dz && dK, "scatter_rows: bad argument");
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((W + 255) / 256, C), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), C, N, W, ids, dz, dK);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}

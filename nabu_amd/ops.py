@@ -232,3 +232,59 @@ def check_persist_status(device=None):
                 'results of this step are invalid' % (code, code // 4,
                                                       {1: 'forward pass', 2: 'backward pass',
                                                        3: 'start-up handshake'}.get(code % 4, '?')))
+
+
+# ---------------------------------------------------------------- speller step kernels
+def lstm_cell_fwd(step, seq_len_dev, z, bias, emb_rows, ids, c_prev, h_prev, acts, c_new, h_new):
+    B, U = c_prev.shape
+    check(_hip.lib().nabu_lstm_cell_fwd(B, U, step, ptr(seq_len_dev), ptr(z), ptr(bias), ptr(emb_rows),
+                                        ptr(ids), ptr(c_prev), ptr(h_prev), ptr(acts), ptr(c_new), ptr(h_new),
+                                        stream()), 'nabu_lstm_cell_fwd')
+
+
+def lstm_cell_bwd(step, seq_len_dev, acts, c_new, c_prev, dh, dh2, dc_in, dz, dc_out):
+    B, U = c_prev.shape
+    check(_hip.lib().nabu_lstm_cell_bwd(B, U, step, ptr(seq_len_dev), ptr(acts), ptr(c_new), ptr(c_prev),
+                                        ptr(dh), ptr(dh2), ptr(dc_in), ptr(dz), ptr(dc_out), stream()),
+          'nabu_lstm_cell_bwd')
+
+
+def attn_desc(B, Te, E, U, kind, K=0, F=0):
+    return _hip.AttnDesc(ctypes.sizeof(_hip.AttnDesc), B, Te, E, U, kind, K, F)
+
+
+def attn_fwd(desc, step, dec_len, enc_len, keys, values, q, v, conv_kernel, conv_proj, align_prev,
+             ctx_prev, align, ctx):
+    check(_hip.lib().nabu_attn_fwd(ctypes.byref(desc), step, ptr(dec_len), ptr(enc_len), ptr(keys), ptr(values),
+                                   ptr(q), ptr(v), ptr(conv_kernel), ptr(conv_proj), ptr(align_prev),
+                                   ptr(ctx_prev), ptr(align), ptr(ctx), stream()), 'nabu_attn_fwd')
+
+
+def attn_bwd(desc, step, dec_len, enc_len, keys, values, q, v, conv_kernel, conv_proj, align_prev, align,
+             dctx, dalign_in, dq, dkeys, dv_part, dcp_part, dck_part, dalign_out):
+    check(_hip.lib().nabu_attn_bwd(ctypes.byref(desc), step, ptr(dec_len), ptr(enc_len), ptr(keys), ptr(values),
+                                   ptr(q), ptr(v), ptr(conv_kernel), ptr(conv_proj), ptr(align_prev),
+                                   ptr(align), ptr(dctx), ptr(dalign_in), ptr(dq), ptr(dkeys), ptr(dv_part),
+                                   ptr(dcp_part), ptr(dck_part), ptr(dalign_out), stream()), 'nabu_attn_bwd')
+
+
+def mask_time_(x, len_dev):
+    B, L, F = x.shape
+    check(_hip.lib().nabu_mask_time_f32(B, L, F, ptr(x), ptr(len_dev), stream()), 'nabu_mask_time_f32')
+    return x
+
+
+def swap01(x):
+    """[L,B,F] -> [B,L,F] (new tensor)."""
+    L, B, F = x.shape
+    y = torch.empty((B, L, F), dtype=x.dtype, device=x.device)
+    check(_hip.lib().nabu_swap01_f32(L, B, F, ptr(x), ptr(y), stream()), 'nabu_swap01_f32')
+    return y
+
+
+def scatter_rows(ids, dz, dK):
+    """dK[c,:] = sum_{i: ids[i]==c} dz[i,:]; ids [N] int32, dz [N,W], dK [C,W]."""
+    N, W = dz.shape
+    check(_hip.lib().nabu_scatter_rows_f32(dK.shape[0], N, W, ptr(ids), ptr(dz), ptr(dK), stream()),
+          'nabu_scatter_rows_f32')
+    return dK
