@@ -92,6 +92,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--mode', default='auto', choices=['auto', 'stepwise', 'persistent'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg3'],
+                    help='cfg2 (default) is the BASELINE.json metric; cfg3 = same encoder + Speller, for information')
     args = ap.parse_args()
 
     import torch
@@ -113,9 +115,14 @@ def main():
     layer.LSTM_MODE[0] = {'auto': ops.LSTM_AUTO, 'stepwise': ops.LSTM_STEPWISE,
                           'persistent': ops.LSTM_PERSISTENT}[args.mode]
 
-    mc, tc, ec = recipes.load_recipe('cfg2_listener_ctc')
-    data = SyntheticData(B, T, D, min_frames=T, min_labels=20, max_labels=60, time_reduction=8,
-                         seed=4234 + rank)
+    if args.workload == 'cfg3':
+        mc, tc, ec = recipes.load_recipe('cfg3_las_vanilla')
+        data = SyntheticData(B, T, D, min_frames=T, min_labels=20, max_labels=79, eos=True, time_reduction=8,
+                             seed=3234 + rank)
+    else:
+        mc, tc, ec = recipes.load_recipe('cfg2_listener_ctc')
+        data = SyntheticData(B, T, D, min_frames=T, min_labels=20, max_labels=60, time_reduction=8,
+                             seed=4234 + rank)
     tr = trainer_factory.factory('standard')(conf=tc, dataconf=data, modelconf=mc, evaluatorconf=ec,
                                              expdir=None, server=server, task_index=rank)
     batches = [tr.to_device(data.batch(i)) for i in range(2)]      # resident in HBM
@@ -163,7 +170,9 @@ def main():
                         'events recorded by the library around the recurrent launches'}
     step_bytes_total = 2 * 2 * sum(LAYER_T) * step_bytes(B, H)
     out = {
-        'metric': 'utterances/sec training step, 4x512 Listener+CTC, batch 32x1000x40 fbank',
+        'metric': ('utterances/sec training step, 4x512 Listener+CTC, batch 32x1000x40 fbank'
+                   if args.workload == 'cfg2' else
+                   'utterances/sec training step, Listener-512 + Speller (vanilla attention), batch 32x1000x40'),
         'value': round(world * B * args.steps / dt, 2), 'unit': 'utterances/sec', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
@@ -176,7 +185,7 @@ def main():
         'hbm_roofline_frac_whole_step': round(step_bytes_total / (dt / args.steps) / (HBM_PEAK_GBS * 1e9), 4),
         'final_loss': round(final_loss, 4),
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.workload == 'cfg2':
         out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))
 

@@ -205,6 +205,45 @@ int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
                   float *dv_part, float *dconv_proj_part, float *dconv_kernel_part,
                   float *dalign_out, nabu_stream_t stream);
 
+/* Whole-sequence decoder driver: RNNDecoder._decode over all L = max(dec_len)
+ * steps in one call (rnn_decoder.py:59-82: ScheduledEmbeddingTrainingHelper with
+ * sampling probability 0, BasicDecoder, dynamic_decode(impute_finished=True)),
+ * i.e. per step: recurrent GEMMs + nabu_lstm_cell_fwd per layer (optional output
+ * dropout, speller.py:38-43), query GEMM, nabu_attn_fwd; then ONE projection GEMM for
+ * all steps (rnn_cell.py:145-155).  nabu_speller_bwd is its gradient; weight
+ * gradients that are sums over steps are single GEMMs over all steps.
+ *   values [B,Te,E] encoder output (rows >= enc_len zero), ids [L,B] decoder input
+ *   labels (row 0 = C-1, then the targets shifted by one), logits [B,L,C].
+ * Kernel layouts are TF's: lstm_kernel[0] [(C+E+U),4U] (rows: one-hot, context, h),
+ * lstm_kernel[n>0] [(2U),4U], memory_kernel [E,U], query_kernel [U,U], attention_v [U],
+ * conv_kernel [K,F], conv_proj [F,U], out_kernel [(U+E),C] (rows: h, context), out_bias [C]. */
+#define NABU_SPELLER_MAX_LAYERS 4
+typedef struct {
+  uint32_t size;
+  int32_t B, Te, E, U, C, L, num_layers;
+  int32_t kind, K, F;                 /* attention: see nabu_attn_desc */
+  float keep_prob;                    /* output dropout of every LSTM layer; 1 = off */
+  unsigned long long seed, seed_offset;
+} nabu_speller_desc;
+typedef struct {
+  const float *memory_kernel, *query_kernel, *attention_v, *conv_kernel, *conv_proj, *out_kernel, *out_bias;
+  const float *lstm_kernel[NABU_SPELLER_MAX_LAYERS], *lstm_bias[NABU_SPELLER_MAX_LAYERS];
+} nabu_speller_params;
+typedef struct {
+  float *memory_kernel, *query_kernel, *attention_v, *conv_kernel, *conv_proj, *out_kernel, *out_bias;
+  float *lstm_kernel[NABU_SPELLER_MAX_LAYERS], *lstm_bias[NABU_SPELLER_MAX_LAYERS];
+} nabu_speller_grads;
+size_t nabu_speller_reserve_bytes(const nabu_speller_desc *d);
+size_t nabu_speller_ws_bytes(const nabu_speller_desc *d);
+int nabu_speller_fwd(const nabu_speller_desc *d, const float *values, const int32_t *enc_len,
+                     const int32_t *ids, const int32_t *dec_len, const nabu_speller_params *p,
+                     float *logits, void *reserve, void *ws, size_t ws_bytes, nabu_stream_t stream);
+/* every gradient buffer is overwritten; dvalues [B,Te,E] */
+int nabu_speller_bwd(const nabu_speller_desc *d, const float *values, const int32_t *enc_len,
+                     const int32_t *ids, const int32_t *dec_len, const nabu_speller_params *p,
+                     const float *dlogits, void *reserve, const nabu_speller_grads *g,
+                     float *dvalues, void *ws, size_t ws_bytes, nabu_stream_t stream);
+
 /* x[b,t,:] = 0 for t >= len[b] (dynamic_decode zeroes the outputs of finished rows). */
 int nabu_mask_time_f32(int B, int L, int F, float *x, const int32_t *len, nabu_stream_t stream);
 /* y[b,l,:] = x[l,b,:] (time-major per-step buffers <-> the batch-major API). */

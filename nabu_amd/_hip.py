@@ -45,6 +45,10 @@ SIGNATURES = {
     'nabu_lstm_cell_bwd': (_i, [_i, _i, _i] + [_vp] * 9 + [_vp]),
     'nabu_attn_fwd': (_i, [_vp, _i] + [_vp] * 12 + [_vp]),
     'nabu_attn_bwd': (_i, [_vp, _i] + [_vp] * 18 + [_vp]),
+    'nabu_speller_reserve_bytes': (_sz, [_vp]),
+    'nabu_speller_ws_bytes': (_sz, [_vp]),
+    'nabu_speller_fwd': (_i, [_vp] * 9 + [_sz, _vp]),
+    'nabu_speller_bwd': (_i, [_vp] * 11 + [_sz, _vp]),
     'nabu_mask_time_f32': (_i, [_i, _i, _i, _vp, _vp, _vp]),
     'nabu_swap01_f32': (_i, [_i, _i, _i, _vp, _vp, _vp]),
     'nabu_scatter_rows_f32': (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -116,6 +120,22 @@ class Workspace(object):
             buf = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=device)
             cls._bufs[key] = buf
         return buf
+
+
+SPELLER_MAX_LAYERS = 4
+
+
+class SpellerDesc(_c.Structure):
+    _fields_ = [('size', _c.c_uint32)] + [(n, _c.c_int32) for n in
+                                          ('B', 'Te', 'E', 'U', 'C', 'L', 'num_layers', 'kind', 'K', 'F')] + \
+               [('keep_prob', _c.c_float), ('seed', _c.c_ulonglong), ('seed_offset', _c.c_ulonglong)]
+
+
+class SpellerPtrs(_c.Structure):
+    """nabu_speller_params / nabu_speller_grads (same layout, const or not)"""
+    _fields_ = [(n, _c.c_void_p) for n in ('memory_kernel', 'query_kernel', 'attention_v', 'conv_kernel',
+                                           'conv_proj', 'out_kernel', 'out_bias')] + \
+               [('lstm_kernel', _c.c_void_p * SPELLER_MAX_LAYERS), ('lstm_bias', _c.c_void_p * SPELLER_MAX_LAYERS)]
 
 
 class AttnDesc(_c.Structure):

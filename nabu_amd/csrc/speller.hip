@@ -503,3 +503,283 @@ extern "C" int nabu_scatter_rows_f32(int C, int N, int W, const int32_t *ids, co
   NABU_LAUNCH_CHECK();
   return 0;
 }
+
+// ===========================================================================
+// Whole-sequence decoder driver: the per-step launch sequence of
+// RNNDecoder._decode runs here, in C++, so that a decoder step costs its kernel
+// launches only (a Python/ctypes loop spent ~15 us of host time per launch).
+namespace nabu {
+
+struct SpLayout {
+  size_t H[NABU_SPELLER_MAX_LAYERS], Cs[NABU_SPELLER_MAX_LAYERS], Ho[NABU_SPELLER_MAX_LAYERS],
+      acts[NABU_SPELLER_MAX_LAYERS];
+  size_t ctx, align, q, keys, logits_tm, total;   // offsets in floats
+};
+
+static SpLayout sp_layout(const nabu_speller_desc *d) {
+  SpLayout s;
+  const size_t B = d->B, L = d->L, U = d->U, E = d->E, Te = d->Te, C = d->C;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 3) / 4 * 4; return r; };
+  for (int n = 0; n < d->num_layers; ++n) {
+    s.H[n] = take((L + 1) * B * U);
+    s.Cs[n] = take((L + 1) * B * U);
+    s.Ho[n] = d->keep_prob < 1.f ? take((L + 1) * B * U) : s.H[n];
+    s.acts[n] = take(L * B * 4 * U);
+  }
+  s.ctx = take((L + 1) * B * E);
+  s.align = take((L + 1) * B * Te);
+  s.q = take(L * B * U);
+  s.keys = take(B * Te * U);
+  s.logits_tm = take(L * B * C);
+  s.total = o;
+  return s;
+}
+
+struct SpWs {
+  size_t z, dl, dH, dCtx, dkeys, dv, dwf, dck, dq, dz[NABU_SPELLER_MAX_LAYERS], dh[2][NABU_SPELLER_MAX_LAYERS],
+      dc[2][NABU_SPELLER_MAX_LAYERS], dctx[2], dal[2], dx, tmp, gemm, gemm_bytes, total;
+};
+
+static SpWs sp_ws(const nabu_speller_desc *d) {
+  SpWs s;
+  const size_t B = d->B, L = d->L, U = d->U, E = d->E, Te = d->Te, C = d->C, F = d->F, K = d->K;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 3) / 4 * 4; return r; };
+  s.z = take(B * 4 * U);
+  s.dl = take(L * B * C);
+  s.dH = take(L * B * U);
+  s.dCtx = take(L * B * E);
+  s.dkeys = take(B * Te * U);
+  s.dv = take(B * U);
+  s.dwf = take(B * F * U + 4);
+  s.dck = take(B * K * F + 4);
+  s.dq = take(L * B * U);
+  for (int n = 0; n < d->num_layers; ++n) {
+    s.dz[n] = take(L * B * 4 * U);
+    for (int i = 0; i < 2; ++i) { s.dh[i][n] = take(B * U); s.dc[i][n] = take(B * U); }
+  }
+  for (int i = 0; i < 2; ++i) { s.dctx[i] = take(B * E); s.dal[i] = take(B * Te); }
+  s.dx = take(B * U);
+  s.tmp = take(B * U);
+  size_t g = 0;
+  auto mx = [&](size_t v) { if (v > g) g = v; };
+  const int BL = (int)(B * L), BT = (int)(B * Te);
+  mx(nabu_gemm_ws_bytes((int)B, (int)(4 * U), (int)E)); mx(nabu_gemm_ws_bytes((int)B, (int)(4 * U), (int)U));
+  mx(nabu_gemm_ws_bytes((int)B, (int)U, (int)U)); mx(nabu_gemm_ws_bytes((int)B, (int)E, (int)(4 * U)));
+  mx(nabu_gemm_ws_bytes((int)B, (int)U, (int)(4 * U)));
+  mx(nabu_gemm_ws_bytes(BT, (int)U, (int)E)); mx(nabu_gemm_ws_bytes(BT, (int)E, (int)U));
+  mx(nabu_gemm_ws_bytes((int)E, (int)U, BT));
+  mx(nabu_gemm_ws_bytes(BL, (int)C, (int)U)); mx(nabu_gemm_ws_bytes(BL, (int)C, (int)E));
+  mx(nabu_gemm_ws_bytes((int)U, (int)C, BL)); mx(nabu_gemm_ws_bytes((int)E, (int)C, BL));
+  mx(nabu_gemm_ws_bytes(BL, (int)U, (int)C)); mx(nabu_gemm_ws_bytes(BL, (int)E, (int)C));
+  mx(nabu_gemm_ws_bytes((int)U, (int)U, BL)); mx(nabu_gemm_ws_bytes((int)E, (int)(4 * U), BL));
+  mx(nabu_gemm_ws_bytes((int)U, (int)(4 * U), BL)); mx(nabu_gemm_ws_bytes((int)Te, (int)E, (int)L));
+  mx(nabu_colsum_ws_bytes(BL, (int)(4 * U))); mx(nabu_colsum_ws_bytes((int)B, (int)(F * U + K * F + U)));
+  s.gemm_bytes = (g + 255) / 256 * 256;
+  s.gemm = take(s.gemm_bytes / 4 + 4);
+  s.total = o;
+  return s;
+}
+
+static int check_sp(const nabu_speller_desc *d) {
+  if (!d || d->size != sizeof(nabu_speller_desc)) return fail(NABU_EINVAL, "speller: bad descriptor size");
+  if (d->B <= 0 || d->Te <= 0 || d->E <= 0 || d->U <= 0 || d->C <= 1 || d->L <= 0)
+    return fail(NABU_EINVAL, "speller: bad dimensions");
+  if (d->num_layers < 1 || d->num_layers > NABU_SPELLER_MAX_LAYERS) return fail(NABU_EUNSUP, "speller: 1..%d layers", NABU_SPELLER_MAX_LAYERS);
+  if (d->U % 4 || d->E % 4) return fail(NABU_EUNSUP, "speller: num_units and encoder dim must be multiples of 4");
+  if (!(d->keep_prob > 0.f && d->keep_prob <= 1.f)) return fail(NABU_EINVAL, "speller: keep_prob out of (0,1]");
+  nabu_attn_desc a = {sizeof(nabu_attn_desc), d->B, d->Te, d->E, d->U, d->kind, d->K, d->F};
+  return check_attn(&a);
+}
+
+// C = A·B (+ beta*C) on row-major contiguous operands
+static int mm(bool ta, bool tb, int M, int N, int K, const float *A, int lda, const float *Bm, int ldb,
+              float beta, float *C, int ldc, const float *bias, float *ws, size_t wsb, nabu_stream_t st) {
+  return nabu_gemm_f32(ta, tb, M, N, K, 1.f, A, lda, Bm, ldb, beta, C, ldc, bias, 0, 0, 0, ws, wsb, st);
+}
+#define SP_TRY(call) do { int e_ = (call); if (e_) return e_; } while (0)
+
+}  // namespace nabu
+
+extern "C" size_t nabu_speller_reserve_bytes(const nabu_speller_desc *d) {
+  if (check_sp(d)) return 0;
+  return sp_layout(d).total * sizeof(float);
+}
+extern "C" size_t nabu_speller_ws_bytes(const nabu_speller_desc *d) {
+  if (check_sp(d)) return 0;
+  return sp_ws(d).total * sizeof(float);
+}
+
+extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values, const int32_t *enc_len,
+                                const int32_t *ids, const int32_t *dec_len, const nabu_speller_params *p,
+                                float *logits, void *reserve, void *ws, size_t ws_bytes,
+                                nabu_stream_t stream) {
+  if (int e = check_sp(d)) return e;
+  NABU_CHECK_ARG(values && enc_len && ids && dec_len && p && logits && reserve && ws, "speller_fwd: null pointer");
+  const SpLayout R = sp_layout(d);
+  const SpWs W = sp_ws(d);
+  if (ws_bytes < W.total * sizeof(float)) return fail(NABU_EWS, "speller_fwd: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float *r = static_cast<float *>(reserve), *w = static_cast<float *>(ws);
+  const int B = d->B, L = d->L, U = d->U, E = d->E, Te = d->Te, C = d->C, nl = d->num_layers;
+  float *gw = w + W.gemm;
+  const size_t gwb = W.gemm_bytes;
+  const nabu_attn_desc ad = {sizeof(nabu_attn_desc), B, Te, E, U, d->kind, d->K, d->F};
+  const bool drop = d->keep_prob < 1.f;
+  // zero initial state (index 0 of every time-major array)
+  for (int n = 0; n < nl; ++n) {
+    NABU_HIP(hipMemsetAsync(r + R.H[n], 0, (size_t)B * U * 4, s));
+    NABU_HIP(hipMemsetAsync(r + R.Cs[n], 0, (size_t)B * U * 4, s));
+    if (drop) NABU_HIP(hipMemsetAsync(r + R.Ho[n], 0, (size_t)B * U * 4, s));
+  }
+  NABU_HIP(hipMemsetAsync(r + R.ctx, 0, (size_t)B * E * 4, s));
+  NABU_HIP(hipMemsetAsync(r + R.align, 0, (size_t)B * Te * 4, s));
+  // keys = memory_layer(values)
+  SP_TRY(mm(false, false, B * Te, U, E, values, E, p->memory_kernel, U, 0.f, r + R.keys, U, nullptr, gw, gwb, stream));
+  float *z = w + W.z;
+  for (int t = 0; t < L; ++t) {
+    for (int n = 0; n < nl; ++n) {
+      const float *Kn = p->lstm_kernel[n];
+      float *Hn = r + R.H[n], *Cn = r + R.Cs[n];
+      const size_t cur = (size_t)t * B * U, nxt = (size_t)(t + 1) * B * U;
+      if (n == 0) {
+        SP_TRY(mm(false, false, B, 4 * U, E, r + R.ctx + (size_t)t * B * E, E, Kn + (size_t)C * 4 * U, 4 * U, 0.f, z, 4 * U, nullptr, gw, gwb, stream));
+        SP_TRY(mm(false, false, B, 4 * U, U, Hn + cur, U, Kn + (size_t)(C + E) * 4 * U, 4 * U, 1.f, z, 4 * U, nullptr, gw, gwb, stream));
+        SP_TRY(nabu_lstm_cell_fwd(B, U, t, dec_len, z, p->lstm_bias[0], Kn, ids + (size_t)t * B, Cn + cur, Hn + cur,
+                                  r + R.acts[0] + (size_t)t * B * 4 * U, Cn + nxt, Hn + nxt, stream));
+      } else {
+        SP_TRY(mm(false, false, B, 4 * U, U, r + R.Ho[n - 1] + nxt, U, Kn, 4 * U, 0.f, z, 4 * U, nullptr, gw, gwb, stream));
+        SP_TRY(mm(false, false, B, 4 * U, U, Hn + cur, U, Kn + (size_t)U * 4 * U, 4 * U, 1.f, z, 4 * U, nullptr, gw, gwb, stream));
+        SP_TRY(nabu_lstm_cell_fwd(B, U, t, dec_len, z, p->lstm_bias[n], nullptr, nullptr, Cn + cur, Hn + cur,
+                                  r + R.acts[n] + (size_t)t * B * 4 * U, Cn + nxt, Hn + nxt, stream));
+      }
+      if (drop)
+        SP_TRY(nabu_dropout_f32((size_t)B * U, Hn + nxt, r + R.Ho[n] + nxt, d->keep_prob, d->seed,
+                                d->seed_offset + (unsigned long long)t * nl + n, stream));
+    }
+    const float *htop = r + R.Ho[nl - 1] + (size_t)(t + 1) * B * U;
+    float *qt = r + R.q + (size_t)t * B * U;
+    SP_TRY(mm(false, false, B, U, U, htop, U, p->query_kernel, U, 0.f, qt, U, nullptr, gw, gwb, stream));
+    SP_TRY(nabu_attn_fwd(&ad, t, dec_len, enc_len, r + R.keys, values, qt, p->attention_v, p->conv_kernel,
+                         p->conv_proj, r + R.align + (size_t)t * B * Te, r + R.ctx + (size_t)t * B * E,
+                         r + R.align + (size_t)(t + 1) * B * Te, r + R.ctx + (size_t)(t + 1) * B * E, stream));
+  }
+  // output projection of all steps: [h_t, ctx_t]·W + b, then batch-major + impute_finished
+  float *ltm = r + R.logits_tm;
+  SP_TRY(mm(false, false, L * B, C, U, r + R.Ho[nl - 1] + (size_t)B * U, U, p->out_kernel, C, 0.f, ltm, C, p->out_bias, gw, gwb, stream));
+  SP_TRY(mm(false, false, L * B, C, E, r + R.ctx + (size_t)B * E, E, p->out_kernel + (size_t)U * C, C, 1.f, ltm, C, nullptr, gw, gwb, stream));
+  SP_TRY(nabu_swap01_f32(L, B, C, ltm, logits, stream));
+  SP_TRY(nabu_mask_time_f32(B, L, C, logits, dec_len, stream));
+  (void)s;
+  return 0;
+}
+
+extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values, const int32_t *enc_len,
+                                const int32_t *ids, const int32_t *dec_len, const nabu_speller_params *p,
+                                const float *dlogits, void *reserve, const nabu_speller_grads *g,
+                                float *dvalues, void *ws, size_t ws_bytes, nabu_stream_t stream) {
+  if (int e = check_sp(d)) return e;
+  NABU_CHECK_ARG(values && enc_len && ids && dec_len && p && dlogits && reserve && g && dvalues && ws,
+                 "speller_bwd: null pointer");
+  const SpLayout R = sp_layout(d);
+  const SpWs W = sp_ws(d);
+  if (ws_bytes < W.total * sizeof(float)) return fail(NABU_EWS, "speller_bwd: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float *r = static_cast<float *>(reserve), *w = static_cast<float *>(ws);
+  const int B = d->B, L = d->L, U = d->U, E = d->E, Te = d->Te, C = d->C, nl = d->num_layers, F = d->F, K = d->K;
+  float *gw = w + W.gemm;
+  const size_t gwb = W.gemm_bytes;
+  const nabu_attn_desc ad = {sizeof(nabu_attn_desc), B, Te, E, U, d->kind, d->K, d->F};
+  const bool drop = d->keep_prob < 1.f;
+  const int BL = B * L;
+  float *dl = w + W.dl, *dH = w + W.dH, *dCtx = w + W.dCtx, *dkeys = w + W.dkeys, *dq = w + W.dq;
+  const float *htop_all = r + R.Ho[nl - 1] + (size_t)B * U;   // h_top[t], t = 0..L-1
+  const float *ctx1 = r + R.ctx + (size_t)B * E;              // ctx[t]
+  // output projection
+  SP_TRY(nabu_swap01_f32(B, L, C, dlogits, dl, stream));      // [B,L,C] -> [L,B,C]
+  SP_TRY(mm(true, false, U, C, BL, htop_all, U, dl, C, 0.f, g->out_kernel, C, nullptr, gw, gwb, stream));
+  SP_TRY(mm(true, false, E, C, BL, ctx1, E, dl, C, 0.f, g->out_kernel + (size_t)U * C, C, nullptr, gw, gwb, stream));
+  SP_TRY(nabu_colsum_f32(BL, C, dl, C, 0.f, g->out_bias, gw, gwb, stream));
+  SP_TRY(mm(false, true, BL, U, C, dl, C, p->out_kernel, C, 0.f, dH, U, nullptr, gw, gwb, stream));
+  SP_TRY(mm(false, true, BL, E, C, dl, C, p->out_kernel + (size_t)U * C, C, 0.f, dCtx, E, nullptr, gw, gwb, stream));
+  NABU_HIP(hipMemsetAsync(dkeys, 0, (size_t)B * Te * U * 4, s));
+  NABU_HIP(hipMemsetAsync(w + W.dv, 0, (size_t)B * U * 4, s));
+  if (d->kind) {
+    NABU_HIP(hipMemsetAsync(w + W.dwf, 0, (size_t)B * F * U * 4, s));
+    NABU_HIP(hipMemsetAsync(w + W.dck, 0, (size_t)B * K * F * 4, s));
+  }
+  for (int n = 0; n < nl; ++n) {
+    NABU_HIP(hipMemsetAsync(w + W.dh[0][n], 0, (size_t)B * U * 4, s));
+    NABU_HIP(hipMemsetAsync(w + W.dc[0][n], 0, (size_t)B * U * 4, s));
+  }
+  int cur = 0;   // index of the carries coming from step t+1
+  const float *dctx_carry = nullptr, *dal_carry = nullptr;
+  for (int t = L - 1; t >= 0; --t) {
+    float *dCt = dCtx + (size_t)t * B * E;
+    if (dctx_carry) SP_TRY(nabu_axpy_f32((size_t)B * E, 1.f, dctx_carry, dCt, stream));
+    float *dal_out = d->kind ? w + W.dal[t & 1] : nullptr;
+    float *dqt = dq + (size_t)t * B * U;
+    SP_TRY(nabu_attn_bwd(&ad, t, dec_len, enc_len, r + R.keys, values, r + R.q + (size_t)t * B * U, p->attention_v,
+                         p->conv_kernel, p->conv_proj, r + R.align + (size_t)t * B * Te,
+                         r + R.align + (size_t)(t + 1) * B * Te, dCt, dal_carry, dqt, dkeys, w + W.dv,
+                         d->kind ? w + W.dwf : nullptr, d->kind ? w + W.dck : nullptr, dal_out, stream));
+    dal_carry = dal_out;
+    float *dHt = dH + (size_t)t * B * U;
+    SP_TRY(mm(false, true, B, U, U, dqt, U, p->query_kernel, U, 1.f, dHt, U, nullptr, gw, gwb, stream));
+    const float *dtop = dHt;
+    for (int n = nl - 1; n >= 0; --n) {
+      const float *Kn = p->lstm_kernel[n];
+      const float *dh_in = dtop;
+      if (drop) {
+        SP_TRY(nabu_dropout_f32((size_t)B * U, dtop, w + W.tmp, d->keep_prob, d->seed,
+                                d->seed_offset + (unsigned long long)t * nl + n, stream));
+        dh_in = w + W.tmp;
+      }
+      float *dzt = w + W.dz[n] + (size_t)t * B * 4 * U;
+      const float *Cn = r + R.Cs[n];
+      SP_TRY(nabu_lstm_cell_bwd(B, U, t, dec_len, r + R.acts[n] + (size_t)t * B * 4 * U, Cn + (size_t)(t + 1) * B * U,
+                                Cn + (size_t)t * B * U, dh_in, w + W.dh[cur][n], w + W.dc[cur][n], dzt,
+                                w + W.dc[cur ^ 1][n], stream));
+      if (n == 0) {
+        float *nx = w + W.dctx[t & 1];
+        SP_TRY(mm(false, true, B, E, 4 * U, dzt, 4 * U, Kn + (size_t)C * 4 * U, 4 * U, 0.f, nx, E, nullptr, gw, gwb, stream));
+        dctx_carry = nx;
+        SP_TRY(mm(false, true, B, U, 4 * U, dzt, 4 * U, Kn + (size_t)(C + E) * 4 * U, 4 * U, 0.f, w + W.dh[cur ^ 1][0], U, nullptr, gw, gwb, stream));
+      } else {
+        SP_TRY(mm(false, true, B, U, 4 * U, dzt, 4 * U, Kn, 4 * U, 0.f, w + W.dx, U, nullptr, gw, gwb, stream));
+        SP_TRY(mm(false, true, B, U, 4 * U, dzt, 4 * U, Kn + (size_t)U * 4 * U, 4 * U, 0.f, w + W.dh[cur ^ 1][n], U, nullptr, gw, gwb, stream));
+        dtop = w + W.dx;
+      }
+    }
+    cur ^= 1;
+  }
+  // sums over steps as single GEMMs
+  SP_TRY(mm(true, false, U, U, BL, htop_all, U, dq, U, 0.f, g->query_kernel, U, nullptr, gw, gwb, stream));
+  for (int n = 0; n < nl; ++n) {
+    const float *dzn = w + W.dz[n];
+    float *gK = g->lstm_kernel[n];
+    if (n == 0) {
+      SP_TRY(nabu_scatter_rows_f32(C, BL, 4 * U, ids, dzn, gK, stream));
+      SP_TRY(mm(true, false, E, 4 * U, BL, r + R.ctx, E, dzn, 4 * U, 0.f, gK + (size_t)C * 4 * U, 4 * U, nullptr, gw, gwb, stream));
+      SP_TRY(mm(true, false, U, 4 * U, BL, r + R.H[0], U, dzn, 4 * U, 0.f, gK + (size_t)(C + E) * 4 * U, 4 * U, nullptr, gw, gwb, stream));
+    } else {
+      SP_TRY(mm(true, false, U, 4 * U, BL, r + R.Ho[n - 1] + (size_t)B * U, U, dzn, 4 * U, 0.f, gK, 4 * U, nullptr, gw, gwb, stream));
+      SP_TRY(mm(true, false, U, 4 * U, BL, r + R.H[n], U, dzn, 4 * U, 0.f, gK + (size_t)U * 4 * U, 4 * U, nullptr, gw, gwb, stream));
+    }
+    SP_TRY(nabu_colsum_f32(BL, 4 * U, dzn, 4 * U, 0.f, g->lstm_bias[n], gw, gwb, stream));
+  }
+  SP_TRY(nabu_colsum_f32(B, U, w + W.dv, U, 0.f, g->attention_v, gw, gwb, stream));
+  if (d->kind) {
+    SP_TRY(nabu_colsum_f32(B, F * U, w + W.dwf, F * U, 0.f, g->conv_proj, gw, gwb, stream));
+    SP_TRY(nabu_colsum_f32(B, K * F, w + W.dck, K * F, 0.f, g->conv_kernel, gw, gwb, stream));
+  }
+  // keys = values·Wmem ; context_t = align_t^T·values
+  SP_TRY(mm(true, false, E, U, B * Te, values, E, dkeys, U, 0.f, g->memory_kernel, U, nullptr, gw, gwb, stream));
+  SP_TRY(mm(false, true, B * Te, E, U, dkeys, U, p->memory_kernel, U, 0.f, dvalues, E, nullptr, gw, gwb, stream));
+  const float *al1 = r + R.align + (size_t)B * Te;
+  for (int b = 0; b < B; ++b)
+    SP_TRY(mm(true, false, Te, E, L, al1 + (size_t)b * Te, B * Te, dCtx + (size_t)b * E, B * E, 1.f,
+              dvalues + (size_t)b * Te * E, E, nullptr, gw, gwb, stream));
+  return 0;
+}
