@@ -6,20 +6,26 @@
 // W_h every step.  Here one launch covers the whole sequence and W_h never
 // leaves the register file.
 //
-// DECOMPOSITION (8 "units" x 32 workgroups on the 8 XCDs x 32 CUs):
-//   unit = (direction, shard of BS=8 batch rows); a unit's P = H/16 workgroups
-//   each own 16 hidden units (= 64 gate columns) of that direction, i.e. a
-//   [H x 64] slice of W_h = H*64*4 B (128 KiB at H=512) held in VGPRs
-//   (64 registers per lane at 512 threads).  Block b belongs to unit b % NU, so
-//   with the observed round-robin block->XCD placement a unit lives on one XCD.
+// DECOMPOSITION.  unit = (direction, shard of BS batch rows); a unit's P = H/16
+// workgroups each own 16 hidden units (= 64 gate columns) of that direction, i.e.
+// a [H x 64] slice of W_h (128 KiB at H=512) held in VGPRs for the whole sequence.
+// Two geometries (template parameter BS):
+//   BS = 4: 256-thread workgroups (one wave per SIMD, 128 weight registers per
+//           lane), TWO workgroups per CU that belong to different units.  While one
+//           waits for its exchange the other multiplies: the hardware interleaves
+//           the two waves of a SIMD, which hides the hand-off latency.  cfg2:
+//           16 units x 32 workgroups = 512 = 2 per CU.
+//   BS = 8: 512-thread workgroups (two waves per SIMD, 64 weight registers per
+//           lane), one per CU; used when the batch is too large for BS = 4.
+// Block b belongs to unit b % NU, so with the observed round-robin block->XCD
+// placement a unit lives on one XCD.
 //
 // PER-STEP EXCHANGE (the only inter-workgroup communication):
-//   forward : all-gather of h_t      — every workgroup publishes its [16 x 8]
-//             slice (512 B, 16-byte stores) and reads the unit's whole [H x 8]
-//             vector (16 KiB);
+//   forward : all-gather of h_t      — every workgroup publishes its [16 x BS]
+//             slice with 16-byte stores and reads the unit's whole [H x BS] vector;
 //   backward: reduce-scatter of dh   — every workgroup publishes its partial
-//             product [8 x H] (16 KiB) cut into per-destination pieces and reads
-//             the P pieces addressed to it, summing them in a fixed order.
+//             product [BS x H] cut into per-destination pieces and reads the P
+//             pieces addressed to it, summing them in a fixed order.
 //   THE DATA IS THE FLAG: exchange slots are pre-filled with the bit pattern
 //   0xFFFFFFFF (a NaN no h or dh value can take); a consumer re-loads a slot
 //   until no word holds the sentinel.  No flags, no fences, no atomics; every
@@ -37,10 +43,9 @@
 //   Every spin is bounded by a wall-clock timeout; a timeout sets a status
 //   word, makes every workgroup leave, and is reported to the host.
 //
-// MATH per workgroup and step: [8 x H] x [H x 64] on the fp32 VALU with packed
-// FMAs (v_pk_fma_f32; 2*8*H*64 flop = 524 kflop at H=512 = 2048 cycles at the
-// CU's fp32 peak): lanes are (hidden unit, k-slice) / (k-quad, gate) register
-// tiles of 8x4 accumulators so that one 16-byte LDS broadcast read feeds 16 FMAs.
+// MATH per workgroup and step: [BS x H] x [H x 64] on the fp32 VALU with packed
+// FMAs (v_pk_fma_f32): lanes are (hidden unit, k-slice) / (k-quad, gate) register
+// tiles so that one 16-byte LDS broadcast read feeds 8-16 FMAs.
 #include "lstm_persist.h"
 
 #include <stdlib.h>
@@ -48,9 +53,8 @@
 namespace nabu {
 
 constexpr unsigned SENT = 0xFFFFFFFFu;
-constexpr int PT = 512;   // threads per workgroup (8 wave64, 2 per SIMD)
+constexpr unsigned OOB = 0xFFFFFFF0u;   // buffer offset beyond every exchange ring / tensor: access dropped
 constexpr int UC = 16;    // hidden units per workgroup
-constexpr int BS = 8;     // batch rows per unit
 constexpr int RING = 4;   // exchange ring depth
 constexpr int NCU = 256;  // MI355X
 constexpr size_t TABLE_BYTES = 4096;   // XCC-id table in front of the ring
@@ -72,7 +76,7 @@ struct PersistArgs {
   int *status;
   unsigned long long timeout_ticks;  // wall_clock64 ticks (100 MHz)
   int dbg;  // NABU_PERSIST_DEBUG: 1 no exchange wait, 2 no matrix product, 4 phase stamps,
-            // 8 force write-through publishing (timing experiments only)
+            // 8 force write-through publishing, 16 force BS = 8 (timing experiments only)
 };
 
 __device__ __forceinline__ float dpp_f(float v, const int ctrl_sel) {
@@ -98,6 +102,33 @@ __device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __builtin_am
 
 __device__ __forceinline__ bool has_sentinel(const u32x4 v) {
   return v.x == SENT || v.y == SENT || v.z == SENT || v.w == SENT;
+}
+__device__ __forceinline__ float sel4(int q, float a, float b, float c, float d) {
+  return q == 0 ? a : q == 1 ? b : q == 2 ? c : d;
+}
+
+// PER-STEP PREFETCH.  hipcc's wait-count insertion drains the WHOLE vector memory queue
+// (s_waitcnt vmcnt(0)) at most control-flow joins; a compiler-visible prefetch of the next step's
+// saved tensors would put its HBM latency, or the acknowledgement of the exchange stores, on the
+// critical path.  The prefetch is therefore an LDS-DMA load (buffer_load ... lds: no destination
+// register, so no stale register copies are possible) issued from inline assembly, invisible to
+// the compiler, and claimed with an explicit counted wait before an ordinary LDS read:
+// wait_vm<N>, N = vector memory instructions certainly issued after the prefetch.  Vector memory
+// operations complete in issue order, so waits the compiler inserts for its own loads can only
+// become stricter by the extra operation, never weaker.  Lane l of wave w lands at
+// stage[64 w + l]; out-of-range offsets deliver 0.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 raw_rsrc(const void *base, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  return (i32x4){(int)(unsigned)a, (int)(unsigned)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void prefetch_lds_b32(i32x4 rsrc, unsigned off, const float *smem, const float *stage_wave) {
+  const unsigned m0 = __builtin_amdgcn_readfirstlane((unsigned)((const char *)stage_wave - (const char *)smem));
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(m0), "v"(off), "s"(rsrc) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // publish 16 bytes: plain store when the whole unit shares one L2, else write-through
@@ -129,14 +160,26 @@ struct SpinGuard {
 
 // Kernel start: publish my XCC id, wait for the ids of my unit, decide whether the unit
 // is co-located on one XCD.  Returns false on timeout.  flag[0] = failure, flag[1] = coloc.
-__device__ __forceinline__ bool unit_handshake(const PersistArgs &p, int unit, int NU, int P, int *flag) {
+// Logical identity of a block.  Blocks b and b+256 share a CU (measured: the dispatcher fills
+// every CU once before it places a second workgroup), so the second wave of blocks is rotated by
+// NU/2 units: the two workgroups of a CU then belong to DIFFERENT units of the same XCD and can
+// interleave (same-unit workgroups are in lockstep and would always collide on the VALU).
+__device__ __forceinline__ void block_identity(int NU, int *unit, int *slot) {
+  const int b = blockIdx.x;
+  int u = b % NU;
+  if (b >= NCU && NCU % NU == 0) u = (u + NU / 2) % NU;
+  *unit = u;
+  *slot = b / NU;
+}
+
+__device__ __forceinline__ bool unit_handshake(const PersistArgs &p, int unit, int slot, int NU, int P, int *flag) {
   const int tid = threadIdx.x;
   const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));  // HW_REG_XCC_ID
   if (tid == 0) {
     flag[0] = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     flag[1] = 0;
-    p.status[16 + blockIdx.x] = (int)xcc;   // diagnostic
-    __hip_atomic_store(p.table + blockIdx.x, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x < 256) p.status[16 + blockIdx.x] = (int)xcc;   // diagnostic
+    __hip_atomic_store(p.table + unit + NU * slot, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   if (flag[0]) return false;   // an earlier kernel of this workspace timed out
@@ -163,50 +206,59 @@ __device__ __forceinline__ bool unit_handshake(const PersistArgs &p, int unit, i
   return flag[0] == 0;
 }
 
-// LDS carve (floats)
-template <int KPL>
+// ===========================================================================
+// forward.  KPL = k values per lane, BS = batch rows per unit, threads = 64*BS.
+// One __syncthreads per step: wave w gathers and multiplies ITS k range only (h staged in a
+// wave-private LDS region), the waves' partial sums meet in a double-buffered LDS tile.
+template <int KPL, int BS>
 struct FwdLds {
-  static constexpr int H = 32 * KPL;
+  static constexpr int NKS = 4 * BS;             // k-slices (4 per wave)
+  static constexpr int H = NKS * KPL;
   static constexpr int SLICE = KPL * BS + 4;     // padded k-slice of the h vector
-  static constexpr int HS = 0;                   // 32 slices
-  static constexpr int PART = HS + 32 * SLICE;   // [8 waves][512]
-  static constexpr int XS = PART + 8 * 512;      // [32][17] x-projection of the step
-  static constexpr int SG = XS + 32 * 17;        // [32][17] activations to store
-  static constexpr int SC = SG + 32 * 17;        // [8][17] cell state to store
-  static constexpr int SO = SC + 8 * 17;         // [8][17] output to store
-  static constexpr int FLAG = SO + 8 * 17;
+  static constexpr int HS = 0;
+  static constexpr int PART = HS + NKS * SLICE;  // [2][BS waves][64*BS]
+  static constexpr int XST = PART + 2 * BS * 64 * BS;   // [2][64*BS] prefetched x-projection
+  static constexpr int FLAG = XST + 2 * 64 * BS;
   static constexpr int TOTAL = FLAG + 4;
 };
 
-// ===========================================================================
-// forward
-template <int KPL>
-__global__ __launch_bounds__(PT) void lstm_persist_fwd_kernel(PersistArgs p) {
-  using L = FwdLds<KPL>;
+__device__ __forceinline__ float row_shl_f(float v, const int n) {   // lane i <- lane i+n of its 16-lane row
+  const int x = __builtin_bit_cast(int, v);
+  int r;
+  switch (n) {
+    case 4: r = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xF, 0xF, true); break;
+    case 8: r = __builtin_amdgcn_update_dpp(0, x, 0x108, 0xF, 0xF, true); break;
+    default: r = __builtin_amdgcn_update_dpp(0, x, 0x10C, 0xF, 0xF, true); break;
+  }
+  return __builtin_bit_cast(float, r);
+}
+
+template <int KPL, int BS>
+__global__ __launch_bounds__(64 * BS, 2) void lstm_persist_fwd_kernel(PersistArgs p) {
+  using L = FwdLds<KPL, BS>;
+  constexpr int PT = 64 * BS, NW = BS, RPL = BS / 4;   // threads, waves, rows handed off per lane
   constexpr int H = L::H;
   constexpr int P = H / UC;
-  constexpr int NQ = (H * BS / 4 + PT - 1) / PT;   // 16-byte pieces of the h vector per thread
+  constexpr int WP = H / 4;                        // 16-byte pieces of h gathered by one wave
+  constexpr int NQ = (WP + 63) / 64;               // ... per lane
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *hs = smem + L::HS, *part = smem + L::PART, *xs = smem + L::XS;
-  float *sg = smem + L::SG, *sc = smem + L::SC, *so = smem + L::SO;
+  float *hs = smem + L::HS, *part = smem + L::PART, *xst = smem + L::XST;
   int *flag = reinterpret_cast<int *>(smem + L::FLAG);
 
-  const int tid = threadIdx.x, w = tid >> 6;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const int NU = 2 * p.nshard;
-  const int unit = blockIdx.x % NU, slot = blockIdx.x / NU;
+  int unit, slot;
+  block_identity(NU, &unit, &slot);
   const int dir = unit & 1, shard = unit >> 1;
   const int U0 = slot * UC, b0 = shard * BS;
   const int T = p.T;
   // matrix-phase identity: (hidden unit, k-slice); 4 adjacent lanes = 4 k-slices
   const int fu = (tid >> 2) & 15, fq = tid & 3, ks = 4 * w + fq;
-  // gate-phase identity: (gate, batch row, hidden unit); 4 adjacent lanes = 4 gates
-  const int gg = tid & 3, gb = (tid >> 2) & 7, gu = tid >> 5;
+  // gate-phase identity: (gate, batch row, hidden unit); 4 adjacent lanes = 4 gates.  Loads and
+  // stores of the per-step tensors use it directly (16-byte runs per gate and row).
+  const int gg = tid & 3, gb = (tid >> 2) & (BS - 1), gu = tid / (4 * BS);
   const int gbg = b0 + gb;
   const int n_g = gbg < p.B ? p.len[gbg] : 0;
-  // memory-phase identity: (hidden unit fastest -> 64-byte segments, gate, batch row)
-  const int iu = tid & 15, ig = (tid >> 4) & 3, ib = tid >> 6;
-  const int ibg = b0 + ib;
-  const int n_i = ibg < p.B ? p.len[ibg] : 0;
 
   // this lane's slice of W_h stays in registers for the whole sequence (gate pairs packed)
   f32x2 Wr[KPL][2];
@@ -220,8 +272,14 @@ __global__ __launch_bounds__(PT) void lstm_persist_fwd_kernel(PersistArgs p) {
     }
   }
   float c_state = 0.f, h_state = 0.f;
-  if (!unit_handshake(p, unit, NU, P, flag)) return;
+  if (!unit_handshake(p, unit, slot, NU, P, flag)) return;
   const bool coloc = flag[1] != 0;
+  // Two workgroups of different units share a CU (BS = 4): start the upper half of the
+  // units half a step late so that one multiplies while the other waits for its exchange.
+  if (BS == 4 && unit >= NU / 2 && !(p.dbg & 32)) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < 100) __builtin_amdgcn_s_sleep(4);
+  }
 
   const size_t slot_bytes = (size_t)H * BS * 4;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -230,17 +288,30 @@ __global__ __launch_bounds__(PT) void lstm_persist_fwd_kernel(PersistArgs p) {
   const unsigned pub_off = (unsigned)(((U0 + gu) * BS + gb) * 4);
   const u32x4 sent4 = {SENT, SENT, SENT, SENT};
 
+  // x-projection of step s (GEMM output, bias included), fetched one step ahead so that its
+  // HBM latency never sits in front of the exchange loads (vector loads return in order)
+  // (Branch-free: a buffer load with an out-of-range offset returns 0, which is the value an
+  // inactive row needs.  Straight-line code lets hipcc count outstanding operations exactly
+  // instead of draining the whole queue at control-flow joins.)
+  float *const gbase = p.gates[dir] + (size_t)gbg * T * 4 * H + (size_t)gg * H + U0 + gu;
+  const i32x4 rg = raw_rsrc(p.gates[dir], (unsigned)((size_t)p.B * T * 4 * H * 4));
+  const unsigned goff = (unsigned)(((size_t)gbg * T * 4 * H + (size_t)gg * H + U0 + gu) * 4);
+  auto fetch_x = [&](int s) {   // -> xst[s & 1][tid]
+    const int t = dir ? n_g - 1 - s : s;
+    const unsigned off = (s < n_g && !(p.dbg & 64)) ? goff + (unsigned)t * (unsigned)(16 * H) : OOB;
+    prefetch_lds_b32(rg, off, smem, xst + (s & 1) * PT + 64 * w);
+  };
+  fetch_x(0);
+  // all prologue loads (W_h, the first prefetch) are complete before the loop
+  wait_vm<0>();
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), visible to the compiler's bookkeeping
+  float xnext = xst[tid];
+
   for (int s = 0; s < p.max_len; ++s) {
     NABU_STAMP(0, 0);
-    // (a) x-projection of this step (GEMM output, bias included), coalesced
-    const bool act_i = s < n_i;
-    const int t_i = dir ? n_i - 1 - s : s;
-    float xg = 0.f;
-    if (act_i) xg = p.gates[dir][((size_t)ibg * T + t_i) * 4 * H + ig * H + U0 + iu];
-
-    // (b) wait for h_{s-1} of the whole unit
+    // (a) wait for h_{s-1}: wave w gathers the k range it multiplies, nothing else
     if (s > 0 && !(p.dbg & 1)) {
-      const unsigned base = (unsigned)(((s - 1) % RING) * slot_bytes);
+      const unsigned base = (unsigned)(((s - 1) % RING) * slot_bytes) + (unsigned)(w * WP) * 16u;
       u32x4 v[NQ] = {};
       SpinGuard guard;
       guard.start();
@@ -250,13 +321,13 @@ __global__ __launch_bounds__(PT) void lstm_persist_fwd_kernel(PersistArgs p) {
         bool ok = true;
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-          const int qr = tid + i * PT, q = min(qr, H * BS / 4 - 1);
+          const int qr = lane + i * 64, q = min(qr, WP - 1);
           v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (unsigned)q * 16u, 0, 16);
-          ok = ok && (qr >= H * BS / 4 || !has_sentinel(v[i]));
+          ok = ok && (qr >= WP || !has_sentinel(v[i]));
         }
         if (__all(ok)) break;
         if (guard.expired(p)) {
-          if ((tid & 63) == 0) {
+          if (lane == 0) {
             flag[0] = 1;
             __hip_atomic_store(p.status, 1 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
@@ -265,39 +336,57 @@ __global__ __launch_bounds__(PT) void lstm_persist_fwd_kernel(PersistArgs p) {
       }
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
-        const int q = tid + i * PT;
-        if (q < H * BS / 4) {
-          const int k = (q * 4) / BS;
+        const int qr = lane + i * 64;
+        if (qr < WP) {
+          const int q = w * WP + qr, k = (q * 4) / BS;
           *reinterpret_cast<u32x4 *>(hs + q * 4 + (k / KPL) * 4) = v[i];
         }
       }
     }
     NABU_STAMP(0, 1);
-    xs[(ib * 4 + ig) * 17 + iu] = xg;
-    __syncthreads();                                            // B1
-    if (flag[0]) return;
-    NABU_STAMP(0, 2);
+    const float xg = xnext;
+    fetch_x(s + 1);
 
-    // reset my piece of the slot everybody finished reading (h_{s-2})
-    if (s >= 2 && pub_lane) xstore(sent4, rs, (unsigned)(((s - 2) % RING) * slot_bytes) + pub_off, coloc);
-
-    // (c) recurrent product on the VALU (packed FMAs): acc[b][g] += h[b][k] * W[k][g]
+    // (b) recurrent product on the VALU (packed FMAs): acc[b][g] += h[b][k] * W[k][g].
+    // The staged h is read back by the wave that wrote it: LDS operations of one wave execute
+    // in order, no barrier.
     f32x2 acc[BS][2];
 #pragma unroll
     for (int b = 0; b < BS; ++b) acc[b][0] = acc[b][1] = (f32x2){0.f, 0.f};
     if (s > 0 && !(p.dbg & 2)) {
       const float *hrow = hs + ks * L::SLICE;
+      // software pipeline: the LDS broadcast reads of chunk c+1 (CH k values) are issued before
+      // the FMAs of chunk c
+      constexpr int RQ = BS / 4, CHW = 4 / RQ > 0 ? 4 / RQ : 1;   // 4 reads (16 VGPRs) per chunk
+      constexpr int CH = KPL < CHW ? KPL : CHW, NCH = KPL / CH;
+      float4 hq[2][CH * RQ];
 #pragma unroll
-      for (int j = 0; j < KPL; ++j) {
-        const float4 h0 = *reinterpret_cast<const float4 *>(hrow + j * BS);
-        const float4 h1 = *reinterpret_cast<const float4 *>(hrow + j * BS + 4);
-        const float hb[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+      for (int i = 0; i < CH * RQ; ++i) hq[0][i] = *reinterpret_cast<const float4 *>(hrow + 4 * i);
 #pragma unroll
-        for (int b = 0; b < BS; ++b) {
-          const f32x2 hh = {hb[b], hb[b]};
-          acc[b][0] = __builtin_elementwise_fma(hh, Wr[j][0], acc[b][0]);
-          acc[b][1] = __builtin_elementwise_fma(hh, Wr[j][1], acc[b][1]);
+      for (int ch = 0; ch < NCH; ++ch) {
+        if (ch + 1 < NCH) {
+#pragma unroll
+          for (int i = 0; i < CH * RQ; ++i)
+            hq[(ch + 1) & 1][i] = *reinterpret_cast<const float4 *>(hrow + (ch + 1) * CH * BS + 4 * i);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+          const int j = ch * CH + jj;
+#pragma unroll
+          for (int i = 0; i < RQ; ++i) {
+            const float4 h4 = hq[ch & 1][jj * RQ + i];
+            const float hb[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+              const int b = 4 * i + bb;
+              const f32x2 hh = {hb[bb], hb[bb]};
+              acc[b][0] = __builtin_elementwise_fma(hh, Wr[j][0], acc[b][0]);
+              acc[b][1] = __builtin_elementwise_fma(hh, Wr[j][1], acc[b][1]);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       // sum the 4 k-slices of the quad (all lanes get the total)
 #pragma unroll
@@ -310,23 +399,28 @@ __global__ __launch_bounds__(PT) void lstm_persist_fwd_kernel(PersistArgs p) {
           acc[b][g >> 1][g & 1] = v;
         }
     }
-    NABU_STAMP(0, 3);
-    {  // lane fq hands rows 2fq, 2fq+1 of its wave's partial to the gate phase
-      float *dst = part + w * 512 + (fu * BS + 2 * fq) * 4;
-      f32x2 a0 = fq == 0 ? acc[0][0] : fq == 1 ? acc[2][0] : fq == 2 ? acc[4][0] : acc[6][0];
-      f32x2 a1 = fq == 0 ? acc[0][1] : fq == 1 ? acc[2][1] : fq == 2 ? acc[4][1] : acc[6][1];
-      f32x2 b0_ = fq == 0 ? acc[1][0] : fq == 1 ? acc[3][0] : fq == 2 ? acc[5][0] : acc[7][0];
-      f32x2 b1_ = fq == 0 ? acc[1][1] : fq == 1 ? acc[3][1] : fq == 2 ? acc[5][1] : acc[7][1];
-      *reinterpret_cast<float4 *>(dst) = make_float4(a0.x, a0.y, a1.x, a1.y);
-      *reinterpret_cast<float4 *>(dst + 4) = make_float4(b0_.x, b0_.y, b1_.x, b1_.y);
-    }
-    __syncthreads();                                            // B2
-    NABU_STAMP(0, 4);
-
-    // (d) gates: thread = (gate gg, row gb, unit gu); part[w][tid] is its partial
-    float z = xs[(gb * 4 + gg) * 17 + gu];
+    NABU_STAMP(0, 2);
+    float *const pbuf = part + (s & 1) * (NW * PT);
+    {  // lane fq hands rows fq*RPL .. fq*RPL+RPL-1 of its wave's partial to the gate phase
+      float *dst = pbuf + w * PT + (fu * BS + fq * RPL) * 4;
 #pragma unroll
-    for (int ww = 0; ww < 8; ++ww) z += part[ww * 512 + tid];
+      for (int i = 0; i < RPL; ++i) {
+        float4 r;
+        r.x = sel4(fq, acc[i][0].x, acc[RPL + i][0].x, acc[2 * RPL + i][0].x, acc[3 * RPL + i][0].x);
+        r.y = sel4(fq, acc[i][0].y, acc[RPL + i][0].y, acc[2 * RPL + i][0].y, acc[3 * RPL + i][0].y);
+        r.z = sel4(fq, acc[i][1].x, acc[RPL + i][1].x, acc[2 * RPL + i][1].x, acc[3 * RPL + i][1].x);
+        r.w = sel4(fq, acc[i][1].y, acc[RPL + i][1].y, acc[2 * RPL + i][1].y, acc[3 * RPL + i][1].y);
+        *reinterpret_cast<float4 *>(dst + 4 * i) = r;
+      }
+    }
+    __syncthreads();                                            // the step's only barrier
+    if (flag[0]) return;
+    NABU_STAMP(0, 3);
+
+    // (c) gates: thread = (gate gg, row gb, unit gu); pbuf[w][tid] are its partials
+    float z = xg;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) z += pbuf[ww * PT + tid];
     const float a = (gg == 1) ? fast_tanh(z) : fast_sigmoid(gg == 2 ? z + 1.0f : z);
     const float gi = QUAD_BCAST(a, 0), gj = QUAD_BCAST(a, 1), gf = QUAD_BCAST(a, 2), go = QUAD_BCAST(a, 3);
     const bool act_g = s < n_g;
@@ -334,131 +428,158 @@ __global__ __launch_bounds__(PT) void lstm_persist_fwd_kernel(PersistArgs p) {
     const float h_new = fast_tanh(c_new) * go;
     if (act_g) { c_state = c_new; h_state = h_new; }
 
-    NABU_STAMP(0, 5);
-    // (e) publish h_s (frozen rows republish their state): 4 rows -> one 16-byte store
+    // (d) publish h_s (frozen rows republish their state): 4 rows -> one 16-byte store.
+    // Ordering of my slot reset (issued two steps ago) before this store: vector memory
+    // operations complete in issue order and the exchange loads issued after that reset have
+    // been consumed, so the reset is performed.
     {
-      const float h1 = __shfl_down(h_state, 4), h2 = __shfl_down(h_state, 8), h3 = __shfl_down(h_state, 12);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my reset (and older stores) are performed
-      if (pub_lane && s + 1 < p.max_len) {
-        u32x4 pv;
-        pv.x = __builtin_bit_cast(unsigned, h_state);
-        pv.y = __builtin_bit_cast(unsigned, h1);
-        pv.z = __builtin_bit_cast(unsigned, h2);
-        pv.w = __builtin_bit_cast(unsigned, h3);
-        xstore(pv, rs, (unsigned)((s % RING) * slot_bytes) + pub_off, coloc);
-      }
+      const float h1 = row_shl_f(h_state, 4), h2 = row_shl_f(h_state, 8), h3 = row_shl_f(h_state, 12);
+      u32x4 pv;
+      pv.x = __builtin_bit_cast(unsigned, h_state);
+      pv.y = __builtin_bit_cast(unsigned, h1);
+      pv.z = __builtin_bit_cast(unsigned, h2);
+      pv.w = __builtin_bit_cast(unsigned, h3);
+      // (stores of the other lanes go out of range and are dropped by the buffer bounds check)
+      xstore(pv, rs, (pub_lane && s + 1 < p.max_len) ? (unsigned)((s % RING) * slot_bytes) + pub_off : OOB, coloc);
+      // hand back my piece of h_{s-2}: every wave of this workgroup has seen h_{s-1} of every
+      // producer (barrier above), and a producer publishes h_{s-1} only after all its waves
+      // finished reading h_{s-2}
+      xstore(sent4, rs, (pub_lane && s >= 2) ? (unsigned)(((s - 2) % RING) * slot_bytes) + pub_off : OOB, coloc);
     }
+    // claim the prefetched x-projection: 2 = the publish and the reset store above.  (Here, in
+    // front of the result stores: a later wait would also wait for those.)
+    wait_vm<2>();
+    xnext = xst[((s + 1) & 1) * PT + tid];
+    NABU_STAMP(0, 4);
 
-    NABU_STAMP(0, 6);
-    // (f) off the critical path: results to HBM in 64-byte segments
-    sg[(gb * 4 + gg) * 17 + gu] = a;
-    if (gg == 0) {
-      sc[gb * 17 + gu] = c_new;
-      so[gb * 17 + gu] = act_g ? h_new : 0.f;
-    }
-    __syncthreads();                                            // B3
-    NABU_STAMP(0, 7);
-    if (ibg < p.B) {
-      if (act_i) p.gates[dir][((size_t)ibg * T + t_i) * 4 * H + ig * H + U0 + iu] = sg[(ib * 4 + ig) * 17 + iu];
-      if (ig == 0) {
-        if (act_i) p.cs[dir][((size_t)ibg * T + t_i) * H + U0 + iu] = sc[ib * 17 + iu];
-        p.out[((size_t)ibg * T + (act_i ? t_i : s)) * 2 * H + (size_t)dir * H + U0 + iu] = so[ib * 17 + iu];
+    // (e) off the critical path: activations (in place over the x-projection), cell state, output
+    if (gbg < p.B && !(p.dbg & 128)) {
+      const int t_g = dir ? n_g - 1 - s : s;
+      if (act_g) {
+        gbase[(size_t)t_g * 4 * H] = a;
+        if (gg == 0) p.cs[dir][((size_t)gbg * T + t_g) * H + U0 + gu] = c_new;
       }
+      if (gg == 1)
+        p.out[((size_t)gbg * T + (act_g ? t_g : s)) * 2 * H + (size_t)dir * H + U0 + gu] = act_g ? h_new : 0.f;
     }
-    NABU_STAMP(0, 8);
+    NABU_STAMP(0, 5);
   }
 }
 
 // ===========================================================================
-// backward
-template <int KPL>
+// backward.  Lanes are (gate quarter cq, k-quad kq); NKQ k-quads per lane.  One __syncthreads
+// per step: wave w reduces exactly the pieces its own gate threads need (wave-private LDS
+// transpose), dz meets in a double-buffered LDS tile.
+template <int BS>
 struct BwdLds {
-  static constexpr int QS = 16 * BS + 4;         // padded gate quarter of dz [16 cols][8 rows]
-  static constexpr int DZ = 0;                   // 4 quarters
-  static constexpr int RED = DZ + 4 * QS;        // [16 groups][128] partial dh sums
-  static constexpr int XS = RED + 16 * 128;      // [32][17] saved activations
-  static constexpr int XC = XS + 32 * 17;        // [3][8][17] c, c_prev, dout
-  static constexpr int SG = XC + 3 * 8 * 17;     // [32][17] dz to store
-  static constexpr int FLAG = SG + 32 * 17;
+  static constexpr int QS = 16 * BS + 4;           // padded gate quarter of dz [16 cols][BS rows]
+  static constexpr int DZ = 0;                     // [2][4 quarters]
+  static constexpr int RED = DZ + 2 * 4 * QS;      // [16 groups][16*BS] partial dh sums
+  static constexpr int XST = RED + 16 * 16 * BS;   // [2][3][64*BS] prefetched saved values
+  static constexpr int FLAG = XST + 2 * 3 * 64 * BS;
   static constexpr int TOTAL = FLAG + 4;
 };
 
-template <int KPL>
-__global__ __launch_bounds__(PT) void lstm_persist_bwd_kernel(PersistArgs p) {
-  using L = BwdLds<KPL>;
-  constexpr int H = 32 * KPL;
+template <int H, int BS>
+__global__ __launch_bounds__(64 * BS, 2) void lstm_persist_bwd_kernel(PersistArgs p) {
+  using L = BwdLds<BS>;
+  constexpr int PT = 64 * BS;
   constexpr int P = H / UC;
-  constexpr int KQ = H / 4;                       // k-quads of the product's output
-  static_assert(KQ * 4 <= PT, "backward kernel supports H <= 512");
+  constexpr int KQ = H / 4;                         // k-quads of the product's output
+  constexpr int LQ = PT / 4;                        // lanes along the k-quad axis
+  constexpr int NKQ = (KQ + LQ - 1) / LQ;           // k-quads per lane (1 or 2)
+  constexpr int PPB = UC * BS / 4;                  // 16-byte pieces per source piece
+  constexpr int NQ = (P + 15) / 16;                 // sources per lane (16 source groups per wave)
+  static_assert(NKQ <= 2, "backward kernel supports H <= 512");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *dzs = smem + L::DZ, *red = smem + L::RED, *xs = smem + L::XS, *xc = smem + L::XC;
-  float *sg = smem + L::SG;
+  float *dzs = smem + L::DZ, *red = smem + L::RED, *xst = smem + L::XST;
   int *flag = reinterpret_cast<int *>(smem + L::FLAG);
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const int NU = 2 * p.nshard;
-  const int unit = blockIdx.x % NU, slot = blockIdx.x / NU;
+  int unit, slot;
+  block_identity(NU, &unit, &slot);
   const int dir = unit & 1, shard = unit >> 1;
   const int U0 = slot * UC, b0 = shard * BS;
   const int T = p.T;
-  // matrix-phase identity: (gate quarter cq, k-quad kq)
-  const int cq = tid & 3, kq = tid >> 2;
-  const bool mat_lane = kq < KQ;
-  // gate-phase / memory-phase identities as in the forward kernel
-  const int gg = tid & 3, gb = (tid >> 2) & 7, gu = tid >> 5;
+  const int cq = tid & 3, kq0 = tid >> 2;
+  // gate-phase identity as in the forward kernel; also used for every per-step load and store
+  const int gg = tid & 3, gb = (tid >> 2) & (BS - 1), gu = tid / (4 * BS);
   const int gbg = b0 + gb;
   const int n_g = gbg < p.B ? p.len[gbg] : 0;
-  const int iu = tid & 15, ig = (tid >> 4) & 3, ib = tid >> 6;
-  const int ibg = b0 + ib;
-  const int n_i = ibg < p.B ? p.len[ibg] : 0;
+  // exchange identity: wave w sums, over all sources, the 4 pieces (pos) its own gate threads
+  // consume; lane = (source group, piece)
+  const int xgrp = lane >> 2, xpos = 4 * w + (lane & 3);
 
-  // Wr[c][jp] = (W_h[4kq+2jp][cq*H + U0 + c], W_h[4kq+2jp+1][...]) — k pairs packed
-  f32x2 Wr[16][2];
-  if (mat_lane) {
-    const float *Wh = p.kernel[dir] + (size_t)p.D * 4 * H + (size_t)cq * H + U0;
+  // Wr[m][c][jp] = (W_h[4kq+2jp][cq*H + U0 + c], W_h[4kq+2jp+1][...]), kq = kq0 + m*LQ
+  f32x2 Wr[NKQ][16][2];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      Wr[c][0] = (f32x2){Wh[(size_t)(4 * kq + 0) * 4 * H + c], Wh[(size_t)(4 * kq + 1) * 4 * H + c]};
-      Wr[c][1] = (f32x2){Wh[(size_t)(4 * kq + 2) * 4 * H + c], Wh[(size_t)(4 * kq + 3) * 4 * H + c]};
+  for (int m = 0; m < NKQ; ++m) {
+    const int kq = kq0 + m * LQ;
+    if (kq < KQ) {
+      const float *Wh = p.kernel[dir] + (size_t)p.D * 4 * H + (size_t)cq * H + U0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        Wr[m][c][0] = (f32x2){Wh[(size_t)(4 * kq + 0) * 4 * H + c], Wh[(size_t)(4 * kq + 1) * 4 * H + c]};
+        Wr[m][c][1] = (f32x2){Wh[(size_t)(4 * kq + 2) * 4 * H + c], Wh[(size_t)(4 * kq + 3) * 4 * H + c]};
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) Wr[m][c][0] = Wr[m][c][1] = (f32x2){0.f, 0.f};
     }
-  } else {
-#pragma unroll
-    for (int c = 0; c < 16; ++c) Wr[c][0] = Wr[c][1] = (f32x2){0.f, 0.f};
   }
   float dc_state = 0.f;
-  if (!unit_handshake(p, unit, NU, P, flag)) return;
+  if (!unit_handshake(p, unit, slot, NU, P, flag)) return;
   const bool coloc = flag[1] != 0;
+  if (BS == 4 && unit >= NU / 2 && !(p.dbg & 32)) {   // see the forward kernel
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < 100) __builtin_amdgcn_s_sleep(4);
+  }
 
-  // ring slot = [dest P][src P][16 u][8 b] floats
-  const size_t piece_bytes = (size_t)UC * BS * 4;          // 512
+  // ring slot = [dest P][src P][16 u][BS b] floats
+  const size_t piece_bytes = (size_t)UC * BS * 4;
   const size_t block_bytes = (size_t)P * piece_bytes;      // what one destination reads
   const size_t slot_bytes = (size_t)P * block_bytes;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       p.xbuf + (size_t)unit * RING * slot_bytes, 0, (int)(RING * slot_bytes), 0x00020000);
   const u32x4 sent4 = {SENT, SENT, SENT, SENT};
 
-  // saved forward values of step s (coalesced), fetched one step ahead
-  auto fetch = [&](int s, float &av, float &xv) {
-    av = 0.f; xv = 0.f;
-    if (s >= 0 && s < n_i) {
-      const int t = dir ? n_i - 1 - s : s;
-      av = p.gates[dir][((size_t)ibg * T + t) * 4 * H + ig * H + U0 + iu];
-      if (ig == 0) xv = p.cs[dir][((size_t)ibg * T + t) * H + U0 + iu];
-      else if (ig == 1) xv = s > 0 ? p.cs[dir][((size_t)ibg * T + (dir ? t + 1 : t - 1)) * H + U0 + iu] : 0.f;
-      else if (ig == 2) xv = p.dout[((size_t)ibg * T + t) * 2 * H + (size_t)dir * H + U0 + iu];
-    }
+  // saved forward values of step s, fetched one step ahead: av = my gate's activation,
+  // xv = c (gate lane 0) / c_prev (lane 1) / dout (lane 2), shared across the quad below
+  // (Branch-free as in the forward kernel: out-of-range buffer loads return 0.)
+  float *const gbase = p.gates[dir] + (size_t)gbg * T * 4 * H + (size_t)gg * H + U0 + gu;
+  const i32x4 rg = raw_rsrc(p.gates[dir], (unsigned)((size_t)p.B * T * 4 * H * 4));
+  const i32x4 rc = raw_rsrc(p.cs[dir], (unsigned)((size_t)p.B * T * H * 4));
+  const i32x4 rd = raw_rsrc(p.dout, (unsigned)((size_t)p.B * T * 2 * H * 4));
+  const unsigned goff = (unsigned)(((size_t)gbg * T * 4 * H + (size_t)gg * H + U0 + gu) * 4);
+  const unsigned coff = (unsigned)(((size_t)gbg * T * H + U0 + gu) * 4);
+  const unsigned doff = (unsigned)(((size_t)gbg * T * 2 * H + (size_t)dir * H + U0 + gu) * 4);
+  // av = my gate's activation; xc = c (gate lane 0) / c_prev (lane 1), xd = dout (lane 2), else 0
+  auto fetch = [&](int s) {   // -> xst[s & 1][0..2][tid]; only called with s >= 0
+    const bool act = s >= 0 && s < n_g && !(p.dbg & 64);
+    const int t = dir ? n_g - 1 - s : s;
+    const int tc = gg == 0 ? t : (dir ? t + 1 : t - 1);     // c of this step / of the previous one
+    const bool want_c = act && (gg == 0 || (gg == 1 && s > 0));
+    float *st = xst + (s & 1) * 3 * PT + 64 * w;
+    prefetch_lds_b32(rg, act ? goff + (unsigned)t * (unsigned)(16 * H) : OOB, smem, st);
+    prefetch_lds_b32(rc, want_c ? coff + (unsigned)tc * (unsigned)(4 * H) : OOB, smem, st + PT);
+    prefetch_lds_b32(rd, (act && gg == 2) ? doff + (unsigned)t * (unsigned)(8 * H) : OOB, smem, st + 2 * PT);
   };
-  float av, xv;
-  fetch(p.max_len - 1, av, xv);
+  auto fetched = [&](int s, float &av, float &xv) {
+    const float *st = xst + (s & 1) * 3 * PT + tid;
+    av = st[0];
+    xv = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, st[PT]) | __builtin_bit_cast(unsigned, st[2 * PT]));
+  };
+  float av_next, xv_next;
+  fetch(p.max_len - 1);
+  wait_vm<0>();
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see the forward kernel
+  fetched(p.max_len - 1, av_next, xv_next);
 
   for (int s = p.max_len - 1; s >= 0; --s) {
     NABU_STAMP(1, 0);
-    const bool act_i = s < n_i;
-    const int t_i = dir ? n_i - 1 - s : s;
-
-    // (b) reduce-scatter input: the P partial products addressed to me (step s+1)
+    // (a) reduce-scatter input: the partial products of step s+1 addressed to me
     float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
-    constexpr int NQ = (P * 32 + PT - 1) / PT;
     u32x4 v[NQ] = {};
     const unsigned base = (unsigned)(((s + 1) % RING) * slot_bytes + (size_t)slot * block_bytes);
     const bool have_in = s + 1 < p.max_len && !(p.dbg & 1);
@@ -469,14 +590,14 @@ __global__ __launch_bounds__(PT) void lstm_persist_bwd_kernel(PersistArgs p) {
         bool ok = true;
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-          const int qr = tid + i * PT, q = min(qr, P * 32 - 1);   // see the forward kernel
-          v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (unsigned)q * 16u, 0, 16);
+          const int sr = xgrp + 16 * i, src = min(sr, P - 1);   // see the forward kernel
+          v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (unsigned)(src * PPB + xpos) * 16u, 0, 16);
           // a surplus lane's piece may already have been handed back by its owner: ignore it
-          ok = ok && (qr >= P * 32 || !has_sentinel(v[i]));
+          ok = ok && (sr >= P || !has_sentinel(v[i]));
         }
         if (__all(ok)) break;
         if (guard.expired(p)) {
-          if ((tid & 63) == 0) {
+          if (lane == 0) {
             flag[0] = 1;
             __hip_atomic_store(p.status, 2 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
@@ -485,42 +606,31 @@ __global__ __launch_bounds__(PT) void lstm_persist_bwd_kernel(PersistArgs p) {
       }
     }
     NABU_STAMP(1, 1);
-    // stage this step's saved values (fetched during the previous iteration) ...
-    xs[(ib * 4 + ig) * 17 + iu] = av;
-    if (ig < 3) xc[(ig * 8 + ib) * 17 + iu] = xv;
-    // ... and start fetching the next step's while this one computes
-    fetch(s - 1, av, xv);
     if (have_in) {
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
-        const int q = tid + i * PT;
-        if (q < P * 32) {
+        const int src = xgrp + 16 * i;
+        if (src < P) {
           const f32x4 fv = __builtin_bit_cast(f32x4, v[i]);
           psum.x += fv.x;
           psum.y += fv.y;
           psum.z += fv.z;
           psum.w += fv.w;
-          // I am the only reader of this block: hand the slot back
-          xstore(sent4, rs, base + (unsigned)q * 16u, coloc);
         }
       }
     }
-    // group tid/32 holds the sum over sources {tid/32 + 16m}; element (tid%32) = (u = ./2, 4 rows)
-    *reinterpret_cast<float4 *>(red + (tid >> 5) * 128 + (tid & 31) * 4) = psum;
-    __syncthreads();                                            // B1
-    if (flag[0]) return;
-    NABU_STAMP(1, 2);
+    // wave-private transpose: group xgrp holds the sum over the sources {xgrp + 16 i}
+    *reinterpret_cast<float4 *>(red + xgrp * (UC * BS) + xpos * 4) = psum;
+    const float a = av_next, xv = xv_next;
 
-    // (c) gate gradients: thread = (gate gg, row gb, unit gu)
+    // (b) gate gradients: thread = (gate gg, row gb, unit gu)
     float dh = 0.f;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) dh += red[(gg + 4 * m) * 128 + gu * 8 + gb];
+    for (int m = 0; m < 4; ++m) dh += red[(gg + 4 * m) * (UC * BS) + gu * BS + gb];
     dh += QUAD_XOR1(dh);
     dh += QUAD_XOR2(dh);
-    const float a = xs[(gb * 4 + gg) * 17 + gu];
     const float gi = QUAD_BCAST(a, 0), gj = QUAD_BCAST(a, 1), gf = QUAD_BCAST(a, 2), go = QUAD_BCAST(a, 3);
-    const float c = xc[(0 * 8 + gb) * 17 + gu], cprev = xc[(1 * 8 + gb) * 17 + gu];
-    const float dout = xc[(2 * 8 + gb) * 17 + gu];
+    const float c = QUAD_BCAST(xv, 0), cprev = QUAD_BCAST(xv, 1), dout = QUAD_BCAST(xv, 2);
     const bool act_g = s < n_g;
     const float tc = fast_tanh(c);
     const float dht = dout + dh;
@@ -533,69 +643,103 @@ __global__ __launch_bounds__(PT) void lstm_persist_bwd_kernel(PersistArgs p) {
                    : dht * tc * go * (1.f - go);
       dc_state = dct * gf;
     }
-    dzs[gg * L::QS + gu * BS + gb] = dz;
-    sg[(gb * 4 + gg) * 17 + gu] = dz;
+    float *const dzb = dzs + (s & 1) * (4 * L::QS);
+    dzb[gg * L::QS + gu * BS + gb] = dz;
+    NABU_STAMP(1, 2);
+    __syncthreads();                                            // the step's only barrier
+    if (flag[0]) return;
     NABU_STAMP(1, 3);
-    __syncthreads();                                            // B2
-    NABU_STAMP(1, 4);
+    // next step's saved values travel while this one multiplies
+    // I am the only reader of my pieces: hand the slot back
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int src = xgrp + 16 * i;
+      xstore(sent4, rs, (have_in && src < P) ? base + (unsigned)(src * PPB + xpos) * 16u : OOB, coloc);
+    }
+    if (s > 0) fetch(s - 1);
 
-    // (d) partial product for step s-1: acc[b][j] = sum_c dz[b][cq,c] * W[4kq+j][cq,c]
+    // (c) partial product for step s-1: acc[m][b][j] = sum_c dz[b][cq,c] * W[4kq_m+j][cq,c]
     if (s > 0) {
-      f32x2 acc[BS][2];
+      f32x2 acc[NKQ][BS][2];
 #pragma unroll
-      for (int b = 0; b < BS; ++b) acc[b][0] = acc[b][1] = (f32x2){0.f, 0.f};
-      const float *dq = dzs + cq * L::QS;
+      for (int m = 0; m < NKQ; ++m)
+#pragma unroll
+        for (int b = 0; b < BS; ++b) acc[m][b][0] = acc[m][b][1] = (f32x2){0.f, 0.f};
+      const float *dq = dzb + cq * L::QS;
       if (!(p.dbg & 2)) {
+        // all 16 column reads of this lane's gate quarter are issued up front (<= 32 VGPRs)
+        constexpr int RQ = BS / 4;
+        float4 dqv[16 * RQ];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const float4 d0 = *reinterpret_cast<const float4 *>(dq + c * BS);
-          const float4 d1 = *reinterpret_cast<const float4 *>(dq + c * BS + 4);
-          const float db[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        for (int i = 0; i < 16 * RQ; ++i) dqv[i] = *reinterpret_cast<const float4 *>(dq + 4 * i);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int b = 0; b < BS; ++b) {
-            const f32x2 dd = {db[b], db[b]};
-            acc[b][0] = __builtin_elementwise_fma(dd, Wr[c][0], acc[b][0]);
-            acc[b][1] = __builtin_elementwise_fma(dd, Wr[c][1], acc[b][1]);
+        for (int c2 = 0; c2 < 16; ++c2)
+#pragma unroll
+          for (int i = 0; i < RQ; ++i) {
+            const float4 d4 = dqv[c2 * RQ + i];
+            const float db[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int m = 0; m < NKQ; ++m)
+#pragma unroll
+              for (int bb = 0; bb < 4; ++bb) {
+                const int b = 4 * i + bb;
+                const f32x2 dd = {db[bb], db[bb]};
+                acc[m][b][0] = __builtin_elementwise_fma(dd, Wr[m][c2][0], acc[m][b][0]);
+                acc[m][b][1] = __builtin_elementwise_fma(dd, Wr[m][c2][1], acc[m][b][1]);
+              }
           }
-        }
       }
-      // quad all-reduce over the 4 gate quarters; lane cq then keeps k = 4kq + cq, all 8 rows
-      float r[BS];
+      // quad all-reduce over the 4 gate quarters; lane cq then keeps k = 4kq + cq, all rows
+      float r[NKQ][BS];
 #pragma unroll
-      for (int b = 0; b < BS; ++b) {
-        float t[4];
+      for (int m = 0; m < NKQ; ++m)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float x = acc[b][j >> 1][j & 1];
-          x += QUAD_XOR1(x);
-          x += QUAD_XOR2(x);
-          t[j] = x;
+        for (int b = 0; b < BS; ++b) {
+          float t[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float x = acc[m][b][j >> 1][j & 1];
+            x += QUAD_XOR1(x);
+            x += QUAD_XOR2(x);
+            t[j] = x;
+          }
+          r[m][b] = sel4(cq, t[0], t[1], t[2], t[3]);
         }
-        r[b] = cq == 0 ? t[0] : cq == 1 ? t[1] : cq == 2 ? t[2] : t[3];
-      }
-      NABU_STAMP(1, 5);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my slot resets are performed before I publish
-      NABU_STAMP(1, 6);
-      if (mat_lane) {
+      NABU_STAMP(1, 4);
+      // publish.  My slot resets of this slot's previous use were issued three steps ago and
+      // exchange loads issued after them have been consumed: they are performed (in-order
+      // completion of vector memory operations).
+#pragma unroll
+      for (int m = 0; m < NKQ; ++m) {
+        const int kq = kq0 + m * LQ;
         const int k = 4 * kq + cq;
         const int dest = k / UC, ul = k % UC;
         const unsigned off = (unsigned)((s % RING) * slot_bytes + (size_t)dest * block_bytes +
                                         (size_t)slot * piece_bytes + (size_t)ul * BS * 4);
-        u32x4 p0, p1;
-        p0.x = __builtin_bit_cast(unsigned, r[0]); p0.y = __builtin_bit_cast(unsigned, r[1]);
-        p0.z = __builtin_bit_cast(unsigned, r[2]); p0.w = __builtin_bit_cast(unsigned, r[3]);
-        p1.x = __builtin_bit_cast(unsigned, r[4]); p1.y = __builtin_bit_cast(unsigned, r[5]);
-        p1.z = __builtin_bit_cast(unsigned, r[6]); p1.w = __builtin_bit_cast(unsigned, r[7]);
-        xstore(p0, rs, off, coloc);
-        xstore(p1, rs, off + 16, coloc);
+#pragma unroll
+        for (int i = 0; i < BS / 4; ++i) {
+          u32x4 pv;
+          pv.x = __builtin_bit_cast(unsigned, r[m][4 * i]);
+          pv.y = __builtin_bit_cast(unsigned, r[m][4 * i + 1]);
+          pv.z = __builtin_bit_cast(unsigned, r[m][4 * i + 2]);
+          pv.w = __builtin_bit_cast(unsigned, r[m][4 * i + 3]);
+          xstore(pv, rs, kq < KQ ? off + 16 * i : OOB, coloc);
+        }
       }
     }
-
-    NABU_STAMP(1, 7);
-    // (e) dz to HBM (in place over the activations) in 64-byte segments; padded frames get 0
-    if (ibg < p.B)
-      p.gates[dir][((size_t)ibg * T + (act_i ? t_i : s)) * 4 * H + ig * H + U0 + iu] = sg[(ib * 4 + ig) * 17 + iu];
-    NABU_STAMP(1, 8);
+    // claim the prefetched values here, in front of the dz store (see the forward kernel)
+    if (s > 0) {
+      wait_vm<NKQ * (BS / 4)>();   // N = the publish stores above
+      fetched(s - 1, av_next, xv_next);
+    }
+    NABU_STAMP(1, 5);
+    // (d) dz to HBM (in place over the activations); padded frames get 0
+    if (gbg < p.B && !(p.dbg & 128)) {
+      const int t_g = dir ? n_g - 1 - s : s;
+      gbase[(size_t)(act_g ? t_g : s) * 4 * H] = dz;
+    }
+    NABU_STAMP(1, 6);
   }
 }
 
@@ -613,37 +757,50 @@ static int cu_count() {
   return n;
 }
 
-static int nshard_of(int B) { return (B + BS - 1) / BS; }
+// geometry: BS = 4 (two 256-thread workgroups per CU) when the batch fits, else BS = 8
+static int pick_bs(int B, int H) {
+  const int P = H / UC;
+  if (2 * ((B + 3) / 4) * P <= 2 * NCU) return 4;
+  if (2 * ((B + 7) / 8) * P <= NCU) return 8;
+  return 0;
+}
 
 bool lstm_persist_supported(int B, int T, int H) {
   if (!(H == 64 || H == 128 || H == 256 || H == 512)) return false;
   if (B <= 0 || T <= 0) return false;
-  const int grid = 2 * nshard_of(B) * (H / UC);
-  return grid <= NCU;
+  return pick_bs(B, H) != 0;
+}
+
+static size_t ring_bytes(bool fwd, int BS, int nshard, int H) {
+  const size_t NU = 2 * (size_t)nshard, P = H / UC;
+  return fwd ? NU * RING * (size_t)H * BS * 4 : NU * RING * P * P * UC * BS * 4;
 }
 
 size_t lstm_persist_ws_bytes(int B, int T, int H) {
   if (!lstm_persist_supported(B, T, H)) return 0;
-  const size_t NU = 2 * (size_t)nshard_of(B), P = H / UC;
-  const size_t fwd = NU * RING * (size_t)H * BS * 4;
-  const size_t bwd = NU * RING * P * P * UC * BS * 4;
-  return TABLE_BYTES + (fwd > bwd ? fwd : bwd);
+  size_t m = 0;
+  for (int BS = 4; BS <= 8; BS += 4) {   // either geometry may be selected at run time
+    const int ns = (B + BS - 1) / BS;
+    for (int f = 0; f < 2; ++f) {
+      const size_t r = ring_bytes(f != 0, BS, ns, H);
+      if (r > m) m = r;
+    }
+  }
+  return TABLE_BYTES + m;
 }
 
-static constexpr size_t PERSIST_LDS = 96 * 1024;   // > half of 160 KiB: exactly one workgroup per CU
-
 template <typename K>
-static int launch(K kernel, const PersistArgs &a, int grid, hipStream_t stream) {
-  static thread_local const void *configured[8] = {nullptr};
+static int launch(K kernel, const PersistArgs &a, int grid, int threads, size_t lds, hipStream_t stream) {
+  static thread_local const void *configured[32] = {nullptr};
   const void *fn = reinterpret_cast<const void *>(kernel);
   bool done = false;
   for (auto c : configured) done = done || c == fn;
   if (!done) {
-    NABU_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PERSIST_LDS));
+    NABU_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (auto &c : configured)
       if (!c) { c = fn; break; }
   }
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(PT), PERSIST_LDS, stream, a);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, stream, a);
   NABU_LAUNCH_CHECK();
   return 0;
 }
@@ -655,7 +812,10 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
   const size_t need = lstm_persist_ws_bytes(B, T, H);
   if (ws_bytes < need) return fail(NABU_EWS, "persistent LSTM: workspace %zu < %zu", ws_bytes, need);
   PersistArgs a;
-  a.B = B; a.T = T; a.D = D; a.H = H; a.max_len = max_len; a.nshard = nshard_of(B);
+  { const char *e = getenv("NABU_PERSIST_DEBUG"); a.dbg = e ? atoi(e) : 0; }
+  int BS = pick_bs(B, H);
+  if ((a.dbg & 16) && 2 * ((B + 7) / 8) * (H / UC) <= NCU) BS = 8;
+  a.B = B; a.T = T; a.D = D; a.H = H; a.max_len = max_len; a.nshard = (B + BS - 1) / BS;
   a.len = len;
   for (int i = 0; i < 2; ++i) { a.kernel[i] = kernel[i]; a.gates[i] = gates[i]; a.cs[i] = cs[i]; }
   a.out = out; a.dout = dout;
@@ -663,21 +823,26 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
   a.table = static_cast<unsigned *>(ws);
   a.xbuf = static_cast<char *>(ws) + TABLE_BYTES;
   a.timeout_ticks = 20000000ull;   // 0.2 s at 100 MHz: a step takes microseconds
-  { const char *e = getenv("NABU_PERSIST_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   const int NU = 2 * a.nshard, P = H / UC;
   const int grid = NU * P;
-  if (grid > cu_count()) return fail(NABU_EUNSUP, "persistent LSTM: %d workgroups > %d CUs", grid, cu_count());
-  const size_t ring = fwd ? (size_t)NU * RING * H * BS * 4 : (size_t)NU * RING * P * P * UC * BS * 4;
-  NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + ring, stream));
-#define NABU_PERSIST_CASE(kpl)                                                              \
-  case 32 * kpl:                                                                            \
-    return fwd ? launch(lstm_persist_fwd_kernel<kpl>, a, grid, stream)                       \
-               : launch(lstm_persist_bwd_kernel<kpl>, a, grid, stream);
+  const int per_cu = BS == 4 ? 2 : 1;
+  if (grid > per_cu * cu_count())
+    return fail(NABU_EUNSUP, "persistent LSTM: %d workgroups > %d x %d CUs", grid, per_cu, cu_count());
+  NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + ring_bytes(fwd, BS, a.nshard, H), stream));
+  // dynamic LDS chosen so that exactly `per_cu` workgroups fit on a CU (160 KiB)
+  const size_t lds = BS == 4 ? 64 * 1024 : 96 * 1024;
+#define NABU_PERSIST_CASE(h)                                                                         \
+  case h:                                                                                            \
+    if (BS == 4)                                                                                     \
+      return fwd ? launch(lstm_persist_fwd_kernel<h / 16, 4>, a, grid, 256, lds, stream)             \
+                 : launch(lstm_persist_bwd_kernel<h, 4>, a, grid, 256, lds, stream);                 \
+    return fwd ? launch(lstm_persist_fwd_kernel<h / 32, 8>, a, grid, 512, lds, stream)               \
+               : launch(lstm_persist_bwd_kernel<h, 8>, a, grid, 512, lds, stream);
   switch (H) {
-    NABU_PERSIST_CASE(2)
-    NABU_PERSIST_CASE(4)
-    NABU_PERSIST_CASE(8)
-    NABU_PERSIST_CASE(16)
+    NABU_PERSIST_CASE(64)
+    NABU_PERSIST_CASE(128)
+    NABU_PERSIST_CASE(256)
+    NABU_PERSIST_CASE(512)
   }
   return fail(NABU_EUNSUP, "persistent LSTM: unsupported H=%d", H);
 }
