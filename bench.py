@@ -160,8 +160,16 @@ def main():
     per_launch_bytes = tot_bytes / max(launches, 1)
     per_launch_s = tot_ms * 1e-3 / max(launches, 1)
     achieved = per_launch_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
+    # HBM traffic per launch of the same kernels from the PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE, separate runs of this command; summarised by tools/pmc_summary.py with the
+    # gfx950 corrections of MI355X_MICROARCH.md).  null when this workload was not profiled.
+    traffic = None
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_cfg2_pmc_traffic.json')
+    if persistent and args.workload == 'cfg2' and os.path.exists(pmc):
+        with open(pmc) as fid:
+            traffic = int(json.load(fid)['lstm_persist_traffic_bytes_per_launch'])
     roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                 'kernel': 'lstm_persist_{fwd,bwd}' if persistent else 'lstm_step_{fwd,bwd}_kernel',
                 'bytes_per_launch': int(per_launch_bytes), 'us_per_launch': round(per_launch_s * 1e6, 3),
                 'launches_timed': launches,
