@@ -1,0 +1,123 @@
+"""GPU: the HIP path (through the recipe API and the C ABI) against the committed golden
+fixtures of tests/golden/ — loss, every gradient of step 0, and the loss trajectory under
+clip + Adam.  Nothing here executes the oracle: the expected numbers are data.  Tolerances:
+per-step loss 1e-3 relative is the BASELINE.json north_star bar; fp32 kernels achieve ~1e-5,
+which is what is asserted."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from nabu_amd import recipes
+from nabu_amd.processing.synthetic import SyntheticData
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLD, name + '.npz')))
+
+
+def unpack(fx, prefix):
+    return {k[len(prefix):].replace('|', '/'): v for k, v in fx.items() if k.startswith(prefix)}
+
+
+def batch_of(fx, s):
+    return dict(inputs={'features': fx['x%d' % s]}, input_seq_length={'features': fx['xl%d' % s]},
+                targets={'text': fx['y%d' % s]}, target_seq_length={'text': fx['yl%d' % s]})
+
+
+def trainer_with_weights(recipe, over, data, weights, first_batch):
+    from nabu_amd.neuralnetworks.trainers import trainer_factory
+    mc, tc, ec = recipes.load_recipe(recipe, **over)
+    tr = trainer_factory.factory('standard')(conf=tc, dataconf=data, modelconf=mc, evaluatorconf=ec,
+                                             expdir=None, server=None, task_index=0)
+    b0 = tr.to_device(first_batch)
+    with torch.no_grad():       # creates the variables (lazily, like the reference's graph build)
+        tr.model(b0['inputs'], b0['input_seq_length'], b0['targets'], b0['target_seq_length'], False)
+    assert sorted(tr.model.store.state_dict()) == sorted(weights), 'variable names differ from the reference names'
+    tr.model.store.load_state_dict(weights)
+    return tr
+
+
+def check_grads(tr, want, tol=3e-4):
+    for v in tr.model.variables:
+        got = v.grad.cpu().numpy().astype(np.float64).reshape(want[v.name].shape)
+        ref = want[v.name].astype(np.float64)
+        err = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err < tol, (v.name, err)
+
+
+def step0_grads(tr, batch, loss_name):
+    from nabu_amd.autodiff import Tape
+    from nabu_amd.neuralnetworks.trainers import loss_functions
+    b = tr.to_device(batch)
+    for v in tr.model.variables:
+        if v.grad is not None:
+            v.grad.zero_()
+    with Tape() as tape:
+        logits, lsl = tr.model(b['inputs'], b['input_seq_length'], b['targets'], b['target_seq_length'], True)
+        loss = getattr(loss_functions, loss_name)(b['targets'], logits, lsl, b['target_seq_length'])
+    tape.backward(loss)
+    loss_functions.check_status()
+    return float(loss.item())
+
+
+@pytest.mark.parametrize('name,recipe', [('cfg1_small', 'cfg1_dblstm_ctc'), ('cfg2_small', 'cfg2_listener_ctc')])
+def test_ctc_recipes_match_golden(name, recipe):
+    fx = load(name)
+    B, T, D, H, nl, C, steps, seed = [int(v) for v in fx['meta']]
+    over = {'encoder.num_units': H, 'encoder.num_layers': nl, 'trainer.batch_size': B}
+    tr = trainer_with_weights(recipe, over, SyntheticData(B, T, D), unpack(fx, 'w:'), batch_of(fx, 0))
+    loss0 = step0_grads(tr, batch_of(fx, 0), 'CTC')
+    assert abs(loss0 - fx['losses'][0]) / fx['losses'][0] < 2e-5
+    check_grads(tr, unpack(fx, 'g:'))
+    losses = [float(tr.step(tr.to_device(batch_of(fx, s))).item()) for s in range(steps)]
+    rel = np.abs(np.array(losses) - fx['losses']) / fx['losses']
+    assert rel.max() < 1e-3 and rel.max() < 5e-5, (losses, fx['losses'])
+    # weights after `steps` clip+Adam updates (an element whose gradient is rounding noise may
+    # move by lr per step in either direction)
+    wT = unpack(fx, 'wT:')
+    st = tr.model.store.state_dict()
+    for k in wT:
+        d = np.abs(st[k] - wT[k])
+        assert d.max() < (steps + 0.5) * 1e-3 and d.mean() < 2e-5, (k, d.max(), d.mean())
+
+
+@pytest.mark.parametrize('name,recipe', [('cfg3_small', 'cfg3_las_vanilla'), ('cfg5_small', 'cfg5_las_location')])
+def test_las_recipes_match_golden(name, recipe):
+    fx = load(name)
+    B, T, D, H, nl, C, steps, seed, U, K, F = [int(v) for v in fx['meta']]
+    over = {'encoder.num_units': H, 'decoder.num_units': U, 'trainer.batch_size': B}
+    if K:
+        over.update({'decoder.numfilt': F, 'decoder.filtersize': K})
+    tr = trainer_with_weights(recipe, over, SyntheticData(B, T, D, eos=True), unpack(fx, 'w:'), batch_of(fx, 0))
+    loss0 = step0_grads(tr, batch_of(fx, 0), 'average_cross_entropy')
+    assert abs(loss0 - fx['losses'][0]) / fx['losses'][0] < 2e-5
+    check_grads(tr, unpack(fx, 'g:'))
+    losses = [float(tr.step(tr.to_device(batch_of(fx, s))).item()) for s in range(steps)]
+    rel = np.abs(np.array(losses) - fx['losses']) / fx['losses']
+    assert rel.max() < 1e-3 and rel.max() < 1e-4, (losses, fx['losses'])
+
+
+def test_cfg1_exact_matches_golden():
+    """BASELINE.json configs[0] at its full size (2x256 DBLSTM, 8 x 200 x 40): 3-step loss
+    trajectory, gradient norms and sampled gradient entries of step 0"""
+    from tests.golden import make_golden as G       # generators only (seeded numpy); no oracle math runs
+    fx = load('cfg1_exact')
+    names, data = G.cfg1_exact_setup()
+    w = G.draw_weights(names)
+    tr = trainer_with_weights('cfg1_dblstm_ctc', {}, data, w, data.batch(0))
+    loss0 = step0_grads(tr, data.batch(0), 'CTC')
+    assert abs(loss0 - fx['losses'][0]) / fx['losses'][0] < 2e-5
+    for v in tr.model.variables:
+        g = v.grad.cpu().numpy().astype(np.float64).ravel()
+        key = v.name.replace('/', '|')
+        assert abs(np.sqrt((g ** 2).sum()) - fx['gnorm:' + key]) / fx['gnorm:' + key] < 2e-4, v.name
+        ref = fx['gsample:' + key]
+        assert np.abs(g[G.sample_index(v.name, g.size)] - ref).max() < 3e-4 * np.abs(ref).max() + 1e-6, v.name
+    losses = [float(tr.step(tr.to_device(data.batch(s))).item()) for s in range(3)]
+    rel = np.abs(np.array(losses) - fx['losses']) / fx['losses']
+    assert rel.max() < 1e-3 and rel.max() < 5e-5, (losses, fx['losses'])
