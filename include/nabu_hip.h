@@ -206,10 +206,11 @@ int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
                   float *dalign_out, nabu_stream_t stream);
 
 /* Whole-sequence decoder driver: RNNDecoder._decode over all L = max(dec_len)
- * steps in one call (rnn_decoder.py:59-82: ScheduledEmbeddingTrainingHelper with
- * sampling probability 0, BasicDecoder, dynamic_decode(impute_finished=True)),
+ * steps in one call (rnn_decoder.py:59-82: ScheduledEmbeddingTrainingHelper,
+ * BasicDecoder, dynamic_decode(impute_finished=True)),
  * i.e. per step: recurrent GEMMs + nabu_lstm_cell_fwd per layer (optional output
- * dropout, speller.py:38-43), query GEMM, nabu_attn_fwd; then ONE projection GEMM for
+ * dropout, speller.py:38-43), query GEMM, nabu_attn_fwd (with sample_prob > 0 also the step's
+ * projection + nabu_sample_ids for the next input); then ONE projection GEMM for
  * all steps (rnn_cell.py:145-155).  nabu_speller_bwd is its gradient; weight
  * gradients that are sums over steps are single GEMMs over all steps.
  *   values [B,Te,E] encoder output (rows >= enc_len zero), ids [L,B] decoder input
@@ -224,6 +225,8 @@ typedef struct {
   int32_t kind, K, F;                 /* attention: see nabu_attn_desc */
   float keep_prob;                    /* output dropout of every LSTM layer; 1 = off */
   unsigned long long seed, seed_offset;
+  float sample_prob;                  /* scheduled sampling probability (speller.cfg sample_prob); 0 = off */
+  unsigned long long sample_seed, sample_offset;
 } nabu_speller_desc;
 typedef struct {
   const float *memory_kernel, *query_kernel, *attention_v, *conv_kernel, *conv_proj, *out_kernel, *out_bias;
@@ -233,6 +236,19 @@ typedef struct {
   float *memory_kernel, *query_kernel, *attention_v, *conv_kernel, *conv_proj, *out_kernel, *out_bias;
   float *lstm_kernel[NABU_SPELLER_MAX_LAYERS], *lstm_bias[NABU_SPELLER_MAX_LAYERS];
 } nabu_speller_grads;
+/* Scheduled sampling — tf.contrib.seq2seq.ScheduledEmbeddingTrainingHelper as used by
+ * rnn_decoder.py:59-66: after step t, row b draws select ~ Bernoulli(sample_prob); if selected
+ * the decoder input of step t+1 is a sample from Categorical(softmax(logits_t[b])) instead of
+ * the target y_t (no gradient flows through the sample).
+ *   out_ids[b] = select ? sample : teacher_ids[b];  logits [B,C];
+ * Philox4x32-10, counter (b, offset), key seed: a pure function of its arguments. */
+int nabu_sample_ids(int B, int C, const float *logits, float prob, unsigned long long seed,
+                    unsigned long long offset, const int32_t *teacher_ids, int32_t *out_ids,
+                    nabu_stream_t stream);
+/* The decoder inputs actually used by the last nabu_speller_fwd on `reserve` ([L,B] int32,
+ * equal to `ids` when sample_prob == 0), copied to out_ids (device). */
+int nabu_speller_decoder_inputs(const nabu_speller_desc *d, const void *reserve, int32_t *out_ids,
+                                nabu_stream_t stream);
 size_t nabu_speller_reserve_bytes(const nabu_speller_desc *d);
 size_t nabu_speller_ws_bytes(const nabu_speller_desc *d);
 int nabu_speller_fwd(const nabu_speller_desc *d, const float *values, const int32_t *enc_len,

@@ -45,6 +45,8 @@ SIGNATURES = {
     'nabu_lstm_cell_bwd': (_i, [_i, _i, _i] + [_vp] * 9 + [_vp]),
     'nabu_attn_fwd': (_i, [_vp, _i] + [_vp] * 12 + [_vp]),
     'nabu_attn_bwd': (_i, [_vp, _i] + [_vp] * 18 + [_vp]),
+    'nabu_sample_ids': (_i, [_i, _i, _vp, _f, _c.c_ulonglong, _c.c_ulonglong, _vp, _vp, _vp]),
+    'nabu_speller_decoder_inputs': (_i, [_vp, _vp, _vp, _vp]),
     'nabu_speller_reserve_bytes': (_sz, [_vp]),
     'nabu_speller_ws_bytes': (_sz, [_vp]),
     'nabu_speller_fwd': (_i, [_vp] * 9 + [_sz, _vp]),
@@ -128,7 +130,8 @@ SPELLER_MAX_LAYERS = 4
 class SpellerDesc(_c.Structure):
     _fields_ = [('size', _c.c_uint32)] + [(n, _c.c_int32) for n in
                                           ('B', 'Te', 'E', 'U', 'C', 'L', 'num_layers', 'kind', 'K', 'F')] + \
-               [('keep_prob', _c.c_float), ('seed', _c.c_ulonglong), ('seed_offset', _c.c_ulonglong)]
+               [('keep_prob', _c.c_float), ('seed', _c.c_ulonglong), ('seed_offset', _c.c_ulonglong),
+                ('sample_prob', _c.c_float), ('sample_seed', _c.c_ulonglong), ('sample_offset', _c.c_ulonglong)]
 
 
 class SpellerPtrs(_c.Structure):

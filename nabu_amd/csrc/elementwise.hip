@@ -149,6 +149,34 @@ __global__ __launch_bounds__(256) void dropout_kernel(size_t n, const float *__r
   }
 }
 
+// scheduled sampling (ScheduledEmbeddingTrainingHelper): one thread per row
+__global__ __launch_bounds__(256) void sample_ids_kernel(int B, int C, const float *__restrict__ logits,
+                                                         float prob, unsigned long long seed,
+                                                         unsigned long long offset,
+                                                         const int32_t *__restrict__ teacher,
+                                                         int32_t *__restrict__ out) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const uint4 r = philox4x32_10(make_uint4((unsigned)b, 0u, (unsigned)offset, (unsigned)(offset >> 32)),
+                                make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+  int id = teacher[b];
+  if (u01(r.x) < prob) {
+    const float *l = logits + (size_t)b * C;
+    float m = l[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, l[c]);
+    float tot = 0.f;
+    for (int c = 0; c < C; ++c) tot += expf(l[c] - m);
+    const float target = u01(r.y) * tot;        // inverse CDF of softmax(l)
+    float acc = 0.f;
+    id = C - 1;
+    for (int c = 0; c < C; ++c) {
+      acc += expf(l[c] - m);
+      if (acc > target) { id = c; break; }
+    }
+  }
+  out[b] = id;
+}
+
 __global__ __launch_bounds__(256) void gaussian_noise_kernel(size_t n, const float *__restrict__ x,
                                                              float *__restrict__ y, float stddev,
                                                              unsigned long long seed,
@@ -276,6 +304,18 @@ extern "C" int nabu_dropout_f32(size_t n, const float *x, float *y, float keep_p
   NABU_CHECK_ARG(x && y && keep_prob > 0.f && keep_prob <= 1.f, "dropout: bad argument");
   hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), n, x, y, keep_prob, seed, offset);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_sample_ids(int B, int C, const float *logits, float prob, unsigned long long seed,
+                               unsigned long long offset, const int32_t *teacher_ids, int32_t *out_ids,
+                               nabu_stream_t stream) {
+  if (B == 0) return 0;
+  NABU_CHECK_ARG(B > 0 && C > 0 && logits && teacher_ids && out_ids && prob >= 0.f && prob <= 1.f,
+                 "sample_ids: bad argument");
+  hipLaunchKernelGGL(sample_ids_kernel, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     B, C, logits, prob, seed, offset, teacher_ids, out_ids);
   NABU_LAUNCH_CHECK();
   return 0;
 }

@@ -513,7 +513,7 @@ namespace nabu {
 struct SpLayout {
   size_t H[NABU_SPELLER_MAX_LAYERS], Cs[NABU_SPELLER_MAX_LAYERS], Ho[NABU_SPELLER_MAX_LAYERS],
       acts[NABU_SPELLER_MAX_LAYERS];
-  size_t ctx, align, q, keys, logits_tm, total;   // offsets in floats
+  size_t ctx, align, q, keys, logits_tm, ids, total;   // offsets in floats (ids: [L,B] int32)
 };
 
 static SpLayout sp_layout(const nabu_speller_desc *d) {
@@ -532,6 +532,7 @@ static SpLayout sp_layout(const nabu_speller_desc *d) {
   s.q = take(L * B * U);
   s.keys = take(B * Te * U);
   s.logits_tm = take(L * B * C);
+  s.ids = take(L * B);
   s.total = o;
   return s;
 }
@@ -589,6 +590,7 @@ static int check_sp(const nabu_speller_desc *d) {
   if (d->num_layers < 1 || d->num_layers > NABU_SPELLER_MAX_LAYERS) return fail(NABU_EUNSUP, "speller: 1..%d layers", NABU_SPELLER_MAX_LAYERS);
   if (d->U % 4 || d->E % 4) return fail(NABU_EUNSUP, "speller: num_units and encoder dim must be multiples of 4");
   if (!(d->keep_prob > 0.f && d->keep_prob <= 1.f)) return fail(NABU_EINVAL, "speller: keep_prob out of (0,1]");
+  if (!(d->sample_prob >= 0.f && d->sample_prob <= 1.f)) return fail(NABU_EINVAL, "speller: sample_prob out of [0,1]");
   nabu_attn_desc a = {sizeof(nabu_attn_desc), d->B, d->Te, d->E, d->U, d->kind, d->K, d->F};
   return check_attn(&a);
 }
@@ -605,6 +607,15 @@ static int mm(bool ta, bool tb, int M, int N, int K, const float *A, int lda, co
 extern "C" size_t nabu_speller_reserve_bytes(const nabu_speller_desc *d) {
   if (check_sp(d)) return 0;
   return sp_layout(d).total * sizeof(float);
+}
+extern "C" int nabu_speller_decoder_inputs(const nabu_speller_desc *d, const void *reserve, int32_t *out_ids,
+                                           nabu_stream_t stream) {
+  if (int e = check_sp(d)) return e;
+  NABU_CHECK_ARG(reserve && out_ids, "speller_decoder_inputs: null pointer");
+  const SpLayout R = sp_layout(d);
+  NABU_HIP(hipMemcpyAsync(out_ids, static_cast<const float *>(reserve) + R.ids, (size_t)d->L * d->B * 4,
+                          hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+  return 0;
 }
 extern "C" size_t nabu_speller_ws_bytes(const nabu_speller_desc *d) {
   if (check_sp(d)) return 0;
@@ -635,6 +646,10 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
   }
   NABU_HIP(hipMemsetAsync(r + R.ctx, 0, (size_t)B * E * 4, s));
   NABU_HIP(hipMemsetAsync(r + R.align, 0, (size_t)B * Te * 4, s));
+  // decoder inputs actually used (scheduled sampling replaces entries of rows 1..L-1 below)
+  int32_t *ids_used = reinterpret_cast<int32_t *>(r + R.ids);
+  NABU_HIP(hipMemcpyAsync(ids_used, ids, (size_t)L * B * 4, hipMemcpyDeviceToDevice, s));
+  const bool sampling = d->sample_prob > 0.f;
   // keys = memory_layer(values)
   SP_TRY(mm(false, false, B * Te, U, E, values, E, p->memory_kernel, U, 0.f, r + R.keys, U, nullptr, gw, gwb, stream));
   float *z = w + W.z;
@@ -646,7 +661,7 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
       if (n == 0) {
         SP_TRY(mm(false, false, B, 4 * U, E, r + R.ctx + (size_t)t * B * E, E, Kn + (size_t)C * 4 * U, 4 * U, 0.f, z, 4 * U, nullptr, gw, gwb, stream));
         SP_TRY(mm(false, false, B, 4 * U, U, Hn + cur, U, Kn + (size_t)(C + E) * 4 * U, 4 * U, 1.f, z, 4 * U, nullptr, gw, gwb, stream));
-        SP_TRY(nabu_lstm_cell_fwd(B, U, t, dec_len, z, p->lstm_bias[0], Kn, ids + (size_t)t * B, Cn + cur, Hn + cur,
+        SP_TRY(nabu_lstm_cell_fwd(B, U, t, dec_len, z, p->lstm_bias[0], Kn, ids_used + (size_t)t * B, Cn + cur, Hn + cur,
                                   r + R.acts[0] + (size_t)t * B * 4 * U, Cn + nxt, Hn + nxt, stream));
       } else {
         SP_TRY(mm(false, false, B, 4 * U, U, r + R.Ho[n - 1] + nxt, U, Kn, 4 * U, 0.f, z, 4 * U, nullptr, gw, gwb, stream));
@@ -664,6 +679,15 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
     SP_TRY(nabu_attn_fwd(&ad, t, dec_len, enc_len, r + R.keys, values, qt, p->attention_v, p->conv_kernel,
                          p->conv_proj, r + R.align + (size_t)t * B * Te, r + R.ctx + (size_t)t * B * E,
                          r + R.align + (size_t)(t + 1) * B * Te, r + R.ctx + (size_t)(t + 1) * B * E, stream));
+    if (sampling && t + 1 < L) {
+      // ScheduledEmbeddingTrainingHelper: the step's logits decide the next input of selected rows
+      float *lt = r + R.logits_tm + (size_t)t * B * C;
+      SP_TRY(mm(false, false, B, C, U, htop, U, p->out_kernel, C, 0.f, lt, C, p->out_bias, gw, gwb, stream));
+      SP_TRY(mm(false, false, B, C, E, r + R.ctx + (size_t)(t + 1) * B * E, E, p->out_kernel + (size_t)U * C, C, 1.f, lt, C,
+                nullptr, gw, gwb, stream));
+      SP_TRY(nabu_sample_ids(B, C, lt, d->sample_prob, d->sample_seed, d->sample_offset + (unsigned long long)t,
+                             ids + (size_t)(t + 1) * B, ids_used + (size_t)(t + 1) * B, stream));
+    }
   }
   // output projection of all steps: [h_t, ctx_t]·W + b, then batch-major + impute_finished
   float *ltm = r + R.logits_tm;
@@ -760,7 +784,7 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
     const float *dzn = w + W.dz[n];
     float *gK = g->lstm_kernel[n];
     if (n == 0) {
-      SP_TRY(nabu_scatter_rows_f32(C, BL, 4 * U, ids, dzn, gK, stream));
+      SP_TRY(nabu_scatter_rows_f32(C, BL, 4 * U, reinterpret_cast<const int32_t *>(r + R.ids), dzn, gK, stream));
       SP_TRY(mm(true, false, E, 4 * U, BL, r + R.ctx, E, dzn, 4 * U, 0.f, gK + (size_t)C * 4 * U, 4 * U, nullptr, gw, gwb, stream));
       SP_TRY(mm(true, false, U, 4 * U, BL, r + R.H[0], U, dzn, 4 * U, 0.f, gK + (size_t)(C + E) * 4 * U, 4 * U, nullptr, gw, gwb, stream));
     } else {

@@ -5,7 +5,8 @@ label C-1, build the cell, run it over the whole target sequence — but
 ``tf.contrib.seq2seq.dynamic_decode`` over a ScheduledEmbeddingTrainingHelper is
 ``dynamic_decode`` below: ONE call into the C ABI (nabu_speller_fwd) whose C++
 driver launches, per decoder step, the recurrent GEMMs, the fused LSTM-cell
-kernel, the query GEMM and the fused attention kernel, and one output-projection
+kernel, the query GEMM and the fused attention kernel (plus, with sample_prob > 0,
+the step's projection and the scheduled-sampling kernel), and one output-projection
 GEMM for all steps at the end.  Its gradient (nabu_speller_bwd) is the mirrored
 loop with hand-written backward kernels; weight gradients that are sums over
 steps are single GEMMs over all steps."""
@@ -45,10 +46,6 @@ def dynamic_decode(cell, encoded, encoded_seq_length, targets, target_seq_length
     encoded [B,Te,E] (rows >= length zero), targets [B,Lt] int32 (already holding EOS
     where the recipe uses it), target_seq_length [B].  Returns logits [B,L,C] with
     L = max(target_seq_length); rows of finished utterances are zero."""
-    if sample_prob > 0 and is_training:
-        raise NotImplementedError(
-            'scheduled sampling (sample_prob > 0) is not implemented on the HIP path yet; set '
-            'sample_prob = 0 in the [decoder] section')
     wrapper = cell._cell
     mech = wrapper.attention_mechanism
     cells = wrapper.cells
@@ -79,8 +76,15 @@ def dynamic_decode(cell, encoded, encoded_seq_length, targets, target_seq_length
     seed, offset = nops.global_rng().next() if keep < 1 else (0, 0)
     if keep < 1:
         nops.global_rng().offset += L * nl          # one mask per (step, layer)
+    # scheduled sampling (ScheduledEmbeddingTrainingHelper, rnn_decoder.py:59-66); like the
+    # reference it is active whenever _decode runs, in the training and the validation graph
+    sprob = float(sample_prob)
+    sseed, soffset = nops.global_rng().next() if sprob > 0 else (0, 0)
+    if sprob > 0:
+        nops.global_rng().offset += L
     desc = _hip.SpellerDesc(ctypes.sizeof(_hip.SpellerDesc), B, Te, E, U, C, L, nl, mech.kind,
-                            mech.filtersize, mech.numfilt, keep, seed, offset * 1000003)
+                            mech.filtersize, mech.numfilt, keep, seed, offset * 1000003,
+                            sprob, sseed, soffset * 1000003)
     lib = _hip.lib()
     reserve_bytes = lib.nabu_speller_reserve_bytes(ctypes.byref(desc))
     ws_bytes = lib.nabu_speller_ws_bytes(ctypes.byref(desc))
@@ -114,7 +118,18 @@ def dynamic_decode(cell, encoded, encoded_seq_length, targets, target_seq_length
         return [dvalues]
 
     record([encoded], [logits], backward)
+    dynamic_decode.last = (desc, reserve)           # for decoder_inputs() below (tests, diagnostics)
     return logits, tlen
+
+
+def decoder_inputs():
+    """[L,B] int32 labels the last dynamic_decode fed to the cell (row 0 = SOS; later rows are the
+    targets shifted by one, or samples where scheduled sampling replaced them)"""
+    desc, reserve = dynamic_decode.last
+    out = torch.empty((desc.L, desc.B), dtype=torch.int32, device=reserve.device)
+    _hip.check(_hip.lib().nabu_speller_decoder_inputs(ctypes.byref(desc), _hip.ptr(reserve), _hip.ptr(out),
+                                                      _hip.stream()), 'nabu_speller_decoder_inputs')
+    return out
 
 
 class RNNDecoder(ed_decoder.EDDecoder, metaclass=ABCMeta):

@@ -133,6 +133,15 @@ def dropout(x, keep_prob, seed, offset):
     return y
 
 
+def sample_ids(logits, prob, seed, offset, teacher_ids):
+    """scheduled-sampling choice of the next decoder input (ScheduledEmbeddingTrainingHelper)"""
+    B, C = logits.shape
+    out = torch.empty_like(teacher_ids)
+    check(_hip.lib().nabu_sample_ids(B, C, ptr(logits), prob, seed, offset, ptr(teacher_ids), ptr(out), stream()),
+          'nabu_sample_ids')
+    return out
+
+
 def gaussian_noise(x, stddev, seed, offset):
     y = torch.empty_like(x)
     check(_hip.lib().nabu_gaussian_noise_f32(x.numel(), ptr(x), ptr(y), stddev, seed, offset, stream()),

@@ -422,9 +422,14 @@ def _prob_bwd(dalpha, alpha, score, mask, kind):
 
 
 def speller_fwd(enc, enc_len, targets, target_len, p, attention='vanilla',
-                probability_fn='softmax'):
+                probability_fn='softmax', dec_inputs=None):
     """RNNDecoder._decode (rnn_decoder.py:13-82) with Speller.create_cell
     (speller.py:13-69), sample_prob=0, dropout=1.
+
+    dec_inputs [B,L] (optional): the decoder input labels to use instead of
+    [SOS, targets[:-1]] — the inputs a ScheduledEmbeddingTrainingHelper run with
+    sample_prob > 0 actually fed (samples carry no gradient, so given its inputs
+    the computation is the deterministic one below).
 
     enc [B,Te,E], targets [B,Lmax] int (already containing EOS where the recipe
     uses string_eos), target_len [B].
@@ -451,6 +456,8 @@ def speller_fwd(enc, enc_len, targets, target_len, p, attention='vanilla',
     sos = C - 1                                                    # rnn_decoder.py:46-47
     inp_ids = np.concatenate([np.full((B, 1), sos, np.int64),
                               np.asarray(targets)[:, :L].astype(np.int64)], 1)
+    if dec_inputs is not None:
+        inp_ids = np.asarray(dec_inputs).astype(np.int64)
     logits = np.zeros((B, L, C), dt)
     steps = []
     for t in range(L):

@@ -167,3 +167,81 @@ def test_las_training_trajectory_matches_oracle(recipe, over):
     rel = np.abs(np.array(losses) - np.array(ref)) / np.abs(ref)
     assert rel.max() < 1e-3, (losses, ref)
     assert rel.max() < 1e-4, (losses, ref)
+
+
+def test_sample_ids_distribution_and_determinism():
+    """nabu_sample_ids: Bernoulli(prob) selection, then a draw from softmax(logits)"""
+    from nabu_amd import ops
+    B, C = 200000, 7
+    row = np.array([0.3, -1.0, 2.0, 0.0, 1.1, -3.0, 0.5], np.float32)
+    lg = torch.tensor(np.tile(row, (B, 1)), device='cuda')
+    teacher = torch.full((B,), 5, dtype=torch.int32, device='cuda')
+    a = ops.sample_ids(lg, 1.0, 11, 3, teacher)
+    b = ops.sample_ids(lg, 1.0, 11, 3, teacher)
+    assert torch.equal(a, b)                                       # pure function of (seed, offset)
+    assert not torch.equal(a, ops.sample_ids(lg, 1.0, 11, 4, teacher))
+    freq = np.bincount(a.cpu().numpy(), minlength=C) / B
+    sm = np.exp(row - row.max()); sm /= sm.sum()
+    assert np.abs(freq - sm).max() < 5e-3, (freq, sm)
+    assert torch.equal(ops.sample_ids(lg, 0.0, 11, 3, teacher), teacher)
+    part = ops.sample_ids(lg, 0.3, 11, 3, teacher).cpu().numpy()
+    changed = (part != 5).mean()                                   # P(select) * P(sample != 5)
+    assert abs(changed - 0.3 * (1 - sm[5])) < 5e-3
+
+
+@pytest.mark.parametrize('attention', ['vanilla', 'location_aware'])
+def test_scheduled_sampling_matches_oracle_given_its_samples(attention):
+    """sample_prob > 0 (speller.cfg default 0.1): the samples are random, but given the decoder
+    inputs that were drawn the computation is deterministic — logits, loss and gradients must
+    match the oracle run on those inputs (no gradient flows through a sample)."""
+    from nabu_amd import variables as vs
+    from nabu_amd.autodiff import Tape, SeqLen
+    from nabu_amd.neuralnetworks.models.ed_decoders import ed_decoder_factory, rnn_decoder
+    from nabu_amd.neuralnetworks.trainers import loss_functions
+    rng = np.random.default_rng(17)
+    B, Te, E, C, U = 6, 11, 16, 8, 16
+    over = {'decoder.num_layers': 1, 'decoder.num_units': U, 'decoder.attention': attention,
+            'decoder.sample_prob': 0.6}
+    if attention == 'location_aware':
+        over.update({'decoder.numfilt': 3, 'decoder.filtersize': 5})
+    mc, _, _ = recipes.load_recipe('cfg3_las_vanilla', **over)
+    dec = ed_decoder_factory.factory('speller')(mc, {'text': C}, None)
+    enc_len = np.array([11, 9, 11, 4, 7, 10], np.int32)
+    enc = rng.normal(size=(B, Te, E)).astype(np.float32)
+    enc *= (np.arange(Te)[None, :, None] < enc_len[:, None, None])
+    tlen = np.array([6, 3, 5, 6, 2, 6], np.int32)
+    tg = rng.integers(0, C - 1, (B, 6)).astype(np.int32)
+    for b in range(B):
+        tg[b, tlen[b] - 1] = C - 1
+        tg[b, tlen[b]:] = 0
+    store = vs.VariableStore(seed=5)
+    dev = torch.device('cuda')
+    tgd = torch.tensor(tg, device=dev)
+    with vs.as_default(store), Tape() as tape:
+        logits, lsl, _ = dec({'features': torch.tensor(enc, device=dev)}, {'features': SeqLen(enc_len, dev)},
+                             {'text': tgd}, {'text': SeqLen(tlen, dev)}, True)
+        loss = loss_functions.average_cross_entropy({'text': tgd}, logits, lsl, {'text': SeqLen(tlen, dev)})
+    used = rnn_decoder.decoder_inputs().cpu().numpy().T            # [B,L]
+    teacher = np.concatenate([np.full((B, 1), C - 1), tg[:, :5]], 1)
+    assert np.all(used[:, 0] == C - 1)
+    assert used.min() >= 0 and used.max() < C
+    frac = (used[:, 1:] != teacher[:, 1:]).mean()
+    assert 0.2 < frac < 0.9, frac                                  # ~0.6 * P(sample != target)
+    tape.backward(loss)
+    p = speller_params(store.state_dict(), 1, attention)
+    rl, rll, cache = O.speller_fwd(enc.astype(np.float64), enc_len, tg, tlen, p, attention, dec_inputs=used)
+    assert np.abs(logits['text'].cpu().numpy() - rl).max() < 2e-5
+    rloss, dlg = O.average_cross_entropy(rl, tg, rll, tlen)
+    assert abs(float(loss.item()) - rloss) / rloss < 1e-5
+    _, rg = O.speller_bwd(dlg, cache)
+    rel = lambda a, b_: np.abs(a - b_).max() / (np.abs(b_).max() + 1e-12)
+    for k, name in grad_names(1, attention).items():
+        g = store.vars[name].grad.cpu().numpy().astype(np.float64).reshape(rg[k].shape)
+        assert rel(g, rg[k]) < 2e-4, k
+    q = PRE + 'attention_wrapper/multi_rnn_cell/cell_0/lstm_cell/'
+    assert rel(store.vars[q + 'kernel'].grad.cpu().numpy(), rg['lstm'][0]['kernel']) < 2e-4
+    # a second pass draws different samples (the RNG offset advances)
+    with vs.as_default(store), Tape():
+        dec({'features': torch.tensor(enc, device=dev)}, {'features': SeqLen(enc_len, dev)},
+            {'text': tgd}, {'text': SeqLen(tlen, dev)}, True)
+    assert not np.array_equal(rnn_decoder.decoder_inputs().cpu().numpy().T, used)
