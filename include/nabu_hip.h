@@ -304,6 +304,25 @@ int nabu_sum_f32(size_t n, const float *x, float scale, float *out, nabu_stream_
 /* y += a*x : gradient accumulation where a tensor has several consumers. */
 int nabu_axpy_f32(size_t n, float a, const float *x, float *y, nabu_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * DNNDecoder hidden layers (models/ed_decoders/dnn_decoder.py:40-51):
+ * tf.contrib.layers.fully_connected = linear + ReLU, optional
+ * tf.contrib.layers.layer_norm, dropout.  The linear part is nabu_gemm_f32.
+ *   relu:      y = max(x, 0);  relu_bwd: dx = y > 0 ? dy : 0   (in place allowed)
+ *   layer_norm (TF-1.8 contrib defaults begin_norm_axis=1, begin_params_axis=-1,
+ *   variance_epsilon 1e-12): for a [B,T,F] input the moments are taken over ALL of
+ *   (T,F) per batch row — padded frames included — and gamma/beta are [F]:
+ *     y[b,n] = (x[b,n] - mean_b) * rstd_b * gamma[n % F] + beta[n % F],  n < N = T*F
+ *   fwd saves mean[B], rstd[B]; bwd writes dx and the per-row partial sums
+ *   dgamma_part/dbeta_part [B,F] (reduce them with nabu_colsum_f32; deterministic). */
+int nabu_relu_f32(size_t n, const float *x, float *y, nabu_stream_t stream);
+int nabu_relu_bwd_f32(size_t n, const float *y, const float *dy, float *dx, nabu_stream_t stream);
+int nabu_layer_norm_fwd(int B, int N, int F, const float *x, const float *gamma, const float *beta,
+                        float eps, float *y, float *mean, float *rstd, nabu_stream_t stream);
+int nabu_layer_norm_bwd(int B, int N, int F, const float *x, const float *gamma, const float *dy,
+                        const float *mean, const float *rstd, float *dx, float *dgamma_part,
+                        float *dbeta_part, nabu_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -222,6 +222,89 @@ __global__ __launch_bounds__(256) void axpy_kernel(size_t n, float a, const floa
     y[i] = fmaf(a, x[i], y[i]);
 }
 
+__global__ __launch_bounds__(256) void relu_kernel(size_t n, const float *__restrict__ x, float *__restrict__ y) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    y[i] = fmaxf(x[i], 0.f);
+}
+__global__ __launch_bounds__(256) void relu_bwd_kernel(size_t n, const float *__restrict__ y,
+                                                       const float *__restrict__ dy, float *__restrict__ dx) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+// block-wide sums of two values (fixed tree: deterministic)
+__device__ __forceinline__ void block_sum2(float &a, float &b, float *red) {
+  red[threadIdx.x] = a;
+  red[256 + threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red[threadIdx.x] += red[threadIdx.x + o];
+      red[256 + threadIdx.x] += red[256 + threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  a = red[0];
+  b = red[256];
+  __syncthreads();
+}
+
+// one workgroup per batch row; moments over all N = T*F elements of the row
+__global__ __launch_bounds__(256) void layer_norm_fwd_kernel(int N, int F, const float *__restrict__ x,
+                                                             const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, float eps,
+                                                             float *__restrict__ y, float *__restrict__ mean,
+                                                             float *__restrict__ rstd) {
+  __shared__ float red[512];
+  const float *xr = x + (size_t)blockIdx.x * N;
+  float *yr = y + (size_t)blockIdx.x * N;
+  float s = 0.f, dummy = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) s += xr[i];
+  block_sum2(s, dummy, red);
+  const float mu = s / N;
+  float v = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) { const float d = xr[i] - mu; v = fmaf(d, d, v); }
+  block_sum2(v, dummy, red);
+  const float rs = rsqrtf(v / N + eps);
+  for (int i = threadIdx.x; i < N; i += 256) yr[i] = (xr[i] - mu) * rs * gamma[i % F] + beta[i % F];
+  if (threadIdx.x == 0) { mean[blockIdx.x] = mu; rstd[blockIdx.x] = rs; }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma; partial dgamma/dbeta per row
+__global__ __launch_bounds__(256) void layer_norm_bwd_kernel(int N, int F, const float *__restrict__ x,
+                                                             const float *__restrict__ gamma,
+                                                             const float *__restrict__ dy,
+                                                             const float *__restrict__ mean,
+                                                             const float *__restrict__ rstd, float *__restrict__ dx,
+                                                             float *__restrict__ dgp, float *__restrict__ dbp) {
+  __shared__ float red[512];
+  const size_t row = (size_t)blockIdx.x * N;
+  const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const float g = dy[row + i] * gamma[i % F], xh = (x[row + i] - mu) * rs;
+    s1 += g;
+    s2 = fmaf(g, xh, s2);
+  }
+  block_sum2(s1, s2, red);
+  const float m1 = s1 / N, m2 = s2 / N;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const float g = dy[row + i] * gamma[i % F], xh = (x[row + i] - mu) * rs;
+    dx[row + i] = rs * (g - m1 - xh * m2);
+  }
+  // per-feature sums over the row's T frames (thread f walks its column: fixed order)
+  for (int f = threadIdx.x; f < F; f += 256) {
+    float a = 0.f, b = 0.f;
+    for (int i = f; i < N; i += F) {
+      const float d = dy[row + i];
+      a = fmaf(d, (x[row + i] - mu) * rs, a);
+      b += d;
+    }
+    dgp[(size_t)blockIdx.x * F + f] = a;
+    dbp[(size_t)blockIdx.x * F + f] = b;
+  }
+}
+
 static int grid_for(size_t work_items) {
   size_t b = (work_items + 255) / 256;
   if (b > 2048) b = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
@@ -342,6 +425,43 @@ extern "C" int nabu_axpy_f32(size_t n, float a, const float *x, float *y, nabu_s
   if (n == 0) return 0;
   NABU_CHECK_ARG(x && y, "axpy: null pointer");
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), n, a, x, y);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_relu_f32(size_t n, const float *x, float *y, nabu_stream_t stream) {
+  if (n == 0) return 0;
+  NABU_CHECK_ARG(x && y, "relu: null pointer");
+  hipLaunchKernelGGL(relu_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), n, x, y);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_relu_bwd_f32(size_t n, const float *y, const float *dy, float *dx, nabu_stream_t stream) {
+  if (n == 0) return 0;
+  NABU_CHECK_ARG(y && dy && dx, "relu_bwd: null pointer");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), n, y, dy, dx);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_layer_norm_fwd(int B, int N, int F, const float *x, const float *gamma, const float *beta,
+                                   float eps, float *y, float *mean, float *rstd, nabu_stream_t stream) {
+  NABU_CHECK_ARG(B > 0 && N > 0 && F > 0 && N % F == 0 && x && gamma && beta && y && mean && rstd,
+                 "layer_norm_fwd: bad argument");
+  hipLaunchKernelGGL(layer_norm_fwd_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), N, F, x, gamma,
+                     beta, eps, y, mean, rstd);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_layer_norm_bwd(int B, int N, int F, const float *x, const float *gamma, const float *dy,
+                                   const float *mean, const float *rstd, float *dx, float *dgamma_part,
+                                   float *dbeta_part, nabu_stream_t stream) {
+  NABU_CHECK_ARG(B > 0 && N > 0 && F > 0 && N % F == 0 && x && gamma && dy && mean && rstd && dx && dgamma_part &&
+                     dbeta_part, "layer_norm_bwd: bad argument");
+  hipLaunchKernelGGL(layer_norm_bwd_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), N, F, x, gamma,
+                     dy, mean, rstd, dx, dgamma_part, dbeta_part);
   NABU_LAUNCH_CHECK();
   return 0;
 }

@@ -1,11 +1,14 @@
 """DNN decoder (reference: models/ed_decoders/dnn_decoder.py:10-76).  With the CTC
 recipe (num_layers = 0) this is the single 'outlayer' linear map applied to every
-encoder frame: one MFMA GEMM with the bias fused into the epilogue."""
+encoder frame: one MFMA GEMM with the bias fused into the epilogue.  Hidden layers
+(fully_connected = linear + ReLU, optional layer_norm, dropout; :40-51) run on the same
+GEMM plus the relu / layer_norm kernels of the C ABI."""
 import torch
 
 from nabu_amd import ops as hip
 from nabu_amd import variables as vs
 from nabu_amd.autodiff import record, requires_grad
+from nabu_amd.neuralnetworks.components import ops as nops
 from nabu_amd.neuralnetworks.models.ed_decoders import ed_decoder
 
 
@@ -37,6 +40,40 @@ def linear(inputs, num_outputs, scope):
     return out
 
 
+def ones(rng, shape):
+    import numpy as np
+    return np.ones(shape, np.float32)
+
+
+def relu(x):
+    y = hip.relu(x if x.is_contiguous() else x.contiguous())
+    record([x], [y], lambda dy: [hip.relu_bwd(y, dy.contiguous())])
+    return y
+
+
+def layer_norm(inputs, scope='LayerNorm'):
+    """tf.contrib.layers.layer_norm(inputs) with its TF-1.8 defaults (begin_norm_axis=1,
+    begin_params_axis=-1): variables <scope>/beta (zeros) and <scope>/gamma (ones), both [F];
+    the moments of a [B,T,F] input are taken over (T,F) of each batch row."""
+    F = inputs.shape[-1]
+    with vs.variable_scope(scope):
+        beta = vs.get_variable('beta', [F], vs.zeros)
+        gamma = vs.get_variable('gamma', [F], ones)
+    x = inputs if inputs.is_contiguous() else inputs.contiguous()
+    y, mean, rstd = hip.layer_norm_fwd(x, gamma.data, beta.data)
+
+    def backward(dy):
+        dx, dgp, dbp = hip.layer_norm_bwd(x, gamma.data, dy.contiguous(), mean, rstd)
+        for v in (beta, gamma):
+            if v.grad is None:
+                v.grad = torch.zeros_like(v.data)
+        hip.colsum(dgp, gamma.grad)
+        hip.colsum(dbp, beta.grad)
+        return [dx]
+    record([inputs], [y], backward)
+    return y
+
+
 class DNNDecoder(ed_decoder.EDDecoder):
     '''a DNN decoder'''
 
@@ -46,10 +83,14 @@ class DNNDecoder(ed_decoder.EDDecoder):
         for o in self.output_dims:
             with vs.variable_scope(o):
                 output = encoded[first]
-                if int(self.conf['num_layers']) != 0:
-                    raise NotImplementedError(
-                        'DNNDecoder hidden layers (relu/layer_norm) are not on the hot path; '
-                        'the CTC recipe uses num_layers = 0 (DBLSTM/TIMIT/model.cfg:25)')
+                for l in range(int(self.conf['num_layers'])):           # dnn_decoder.py:40-51
+                    # tf.contrib.layers.fully_connected: linear + ReLU
+                    output = relu(linear(output, int(self.conf['num_units']), 'layer%d' % l))
+                    if self.conf['layer_norm'] == 'True':
+                        # TF uniquifies the default scope name of repeated calls
+                        output = layer_norm(output, 'LayerNorm' if l == 0 else 'LayerNorm_%d' % l)
+                    if float(self.conf['dropout']) < 1 and is_training:
+                        output = nops.seq_dropout(output, float(self.conf['dropout']), nops.global_rng())
                 output = linear(output, self.output_dims[o], 'outlayer')   # dnn_decoder.py:53-57
             outputs[o] = output
             output_seq_length[o] = encoded_seq_length[first]

@@ -297,3 +297,38 @@ def scatter_rows(ids, dz, dK):
     check(_hip.lib().nabu_scatter_rows_f32(dK.shape[0], N, W, ptr(ids), ptr(dz), ptr(dK), stream()),
           'nabu_scatter_rows_f32')
     return dK
+
+
+def relu(x):
+    y = torch.empty_like(x)
+    check(_hip.lib().nabu_relu_f32(x.numel(), ptr(x), ptr(y), stream()), 'nabu_relu_f32')
+    return y
+
+
+def relu_bwd(y, dy):
+    dx = torch.empty_like(y)
+    check(_hip.lib().nabu_relu_bwd_f32(y.numel(), ptr(y), ptr(dy), ptr(dx), stream()), 'nabu_relu_bwd_f32')
+    return dx
+
+
+def layer_norm_fwd(x, gamma, beta, eps=1e-12):
+    """x [B,...,F]: moments over everything but the batch axis (tf.contrib.layers.layer_norm)"""
+    B, F = x.shape[0], x.shape[-1]
+    N = x.numel() // B
+    y = torch.empty_like(x)
+    mean = torch.empty(B, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B, dtype=torch.float32, device=x.device)
+    check(_hip.lib().nabu_layer_norm_fwd(B, N, F, ptr(x), ptr(gamma), ptr(beta), eps, ptr(y), ptr(mean), ptr(rstd),
+                                         stream()), 'nabu_layer_norm_fwd')
+    return y, mean, rstd
+
+
+def layer_norm_bwd(x, gamma, dy, mean, rstd):
+    B, F = x.shape[0], x.shape[-1]
+    N = x.numel() // B
+    dx = torch.empty_like(x)
+    dgp = torch.empty((B, F), dtype=torch.float32, device=x.device)
+    dbp = torch.empty((B, F), dtype=torch.float32, device=x.device)
+    check(_hip.lib().nabu_layer_norm_bwd(B, N, F, ptr(x), ptr(gamma), ptr(dy), ptr(mean), ptr(rstd), ptr(dx),
+                                         ptr(dgp), ptr(dbp), stream()), 'nabu_layer_norm_bwd')
+    return dx, dgp, dbp

@@ -260,6 +260,41 @@ def linear_bwd(dout, x, W):
 # --------------------------------------------------------------------------
 # CTC (loss_functions.py:180-214 -> tf.nn.ctc_loss, time_major=False)
 # --------------------------------------------------------------------------
+def relu_fwd(x):
+    return np.maximum(x, 0)
+
+
+def relu_bwd(dy, y):
+    return np.where(y > 0, dy, 0)
+
+
+def layer_norm_fwd(x, gamma, beta, eps=1e-12):
+    """tf.contrib.layers.layer_norm(x) as called at dnn_decoder.py:46-47 with the TF-1.8
+    defaults begin_norm_axis=1, begin_params_axis=-1, variance_epsilon=1e-12: moments over
+    every axis but the batch axis (for [B,T,F]: over time AND features, padded frames
+    included); gamma/beta [F]."""
+    B = x.shape[0]
+    flat = x.reshape(B, -1)
+    mu = flat.mean(1)
+    var = flat.var(1)
+    rstd = 1.0 / np.sqrt(var + eps)
+    sh = (B,) + (1,) * (x.ndim - 1)
+    xh = (x - mu.reshape(sh)) * rstd.reshape(sh)
+    return xh * gamma + beta, (xh, rstd, gamma)
+
+
+def layer_norm_bwd(dy, cache):
+    xh, rstd, gamma = cache
+    B = xh.shape[0]
+    sh = (B,) + (1,) * (xh.ndim - 1)
+    g = dy * gamma
+    m1 = g.reshape(B, -1).mean(1).reshape(sh)
+    m2 = (g * xh).reshape(B, -1).mean(1).reshape(sh)
+    dx = rstd.reshape(sh) * (g - m1 - xh * m2)
+    red = tuple(range(xh.ndim - 1))
+    return dx, (dy * xh).sum(red), dy.sum(red)
+
+
 def _logsumexp2(a, b):
     m = np.maximum(a, b)
     with np.errstate(invalid='ignore'):

@@ -183,3 +183,63 @@ def test_dropout_and_input_noise_paths_run_and_are_regenerable():
                                                     'encoder.dropout': 0.5, 'trainer.batch_size': 3})
     l0 = float(tr.step(tr.to_device(data.batch(0))).item())
     assert np.isfinite(l0)
+
+
+def test_dnn_decoder_hidden_layers_match_oracle():
+    """dnn_decoder.py:40-51 with its shipped defaults (num_layers=1, layer_norm=True): names,
+    logits and every gradient against the oracle"""
+    from nabu_amd import variables as vs
+    from nabu_amd.autodiff import Tape, SeqLen, record
+    from nabu_amd.neuralnetworks.models.ed_decoders import ed_decoder_factory
+    rng = np.random.default_rng(8)
+    B, T, E, C, Hd = 3, 7, 12, 6, 8
+    mc, _, _ = recipes.load_recipe('cfg2_listener_ctc', **{'decoder.num_layers': 2, 'decoder.num_units': Hd,
+                                                           'decoder.layer_norm': 'True'})
+    dec = ed_decoder_factory.factory('dnn_decoder')(mc, {'text': C}, None)
+    enc = rng.normal(size=(B, T, E)).astype(np.float32)
+    dlog = rng.normal(size=(B, T, C)).astype(np.float32)
+    store = vs.VariableStore(seed=2)
+    dev = torch.device('cuda')
+    src = torch.tensor(enc, device=dev)
+    got = {}
+    with vs.as_default(store), Tape() as tape:
+        e = src.clone()
+        record([src], [e], lambda g: [got.setdefault('denc', g)] and [None])
+        logits, lsl, _ = dec({'features': e}, {'features': SeqLen(np.full(B, T, np.int32), dev)}, None, None, True)
+        # perturb gamma/beta away from their (1, 0) initial values so that their use is tested
+        for n in ('DNNDecoder/text/LayerNorm/gamma', 'DNNDecoder/text/LayerNorm_1/beta'):
+            store.vars[n].data += torch.tensor(rng.normal(size=Hd).astype(np.float32), device=dev) * 0.3
+    with vs.as_default(store), Tape() as tape:
+        e = src.clone()
+        record([src], [e], lambda g: [got.setdefault('denc', g)] and [None])
+        logits, lsl, _ = dec({'features': e}, {'features': SeqLen(np.full(B, T, np.int32), dev)}, None, None, True)
+        loss = (logits['text'] * torch.tensor(dlog, device=dev)).sum()
+        record([logits['text']], [loss], lambda g: [torch.tensor(dlog, device=dev)])
+    tape.backward(loss)
+    st = {k: v.astype(np.float64) for k, v in store.state_dict().items()}
+    assert sorted(st) == sorted(['DNNDecoder/text/%s' % n for n in (
+        'layer0/weights', 'layer0/biases', 'LayerNorm/beta', 'LayerNorm/gamma', 'layer1/weights', 'layer1/biases',
+        'LayerNorm_1/beta', 'LayerNorm_1/gamma', 'outlayer/weights', 'outlayer/biases')])
+    P = 'DNNDecoder/text/'
+    x = enc.astype(np.float64)
+    caches = []
+    for l, ln in ((0, 'LayerNorm'), (1, 'LayerNorm_1')):
+        a = O.linear_fwd(x, st[P + 'layer%d/weights' % l], st[P + 'layer%d/biases' % l])
+        r = O.relu_fwd(a)
+        y, c = O.layer_norm_fwd(r, st[P + ln + '/gamma'], st[P + ln + '/beta'])
+        caches.append((x, r, c))
+        x = y
+    ref = O.linear_fwd(x, st[P + 'outlayer/weights'], st[P + 'outlayer/biases'])
+    assert np.abs(logits['text'].cpu().numpy() - ref).max() < 2e-5
+    rel = lambda a, b_: np.abs(a - b_).max() / (np.abs(b_).max() + 1e-12)
+    g = lambda n: store.vars[P + n].grad.cpu().numpy().astype(np.float64)
+    d, dW, db = O.linear_bwd(dlog.astype(np.float64), x, st[P + 'outlayer/weights'])
+    assert rel(g('outlayer/weights'), dW) < 2e-4 and rel(g('outlayer/biases'), db) < 2e-4
+    for l, ln in ((1, 'LayerNorm_1'), (0, 'LayerNorm')):
+        xin, r, c = caches[l]
+        d, dg, dbeta = O.layer_norm_bwd(d, c)
+        assert rel(g(ln + '/gamma'), dg) < 2e-4 and rel(g(ln + '/beta'), dbeta) < 2e-4
+        d = O.relu_bwd(d, r)
+        d, dW, db = O.linear_bwd(d, xin, st[P + 'layer%d/weights' % l])
+        assert rel(g('layer%d/weights' % l), dW) < 2e-4 and rel(g('layer%d/biases' % l), db) < 2e-4
+    assert rel(got['denc'].cpu().numpy(), d) < 2e-4

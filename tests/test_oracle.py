@@ -317,3 +317,26 @@ def test_adam_and_lr_schedule():
     np.testing.assert_allclose(cur, tt.detach().numpy(), rtol=1e-9)
     assert O.learning_rate(1e-3, 0.1, 0, 100) == 1e-3
     np.testing.assert_allclose(O.learning_rate(1e-3, 0.1, 50, 100, 0.5), 1e-3 * 0.1 ** 0.5 * 0.5)
+
+
+def test_relu_layer_norm_vs_torch_autograd():
+    """DNNDecoder hidden-layer pieces: contrib layer_norm normalises over (T,F) per batch row"""
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(3, 5, 4))
+    gamma, beta = rng.normal(size=4), rng.normal(size=4)
+    dy = rng.normal(size=x.shape)
+    y, cache = O.layer_norm_fwd(x, gamma, beta)
+    dx, dg, db = O.layer_norm_bwd(dy, cache)
+    tx = torch.tensor(x, dtype=F64, requires_grad=True)
+    tg = torch.tensor(gamma, dtype=F64, requires_grad=True)
+    tb = torch.tensor(beta, dtype=F64, requires_grad=True)
+    mu = tx.reshape(3, -1).mean(1).reshape(3, 1, 1)
+    var = ((tx - mu) ** 2).reshape(3, -1).mean(1).reshape(3, 1, 1)
+    ty = (tx - mu) / torch.sqrt(var + 1e-12) * tg + tb
+    np.testing.assert_allclose(ty.detach().numpy(), y, atol=1e-12)
+    (ty * torch.tensor(dy)).sum().backward()
+    np.testing.assert_allclose(tx.grad.numpy(), dx, atol=1e-11)
+    np.testing.assert_allclose(tg.grad.numpy(), dg, atol=1e-11)
+    np.testing.assert_allclose(tb.grad.numpy(), db, atol=1e-11)
+    r = O.relu_fwd(x)
+    assert np.array_equal(O.relu_bwd(dy, r), np.where(x > 0, dy, 0))
