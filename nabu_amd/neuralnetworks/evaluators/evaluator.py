@@ -1,0 +1,48 @@
+"""General evaluator (reference: nabu/neuralnetworks/evaluators/evaluator.py:9-146).
+
+An evaluator measures a model on a validation set.  The reference builds a second input
+pipeline from the database sections its conf names and returns (loss variable, update op,
+number of batches); here ``evaluate()`` returns the same triple as plain Python objects:
+a 1-element list holding the running loss, a function that folds validation batch ``i`` into
+it, and the number of batches.  The validation data come from the batch source handed to
+the trainer: ``dataconf.validation(numbatches, batch_size)`` (processing.synthetic), the
+counterpart of the dev sections of database.conf."""
+from abc import ABCMeta, abstractmethod
+
+from nabu_amd.tools.default_conf import apply_defaults, defaults_path
+
+
+class Evaluator(object, metaclass=ABCMeta):
+    '''the general evaluator class'''
+
+    def __init__(self, conf, dataconf, model):
+        '''Args:
+            conf: the evaluator configuration as a ConfigParser ([evaluator] section)
+            dataconf: the batch source the trainer uses (must offer ``validation``)
+            model: the model to be evaluated'''
+        self.conf = dict(conf.items('evaluator'))
+        apply_defaults(self.conf, defaults_path(__file__, self))
+        self.model = model
+        if not hasattr(dataconf, 'validation'):
+            raise Exception('the batch source has no validation(numbatches, batch_size) method')
+        self.data = dataconf.validation(int(self.conf['numbatches']), int(self.conf['batch_size']))
+
+    def evaluate(self):
+        '''Returns:
+            - the loss as a 1-element list (the reference's loss variable)
+            - update(i): folds validation batch i into the loss (the reference's update op)
+            - the number of batches in the validation set'''
+        loss = [0.0]
+        self.reset()
+
+        def update(i):
+            self.update_loss(loss, self.data.batch(i))
+        return loss, update, self.data.num_batches()
+
+    @abstractmethod
+    def reset(self):
+        '''re-initialise the accumulators (the reference's init_validation op)'''
+
+    @abstractmethod
+    def update_loss(self, loss, batch):
+        '''fold one batch (A0 contract, numpy) into loss[0]'''

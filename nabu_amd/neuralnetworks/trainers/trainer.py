@@ -30,6 +30,35 @@ from nabu_amd.tools.default_conf import apply_defaults, defaults_path
 
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-8      # tf.train.AdamOptimizer defaults
 CLIP = 1.0                                         # tf.clip_by_value(grad, -1., 1.)
+CHECKPOINT_SECS = 600                              # MonitoredTrainingSession default
+
+
+class ValidationSaveHook(object):
+    '''saves and restores the validated model (reference components/hooks.py:54-86: a
+    tf.train.Saver over ALL global variables, i.e. weights, Adam slots, global step,
+    learning-rate factor and the validation bookkeeping).  Kept in host memory when the
+    trainer has no expdir.'''
+
+    def __init__(self, filename, trainer):
+        self.filename = filename
+        self.trainer = trainer
+        self._mem = None
+
+    def save(self):
+        st = self.trainer.state()
+        if self.filename is None or self.trainer.task_index != 0:
+            self._mem = st
+        else:
+            os.makedirs(os.path.dirname(self.filename), exist_ok=True)
+            torch.save(st, self.filename)
+            self._mem = st
+
+    def restore(self):
+        if self._mem is None and self.filename is not None and os.path.exists(self.filename):
+            self._mem = torch.load(self.filename, weights_only=False)
+        if self._mem is None:
+            raise Exception('no validated model to restore')
+        self.trainer.load_state(self._mem)
 
 
 class Trainer(object, metaclass=ABCMeta):
@@ -81,8 +110,32 @@ class Trainer(object, metaclass=ABCMeta):
         self.loss_fn = loss_functions.factory(self.conf['loss'])
         self.world = self.server.world_size if self.server is not None else 1
         self.flat = self.flat_grad = self.adam_m = self.adam_v = None
+        # validation part (reference trainer.py:189-265): bookkeeping 'variables' of the
+        # validate/ scope with the reference's initial values
+        self.evaluator = None
+        if (self.evaluatorconf is not None and self.evaluatorconf.has_section('evaluator')
+                and self.evaluatorconf.get('evaluator', 'evaluator') != 'None'):
+            self.evaluator = self._validate()
+        self.validated_step = -int(self.conf['valid_frequency'])
+        self.best_validation = 1.79e+308
+        self.num_tries = 0
+        self.validation_hook = ValidationSaveHook(
+            None if self.expdir is None else os.path.join(self.expdir, 'logdir', 'validated.ckpt'), self)
         self._graph = outputs
         return outputs
+
+    def _validate(self):
+        '''create the evaluator (reference trainer.py:459-477)'''
+        from nabu_amd.neuralnetworks.evaluators import evaluator_factory
+        evaltype = self.evaluatorconf.get('evaluator', 'evaluator')
+        return evaluator_factory.factory(evaltype)(conf=self.evaluatorconf, dataconf=self.data, model=self.model)
+
+    def validation_loss(self):
+        '''run the evaluator over the validation set (reference trainer.py:660-680)'''
+        loss, update_loss, valbatches = self.evaluator.evaluate()
+        for i in range(valbatches):
+            update_loss(i)
+        return loss[0]
 
     def _data(self):
         '''the batch source (reference trainer.py:285-423 builds the queue-runner
@@ -168,6 +221,77 @@ class Trainer(object, metaclass=ABCMeta):
                                ADAM_B1, ADAM_B2, ADAM_EPS, CLIP, 1.0)
         self.last_lr = lr
 
+    # ------------------------------------------------------- state (checkpoints)
+    def state(self):
+        '''everything tf.train.Saver() of the reference's session would write: model
+        variables, Adam slots, global step, learning-rate factor, validation bookkeeping'''
+        if self.flat is None:
+            self._init_optimizer()
+        from nabu_amd.neuralnetworks.components import ops as nops
+        return dict(names=list(self.model.store.order), flat=self.flat.detach().cpu().clone(),
+                    adam_m=self.adam_m.cpu().clone(), adam_v=self.adam_v.cpu().clone(),
+                    global_step=self.global_step, adam_step=self.adam_step,
+                    learning_rate_fact=self.learning_rate_fact, validated_step=self.validated_step,
+                    best_validation=self.best_validation, rng_offset=nops.global_rng().offset)
+
+    def load_state(self, st):
+        if self.flat is None:
+            self._init_optimizer()
+        if list(st['names']) != list(self.model.store.order) or st['flat'].numel() != self.flat.numel():
+            raise Exception('checkpoint does not match the model (variable names / sizes differ)')
+        from nabu_amd.neuralnetworks.components import ops as nops
+        self.flat.copy_(st['flat'])
+        self.adam_m.copy_(st['adam_m'])
+        self.adam_v.copy_(st['adam_v'])
+        self.global_step, self.adam_step = int(st['global_step']), int(st['adam_step'])
+        self.learning_rate_fact = float(st['learning_rate_fact'])
+        self.validated_step = int(st['validated_step'])
+        self.best_validation = float(st['best_validation'])
+        nops.global_rng().offset = int(st['rng_offset'])
+
+    def _ensure_variables(self):
+        '''variables are created by the first call of the model (the reference creates them
+        when it builds the graph): run one forward pass if that has not happened yet'''
+        if self.flat is None and not self.model.store.order:
+            b = self.to_device(self.data.batch(0))
+            with torch.no_grad():
+                self.model(b['inputs'], b['input_seq_length'], b['targets'], b['target_seq_length'], False)
+
+    def _validation_point(self):
+        '''the validation branch of the training loop (reference trainer.py:646-737).
+        Every replica evaluates the same validation set on identical weights, so all of them
+        take the same decision (the reference lets the chief decide and the others wait).
+        Returns True when training must terminate.'''
+        print('WORKER %d: validating model' % self.task_index)
+        prev_val_loss = self.best_validation
+        validation_loss = self.validation_loss()
+        print('WORKER %d: validation loss: %f' % (self.task_index, validation_loss))
+        self.validation_history.append((self.global_step, validation_loss))
+        if validation_loss >= prev_val_loss:
+            print('WORKER %d: validation loss is worse' % self.task_index)
+            if self.conf['num_tries'] != 'None':
+                if self.num_tries == int(self.conf['num_tries']):
+                    self.validation_hook.restore()
+                    print('WORKER %d: terminating training' % self.task_index)
+                    return True
+            self.num_tries += 1
+            if self.conf['go_back'] == 'True':
+                print('WORKER %d: loading previous model' % self.task_index)
+                self.validation_hook.restore()
+            else:
+                self.validated_step = self.global_step
+            if self.conf['valid_adapt'] == 'True':
+                print('WORKER %d: halving learning rate' % self.task_index)
+                self.learning_rate_fact /= 2
+                self.validation_hook.save()
+        else:
+            if self.conf['reset_tries'] == 'True':
+                self.num_tries = 0
+            self.validated_step = self.global_step
+            self.best_validation = validation_loss
+            self.validation_hook.save()
+        return False
+
     # ------------------------------------------------------------------ train
     def train(self, testing=False):
         '''train the model (reference trainer.py:582-792)
@@ -180,8 +304,22 @@ class Trainer(object, metaclass=ABCMeta):
             return []
         is_chief = self.task_index == 0
         history = []
+        self.validation_history = []
         num_steps = outputs['num_steps']
+        # MonitoredTrainingSession(checkpoint_dir=expdir/logdir) restores the latest checkpoint
+        # when one exists (reference trainer.py:625-633) and saves one every 600 s
+        ckpt = None if self.expdir is None else os.path.join(self.expdir, 'logdir', 'model.ckpt')
+        if ckpt is not None and os.path.exists(ckpt):
+            self._ensure_variables()
+            self.load_state(torch.load(ckpt, weights_only=False))
+            print('WORKER %d: resumed from %s at step %d' % (self.task_index, ckpt, self.global_step))
+        last_ckpt = time.time()
         while self.global_step < num_steps:
+            if (self.evaluator is not None
+                    and self.global_step - self.validated_step >= int(self.conf['valid_frequency'])):
+                self._ensure_variables()
+                if self._validation_point():
+                    break
             start = time.time()
             # each replica reads its own shard of the epoch (replaces the shared
             # filename queue on ps:0, trainer.py:342-351)
@@ -193,16 +331,29 @@ class Trainer(object, metaclass=ABCMeta):
                 loss_value = float(loss.item()) / self.world
             else:
                 loss_value = float(loss.item())
+            on_gpu = torch.cuda.is_available()
+            mem_used = torch.cuda.max_memory_allocated() if on_gpu else 0
+            mem_total = torch.cuda.get_device_properties(0).total_memory if on_gpu else 0
             print(('WORKER %d: step %d/%d loss: %f, learning rate: %f \n\t time elapsed: %f sec'
                    '\n\t peak memory usage: %d/%d MB')
                   % (self.task_index, self.global_step, num_steps, loss_value, self.last_lr,
-                     time.time() - start, torch.cuda.max_memory_allocated() / 1e6,
-                     torch.cuda.get_device_properties(0).total_memory / 1e6))
+                     time.time() - start, mem_used / 1e6, mem_total / 1e6))
             history.append((self.global_step, loss_value, self.last_lr))
             self.global_step += 1
+            every = getattr(self, 'checkpoint_steps', None)
+            if is_chief and ckpt is not None and (
+                    time.time() - last_ckpt > CHECKPOINT_SECS or (every and self.global_step % every == 0)):
+                self.save_checkpoint(ckpt)
+                last_ckpt = time.time()
         if is_chief and self.expdir is not None:
+            self.save_checkpoint(ckpt)
             self.save()
         return history
+
+    def save_checkpoint(self, path):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save(self.state(), path + '.tmp')
+        os.replace(path + '.tmp', path)
 
     def save(self):
         '''final model: variables by TF-style name (SaveAtEnd, hooks.py:30-52) and

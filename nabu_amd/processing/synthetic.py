@@ -31,6 +31,14 @@ class SyntheticData(object):
     def num_batches(self):
         return self.batches_per_epoch
 
+    def validation(self, numbatches, batch_size=None):
+        '''a disjoint batch source with the same statistics: the counterpart of the dev
+        sections of the reference's database.conf (evaluators/evaluator.py:37-60)'''
+        v = SyntheticData(self.B if batch_size is None else batch_size, self.T, self.D, self.num_labels,
+                          self.min_frames, self.min_labels, self.max_labels, self.eos, self.time_reduction,
+                          self.seed + 1000003, numbatches, self.input_name, self.target_name)
+        return v
+
     def batch(self, step):
         B, T, D = self.B, self.T, self.D
         r_len = np.random.default_rng([self.seed, step, 0])

@@ -243,3 +243,65 @@ def test_dnn_decoder_hidden_layers_match_oracle():
         d, dW, db = O.linear_bwd(d, xin, st[P + 'layer%d/weights' % l])
         assert rel(g('layer%d/weights' % l), dW) < 2e-4 and rel(g('layer%d/biases' % l), db) < 2e-4
     assert rel(got['denc'].cpu().numpy(), d) < 2e-4
+
+
+def test_train_loop_validates_checkpoints_and_resumes(tmp_path):
+    """Trainer.train with the LossEvaluator (reference loss_evaluator.py:8-64) on the HIP forward
+    path, the validated-model hook, the final model files, and resume from logdir/model.ckpt:
+    an interrupted run continued from its checkpoint reproduces the uninterrupted run bit for bit"""
+    import os
+    over = {'encoder.num_units': 16, 'trainer.batch_size': 3, 'trainer.num_epochs': 1,
+            'trainer.valid_frequency': 3, 'evaluator.batch_size': 2, 'evaluator.numbatches': 2}
+
+    def trainer(expdir, nb):
+        data = SyntheticData(3, 32, 40, min_frames=20, min_labels=2, max_labels=3, time_reduction=8, seed=11,
+                             batches_per_epoch=nb)
+        from nabu_amd.neuralnetworks.trainers import trainer_factory
+        mc, tc, ec = recipes.load_recipe('cfg2_listener_ctc', **over)
+        return trainer_factory.factory('standard')(conf=tc, dataconf=data, modelconf=mc, evaluatorconf=ec,
+                                                   expdir=expdir, server=None, task_index=0)
+    full = trainer(str(tmp_path / 'full'), 6)
+    hist = full.train()
+    assert [h[0] for h in hist] == list(range(6))
+    assert [s for s, _ in full.validation_history] == [0, 3]
+    v0 = full.validation_history[0][1]
+    assert np.isfinite(v0) and v0 > 0
+    for f in ('model/network.ckpt.npz', 'model/model.pkl', 'logdir/validated.ckpt', 'logdir/model.ckpt'):
+        assert os.path.exists(str(tmp_path / 'full' / f)), f
+    # the validation loss is the utterance-weighted mean of the per-batch losses: recompute it
+    ev = full.evaluator
+    loss, update, nb = ev.evaluate()
+    for i in range(nb):
+        update(i)
+    assert nb == 2 and np.isfinite(loss[0])
+    # interrupted run: 3 steps (num_steps must be the same for the learning-rate schedule), resume
+    part = trainer(str(tmp_path / 'part'), 6)
+    part._create_graph()
+    part._graph['num_steps'] = 6
+    part.checkpoint_steps = 3
+    orig = type(part).step
+    calls = {'n': 0}
+
+    class Stop(Exception):
+        pass
+
+    def step_then_stop(self, batch):
+        if calls['n'] == 3:
+            raise Stop()
+        calls['n'] += 1
+        return orig(self, batch)
+    type(part).step = step_then_stop
+    try:
+        with pytest.raises(Stop):
+            part.train()
+    finally:
+        type(part).step = orig
+    assert os.path.exists(str(tmp_path / 'part' / 'logdir' / 'model.ckpt'))
+    from nabu_amd.neuralnetworks.components import ops as nops
+    cont = trainer(str(tmp_path / 'part'), 6)
+    hist2 = cont.train()
+    assert [h[0] for h in hist2] == [3, 4, 5]
+    np.testing.assert_array_equal(np.array([h[1] for h in hist2]), np.array([h[1] for h in hist[3:]]))
+    a, b = full.model.store.state_dict(), cont.model.store.state_dict()
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
