@@ -765,10 +765,21 @@ static int pick_bs(int B, int H) {
   return 0;
 }
 
+// Batches that need more workgroups than the chip holds run as consecutive launches over
+// chunks of batch rows (the tensors are batch-major, a chunk is a contiguous slab): cfg5's
+// B = 64 at H = 512 is two launches of 32 rows.
+static int chunk_rows(int B, int H) {
+  if (pick_bs(B, H)) return B;
+  int c = 4 * (2 * NCU / (2 * (H / UC)));   // largest BS = 4 batch
+  return c < 4 ? 4 : c;
+}
+
 bool lstm_persist_supported(int B, int T, int H) {
   if (!(H == 64 || H == 128 || H == 256 || H == 512)) return false;
   if (B <= 0 || T <= 0) return false;
-  return pick_bs(B, H) != 0;
+  if ((size_t)B * T * 4 * H * 4 >= 0x80000000ull && (size_t)chunk_rows(B, H) * T * 4 * H * 4 >= 0x80000000ull)
+    return false;   // 32-bit buffer offsets inside one launch
+  return pick_bs(chunk_rows(B, H), H) != 0;
 }
 
 static size_t ring_bytes(bool fwd, int BS, int nshard, int H) {
@@ -778,9 +789,10 @@ static size_t ring_bytes(bool fwd, int BS, int nshard, int H) {
 
 size_t lstm_persist_ws_bytes(int B, int T, int H) {
   if (!lstm_persist_supported(B, T, H)) return 0;
+  const int Bc = chunk_rows(B, H);
   size_t m = 0;
   for (int BS = 4; BS <= 8; BS += 4) {   // either geometry may be selected at run time
-    const int ns = (B + BS - 1) / BS;
+    const int ns = (Bc + BS - 1) / BS;
     for (int f = 0; f < 2; ++f) {
       const size_t r = ring_bytes(f != 0, BS, ns, H);
       if (r > m) m = r;
@@ -805,12 +817,32 @@ static int launch(K kernel, const PersistArgs &a, int grid, int threads, size_t 
   return 0;
 }
 
+static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
+                     const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
+                     const float *dout, int *status, void *ws, size_t ws_bytes, hipStream_t stream);
+
 static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
                const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
                const float *dout, int *status, void *ws, size_t ws_bytes, hipStream_t stream) {
   if (!lstm_persist_supported(B, T, H)) return fail(NABU_EUNSUP, "persistent LSTM: unsupported B=%d H=%d", B, H);
   const size_t need = lstm_persist_ws_bytes(B, T, H);
   if (ws_bytes < need) return fail(NABU_EWS, "persistent LSTM: workspace %zu < %zu", ws_bytes, need);
+  const int Bc = chunk_rows(B, H);
+  for (int b0 = 0; b0 < B; b0 += Bc) {
+    const int nb = B - b0 < Bc ? B - b0 : Bc;
+    float *g2[2] = {gates[0] + (size_t)b0 * T * 4 * H, gates[1] + (size_t)b0 * T * 4 * H};
+    float *c2[2] = {cs[0] + (size_t)b0 * T * H, cs[1] + (size_t)b0 * T * H};
+    const int e = run_chunk(fwd, nb, T, D, H, max_len, len + b0, kernel, g2, c2,
+                            out ? out + (size_t)b0 * T * 2 * H : nullptr,
+                            dout ? dout + (size_t)b0 * T * 2 * H : nullptr, status, ws, ws_bytes, stream);
+    if (e) return e;
+  }
+  return 0;
+}
+
+static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
+                     const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
+                     const float *dout, int *status, void *ws, size_t ws_bytes, hipStream_t stream) {
   PersistArgs a;
   { const char *e = getenv("NABU_PERSIST_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   int BS = pick_bs(B, H);

@@ -231,6 +231,8 @@ def test_pad_unpad_time():
     (32, 30, 16, 512, 'ragged'),
     (8, 25, 40, 256, 'ragged'),                 # the cfg1 geometry
     (4, 10, 8, 128, [6, 4, 6, 3]),              # max(len) < T
+    (64, 12, 16, 512, 'ragged'),                # the cfg5 batch: two launches of 32 rows
+    (40, 9, 8, 512, None),                      # chunk of 32 + chunk of 8
 ])
 def test_blstm_persistent_matches_oracle(B, T, D, H, lens):
     from nabu_amd import ops
