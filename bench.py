@@ -92,6 +92,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--mode', default='auto', choices=['auto', 'stepwise', 'persistent'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gemm-precision', default='f32', choices=['f32', 'bf16x6', 'bf16x3', 'bf16'],
+                    help='arithmetic of the dense products (include/nabu_hip.h nabu_gemm_ex); the BASELINE metric '
+                         'is fp32 = the default; the others are reported as such in config.gemm_arith')
     ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg3'],
                     help='cfg2 (default) is the BASELINE.json metric; cfg3 = same encoder + Speller, for information')
     args = ap.parse_args()
@@ -112,6 +115,7 @@ def main():
     if world == 1:
         torch.cuda.set_device(0)
     _hip.lib()
+    ops.set_gemm_precision(args.gemm_precision)
     layer.LSTM_MODE[0] = {'auto': ops.LSTM_AUTO, 'stepwise': ops.LSTM_STEPWISE,
                           'persistent': ops.LSTM_PERSISTENT}[args.mode]
 
@@ -126,12 +130,15 @@ def main():
     tr = trainer_factory.factory('standard')(conf=tc, dataconf=data, modelconf=mc, evaluatorconf=ec,
                                              expdir=None, server=server, task_index=rank)
     batches = [tr.to_device(data.batch(i)) for i in range(2)]      # resident in HBM
-    for i in range(args.warmup):
+    # the event profiler is armed during the warm-up as well: its first use (event pool creation
+    # inside the HIP runtime) stalls the queue for tens of milliseconds once
+    prof = ops.enable_profiler()
+    for i in range(max(args.warmup, 1)):
         tr.step(batches[i % 2])
     loss_functions.check_status()
     torch.cuda.synchronize()
+    prof.collect()                                                 # drop the warm-up records
     server.barrier()
-    prof = ops.enable_profiler()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = tr.step(batches[i % 2])
@@ -183,12 +190,17 @@ def main():
                    'utterances/sec training step, Listener-512 + Speller (vanilla attention), batch 32x1000x40'),
         'value': round(world * B * args.steps / dt, 2), 'unit': 'utterances/sec', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32' if args.gemm_precision in ('f32', 'bf16x6') else 'f32 state / %s products' % args.gemm_precision,
         'data': 'synthetic',
         'config': {'workload': 'cfg2: Listener 3 pyramidal + 1 BLSTM x512, DNNDecoder, CTC, Adam+clip; '
                                '32 utt x 1000 frames x 40 fbank per GPU',
                    'global_batch': world * B, 'frames': T, 'parallelism': 'dp%d' % world,
-                   'recurrent_path': 'persistent' if persistent else 'stepwise'},
+                   'recurrent_path': 'persistent' if persistent else 'stepwise',
+                   'gemm_arith': {'f32': 'f32 (v_mfma_f32_32x32x2_f32, exact fp32)',
+                                  'bf16x6': 'f32 operands split into 3 bf16 pieces, 6 bf16 MFMA products, f32 accumulate',
+                                  'bf16x3': 'f32 operands split into 2 bf16 pieces, 3 bf16 MFMA products, f32 accumulate',
+                                  'bf16': 'operands rounded to bf16, f32 accumulate'}[args.gemm_precision]},
         'roofline': roofline,
         'hbm_roofline_frac_whole_step': round(step_bytes_total / (dt / args.steps) / (HBM_PEAK_GBS * 1e9), 4),
         'final_loss': round(final_loss, 4),

@@ -53,6 +53,24 @@ const char *nabu_last_error(void);
  * (components/attention.py:163-175) and their autodiff (trainers/trainer.py:556).
  * ws: split-K partial sums; query the size with nabu_gemm_ws_bytes. */
 size_t nabu_gemm_ws_bytes(int M, int N, int K);
+/* Arithmetic of the product (operands and result are fp32 in memory in every mode):
+ *   NABU_GEMM_F32    exact fp32 on v_mfma_f32_32x32x2_f32 (the default);
+ *   NABU_GEMM_BF16   operands rounded to bf16 inside the kernel, fp32 accumulation, on
+ *                    v_mfma_f32_32x32x16_bf16 — the "bf16 MFMA input-to-hidden GEMMs" of
+ *                    BASELINE.json configs[4];
+ *   NABU_GEMM_BF16X3 / NABU_GEMM_BF16X6  each operand split into 2 / 3 bf16 pieces, 3 / 6 bf16
+ *                    MFMA products: ~2^-16 / fp32-level (<= 2^-23) relative accuracy.
+ * NABU_GEMM_DEFAULT = the process default: NABU_GEMM_F32 unless changed by
+ * nabu_gemm_set_default_precision() or the environment variable NABU_GEMM_PRECISION
+ * (f32 | bf16 | bf16x3 | bf16x6).  Shapes the bf16 kernels do not take (K % 32, M % 4, N % 4,
+ * unaligned operands) silently use the exact fp32 kernel — never a lower precision than asked. */
+enum { NABU_GEMM_DEFAULT = 0, NABU_GEMM_F32 = 1, NABU_GEMM_BF16 = 2, NABU_GEMM_BF16X3 = 3, NABU_GEMM_BF16X6 = 4 };
+int nabu_gemm_set_default_precision(int precision);
+int nabu_gemm_get_default_precision(void);
+int nabu_gemm_ex(int precision, int transA, int transB, int M, int N, int K, float alpha,
+                 const float *A, int lda, const float *B, int ldb, float beta, float *C,
+                 int ldc, const float *bias, int kseg, long long a_seg_stride,
+                 long long b_seg_stride, void *ws, size_t ws_bytes, nabu_stream_t stream);
 int nabu_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
                   const float *A, int lda, const float *B, int ldb, float beta,
                   float *C, int ldc, const float *bias, int kseg,

@@ -27,6 +27,10 @@ SIGNATURES = {
     'nabu_gemm_ws_bytes': (_sz, [_i, _i, _i]),
     'nabu_gemm_f32': (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i, _vp, _i, _ll, _ll,
                            _vp, _sz, _vp]),
+    'nabu_gemm_ex': (_i, [_i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i, _vp, _i, _ll, _ll,
+                          _vp, _sz, _vp]),
+    'nabu_gemm_set_default_precision': (_i, [_i]),
+    'nabu_gemm_get_default_precision': (_i, []),
     'nabu_colsum_ws_bytes': (_sz, [_i, _i]),
     'nabu_colsum_f32': (_i, [_i, _i, _vp, _i, _f, _vp, _vp, _sz, _vp]),
     'nabu_blstm_reserve_bytes': (_sz, [_c.POINTER(BlstmDesc)]),
@@ -129,6 +133,8 @@ class Workspace(object):
 
 
 SPELLER_MAX_LAYERS = 4
+GEMM_DEFAULT, GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_BF16X6 = 0, 1, 2, 3, 4
+GEMM_PRECISIONS = {'default': 0, 'f32': 1, 'bf16': 2, 'bf16x3': 3, 'bf16x6': 4}
 
 
 class SpellerDesc(_c.Structure):

@@ -14,26 +14,12 @@
 // Small-MN / long-K products (weight gradients) use deterministic split-K:
 // partial tiles go to a workspace and are summed in fixed order by a second
 // kernel (no float atomics).
-#include "common.h"
+#include "gemm_args.h"
+
+#include <stdlib.h>
+#include <string>
 
 namespace nabu {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;
-
-struct GemmArgs {
-  const float *A, *B, *bias;
-  float *C;
-  float *partial;
-  int M, N, K, lda, ldb, ldc;
-  float alpha, beta;
-  int kseg;
-  long long a_seg, b_seg;
-  int ksplit;  // k-range per z-slice (multiple of BK)
-  int nsplit;
-  int vecA, vecB;  // 16-byte vector loads allowed
-};
 
 // ---- "k-contiguous" operand: element (r,k) at base[r*ld + k] ----------------
 __device__ __forceinline__ void load_kc(float4 (&v)[2], const float *base, int ld, int r0,
@@ -189,12 +175,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
 // no guards and no divergence in the loads (edge tiles clamp their addresses and drop
 // the surplus rows/columns at the store), so the next k-tile's global loads really
 // stay in flight under the current tile's 64 MFMAs per wave.
-constexpr int FBK = 32;
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[FBK][LDT];
-  __shared__ __attribute__((aligned(16))) float Bs[FBK][LDT];
+  // double-buffered operand tiles (2 x 2 x 16.5 KiB = 66 KiB: two workgroups per CU)
+  extern __shared__ __attribute__((aligned(16))) float fsm[];
+  typedef float (*Tile)[LDT];
+#define NABU_ATILE(buf) reinterpret_cast<Tile>(fsm + (buf) * (2 * FBK * LDT))
+#define NABU_BTILE(buf) reinterpret_cast<Tile>(fsm + (buf) * (2 * FBK * LDT) + FBK * LDT)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -214,7 +202,11 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
   //   k-contiguous operand (A with !TA, B with TB): element (r,k) at base[r*ld + k]
   //   r-contiguous operand (A with TA, B with !TB): element (r,k) at base[row(k) + r]
   float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;   // named scalars: arrays ended up in scratch
-#define NABU_GLOAD1(j, k0_)                                                                      \
+  // Load addresses are kept as running pointers (one per 16-byte piece) that advance by a constant
+  // per k-tile; recomputing them cost ~150 integer instructions per tile.  Segmented K (kseg > 0)
+  // has irregular row offsets and recomputes.
+  const float *pa0, *pa1, *pa2, *pa3, *pb0, *pb1, *pb2, *pb3;
+#define NABU_GADDR1(j, k0_)                                                                      \
   {                                                                                              \
     const int idx = tid + 256 * j;                                                               \
     if (TA) {                                                                                    \
@@ -222,25 +214,38 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
       const size_t off = a.kseg > 0 ? (size_t)(k / a.kseg) * (size_t)a.a_seg +                   \
                                           (size_t)(k % a.kseg) * a.lda                           \
                                     : (size_t)k * a.lda;                                         \
-      ra##j = *reinterpret_cast<const float4 *>(a.A + off + min(m0 + 4 * (idx & 31), a.M - 4));  \
+      pa##j = a.A + off + min(m0 + 4 * (idx & 31), a.M - 4);                                     \
     } else {                                                                                     \
-      ra##j = *reinterpret_cast<const float4 *>(a.A + (size_t)min(m0 + (idx >> 3), a.M - 1) * a.lda + \
-                                                (k0_) + 4 * (idx & 7));                          \
+      pa##j = a.A + (size_t)min(m0 + (idx >> 3), a.M - 1) * a.lda + (k0_) + 4 * (idx & 7);       \
     }                                                                                            \
     if (TB) {                                                                                    \
-      rb##j = *reinterpret_cast<const float4 *>(a.B + (size_t)min(n0 + (idx >> 3), a.N - 1) * a.ldb + \
-                                                (k0_) + 4 * (idx & 7));                          \
+      pb##j = a.B + (size_t)min(n0 + (idx >> 3), a.N - 1) * a.ldb + (k0_) + 4 * (idx & 7);       \
     } else {                                                                                     \
       const int k = (k0_) + (idx >> 5);                                                          \
       const size_t off = a.kseg > 0 ? (size_t)(k / a.kseg) * (size_t)a.b_seg +                   \
                                           (size_t)(k % a.kseg) * a.ldb                           \
                                     : (size_t)k * a.ldb;                                         \
-      rb##j = *reinterpret_cast<const float4 *>(a.B + off + min(n0 + 4 * (idx & 31), a.N - 4));  \
+      pb##j = a.B + off + min(n0 + 4 * (idx & 31), a.N - 4);                                     \
     }                                                                                            \
   }
-#define NABU_GLOAD(k0_) { NABU_GLOAD1(0, k0_) NABU_GLOAD1(1, k0_) NABU_GLOAD1(2, k0_) NABU_GLOAD1(3, k0_) }
+#define NABU_GADDR(k0_) { NABU_GADDR1(0, k0_) NABU_GADDR1(1, k0_) NABU_GADDR1(2, k0_) NABU_GADDR1(3, k0_) }
+  const size_t stepA = TA ? (size_t)FBK * a.lda : (size_t)FBK;
+  const size_t stepB = TB ? (size_t)FBK : (size_t)FBK * a.ldb;
+#define NABU_GLOAD1(j, k0_)                                                                      \
+  {                                                                                              \
+    ra##j = *reinterpret_cast<const float4 *>(pa##j);                                            \
+    rb##j = *reinterpret_cast<const float4 *>(pb##j);                                            \
+    pa##j += stepA;                                                                              \
+    pb##j += stepB;                                                                              \
+  }
+#define NABU_GLOAD(k0_)                                                                          \
+  {                                                                                              \
+    if (a.kseg > 0) NABU_GADDR(k0_)                                                              \
+    NABU_GLOAD1(0, k0_) NABU_GLOAD1(1, k0_) NABU_GLOAD1(2, k0_) NABU_GLOAD1(3, k0_)              \
+  }
 #define NABU_SSTORE1(j)                                                                          \
   {                                                                                              \
+    Tile As = NABU_ATILE(sbuf), Bs = NABU_BTILE(sbuf);                                           \
     const int idx = tid + 256 * j;                                                               \
     if (TA) {                                                                                    \
       *reinterpret_cast<float4 *>(&As[idx >> 5][4 * (idx & 31)]) = ra##j;                        \
@@ -257,13 +262,23 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
   }
 #define NABU_SSTORE() { NABU_SSTORE1(0) NABU_SSTORE1(1) NABU_SSTORE1(2) NABU_SSTORE1(3) }
 
+  // Pipeline, ONE barrier per k-tile: while tile i is multiplied out of LDS buffer i%2, the
+  // registers holding tile i+1 (loaded during the previous iteration) are written to the other
+  // buffer and the global loads of tile i+2 are issued — LDS stores and global loads sit between
+  // the MFMAs of the same wave (the matrix pipe runs them asynchronously).
+  int sbuf = 0;
+  NABU_GADDR(kbeg);
   NABU_GLOAD(kbeg);
   NABU_SSTORE();
+  const bool two = kbeg + FBK < kend && !(a.vecA & 2);   // vecA bit 1: timing experiment (no staging)
+  if (two) NABU_GLOAD(kbeg + FBK);
   __syncthreads();
   const int li = lane & 31, lk = lane >> 5;
+  int cur = 0;
   for (int k0 = kbeg; k0 < kend; k0 += FBK) {
-    const bool more = k0 + FBK < kend;
-    if (more) NABU_GLOAD(k0 + FBK);
+    const bool have_next = k0 + FBK < kend && !(a.vecA & 2);       // registers hold tile k0+FBK
+    const bool load_next2 = k0 + 2 * FBK < kend && !(a.vecA & 2);
+    Tile As = NABU_ATILE(cur), Bs = NABU_BTILE(cur);
 #pragma unroll
     for (int kk = 0; kk < FBK; kk += 2) {
       const float a0 = As[kk + lk][wm * 64 + li];
@@ -274,13 +289,21 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      if (kk == 2) {   // a few MFMAs are queued: stage the next tile behind them
+        if (have_next && !(a.vecA & 8)) {
+          sbuf = cur ^ 1;
+          NABU_SSTORE();
+        }
+        if (load_next2 && !(a.vecA & 4)) NABU_GLOAD(k0 + 2 * FBK);
+      }
     }
     __syncthreads();
-    if (more) {
-      NABU_SSTORE();
-      __syncthreads();
-    }
+    cur ^= 1;
   }
+#undef NABU_ATILE
+#undef NABU_BTILE
+#undef NABU_GADDR
+#undef NABU_GADDR1
 #undef NABU_GLOAD
 #undef NABU_SSTORE
 #undef NABU_GLOAD1
@@ -351,11 +374,43 @@ extern "C" size_t nabu_gemm_ws_bytes(int M, int N, int K) {
   return ns > 1 ? (size_t)ns * M * N * sizeof(float) : 0;
 }
 
+static int g_default_precision = 0;   // 0 = not initialised yet
+
+extern "C" int nabu_gemm_get_default_precision(void) {
+  if (g_default_precision == 0) {
+    g_default_precision = NABU_GEMM_F32;
+    if (const char *e = getenv("NABU_GEMM_PRECISION")) {
+      const std::string v(e);
+      if (v == "bf16") g_default_precision = NABU_GEMM_BF16;
+      else if (v == "bf16x3") g_default_precision = NABU_GEMM_BF16X3;
+      else if (v == "bf16x6") g_default_precision = NABU_GEMM_BF16X6;
+    }
+  }
+  return g_default_precision;
+}
+
+extern "C" int nabu_gemm_set_default_precision(int precision) {
+  NABU_CHECK_ARG(precision >= NABU_GEMM_F32 && precision <= NABU_GEMM_BF16X6, "gemm: unknown precision");
+  g_default_precision = precision;
+  return 0;
+}
+
 extern "C" int nabu_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
                              const float *A, int lda, const float *B, int ldb, float beta,
                              float *C, int ldc, const float *bias, int kseg,
                              long long a_seg_stride, long long b_seg_stride, void *ws,
                              size_t ws_bytes, nabu_stream_t stream) {
+  return nabu_gemm_ex(NABU_GEMM_DEFAULT, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, kseg,
+                      a_seg_stride, b_seg_stride, ws, ws_bytes, stream);
+}
+
+extern "C" int nabu_gemm_ex(int precision, int transA, int transB, int M, int N, int K, float alpha,
+                            const float *A, int lda, const float *B, int ldb, float beta,
+                            float *C, int ldc, const float *bias, int kseg,
+                            long long a_seg_stride, long long b_seg_stride, void *ws,
+                            size_t ws_bytes, nabu_stream_t stream) {
+  NABU_CHECK_ARG(precision >= NABU_GEMM_DEFAULT && precision <= NABU_GEMM_BF16X6, "gemm: unknown precision");
+  if (precision == NABU_GEMM_DEFAULT) precision = nabu_gemm_get_default_precision();
   NABU_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "gemm: negative dimension");
   if (M == 0 || N == 0) return 0;
   NABU_CHECK_ARG(A && B && C, "gemm: null pointer");
@@ -377,14 +432,28 @@ extern "C" int nabu_gemm_f32(int transA, int transB, int M, int N, int K, float 
   auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   a.vecA = al16(A) && lda % 4 == 0 && (a_seg_stride % 4 == 0);
   a.vecB = al16(B) && ldb % 4 == 0 && (b_seg_stride % 4 == 0);
+  if (const char *e = getenv("NABU_GEMM_NOSTAGE")) a.vecA |= 2 * atoi(e);   // timing experiments: 1 nothing, 2 no loads, 4 no LDS stores
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, a.nsplit), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool fast = M % 4 == 0 && N % 4 == 0 && K > 0 && K % FBK == 0 && a.vecA && a.vecB;
+  if (fast && precision != NABU_GEMM_F32) {
+    if (int e = gemm_bf16_launch(a, transA != 0, transB != 0, precision - NABU_GEMM_BF16 + 1, grid, s)) return e;
+  } else
   if (fast) {
-    if (transA && transB) hipLaunchKernelGGL((gemm_f32_fast_kernel<true, true>), grid, block, 0, s, a);
-    else if (transA) hipLaunchKernelGGL((gemm_f32_fast_kernel<true, false>), grid, block, 0, s, a);
-    else if (transB) hipLaunchKernelGGL((gemm_f32_fast_kernel<false, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_f32_fast_kernel<false, false>), grid, block, 0, s, a);
+    const size_t lds = 4 * (size_t)FBK * LDT * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+      const void *fns[4] = {reinterpret_cast<const void *>(gemm_f32_fast_kernel<true, true>),
+                            reinterpret_cast<const void *>(gemm_f32_fast_kernel<true, false>),
+                            reinterpret_cast<const void *>(gemm_f32_fast_kernel<false, true>),
+                            reinterpret_cast<const void *>(gemm_f32_fast_kernel<false, false>)};
+      for (const void *f : fns) NABU_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured = true;
+    }
+    if (transA && transB) hipLaunchKernelGGL((gemm_f32_fast_kernel<true, true>), grid, block, lds, s, a);
+    else if (transA) hipLaunchKernelGGL((gemm_f32_fast_kernel<true, false>), grid, block, lds, s, a);
+    else if (transB) hipLaunchKernelGGL((gemm_f32_fast_kernel<false, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((gemm_f32_fast_kernel<false, false>), grid, block, lds, s, a);
   } else
   if (transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, a);
   else if (transA) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, a);

@@ -19,9 +19,10 @@ def _f32(t, name):
 
 def gemm(a, b, c, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None,
          M=None, N=None, K=None, lda=None, ldb=None, ldc=None,
-         kseg=0, a_seg=0, b_seg=0):
+         kseg=0, a_seg=0, b_seg=0, precision='default'):
     """c = alpha*op(a)@op(b) + beta*c + bias on 2-D row-major tensors (or raw
-    views when M/N/K/ld* are given explicitly)."""
+    views when M/N/K/ld* are given explicitly).  precision: 'default' | 'f32' | 'bf16' |
+    'bf16x3' | 'bf16x6' (include/nabu_hip.h, nabu_gemm_ex)."""
     L = _hip.lib()
     if M is None:
         M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
@@ -29,11 +30,21 @@ def gemm(a, b, c, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None,
         lda, ldb, ldc = a.stride(0), b.stride(0), c.stride(0)
     ws_bytes = L.nabu_gemm_ws_bytes(M, N, K)
     ws = Workspace.get(ws_bytes, c.device, 'gemm') if ws_bytes else None
-    check(L.nabu_gemm_f32(int(trans_a), int(trans_b), M, N, K, alpha, a.data_ptr(), lda,
-                          b.data_ptr(), ldb, beta, c.data_ptr(), ldc,
-                          bias.data_ptr() if bias is not None else None, kseg, a_seg, b_seg,
-                          ptr(ws), ws_bytes, stream()), 'nabu_gemm_f32')
+    check(L.nabu_gemm_ex(_hip.GEMM_PRECISIONS[precision], int(trans_a), int(trans_b), M, N, K, alpha,
+                         a.data_ptr(), lda, b.data_ptr(), ldb, beta, c.data_ptr(), ldc,
+                         bias.data_ptr() if bias is not None else None, kseg, a_seg, b_seg,
+                         ptr(ws), ws_bytes, stream()), 'nabu_gemm_ex')
     return c
+
+
+def set_gemm_precision(precision):
+    """process default of every GEMM that does not name a precision ('f32' | 'bf16' | 'bf16x3' | 'bf16x6')"""
+    check(_hip.lib().nabu_gemm_set_default_precision(_hip.GEMM_PRECISIONS[precision]), 'nabu_gemm_set_default_precision')
+
+
+def get_gemm_precision():
+    code = _hip.lib().nabu_gemm_get_default_precision()
+    return [k for k, v in _hip.GEMM_PRECISIONS.items() if v == code][0]
 
 
 def colsum(a, out, beta=0.0):

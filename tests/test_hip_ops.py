@@ -267,3 +267,53 @@ def test_blstm_persistent_is_deterministic_and_mode_is_reported():
     assert L.nabu_blstm_uses_persistent(ctypes.byref(d)) == 0
     d.mode, d.H = ops.LSTM_AUTO, 48
     assert L.nabu_blstm_uses_persistent(ctypes.byref(d)) == 0       # falls back to stepwise
+
+
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('prec,tol', [('bf16x6', 3e-6), ('bf16x3', 2e-5), ('bf16', 1e-2)])
+def test_gemm_bf16_split_precisions(ta, tb, prec, tol):
+    """nabu_gemm_ex on the bf16 matrix pipe: error against float64, relative to max|C|.  bf16x6 must
+    be as accurate as the exact-fp32 MFMA kernel (both are limited by fp32 accumulation)."""
+    from nabu_amd import ops
+    rng = np.random.default_rng(31 + 2 * ta + tb)
+    M, N, K = 392, 260, 1056                     # edge tiles in M and N, K a multiple of 32
+    a = rng.normal(size=(K, M) if ta else (M, K)).astype(np.float32) * np.exp(rng.normal(size=(1, 1))).astype(np.float32)
+    b = rng.normal(size=(N, K) if tb else (K, N)).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64) + bias
+    ad, bd = torch.tensor(a, device='cuda'), torch.tensor(b, device='cuda')
+    out = {}
+    for p in (prec, 'f32'):
+        c = torch.zeros(M, N, device='cuda')
+        ops.gemm(ad, bd, c, bool(ta), bool(tb), bias=torch.tensor(bias, device='cuda'), precision=p)
+        out[p] = np.abs(c.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert out[prec] < tol, out
+    if prec == 'bf16x6':
+        assert out[prec] < 2.0 * out['f32'] + 1e-7, out
+    if prec == 'bf16':
+        assert out[prec] > 1e-4                  # really the low-precision path
+
+
+def test_gemm_bf16x6_split_k_and_segmented_k():
+    """the weight-gradient shapes: deterministic split-K and the shifted h^T dz product"""
+    from nabu_amd import ops
+    rng = np.random.default_rng(5)
+    Bn, T, H, G = 8, 64, 64, 256                 # K = Bn*(T-1) = 504 -> not a multiple of 32: exact-fp32 fallback
+    x = rng.normal(size=(4096, 128)).astype(np.float32)
+    dz = rng.normal(size=(4096, 256)).astype(np.float32)
+    ref = x.astype(np.float64).T @ dz.astype(np.float64)
+    c = torch.zeros(128, 256, device='cuda')
+    ops.gemm(torch.tensor(x, device='cuda'), torch.tensor(dz, device='cuda'), c, True, False, precision='bf16x6')
+    assert np.abs(c.cpu().numpy() - ref).max() / np.abs(ref).max() < 3e-6
+    c2 = torch.zeros(128, 256, device='cuda')
+    ops.gemm(torch.tensor(x, device='cuda'), torch.tensor(dz, device='cuda'), c2, True, False, precision='bf16x6')
+    assert torch.equal(c, c2)                    # split-K partials are reduced in a fixed order
+    # default precision switch
+    assert ops.get_gemm_precision() == 'f32'
+    ops.set_gemm_precision('bf16x6')
+    try:
+        c3 = torch.zeros(128, 256, device='cuda')
+        ops.gemm(torch.tensor(x, device='cuda'), torch.tensor(dz, device='cuda'), c3, True, False)
+        assert torch.equal(c, c3)
+    finally:
+        ops.set_gemm_precision('f32')
