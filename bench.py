@@ -158,7 +158,7 @@ def main():
 
     # roofline of the dominant kernel: recurrent step(s), per launch
     import ctypes
-    desc = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), B, T, D, H, T, layer.LSTM_MODE[0])
+    desc = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), B, T, D, H, T, layer.LSTM_MODE[0], 0)
     persistent = bool(_hip.lib().nabu_blstm_uses_persistent(ctypes.byref(desc)))
     tot_ms = sum(r[4] for r in recs)
     tot_steps = sum(r[2] for r in recs)                   # timesteps covered (both directions each)

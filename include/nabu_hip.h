@@ -105,6 +105,9 @@ typedef struct {
   int32_t B, T, D, H;
   int32_t max_len;    /* max(len) if known on the host, else T */
   int32_t mode;       /* NABU_LSTM_* */
+  int32_t gemm_precision; /* NABU_GEMM_* of the input-to-hidden products X·Wx, dZ·Wx^T, X^T·dZ
+                             (BASELINE.json configs[4]: "bf16 MFMA input-to-hidden GEMMs");
+                             the recurrent weight gradient H^T·dZ follows the process default */
 } nabu_blstm_desc;
 
 size_t nabu_blstm_reserve_bytes(const nabu_blstm_desc *d);

@@ -17,7 +17,8 @@ _vp, _i, _f, _sz, _ll = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t, _c.c_lon
 
 class BlstmDesc(_c.Structure):
     _fields_ = [('size', _c.c_uint32), ('B', _c.c_int32), ('T', _c.c_int32), ('D', _c.c_int32),
-                ('H', _c.c_int32), ('max_len', _c.c_int32), ('mode', _c.c_int32)]
+                ('H', _c.c_int32), ('max_len', _c.c_int32), ('mode', _c.c_int32),
+                ('gemm_precision', _c.c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/nabu_hip.h

@@ -273,7 +273,7 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const in
 
   // time-batched input projections (MFMA): gates_d = x·Wx_d + b_d
   for (int dir = 0; dir < 2; ++dir) {
-    int e = nabu_gemm_f32(0, 0, B * T, 4 * H, D, 1.f, x, D, kern[dir], 4 * H, 0.f, gates[dir],
+    int e = nabu_gemm_ex(d->gemm_precision, 0, 0, B * T, 4 * H, D, 1.f, x, D, kern[dir], 4 * H, 0.f, gates[dir],
                           4 * H, bias[dir], 0, 0, 0, w + L.gemm_off, L.gemm_bytes, stream);
     if (e) return e;
   }
@@ -366,7 +366,7 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
   for (int dir = 0; dir < 2; ++dir) {
     int e;
     // dWx = x^T · dz
-    e = nabu_gemm_f32(1, 0, D, 4 * H, M, 1.f, x, D, gates[dir], 4 * H, 0.f, dkern[dir], 4 * H,
+    e = nabu_gemm_ex(d->gemm_precision, 1, 0, D, 4 * H, M, 1.f, x, D, gates[dir], 4 * H, 0.f, dkern[dir], 4 * H,
                       nullptr, 0, 0, 0, w + L.gemm_off, L.gemm_bytes, stream);
     if (e) return e;
     // dWh = h_{prev}^T · dz : fw pairs (out[b,t-1,:H], dz[b,t]); bw pairs (out[b,t+1,H:], dz[b,t])
@@ -380,7 +380,7 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
     if (e) return e;
     // dx (+)= dz · Wx^T
     if (d_x) {
-      e = nabu_gemm_f32(0, 1, M, D, 4 * H, 1.f, gates[dir], 4 * H, kern[dir], 4 * H,
+      e = nabu_gemm_ex(d->gemm_precision, 0, 1, M, D, 4 * H, 1.f, gates[dir], 4 * H, kern[dir], 4 * H,
                         dir == 0 ? 0.f : 1.f, d_x, D, nullptr, 0, 0, 0, w + L.gemm_off, L.gemm_bytes, stream);
       if (e) return e;
     }

@@ -12,6 +12,9 @@ from nabu_amd.neuralnetworks.components import ops
 # cell scope of tf.contrib.rnn.LayerNormBasicLSTMCell under bidirectional_dynamic_rnn
 _CELL = 'bidirectional_rnn/%s/layer_norm_basic_lstm_cell'
 LSTM_MODE = [hip.LSTM_AUTO]      # tests flip this to compare the two recurrent paths
+# arithmetic of the input-to-hidden GEMMs of the layers built next ('default' | 'f32' | 'bf16' |
+# 'bf16x3' | 'bf16x6'); set by the encoders from their `gemm_precision` cfg key
+GEMM_PRECISION = ['default']
 
 
 def blstm(inputs, sequence_length, num_units, layer_norm=False, scope=None):
@@ -32,7 +35,7 @@ def blstm(inputs, sequence_length, num_units, layer_norm=False, scope=None):
         bf = vs.get_variable((_CELL % 'fw') + '/bias', [4 * H])
         kb = vs.get_variable((_CELL % 'bw') + '/kernel', [D + H, 4 * H])
         bb = vs.get_variable((_CELL % 'bw') + '/bias', [4 * H])
-    plan = hip.BlstmPlan(B, T, D, H, min(lens.max(), T), LSTM_MODE[0])
+    plan = hip.BlstmPlan(B, T, D, H, min(lens.max(), T), LSTM_MODE[0], GEMM_PRECISION[0])
     x = inputs if inputs.is_contiguous() else inputs.contiguous()
     out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
     reserve = torch.empty(plan.reserve_bytes, dtype=torch.uint8, device=x.device)

@@ -10,6 +10,9 @@ class DBLSTM(ed_encoder.EDEncoder):
     def encode(self, inputs, input_seq_length, is_training):
         encoded, encoded_seq_length = {}, {}
         keep = float(self.conf['dropout'])
+        # build addition: arithmetic of the input-to-hidden GEMMs (BASELINE.json configs[4] asks for
+        # bf16 MFMA there); 'default' = the process default = exact fp32
+        layer.GEMM_PRECISION[0] = self.conf.get('gemm_precision', 'default')
         for inp in inputs:
             with vs.variable_scope(inp):
                 if is_training and float(self.conf['input_noise']) > 0:      # dblstm.py:37-42

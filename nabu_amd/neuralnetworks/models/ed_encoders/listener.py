@@ -11,6 +11,9 @@ class Listener(ed_encoder.EDEncoder):
     def encode(self, inputs, input_seq_length, is_training):
         encoded, encoded_seq_length = {}, {}
         keep = float(self.conf['dropout'])
+        # build addition: arithmetic of the input-to-hidden GEMMs (BASELINE.json configs[4] asks for
+        # bf16 MFMA there); 'default' = the process default = exact fp32
+        layer.GEMM_PRECISION[0] = self.conf.get('gemm_precision', 'default')
         for inp in inputs:
             with vs.variable_scope(inp):
                 std_input_noise = float(self.conf['input_noise'])

@@ -61,8 +61,9 @@ def colsum(a, out, beta=0.0):
 class BlstmPlan(object):
     """Shape descriptor + buffers of one BLSTM layer call."""
 
-    def __init__(self, B, T, D, H, max_len, mode=LSTM_AUTO):
-        self.desc = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), B, T, D, H, int(max_len), mode)
+    def __init__(self, B, T, D, H, max_len, mode=LSTM_AUTO, gemm_precision='default'):
+        self.desc = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), B, T, D, H, int(max_len), mode,
+                                   _hip.GEMM_PRECISIONS[gemm_precision])
         L = _hip.lib()
         self.reserve_bytes = L.nabu_blstm_reserve_bytes(ctypes.byref(self.desc))
         self.ws_bytes = L.nabu_blstm_ws_bytes(ctypes.byref(self.desc))

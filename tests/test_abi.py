@@ -33,13 +33,13 @@ def test_host_side_queries_and_argument_errors():
     import ctypes
     from nabu_amd import _hip
     lib = _hip.lib()
-    d = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), 32, 1000, 40, 512, 1000, 0)
+    d = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), 32, 1000, 40, 512, 1000, 0, 0)
     res = lib.nabu_blstm_reserve_bytes(ctypes.byref(d))
     assert res == (2 * 32 * 1000 * 2048 + 2 * 32 * 1000 * 512) * 4
     assert lib.nabu_blstm_ws_bytes(ctypes.byref(d)) > 0
-    bad = _hip.BlstmDesc(4, 32, 1000, 40, 512, 1000, 0)
+    bad = _hip.BlstmDesc(4, 32, 1000, 40, 512, 1000, 0, 0)
     assert lib.nabu_blstm_reserve_bytes(ctypes.byref(bad)) == 0
-    odd = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), 2, 3, 4, 6, 3, 0)       # H % 4 != 0
+    odd = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), 2, 3, 4, 6, 3, 0, 0)       # H % 4 != 0
     assert lib.nabu_blstm_reserve_bytes(ctypes.byref(odd)) == 0
     assert b'multiple of 4' in lib.nabu_last_error()
     assert lib.nabu_ctc_ws_bytes(32, 125, 60) == 32 * 125 * 121 * 4

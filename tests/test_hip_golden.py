@@ -90,7 +90,8 @@ def test_ctc_recipes_match_golden(name, recipe):
 def test_las_recipes_match_golden(name, recipe):
     fx = load(name)
     B, T, D, H, nl, C, steps, seed, U, K, F = [int(v) for v in fx['meta']]
-    over = {'encoder.num_units': H, 'decoder.num_units': U, 'trainer.batch_size': B}
+    over = {'encoder.num_units': H, 'decoder.num_units': U, 'trainer.batch_size': B,
+            'encoder.gemm_precision': 'f32'}          # exact-fp32 parity; the bf16 variant is tested below
     if K:
         over.update({'decoder.numfilt': F, 'decoder.filtersize': K})
     tr = trainer_with_weights(recipe, over, SyntheticData(B, T, D, eos=True), unpack(fx, 'w:'), batch_of(fx, 0))
@@ -121,3 +122,24 @@ def test_cfg1_exact_matches_golden():
     losses = [float(tr.step(tr.to_device(data.batch(s))).item()) for s in range(3)]
     rel = np.abs(np.array(losses) - fx['losses']) / fx['losses']
     assert rel.max() < 1e-3 and rel.max() < 5e-5, (losses, fx['losses'])
+
+
+def test_cfg5_recipe_with_its_bf16_input_gemms_stays_within_the_north_star_tolerance():
+    """BASELINE.json configs[4]: the cfg5 recipe as shipped (encoder.gemm_precision = bf16: operands of
+    the input-to-hidden products rounded to bf16, fp32 accumulation and state) against the fp32
+    golden trajectory: per-step loss within 1e-3 relative (north_star), gradients within 3 %."""
+    fx = load('cfg5_small')
+    B, T, D, H, nl, C, steps, seed, U, K, F = [int(v) for v in fx['meta']]
+    over = {'encoder.num_units': H, 'decoder.num_units': U, 'trainer.batch_size': B,
+            'decoder.numfilt': F, 'decoder.filtersize': K}
+    mc, _, _ = recipes.load_recipe('cfg5_las_location')
+    assert mc.get('encoder', 'gemm_precision') == 'bf16'
+    tr = trainer_with_weights('cfg5_las_location', over, SyntheticData(B, T, D, eos=True), unpack(fx, 'w:'),
+                              batch_of(fx, 0))
+    loss0 = step0_grads(tr, batch_of(fx, 0), 'average_cross_entropy')
+    assert abs(loss0 - fx['losses'][0]) / fx['losses'][0] < 1e-3
+    assert abs(loss0 - fx['losses'][0]) > 0          # really a different arithmetic
+    check_grads(tr, unpack(fx, 'g:'), tol=3e-2)
+    losses = [float(tr.step(tr.to_device(batch_of(fx, s))).item()) for s in range(steps)]
+    rel = np.abs(np.array(losses) - fx['losses']) / fx['losses']
+    assert rel.max() < 1e-3, (losses, fx['losses'])

@@ -261,7 +261,7 @@ def test_blstm_persistent_is_deterministic_and_mode_is_reported():
     for k in a[4]:
         assert np.array_equal(a[4][k], b[4][k])
     L = _hip.lib()
-    d = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), 32, 1000, 40, 512, 1000, ops.LSTM_AUTO)
+    d = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), 32, 1000, 40, 512, 1000, ops.LSTM_AUTO, 0)
     assert L.nabu_blstm_uses_persistent(ctypes.byref(d)) == 1
     d.mode = ops.LSTM_STEPWISE
     assert L.nabu_blstm_uses_persistent(ctypes.byref(d)) == 0
