@@ -95,8 +95,10 @@ def main():
     ap.add_argument('--gemm-precision', default='f32', choices=['f32', 'bf16x6', 'bf16x3', 'bf16'],
                     help='arithmetic of the dense products (include/nabu_hip.h nabu_gemm_ex); the BASELINE metric '
                          'is fp32 = the default; the others are reported as such in config.gemm_arith')
-    ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg3'],
-                    help='cfg2 (default) is the BASELINE.json metric; cfg3 = same encoder + Speller, for information')
+    ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg3', 'cfg5'],
+                    help='cfg2 (default) is the BASELINE.json metric; cfg3 = same encoder + Speller; cfg5 = '
+                         'location-aware LAS, batch 64x1600x80, bf16 input GEMMs (BASELINE.json configs[2]/[4]), '
+                         'for information')
     args = ap.parse_args()
 
     import torch
@@ -119,7 +121,13 @@ def main():
     layer.LSTM_MODE[0] = {'auto': ops.LSTM_AUTO, 'stepwise': ops.LSTM_STEPWISE,
                           'persistent': ops.LSTM_PERSISTENT}[args.mode]
 
-    if args.workload == 'cfg3':
+    global B, T, D
+    if args.workload == 'cfg5':
+        B, T, D = 64, 1600, 80
+        mc, tc, ec = recipes.load_recipe('cfg5_las_location')
+        data = SyntheticData(B, T, D, min_frames=T, min_labels=40, max_labels=159, eos=True, time_reduction=8,
+                             seed=5234 + rank)
+    elif args.workload == 'cfg3':
         mc, tc, ec = recipes.load_recipe('cfg3_las_vanilla')
         data = SyntheticData(B, T, D, min_frames=T, min_labels=20, max_labels=79, eos=True, time_reduction=8,
                              seed=3234 + rank)
@@ -183,18 +191,24 @@ def main():
                 'recurrent_ms_per_step': round(tot_ms / args.steps, 3),
                 'note': 'algorithmic bytes (W_h streamed per timestep model, SURVEY.md 8(d)); '
                         'events recorded by the library around the recurrent launches'}
-    step_bytes_total = 2 * 2 * sum(LAYER_T) * step_bytes(B, H)
+    layer_t = [T >> i for i in range(4)]
+    step_bytes_total = 2 * 2 * sum(layer_t) * step_bytes(B, H)
     out = {
-        'metric': ('utterances/sec training step, 4x512 Listener+CTC, batch 32x1000x40 fbank'
-                   if args.workload == 'cfg2' else
-                   'utterances/sec training step, Listener-512 + Speller (vanilla attention), batch 32x1000x40'),
+        'metric': {'cfg2': 'utterances/sec training step, 4x512 Listener+CTC, batch 32x1000x40 fbank',
+                   'cfg3': 'utterances/sec training step, Listener-512 + Speller (vanilla attention), batch 32x1000x40',
+                   'cfg5': 'utterances/sec training step, Listener-512 + Speller (location-aware attention), '
+                           'bf16 input GEMMs, batch 64x1600x80'}[args.workload],
         'value': round(world * B * args.steps / dt, 2), 'unit': 'utterances/sec', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32' if args.gemm_precision in ('f32', 'bf16x6') else 'f32 state / %s products' % args.gemm_precision,
         'data': 'synthetic',
-        'config': {'workload': 'cfg2: Listener 3 pyramidal + 1 BLSTM x512, DNNDecoder, CTC, Adam+clip; '
-                               '32 utt x 1000 frames x 40 fbank per GPU',
+        'config': {'workload': {'cfg2': 'cfg2: Listener 3 pyramidal + 1 BLSTM x512, DNNDecoder, CTC, Adam+clip; '
+                                        '32 utt x 1000 frames x 40 fbank per GPU',
+                                'cfg3': 'cfg3: cfg2 encoder + Speller (1x512 LSTMCell, Bahdanau attention), '
+                                        'average cross-entropy; 32 utt x 1000 frames x 40 fbank per GPU',
+                                'cfg5': 'cfg5: Listener-512 (bf16 input GEMMs) + Speller (location-aware attention); '
+                                        '64 utt x 1600 frames x 80 fbank per GPU'}[args.workload],
                    'global_batch': world * B, 'frames': T, 'parallelism': 'dp%d' % world,
                    'recurrent_path': 'persistent' if persistent else 'stepwise',
                    'gemm_arith': {'f32': 'f32 (v_mfma_f32_32x32x2_f32, exact fp32)',

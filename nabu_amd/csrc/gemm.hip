@@ -370,7 +370,9 @@ using namespace nabu;
 extern "C" size_t nabu_gemm_ws_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   int ks;
-  const int ns = choose_split(M, N, K, &ks);
+  int ns = choose_split(M, N, K, &ks);
+  const int kc = gemm_skinny_chunk(M, N, K);
+  if (kc && K / kc > ns) ns = K / kc;
   return ns > 1 ? (size_t)ns * M * N * sizeof(float) : 0;
 }
 
@@ -423,6 +425,13 @@ extern "C" int nabu_gemm_ex(int precision, int transA, int transB, int M, int N,
   a.kseg = kseg; a.a_seg = a_seg_stride; a.b_seg = b_seg_stride;
   a.nsplit = K > 0 ? choose_split(M, N, K, &a.ksplit) : 1;
   if (K == 0) a.ksplit = BK;
+  auto al16p = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  // skinny products (decoder steps): exact fp32 whatever the requested precision
+  const int skinny_kc = (!transA && !transB && kseg == 0 && al16p(A) && lda % 4 == 0) ? gemm_skinny_chunk(M, N, K) : 0;
+  if (skinny_kc) {
+    a.ksplit = skinny_kc;
+    a.nsplit = K / skinny_kc;
+  }
   a.partial = nullptr;
   if (a.nsplit > 1) {
     const size_t need = (size_t)a.nsplit * M * N * sizeof(float);
@@ -436,6 +445,9 @@ extern "C" int nabu_gemm_ex(int precision, int transA, int transB, int M, int N,
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, a.nsplit), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool fast = M % 4 == 0 && N % 4 == 0 && K > 0 && K % FBK == 0 && a.vecA && a.vecB;
+  if (skinny_kc) {
+    if (int e = gemm_skinny_launch(a, s)) return e;
+  } else
   if (fast && precision != NABU_GEMM_F32) {
     if (int e = gemm_bf16_launch(a, transA != 0, transB != 0, precision - NABU_GEMM_BF16 + 1, grid, s)) return e;
   } else

@@ -22,6 +22,10 @@ struct GemmArgs {
   int vecA, vecB;  // 16-byte vector loads allowed
 };
 
+// skinny products (gemm_skinny.hip): M <= 64, no transposes
+int gemm_skinny_chunk(int M, int N, int K);
+int gemm_skinny_launch(const GemmArgs &a, hipStream_t stream);
+
 // bf16-split kernels (gemm_bf16.hip); planes = 1 (bf16), 2 (bf16x3) or 3 (bf16x6)
 int gemm_bf16_launch(const GemmArgs &a, bool transA, bool transB, int planes, dim3 grid, hipStream_t stream);
 

@@ -373,6 +373,26 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(int C, int N, int W, 
   dK[(size_t)c * W + col] = s;
 }
 
+// out[c][r] = in[r][c] (32x32 LDS tiles); used once per backward pass to turn the per-step
+// dz·W^T products into row-major products the skinny GEMM kernel takes
+__global__ __launch_bounds__(256) void transpose_kernel(int R, int C, const float *__restrict__ in, int ldin,
+                                                        float *__restrict__ out) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < R && c0 + tx < C) tile[i][tx] = in[(size_t)(r0 + i) * ldin + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < C && r0 + tx < R) out[(size_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+
+static int transpose(int R, int C, const float *in, int ldin, float *out, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, s, R, C, in, ldin, out);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
 static int grid1(size_t n) {
   size_t b = (n + 255) / 256;
   return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
@@ -540,6 +560,7 @@ static SpLayout sp_layout(const nabu_speller_desc *d) {
 struct SpWs {
   size_t z, dl, dH, dCtx, dkeys, dv, dwf, dck, dq, dz[NABU_SPELLER_MAX_LAYERS], dh[2][NABU_SPELLER_MAX_LAYERS],
       dc[2][NABU_SPELLER_MAX_LAYERS], dctx[2], dal[2], dx, tmp, gemm, gemm_bytes, total;
+  size_t wqT, kxT[NABU_SPELLER_MAX_LAYERS], khT[NABU_SPELLER_MAX_LAYERS];   // transposed weights (backward)
 };
 
 static SpWs sp_ws(const nabu_speller_desc *d) {
@@ -563,12 +584,18 @@ static SpWs sp_ws(const nabu_speller_desc *d) {
   for (int i = 0; i < 2; ++i) { s.dctx[i] = take(B * E); s.dal[i] = take(B * Te); }
   s.dx = take(B * U);
   s.tmp = take(B * U);
+  s.wqT = take(U * U);
+  for (int n = 0; n < d->num_layers; ++n) {
+    s.kxT[n] = take(4 * U * (n == 0 ? E : U));
+    s.khT[n] = take(4 * U * U);
+  }
   size_t g = 0;
   auto mx = [&](size_t v) { if (v > g) g = v; };
   const int BL = (int)(B * L), BT = (int)(B * Te);
   mx(nabu_gemm_ws_bytes((int)B, (int)(4 * U), (int)E)); mx(nabu_gemm_ws_bytes((int)B, (int)(4 * U), (int)U));
   mx(nabu_gemm_ws_bytes((int)B, (int)U, (int)U)); mx(nabu_gemm_ws_bytes((int)B, (int)E, (int)(4 * U)));
   mx(nabu_gemm_ws_bytes((int)B, (int)U, (int)(4 * U)));
+  mx(nabu_gemm_ws_bytes((int)B, (int)C, (int)U)); mx(nabu_gemm_ws_bytes((int)B, (int)C, (int)E));
   mx(nabu_gemm_ws_bytes(BT, (int)U, (int)E)); mx(nabu_gemm_ws_bytes(BT, (int)E, (int)U));
   mx(nabu_gemm_ws_bytes((int)E, (int)U, BT));
   mx(nabu_gemm_ws_bytes(BL, (int)C, (int)U)); mx(nabu_gemm_ws_bytes(BL, (int)C, (int)E));
@@ -737,6 +764,19 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
     NABU_HIP(hipMemsetAsync(w + W.dh[0][n], 0, (size_t)B * U * 4, s));
     NABU_HIP(hipMemsetAsync(w + W.dc[0][n], 0, (size_t)B * U * 4, s));
   }
+  // transposed copies of the weights the per-step gradient products use: dz·W^T becomes a
+  // row-major product with M = B rows, which the skinny GEMM kernel streams in a few microseconds
+  SP_TRY(transpose(U, U, p->query_kernel, U, w + W.wqT, s));
+  for (int n = 0; n < nl; ++n) {
+    const float *Kn = p->lstm_kernel[n];
+    if (n == 0) {
+      SP_TRY(transpose(E, 4 * U, Kn + (size_t)C * 4 * U, 4 * U, w + W.kxT[0], s));
+      SP_TRY(transpose(U, 4 * U, Kn + (size_t)(C + E) * 4 * U, 4 * U, w + W.khT[0], s));
+    } else {
+      SP_TRY(transpose(U, 4 * U, Kn, 4 * U, w + W.kxT[n], s));
+      SP_TRY(transpose(U, 4 * U, Kn + (size_t)U * 4 * U, 4 * U, w + W.khT[n], s));
+    }
+  }
   int cur = 0;   // index of the carries coming from step t+1
   const float *dctx_carry = nullptr, *dal_carry = nullptr;
   for (int t = L - 1; t >= 0; --t) {
@@ -750,10 +790,9 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
                          d->kind ? w + W.dwf : nullptr, d->kind ? w + W.dck : nullptr, dal_out, stream));
     dal_carry = dal_out;
     float *dHt = dH + (size_t)t * B * U;
-    SP_TRY(mm(false, true, B, U, U, dqt, U, p->query_kernel, U, 1.f, dHt, U, nullptr, gw, gwb, stream));
+    SP_TRY(mm(false, false, B, U, U, dqt, U, w + W.wqT, U, 1.f, dHt, U, nullptr, gw, gwb, stream));
     const float *dtop = dHt;
     for (int n = nl - 1; n >= 0; --n) {
-      const float *Kn = p->lstm_kernel[n];
       const float *dh_in = dtop;
       if (drop) {
         SP_TRY(nabu_dropout_f32((size_t)B * U, dtop, w + W.tmp, d->keep_prob, d->seed,
@@ -767,12 +806,12 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
                                 w + W.dc[cur ^ 1][n], stream));
       if (n == 0) {
         float *nx = w + W.dctx[t & 1];
-        SP_TRY(mm(false, true, B, E, 4 * U, dzt, 4 * U, Kn + (size_t)C * 4 * U, 4 * U, 0.f, nx, E, nullptr, gw, gwb, stream));
+        SP_TRY(mm(false, false, B, E, 4 * U, dzt, 4 * U, w + W.kxT[0], E, 0.f, nx, E, nullptr, gw, gwb, stream));
         dctx_carry = nx;
-        SP_TRY(mm(false, true, B, U, 4 * U, dzt, 4 * U, Kn + (size_t)(C + E) * 4 * U, 4 * U, 0.f, w + W.dh[cur ^ 1][0], U, nullptr, gw, gwb, stream));
+        SP_TRY(mm(false, false, B, U, 4 * U, dzt, 4 * U, w + W.khT[0], U, 0.f, w + W.dh[cur ^ 1][0], U, nullptr, gw, gwb, stream));
       } else {
-        SP_TRY(mm(false, true, B, U, 4 * U, dzt, 4 * U, Kn, 4 * U, 0.f, w + W.dx, U, nullptr, gw, gwb, stream));
-        SP_TRY(mm(false, true, B, U, 4 * U, dzt, 4 * U, Kn + (size_t)U * 4 * U, 4 * U, 0.f, w + W.dh[cur ^ 1][n], U, nullptr, gw, gwb, stream));
+        SP_TRY(mm(false, false, B, U, 4 * U, dzt, 4 * U, w + W.kxT[n], U, 0.f, w + W.dx, U, nullptr, gw, gwb, stream));
+        SP_TRY(mm(false, false, B, U, 4 * U, dzt, 4 * U, w + W.khT[n], U, 0.f, w + W.dh[cur ^ 1][n], U, nullptr, gw, gwb, stream));
         dtop = w + W.dx;
       }
     }

@@ -317,3 +317,24 @@ def test_gemm_bf16x6_split_k_and_segmented_k():
         assert torch.equal(c, c3)
     finally:
         ops.set_gemm_precision('f32')
+
+
+@pytest.mark.parametrize('M,N,K', [(32, 2048, 1536), (64, 2048, 512), (5, 64, 64), (33, 96, 384), (32, 40, 512)])
+def test_gemm_skinny_rows(M, N, K):
+    """the decoder-step products (M <= 64 batch rows): skinny kernel + split-K reduce, incl. bias/beta;
+    N = 40 is not a multiple of 32 and takes the tile kernel"""
+    from nabu_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    a = rng.normal(size=(M, K)).astype(np.float32)
+    b = rng.normal(size=(K, N)).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    c0 = rng.normal(size=(M, N)).astype(np.float32)
+    ref = 0.5 * (a.astype(np.float64) @ b.astype(np.float64)) + bias + 2.0 * c0
+    c = torch.tensor(c0, device='cuda')
+    ops.gemm(torch.tensor(a, device='cuda'), torch.tensor(b, device='cuda'), c, alpha=0.5, beta=2.0,
+             bias=torch.tensor(bias, device='cuda'))
+    assert np.abs(c.cpu().numpy() - ref).max() / np.abs(ref).max() < 3e-6
+    c2 = torch.tensor(c0, device='cuda')
+    ops.gemm(torch.tensor(a, device='cuda'), torch.tensor(b, device='cuda'), c2, alpha=0.5, beta=2.0,
+             bias=torch.tensor(bias, device='cuda'))
+    assert torch.equal(c, c2)
