@@ -127,17 +127,47 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
     conv_features(p, alp, cf, n);
     __syncthreads();
   }
-  // scores: one wave per encoder frame, lanes over units
-  for (int t = w; t < n; t += AT / 64) {
-    float s = 0.f;
-    for (int u = lane; u < U; u += 64) {
-      float x = keys[(size_t)t * U + u] + q[u];
-      if (p.kind)
-        for (int f = 0; f < p.F; ++f) x = fmaf(cf[t * p.F + f], p.wf[f * U + u], x);
-      s = fmaf(p.v[u], tanhf_(x), s);
+  // scores: waves over encoder frames (4 frames of a wave in flight), lanes over 16-byte groups of
+  // units — the keys are streamed once with coalesced 1 KiB wave loads
+  {
+    const int U4 = U / 4;
+    constexpr int NW = AT / 64, FR = 4;
+    const float4 *keys4 = reinterpret_cast<const float4 *>(keys);
+    const float4 *q4 = reinterpret_cast<const float4 *>(q), *v4 = reinterpret_cast<const float4 *>(p.v);
+    for (int t0 = w; t0 < n; t0 += FR * NW) {
+      float s[FR];
+#pragma unroll
+      for (int i = 0; i < FR; ++i) s[i] = 0.f;
+      for (int u4 = lane; u4 < U4; u4 += 64) {
+        const float4 qq = q4[u4], vv = v4[u4];
+        float4 kx[FR];
+#pragma unroll
+        for (int i = 0; i < FR; ++i) {
+          const int t = min(t0 + i * NW, n - 1);
+          kx[i] = keys4[(size_t)t * U4 + u4];
+        }
+#pragma unroll
+        for (int i = 0; i < FR; ++i) {
+          const int t = t0 + i * NW;
+          float4 x = make_float4(kx[i].x + qq.x, kx[i].y + qq.y, kx[i].z + qq.z, kx[i].w + qq.w);
+          if (p.kind && t < n)
+            for (int f = 0; f < p.F; ++f) {
+              const float c = cf[t * p.F + f];
+              const float4 wf = *reinterpret_cast<const float4 *>(p.wf + (size_t)f * U + 4 * u4);
+              x.x = fmaf(c, wf.x, x.x); x.y = fmaf(c, wf.y, x.y); x.z = fmaf(c, wf.z, x.z); x.w = fmaf(c, wf.w, x.w);
+            }
+          s[i] = fmaf(vv.x, tanhf_(x.x), s[i]);
+          s[i] = fmaf(vv.y, tanhf_(x.y), s[i]);
+          s[i] = fmaf(vv.z, tanhf_(x.z), s[i]);
+          s[i] = fmaf(vv.w, tanhf_(x.w), s[i]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < FR; ++i) {
+        const float tot = wave_sum(s[i]);
+        if (lane == 0 && t0 + i * NW < n) sc[t0 + i * NW] = tot;
+      }
     }
-    s = wave_sum(s);
-    if (lane == 0) sc[t] = s;
   }
   __syncthreads();
   // softmax over the valid frames (score_mask_value = -inf past the length)
@@ -168,11 +198,46 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
     align[t] = a;
   }
   __syncthreads();
-  // context = alignments^T · values : threads over the encoder dimension, coalesced rows
-  for (int e = tid; e < E; e += AT) {
-    float c = 0.f;
-    for (int t = 0; t < n; ++t) c = fmaf(sc[t], vals[(size_t)t * E + e], c);
-    ctx[e] = c;
+  // context = alignments^T · values: threads over 16-byte column groups, the frames split over
+  // the AT / (E/4) thread groups (8 frames of a thread in flight), partial sums through LDS
+  {
+    const int E4 = E / 4;
+    const int nsp = max(1, min(AT / max(E4, 1), 8));    // frame partitions
+    const float4 *vals4 = reinterpret_cast<const float4 *>(vals);
+    // [nsp][AT / nsp] partial sums behind the scalars of `red`, 16-byte aligned
+    float4 *part = reinterpret_cast<float4 *>(smem + ((2 * Te + (p.kind ? Te * p.F : 0) + 64 + 3) & ~3));
+    for (int c0 = 0; c0 < E4; c0 += AT / nsp) {
+      const int e4 = c0 + tid % (AT / nsp), pt = tid / (AT / nsp);
+      if (e4 < E4 && pt < nsp) {
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        int t = pt;
+        for (; t + 3 * nsp < n; t += 4 * nsp) {
+          const float4 a0 = vals4[(size_t)t * E4 + e4], a1 = vals4[(size_t)(t + nsp) * E4 + e4];
+          const float4 a2 = vals4[(size_t)(t + 2 * nsp) * E4 + e4], a3 = vals4[(size_t)(t + 3 * nsp) * E4 + e4];
+          const float w0 = sc[t], w1 = sc[t + nsp], w2 = sc[t + 2 * nsp], w3 = sc[t + 3 * nsp];
+          c.x = fmaf(w0, a0.x, c.x); c.y = fmaf(w0, a0.y, c.y); c.z = fmaf(w0, a0.z, c.z); c.w = fmaf(w0, a0.w, c.w);
+          c.x = fmaf(w1, a1.x, c.x); c.y = fmaf(w1, a1.y, c.y); c.z = fmaf(w1, a1.z, c.z); c.w = fmaf(w1, a1.w, c.w);
+          c.x = fmaf(w2, a2.x, c.x); c.y = fmaf(w2, a2.y, c.y); c.z = fmaf(w2, a2.z, c.z); c.w = fmaf(w2, a2.w, c.w);
+          c.x = fmaf(w3, a3.x, c.x); c.y = fmaf(w3, a3.y, c.y); c.z = fmaf(w3, a3.z, c.z); c.w = fmaf(w3, a3.w, c.w);
+        }
+        for (; t < n; t += nsp) {
+          const float4 a0 = vals4[(size_t)t * E4 + e4];
+          const float w0 = sc[t];
+          c.x = fmaf(w0, a0.x, c.x); c.y = fmaf(w0, a0.y, c.y); c.z = fmaf(w0, a0.z, c.z); c.w = fmaf(w0, a0.w, c.w);
+        }
+        part[pt * (AT / nsp) + (e4 - c0)] = c;
+      }
+      __syncthreads();
+      if (tid < AT / nsp && c0 + tid < E4) {
+        float4 c = part[tid];
+        for (int i = 1; i < nsp; ++i) {
+          const float4 o = part[i * (AT / nsp) + tid];
+          c.x += o.x; c.y += o.y; c.z += o.z; c.w += o.w;
+        }
+        reinterpret_cast<float4 *>(ctx)[c0 + tid] = c;
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -185,7 +250,8 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
   float *ds = alp + Te;                    // [Te] d score
   float *cf = ds + Te;                     // [Te*F]
   float *dcf = cf + (p.kind ? Te * F : 0); // [Te*F]
-  float *red = dcf + (p.kind ? Te * F : 0);  // [NW * U] cross-wave partials (dq / dv), also scalars
+  // [NW * U] cross-wave partials (dq / dv), also scalars; 16-byte aligned
+  float *red = smem + ((2 * Te + (p.kind ? 2 * Te * F : 0) + 3) & ~3);
   float *dq = p.dq + (size_t)b * U;
   float *dal_out = p.dalign_out ? p.dalign_out + (size_t)b * Te : nullptr;
   if (p.step >= p.dec_len[b]) {
@@ -206,12 +272,35 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
     __syncthreads();
     conv_features(p, alp, cf, n);
   }
-  // d alignment[t] = dctx · values[t] (+ the gradient arriving through next step's location features)
-  for (int t = w; t < n; t += NW) {
-    float s = 0.f;
-    for (int e = lane; e < E; e += 64) s = fmaf(dctx[e], vals[(size_t)t * E + e], s);
-    s = wave_sum(s);
-    if (lane == 0) ds[t] = s + (p.dalign_in ? p.dalign_in[(size_t)b * Te + t] : 0.f);
+  // d alignment[t] = dctx · values[t] (+ the gradient arriving through next step's location features):
+  // waves over frames (4 in flight), lanes over 16-byte groups of the encoder dimension
+  {
+    const int E4 = E / 4;
+    constexpr int FR = 4;
+    const float4 *vals4 = reinterpret_cast<const float4 *>(vals);
+    const float4 *dctx4 = reinterpret_cast<const float4 *>(dctx);
+    for (int t0 = w; t0 < n; t0 += FR * NW) {
+      float s[FR];
+#pragma unroll
+      for (int i = 0; i < FR; ++i) s[i] = 0.f;
+      for (int e4 = lane; e4 < E4; e4 += 64) {
+        const float4 dc = dctx4[e4];
+        float4 vv[FR];
+#pragma unroll
+        for (int i = 0; i < FR; ++i) vv[i] = vals4[(size_t)min(t0 + i * NW, n - 1) * E4 + e4];
+#pragma unroll
+        for (int i = 0; i < FR; ++i) {
+          s[i] = fmaf(dc.x, vv[i].x, s[i]); s[i] = fmaf(dc.y, vv[i].y, s[i]);
+          s[i] = fmaf(dc.z, vv[i].z, s[i]); s[i] = fmaf(dc.w, vv[i].w, s[i]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < FR; ++i) {
+        const int t = t0 + i * NW;
+        const float tot = wave_sum(s[i]);
+        if (lane == 0 && t < n) ds[t] = tot + (p.dalign_in ? p.dalign_in[(size_t)b * Te + t] : 0.f);
+      }
+    }
   }
   __syncthreads();
   // softmax backward: dscore = a * (da - sum a*da)
@@ -225,49 +314,88 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
   __syncthreads();
   for (int t = tid; t < Te; t += AT) ds[t] = t < n ? al[t] * (ds[t] - r) : 0.f;
   __syncthreads();
-  // through v·tanh(keys + q + f): lanes own units (u = lane + 64 j), waves split the frames
-  constexpr int MAXJ = 16;                 // U <= 1024
-  float dq_l[MAXJ], dv_l[MAXJ];
+  // through v·tanh(keys + q + f): lanes own 16-byte groups of units (u4 = lane + 64 j), waves split
+  // the frames (2 frames of a wave in flight); keys are read and dkeys updated with 1 KiB wave accesses
+  constexpr int MAXJ = 4;                  // U <= 1024
+  const int U4 = U / 4;
+  float4 dq_l[MAXJ], dv_l[MAXJ];
 #pragma unroll
-  for (int j = 0; j < MAXJ; ++j) dq_l[j] = dv_l[j] = 0.f;
-  for (int t = w; t < n; t += NW) {
-    const float g = ds[t];
-    float dcf_l[16];
+  for (int j = 0; j < MAXJ; ++j) dq_l[j] = dv_l[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const float4 *keys4 = reinterpret_cast<const float4 *>(keys);
+    float4 *dkeys4 = reinterpret_cast<float4 *>(dkeys);
+    const float4 *q4 = reinterpret_cast<const float4 *>(q), *v4 = reinterpret_cast<const float4 *>(p.v);
+    constexpr int FR = 2;
+    for (int t0 = w; t0 < n; t0 += FR * NW) {
+      float dcf_l[FR][16];
 #pragma unroll
-    for (int f = 0; f < 16; ++f) dcf_l[f] = 0.f;
+      for (int i = 0; i < FR; ++i)
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-      const int u = lane + 64 * j;
-      if (u < U) {
-        float x = keys[(size_t)t * U + u] + q[u];
-        if (p.kind)
-          for (int f = 0; f < F; ++f) x = fmaf(cf[t * F + f], p.wf[f * U + u], x);
-        const float th = tanhf_(x);
-        dv_l[j] = fmaf(g, th, dv_l[j]);
-        const float d = g * p.v[u] * (1.f - th * th);
-        dq_l[j] += d;
-        dkeys[(size_t)t * U + u] += d;
-        if (p.kind) {
+        for (int f = 0; f < 16; ++f) dcf_l[i][f] = 0.f;
 #pragma unroll
-          for (int f = 0; f < 16; ++f)
-            if (f < F) dcf_l[f] = fmaf(d, p.wf[f * U + u], dcf_l[f]);
+      for (int j = 0; j < MAXJ; ++j) {
+        const int u4 = lane + 64 * j;
+        if (u4 < U4) {
+          const float4 qq = q4[u4], vv = v4[u4];
+          float4 kx[FR], dk[FR];
+#pragma unroll
+          for (int i = 0; i < FR; ++i) {
+            const size_t o = (size_t)min(t0 + i * NW, n - 1) * U4 + u4;
+            kx[i] = keys4[o];
+            dk[i] = dkeys4[o];
+          }
+#pragma unroll
+          for (int i = 0; i < FR; ++i) {
+            const int t = t0 + i * NW;
+            if (t < n) {
+              const float g = ds[t];
+              float x[4] = {kx[i].x + qq.x, kx[i].y + qq.y, kx[i].z + qq.z, kx[i].w + qq.w};
+              if (p.kind)
+                for (int f = 0; f < F; ++f) {
+                  const float c = cf[t * F + f];
+                  const float4 wf = *reinterpret_cast<const float4 *>(p.wf + (size_t)f * U + 4 * u4);
+                  x[0] = fmaf(c, wf.x, x[0]); x[1] = fmaf(c, wf.y, x[1]); x[2] = fmaf(c, wf.z, x[2]); x[3] = fmaf(c, wf.w, x[3]);
+                }
+              const float vvv[4] = {vv.x, vv.y, vv.z, vv.w};
+              float d[4], th[4];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                th[c] = tanhf_(x[c]);
+                d[c] = g * vvv[c] * (1.f - th[c] * th[c]);
+              }
+              dv_l[j].x = fmaf(g, th[0], dv_l[j].x); dv_l[j].y = fmaf(g, th[1], dv_l[j].y);
+              dv_l[j].z = fmaf(g, th[2], dv_l[j].z); dv_l[j].w = fmaf(g, th[3], dv_l[j].w);
+              dq_l[j].x += d[0]; dq_l[j].y += d[1]; dq_l[j].z += d[2]; dq_l[j].w += d[3];
+              dkeys4[(size_t)t * U4 + u4] = make_float4(dk[i].x + d[0], dk[i].y + d[1], dk[i].z + d[2], dk[i].w + d[3]);
+              if (p.kind) {
+#pragma unroll
+                for (int f = 0; f < 16; ++f)
+                  if (f < F) {
+                    const float4 wf = *reinterpret_cast<const float4 *>(p.wf + (size_t)f * U + 4 * u4);
+                    dcf_l[i][f] = fmaf(d[0], wf.x, fmaf(d[1], wf.y, fmaf(d[2], wf.z, fmaf(d[3], wf.w, dcf_l[i][f]))));
+                  }
+              }
+            }
+          }
         }
       }
-    }
-    if (p.kind) {
+      if (p.kind) {
 #pragma unroll
-      for (int f = 0; f < 16; ++f)
-        if (f < F) {
-          const float s = wave_sum(dcf_l[f]);
-          if (lane == 0) dcf[t * F + f] = s;
-        }
+        for (int i = 0; i < FR; ++i)
+#pragma unroll
+          for (int f = 0; f < 16; ++f)
+            if (f < F) {
+              const float tot = wave_sum(dcf_l[i][f]);
+              if (lane == 0 && t0 + i * NW < n) dcf[(t0 + i * NW) * F + f] = tot;
+            }
+      }
     }
   }
   // cross-wave sums of dq and dv (fixed order)
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j) {
-    const int u = lane + 64 * j;
-    if (u < U) red[w * U + u] = dq_l[j];
+    const int u4 = lane + 64 * j;
+    if (u4 < U4) *reinterpret_cast<float4 *>(red + (size_t)w * U + 4 * u4) = dq_l[j];
   }
   __syncthreads();
   for (int u = tid; u < U; u += AT) {
@@ -278,8 +406,8 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j) {
-    const int u = lane + 64 * j;
-    if (u < U) red[w * U + u] = dv_l[j];
+    const int u4 = lane + 64 * j;
+    if (u4 < U4) *reinterpret_cast<float4 *>(red + (size_t)w * U + 4 * u4) = dv_l[j];
   }
   __syncthreads();
   for (int u = tid; u < U; u += AT) {
@@ -400,7 +528,7 @@ static int grid1(size_t n) {
 
 static size_t attn_lds(const nabu_attn_desc *d, bool bwd) {
   size_t f = 2 * (size_t)d->Te + (d->kind ? (size_t)d->Te * d->F * (bwd ? 2 : 1) : 0);
-  f += bwd ? (size_t)(AT / 64) * d->U : 64;
+  f += bwd ? 4 + (size_t)(AT / 64) * d->U : 64 + 4 + 4 * (size_t)AT;
   return f * sizeof(float);
 }
 
@@ -408,6 +536,7 @@ static int check_attn(const nabu_attn_desc *d) {
   if (!d || d->size != sizeof(nabu_attn_desc)) return fail(NABU_EINVAL, "attention: bad descriptor size");
   if (d->B <= 0 || d->Te <= 0 || d->E <= 0 || d->U <= 0) return fail(NABU_EINVAL, "attention: bad dimensions");
   if (d->U > 1024) return fail(NABU_EUNSUP, "attention: num_units > 1024");
+  if (d->U % 4 || d->E % 4) return fail(NABU_EUNSUP, "attention: num_units and encoder dim must be multiples of 4");
   if (d->kind != 0 && d->kind != 1) return fail(NABU_EINVAL, "attention: unknown kind");
   if (d->kind && (d->K <= 0 || d->F <= 0 || d->F > 16)) return fail(NABU_EUNSUP, "attention: numfilt must be 1..16");
   if (attn_lds(d, true) > 150 * 1024) return fail(NABU_EUNSUP, "attention: encoder length too large for LDS");
