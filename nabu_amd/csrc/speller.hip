@@ -105,11 +105,17 @@ __device__ __forceinline__ void conv_features(const AttnArgs &p, const float *al
   }
 }
 
+// REG = location-aware attention with U <= 512 and F <= 12: the Dense weights of the location
+// features (conv_proj) stay in registers for the whole kernel (forward), and their gradient is
+// accumulated in registers instead of a second pass over all frames (backward).
+constexpr int RJ = 2, RF = 12;
+template <int MODE>   // 0 vanilla, 1 location-aware (generic), 2 location-aware (REG)
 __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
+  constexpr bool REG = MODE == 2, KIND = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int Te = p.Te, U = p.U, E = p.E;
-  float *alp = smem, *sc = alp + Te, *cf = sc + Te, *red = cf + (p.kind ? Te * p.F : 0);
+  float *alp = smem, *sc = alp + Te, *cf = sc + Te, *red = cf + (KIND ? Te * p.F : 0);
   float *align = p.align + (size_t)b * Te;
   float *ctx = p.ctx + (size_t)b * E;
   if (p.step >= p.dec_len[b]) {   // finished row: state frozen
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
   const float *keys = p.keys + (size_t)b * Te * U;
   const float *vals = p.values + (size_t)b * Te * E;
   const float *q = p.q + (size_t)b * U;
-  if (p.kind) {
+  if (KIND) {
     for (int t = tid; t < Te; t += AT) alp[t] = p.align_prev[(size_t)b * Te + t];
     __syncthreads();
     conv_features(p, alp, cf, n);
@@ -134,11 +140,25 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
     constexpr int NW = AT / 64, FR = 4;
     const float4 *keys4 = reinterpret_cast<const float4 *>(keys);
     const float4 *q4 = reinterpret_cast<const float4 *>(q), *v4 = reinterpret_cast<const float4 *>(p.v);
+    float4 wfr[REG ? RF : 1][REG ? RJ : 1];
+    if (REG) {
+#pragma unroll
+      for (int f = 0; f < RF; ++f)
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) {
+          const int u4 = lane + 64 * j;
+          wfr[f][j] = (f < p.F && u4 < U4) ? *reinterpret_cast<const float4 *>(p.wf + (size_t)f * U + 4 * u4)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     for (int t0 = w; t0 < n; t0 += FR * NW) {
       float s[FR];
 #pragma unroll
       for (int i = 0; i < FR; ++i) s[i] = 0.f;
-      for (int u4 = lane; u4 < U4; u4 += 64) {
+#pragma unroll
+      for (int j = 0; j < (REG ? RJ : 4); ++j) {
+        const int u4 = lane + 64 * j;
+        if (u4 >= U4) continue;
         const float4 qq = q4[u4], vv = v4[u4];
         float4 kx[FR];
 #pragma unroll
@@ -150,7 +170,17 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
         for (int i = 0; i < FR; ++i) {
           const int t = t0 + i * NW;
           float4 x = make_float4(kx[i].x + qq.x, kx[i].y + qq.y, kx[i].z + qq.z, kx[i].w + qq.w);
-          if (p.kind && t < n)
+          if (REG) {
+            if (t < n) {
+#pragma unroll
+              for (int f = 0; f < RF; ++f)
+                if (f < p.F) {
+                  const float c = cf[t * p.F + f];
+                  const float4 wf = wfr[f][j];
+                  x.x = fmaf(c, wf.x, x.x); x.y = fmaf(c, wf.y, x.y); x.z = fmaf(c, wf.z, x.z); x.w = fmaf(c, wf.w, x.w);
+                }
+            }
+          } else if (KIND && t < n)
             for (int f = 0; f < p.F; ++f) {
               const float c = cf[t * p.F + f];
               const float4 wf = *reinterpret_cast<const float4 *>(p.wf + (size_t)f * U + 4 * u4);
@@ -205,7 +235,7 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
     const int nsp = max(1, min(AT / max(E4, 1), 8));    // frame partitions
     const float4 *vals4 = reinterpret_cast<const float4 *>(vals);
     // [nsp][AT / nsp] partial sums behind the scalars of `red`, 16-byte aligned
-    float4 *part = reinterpret_cast<float4 *>(smem + ((2 * Te + (p.kind ? Te * p.F : 0) + 64 + 3) & ~3));
+    float4 *part = reinterpret_cast<float4 *>(smem + ((2 * Te + (KIND ? Te * p.F : 0) + 64 + 3) & ~3));
     for (int c0 = 0; c0 < E4; c0 += AT / nsp) {
       const int e4 = c0 + tid % (AT / nsp), pt = tid / (AT / nsp);
       if (e4 < E4 && pt < nsp) {
@@ -241,7 +271,9 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
   }
 }
 
+template <int MODE>
 __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
+  constexpr bool REG = MODE == 2, KIND = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int Te = p.Te, U = p.U, E = p.E, F = p.F;
@@ -249,9 +281,9 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
   float *alp = smem;                       // [Te] previous alignment
   float *ds = alp + Te;                    // [Te] d score
   float *cf = ds + Te;                     // [Te*F]
-  float *dcf = cf + (p.kind ? Te * F : 0); // [Te*F]
+  float *dcf = cf + (KIND ? Te * F : 0); // [Te*F]
   // [NW * U] cross-wave partials (dq / dv), also scalars; 16-byte aligned
-  float *red = smem + ((2 * Te + (p.kind ? 2 * Te * F : 0) + 3) & ~3);
+  float *red = smem + ((2 * Te + (KIND ? 2 * Te * F : 0) + 3) & ~3);
   float *dq = p.dq + (size_t)b * U;
   float *dal_out = p.dalign_out ? p.dalign_out + (size_t)b * Te : nullptr;
   if (p.step >= p.dec_len[b]) {
@@ -267,7 +299,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
   const float *al = p.align + (size_t)b * Te;       // this step's alignments
   const float *dctx = p.dctx + (size_t)b * E;
   float *dkeys = p.dkeys + (size_t)b * Te * U;
-  if (p.kind) {
+  if (KIND) {
     for (int t = tid; t < Te; t += AT) alp[t] = p.align_prev[(size_t)b * Te + t];
     __syncthreads();
     conv_features(p, alp, cf, n);
@@ -316,22 +348,30 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
   __syncthreads();
   // through v·tanh(keys + q + f): lanes own 16-byte groups of units (u4 = lane + 64 j), waves split
   // the frames (2 frames of a wave in flight); keys are read and dkeys updated with 1 KiB wave accesses
-  constexpr int MAXJ = 4;                  // U <= 1024
+  constexpr int MAXJ = REG ? RJ : 4;       // U <= 1024 (REG: U <= 512)
+  constexpr int NF = REG ? RF : 16;
   const int U4 = U / 4;
   float4 dq_l[MAXJ], dv_l[MAXJ];
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j) dq_l[j] = dv_l[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 dwf_l[REG ? RF : 1][REG ? RJ : 1];   // d conv_proj[f, my units], summed over my frames
+  if (REG) {
+#pragma unroll
+    for (int f = 0; f < RF; ++f)
+#pragma unroll
+      for (int j = 0; j < RJ; ++j) dwf_l[f][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   {
     const float4 *keys4 = reinterpret_cast<const float4 *>(keys);
     float4 *dkeys4 = reinterpret_cast<float4 *>(dkeys);
     const float4 *q4 = reinterpret_cast<const float4 *>(q), *v4 = reinterpret_cast<const float4 *>(p.v);
-    constexpr int FR = 2;
+    constexpr int FR = KIND ? 1 : 2;         // frames of a wave in flight (registers!)
     for (int t0 = w; t0 < n; t0 += FR * NW) {
-      float dcf_l[FR][16];
+      float dcf_l[FR][NF];
 #pragma unroll
       for (int i = 0; i < FR; ++i)
 #pragma unroll
-        for (int f = 0; f < 16; ++f) dcf_l[i][f] = 0.f;
+        for (int f = 0; f < NF; ++f) dcf_l[i][f] = 0.f;
 #pragma unroll
       for (int j = 0; j < MAXJ; ++j) {
         const int u4 = lane + 64 * j;
@@ -350,7 +390,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
             if (t < n) {
               const float g = ds[t];
               float x[4] = {kx[i].x + qq.x, kx[i].y + qq.y, kx[i].z + qq.z, kx[i].w + qq.w};
-              if (p.kind)
+              if (KIND)
                 for (int f = 0; f < F; ++f) {
                   const float c = cf[t * F + f];
                   const float4 wf = *reinterpret_cast<const float4 *>(p.wf + (size_t)f * U + 4 * u4);
@@ -367,23 +407,28 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
               dv_l[j].z = fmaf(g, th[2], dv_l[j].z); dv_l[j].w = fmaf(g, th[3], dv_l[j].w);
               dq_l[j].x += d[0]; dq_l[j].y += d[1]; dq_l[j].z += d[2]; dq_l[j].w += d[3];
               dkeys4[(size_t)t * U4 + u4] = make_float4(dk[i].x + d[0], dk[i].y + d[1], dk[i].z + d[2], dk[i].w + d[3]);
-              if (p.kind) {
+              if (KIND) {
 #pragma unroll
-                for (int f = 0; f < 16; ++f)
+                for (int f = 0; f < (REG ? RF : 16); ++f)
                   if (f < F) {
                     const float4 wf = *reinterpret_cast<const float4 *>(p.wf + (size_t)f * U + 4 * u4);
                     dcf_l[i][f] = fmaf(d[0], wf.x, fmaf(d[1], wf.y, fmaf(d[2], wf.z, fmaf(d[3], wf.w, dcf_l[i][f]))));
+                    if (REG) {
+                      const float c = cf[t * F + f];
+                      dwf_l[f][j].x = fmaf(c, d[0], dwf_l[f][j].x); dwf_l[f][j].y = fmaf(c, d[1], dwf_l[f][j].y);
+                      dwf_l[f][j].z = fmaf(c, d[2], dwf_l[f][j].z); dwf_l[f][j].w = fmaf(c, d[3], dwf_l[f][j].w);
+                    }
                   }
               }
             }
           }
         }
       }
-      if (p.kind) {
+      if (KIND) {
 #pragma unroll
         for (int i = 0; i < FR; ++i)
 #pragma unroll
-          for (int f = 0; f < 16; ++f)
+          for (int f = 0; f < NF; ++f)
             if (f < F) {
               const float tot = wave_sum(dcf_l[i][f]);
               if (lane == 0 && t0 + i * NW < n) dcf[(t0 + i * NW) * F + f] = tot;
@@ -415,15 +460,34 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
     for (int i = 0; i < NW; ++i) s += red[i * U + u];
     p.dv_part[(size_t)b * U + u] += s;
   }
-  if (p.kind) {
+  if (KIND) {
     __syncthreads();
     // frames past the length (and frames no wave visited) carry no gradient
     for (int i = tid + n * F; i < Te * F; i += AT) dcf[i] = 0.f;
     __syncthreads();
     const int pb = (p.K - 1) / 2;
-    // d conv_proj[f,u] += sum_t cf[t,f] * dsu[t,u]  — recompute dsu per (f,u) would repeat the tanh;
-    // instead accumulate through dkeys' increment d = dscore*v*(1-th^2) is not stored, so this
-    // term is produced from cf and a second pass over the frames:
+    if (REG) {
+      // d conv_proj[f,u] += sum_t cf[t,f] * d[t,u]: the per-wave register sums, reduced across waves
+      // one feature at a time (fixed order)
+#pragma unroll
+      for (int f = 0; f < RF; ++f) {
+        if (f < F) {
+#pragma unroll
+          for (int j = 0; j < RJ; ++j) {
+            const int u4 = lane + 64 * j;
+            if (u4 < U4) *reinterpret_cast<float4 *>(red + (size_t)w * U + 4 * u4) = dwf_l[f][j];
+          }
+          __syncthreads();
+          for (int u = tid; u < U; u += AT) {
+            float sm = 0.f;
+            for (int i = 0; i < NW; ++i) sm += red[i * U + u];
+            p.dwf_part[((size_t)b * F + f) * U + u] += sm;
+          }
+          __syncthreads();
+        }
+      }
+    } else
+    // d conv_proj[f,u] += sum_t cf[t,f] * d[t,u] with d recomputed in a second pass over the frames
     for (int u = tid; u < U; u += AT) {
       float acc[16];
 #pragma unroll
@@ -590,10 +654,12 @@ extern "C" int nabu_attn_fwd(const nabu_attn_desc *d, int step, const int32_t *d
   p.align = align; p.ctx = ctx;
   const size_t shm = attn_lds(d, false);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool reg = d->kind && d->U <= 256 * RJ && d->F <= RF;
+  auto kern = !d->kind ? attn_fwd_kernel<0> : reg ? attn_fwd_kernel<2> : attn_fwd_kernel<1>;
   if (shm > 64 * 1024)
-    NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_kernel),
+    NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(d->B), dim3(AT), shm, s, p);
+  hipLaunchKernelGGL(kern, dim3(d->B), dim3(AT), shm, s, p);
   NABU_LAUNCH_CHECK();
   return 0;
 }
@@ -620,10 +686,12 @@ extern "C" int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *d
   p.dwf_part = dconv_proj_part; p.dck_part = dconv_kernel_part; p.dalign_out = dalign_out;
   const size_t shm = attn_lds(d, true);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool reg = d->kind && d->U <= 256 * RJ && d->F <= RF;
+  auto kern = !d->kind ? attn_bwd_kernel<0> : reg ? attn_bwd_kernel<2> : attn_bwd_kernel<1>;
   if (shm > 64 * 1024)
-    NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_kernel),
+    NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(d->B), dim3(AT), shm, s, p);
+  hipLaunchKernelGGL(kern, dim3(d->B), dim3(AT), shm, s, p);
   NABU_LAUNCH_CHECK();
   return 0;
 }

@@ -50,7 +50,8 @@ def grad_names(nl, attention):
 
 @pytest.mark.parametrize('attention,nl,U,K,F', [
     ('vanilla', 1, 32, 0, 0), ('vanilla', 2, 16, 0, 0),
-    ('location_aware', 1, 32, 5, 3), ('location_aware', 2, 16, 4, 2), ('location_aware', 1, 64, 11, 10)])
+    ('location_aware', 1, 32, 5, 3), ('location_aware', 2, 16, 4, 2), ('location_aware', 1, 64, 11, 10),
+    ('location_aware', 1, 32, 5, 14)])          # numfilt > 12: the generic location-aware kernels
 def test_speller_step_matches_oracle(attention, nl, U, K, F):
     """decoder alone on a given 'encoded' tensor: logits, loss and every gradient"""
     from nabu_amd import variables as vs
