@@ -325,6 +325,11 @@ int nabu_sum_f32(size_t n, const float *x, float scale, float *out, nabu_stream_
 /* y += a*x : gradient accumulation where a tensor has several consumers. */
 int nabu_axpy_f32(size_t n, float a, const float *x, float *y, nabu_stream_t stream);
 
+/* out[i] = ceil(in[i] / d): the sequence lengths after ops.pyramid_stack
+ * (nabu/neuralnetworks/components/ops.py:56-58), computed where the next layer reads them
+ * (a host-side recomputation + upload would synchronise the stream once per layer). */
+int nabu_ceil_div_i32(int n, const int32_t *in, int d, int32_t *out, nabu_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * DNNDecoder hidden layers (models/ed_decoders/dnn_decoder.py:40-51):
  * tf.contrib.layers.fully_connected = linear + ReLU, optional

@@ -65,6 +65,7 @@ SIGNATURES = {
     'nabu_gaussian_noise_f32': (_i, [_sz, _vp, _vp, _f, _c.c_ulonglong, _c.c_ulonglong, _vp]),
     'nabu_sum_f32': (_i, [_sz, _vp, _f, _vp, _vp]),
     'nabu_axpy_f32': (_i, [_sz, _f, _vp, _vp, _vp]),
+    'nabu_ceil_div_i32': (_i, [_i, _vp, _i, _vp, _vp]),
     'nabu_relu_f32': (_i, [_sz, _vp, _vp, _vp]),
     'nabu_relu_bwd_f32': (_i, [_sz, _vp, _vp, _vp, _vp]),
     'nabu_layer_norm_fwd': (_i, [_i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),

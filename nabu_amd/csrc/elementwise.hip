@@ -305,6 +305,12 @@ __global__ __launch_bounds__(256) void layer_norm_bwd_kernel(int N, int F, const
   }
 }
 
+__global__ __launch_bounds__(256) void ceil_div_kernel(int n, const int32_t *__restrict__ in, int d,
+                                                       int32_t *__restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (in[i] + d - 1) / d;
+}
+
 static int grid_for(size_t work_items) {
   size_t b = (work_items + 255) / 256;
   if (b > 2048) b = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
@@ -462,6 +468,14 @@ extern "C" int nabu_layer_norm_bwd(int B, int N, int F, const float *x, const fl
                      dbeta_part, "layer_norm_bwd: bad argument");
   hipLaunchKernelGGL(layer_norm_bwd_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), N, F, x, gamma,
                      dy, mean, rstd, dx, dgamma_part, dbeta_part);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_ceil_div_i32(int n, const int32_t *in, int d, int32_t *out, nabu_stream_t stream) {
+  if (n == 0) return 0;
+  NABU_CHECK_ARG(n > 0 && d > 0 && in && out, "ceil_div: bad argument");
+  hipLaunchKernelGGL(ceil_div_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), n, in, d, out);
   NABU_LAUNCH_CHECK();
   return 0;
 }

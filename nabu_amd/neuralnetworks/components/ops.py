@@ -27,7 +27,8 @@ def pyramid_stack(inputs, sequence_lengths, numsteps, axis=2, scope=None):
     record([inputs], [outputs], backward)
     lens = SeqLen.wrap(sequence_lengths)
     new_host = -(-lens.host // numsteps)
-    return outputs, SeqLen(new_host.astype(np.int32), device=inputs.device)
+    # the device copy is derived on the device: an upload here would block the host on the stream
+    return outputs, SeqLen(new_host.astype(np.int32), dev_tensor=hip.ceil_div_i32(lens.dev, numsteps))
 
 
 def dense_sequence_to_sparse(sequences, sequence_lengths):

@@ -344,3 +344,9 @@ def layer_norm_bwd(x, gamma, dy, mean, rstd):
     check(_hip.lib().nabu_layer_norm_bwd(B, N, F, ptr(x), ptr(gamma), ptr(dy), ptr(mean), ptr(rstd), ptr(dx),
                                          ptr(dgp), ptr(dbp), stream()), 'nabu_layer_norm_bwd')
     return dx, dgp, dbp
+
+
+def ceil_div_i32(x, d):
+    out = torch.empty_like(x)
+    check(_hip.lib().nabu_ceil_div_i32(x.numel(), ptr(x), int(d), ptr(out), stream()), 'nabu_ceil_div_i32')
+    return out
