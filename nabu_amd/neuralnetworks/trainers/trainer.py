@@ -128,7 +128,10 @@ class Trainer(object, metaclass=ABCMeta):
         '''create the evaluator (reference trainer.py:459-477)'''
         from nabu_amd.neuralnetworks.evaluators import evaluator_factory
         evaltype = self.evaluatorconf.get('evaluator', 'evaluator')
-        return evaluator_factory.factory(evaltype)(conf=self.evaluatorconf, dataconf=self.data, model=self.model)
+        # a synthetic batch source derives its own validation set; on-disk data are described by
+        # the database conf (dev sections named in the evaluator conf)
+        dataconf = self.data if hasattr(self.data, 'validation') else self.dataconf
+        return evaluator_factory.factory(evaltype)(conf=self.evaluatorconf, dataconf=dataconf, model=self.model)
 
     def validation_loss(self):
         '''run the evaluator over the validation set (reference trainer.py:660-680)'''
@@ -148,8 +151,17 @@ class Trainer(object, metaclass=ABCMeta):
             kw = {k: (v == 'True' if v in ('True', 'False') else int(v)) for k, v in d.items('synthetic')}
             kw.setdefault('batch_size', int(self.conf['batch_size']))
             return SyntheticData(**kw)
-        raise Exception('dataconf must be a batch source or contain a [synthetic] section; the '
-                        'TFRecord input pipeline is outside the hot path (SURVEY.md 2.1 row 9)')
+        # the reference's on-disk data (reference trainer.py:289-340): the trainer conf links the model's
+        # input names and the target names to sections of database.conf
+        from nabu_amd.processing import input_pipeline
+        input_names = [n for n in self.model.conf.get('io', 'inputs').split(' ') if n]
+        target_names = [n for n in self.conf['targets'].split(' ') if n]
+        world = self.server.world_size if self.server is not None else 1
+        return input_pipeline.from_sections(
+            d, input_names, [self.conf[i].split(' ') for i in input_names],
+            target_names, [self.conf[o].split(' ') for o in target_names],
+            batch_size=int(self.conf['batch_size']), numbuckets=int(self.conf['numbuckets']),
+            variable_batch_size=self.conf['variable_batch_size'] == 'True', shuffle=True, seed=0)
 
     def learning_rate(self):
         '''exponential decay (non-staircase) times the validation factor

@@ -305,3 +305,26 @@ def test_train_loop_validates_checkpoints_and_resumes(tmp_path):
     a, b = full.model.store.state_dict(), cont.model.store.state_dict()
     for k in a:
         np.testing.assert_array_equal(a[k], b[k])
+
+
+def test_training_from_tfrecord_data_sets(tmp_path):
+    """the trainer reads the reference's on-disk format (TFRecord files written by
+    Array/StringWriter + metadata) through database.conf sections, with length bucketing, and the
+    LossEvaluator reads the dev sections"""
+    from tests.test_data_path import make_dataset
+    from nabu_amd.neuralnetworks.trainers import trainer_factory
+    conf, feats, texts, alphabet = make_dataset(str(tmp_path / 'train'), n=24, dim=40, min_frames=14)
+    dev, _, _, _ = make_dataset(str(tmp_path / 'dev'), n=6, dim=40, seed=5, min_frames=14)
+    conf.read_dict({'devfbank': dict(dev.items('trainfbank')), 'devtext': dict(dev.items('traintext'))})
+    mc, tc, ec = recipes.load_recipe('cfg1_dblstm_ctc', **{
+        'encoder.num_units': 16, 'trainer.batch_size': 4, 'trainer.numbuckets': 2, 'trainer.num_epochs': 1,
+        'trainer.valid_frequency': 3, 'evaluator.batch_size': 2, 'io.output_dims': 4})
+    tc.set('trainer', 'features', 'trainfbank')
+    tc.set('trainer', 'targets', 'text')
+    tc.set('trainer', 'text', 'traintext')
+    tr = trainer_factory.factory('standard')(conf=tc, dataconf=conf, modelconf=mc, evaluatorconf=ec,
+                                             expdir=None, server=None, task_index=0)
+    hist = tr.train()
+    assert len(hist) == tr.data.num_batches() and all(np.isfinite(h[1]) for h in hist)
+    assert [s for s, _ in tr.validation_history][:2] == [0, 3]
+    assert all(np.isfinite(v) and v > 0 for _, v in tr.validation_history)
