@@ -279,12 +279,20 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
     const bool have_next = k0 + FBK < kend && !(a.vecA & 2);       // registers hold tile k0+FBK
     const bool load_next2 = k0 + 2 * FBK < kend && !(a.vecA & 2);
     Tile As = NABU_ATILE(cur), Bs = NABU_BTILE(cur);
+    // operands of k-step kk+2 are read from LDS before the MFMAs of k-step kk are issued (left to
+    // itself hipcc reads them after, and the wave then waits out the LDS latency with an empty pipe)
+    float a0n = As[lk][wm * 64 + li], a1n = As[lk][wm * 64 + 32 + li];
+    float b0n = Bs[lk][wn * 64 + li], b1n = Bs[lk][wn * 64 + 32 + li];
 #pragma unroll
     for (int kk = 0; kk < FBK; kk += 2) {
-      const float a0 = As[kk + lk][wm * 64 + li];
-      const float a1 = As[kk + lk][wm * 64 + 32 + li];
-      const float b0 = Bs[kk + lk][wn * 64 + li];
-      const float b1 = Bs[kk + lk][wn * 64 + 32 + li];
+      const float a0 = a0n, a1 = a1n, b0 = b0n, b1 = b1n;
+      if (kk + 2 < FBK) {
+        a0n = As[kk + 2 + lk][wm * 64 + li];
+        a1n = As[kk + 2 + lk][wm * 64 + 32 + li];
+        b0n = Bs[kk + 2 + lk][wn * 64 + li];
+        b1n = Bs[kk + 2 + lk][wn * 64 + 32 + li];
+      }
+      __builtin_amdgcn_sched_barrier(0);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);

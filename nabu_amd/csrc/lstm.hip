@@ -342,9 +342,11 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
                                 0, (size_t)(T - max_len) * 4 * H * sizeof(float), B, s));
 
   NABU_PROFILE_MARK(g_ev_begin, s);
+  float *db_part = nullptr;   // persistent path: bias-gradient partials [db_rows][2][4H]
+  int db_rows = 0;
   if (use_persistent(d)) {
     int e = lstm_persist_bwd(B, T, D, H, max_len, len, kern, gates, cs, d_out, reinterpret_cast<int *>(w), w + L.persist_off,
-                             L.persist_bytes, s);
+                             L.persist_bytes, &db_part, &db_rows, s);
     if (e) return e;
   } else {
     StepArgs p;
@@ -376,7 +378,12 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
                       dkern[dir] + (size_t)D * 4 * H, 4 * H, nullptr, T > 1 ? T - 1 : 0,
                       (long long)T * 2 * H, (long long)T * 4 * H, w + L.gemm_off, L.gemm_bytes, stream);
     if (e) return e;
-    e = nabu_colsum_f32(M, 4 * H, gates[dir], 4 * H, 0.f, dbias[dir], w + L.gemm_off, L.gemm_bytes, stream);
+    // db = column sums of dz: the persistent kernel already summed them per shard
+    if (db_part)
+      e = nabu_colsum_f32(db_rows, 4 * H, db_part + (size_t)dir * 4 * H, 2 * 4 * H, 0.f, dbias[dir], w + L.gemm_off,
+                          L.gemm_bytes, stream);
+    else
+      e = nabu_colsum_f32(M, 4 * H, gates[dir], 4 * H, 0.f, dbias[dir], w + L.gemm_off, L.gemm_bytes, stream);
     if (e) return e;
     // dx (+)= dz · Wx^T
     if (d_x) {

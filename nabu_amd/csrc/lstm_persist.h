@@ -10,5 +10,8 @@ int lstm_persist_fwd(int B, int T, int D, int H, int max_len, const int32_t *len
                      float *out, int *status, void *ws, size_t ws_bytes, hipStream_t stream);
 int lstm_persist_bwd(int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2],
-                     const float *dout, int *status, void *ws, size_t ws_bytes, hipStream_t stream);
+                     const float *dout, int *status, void *ws, size_t ws_bytes, float **db_part, int *db_rows,
+                     hipStream_t stream);
+// db_part: [db_rows][2 directions][4H] bias-gradient partial sums written by the backward kernels
+// (inside ws); bias gradient of direction d = column sums of db_part[:, d, :]
 }  // namespace nabu

@@ -71,6 +71,8 @@ struct PersistArgs {
   float *cs[2];
   float *out;         // forward
   const float *dout;  // backward
+  float *db_part;     // backward: [shards][2 directions][4H] bias-gradient partial sums (one row per unit)
+  int shard_base;     // first shard of this launch (batches split over several launches)
   unsigned *table;    // [grid] XCC ids, pre-set to SENT
   char *xbuf;         // exchange ring
   int *status;
@@ -529,6 +531,7 @@ __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_bwd_kernel(PersistArg
     }
   }
   float dc_state = 0.f;
+  float db_acc = 0.f;   // bias gradient: my (gate, row, unit) dz summed over the sequence
   if (!unit_handshake(p, unit, slot, NU, P, flag)) return;
   const bool coloc = flag[1] != 0;
   if (BS == 4 && unit >= NU / 2 && !(p.dbg & 32)) {   // see the forward kernel
@@ -643,6 +646,7 @@ __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_bwd_kernel(PersistArg
                    : dht * tc * go * (1.f - go);
       dc_state = dct * gf;
     }
+    db_acc += dz;
     float *const dzb = dzs + (s & 1) * (4 * L::QS);
     dzb[gg * L::QS + gu * BS + gb] = dz;
     NABU_STAMP(1, 2);
@@ -741,6 +745,17 @@ __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_bwd_kernel(PersistArg
     }
     NABU_STAMP(1, 6);
   }
+  // bias gradient of my 64 gate columns, summed over my BS rows: one partial row per unit (the host
+  // adds the shards with the deterministic column-sum kernel) — saves re-reading dz from HBM
+  __syncthreads();
+  red[tid] = db_acc;
+  __syncthreads();
+  if (gb == 0) {
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < BS; ++r) sum += red[gg + 4 * r + 4 * BS * gu];
+    p.db_part[((size_t)(p.shard_base + shard) * 2 + dir) * 4 * H + (size_t)gg * H + U0 + gu] = sum;
+  }
 }
 
 // ===========================================================================
@@ -782,6 +797,9 @@ bool lstm_persist_supported(int B, int T, int H) {
   return pick_bs(chunk_rows(B, H), H) != 0;
 }
 
+// bias-gradient partials of the backward kernel: one row of 2 x 4H per shard (BS = 4 gives the most)
+static size_t db_part_bytes(int B, int H) { return (size_t)((B + 3) / 4) * 2 * 4 * H * sizeof(float); }
+
 static size_t ring_bytes(bool fwd, int BS, int nshard, int H) {
   const size_t NU = 2 * (size_t)nshard, P = H / UC;
   return fwd ? NU * RING * (size_t)H * BS * 4 : NU * RING * P * P * UC * BS * 4;
@@ -798,7 +816,7 @@ size_t lstm_persist_ws_bytes(int B, int T, int H) {
       if (r > m) m = r;
     }
   }
-  return TABLE_BYTES + m;
+  return TABLE_BYTES + m + db_part_bytes(B, H);
 }
 
 template <typename K>
@@ -819,14 +837,18 @@ static int launch(K kernel, const PersistArgs &a, int grid, int threads, size_t 
 
 static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
-                     const float *dout, int *status, void *ws, size_t ws_bytes, hipStream_t stream);
+                     const float *dout, int *status, void *ws, size_t ws_bytes, float *db_part, int *shard_base,
+                     hipStream_t stream);
 
 static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
                const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
-               const float *dout, int *status, void *ws, size_t ws_bytes, hipStream_t stream) {
+               const float *dout, int *status, void *ws, size_t ws_bytes, float **db_part_out, int *db_rows_out,
+               hipStream_t stream) {
   if (!lstm_persist_supported(B, T, H)) return fail(NABU_EUNSUP, "persistent LSTM: unsupported B=%d H=%d", B, H);
   const size_t need = lstm_persist_ws_bytes(B, T, H);
   if (ws_bytes < need) return fail(NABU_EWS, "persistent LSTM: workspace %zu < %zu", ws_bytes, need);
+  float *db_part = reinterpret_cast<float *>(static_cast<char *>(ws) + need - db_part_bytes(B, H));
+  int shards = 0;
   const int Bc = chunk_rows(B, H);
   for (int b0 = 0; b0 < B; b0 += Bc) {
     const int nb = B - b0 < Bc ? B - b0 : Bc;
@@ -834,15 +856,19 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
     float *c2[2] = {cs[0] + (size_t)b0 * T * H, cs[1] + (size_t)b0 * T * H};
     const int e = run_chunk(fwd, nb, T, D, H, max_len, len + b0, kernel, g2, c2,
                             out ? out + (size_t)b0 * T * 2 * H : nullptr,
-                            dout ? dout + (size_t)b0 * T * 2 * H : nullptr, status, ws, ws_bytes, stream);
+                            dout ? dout + (size_t)b0 * T * 2 * H : nullptr, status, ws, ws_bytes, db_part, &shards,
+                            stream);
     if (e) return e;
   }
+  if (db_part_out) *db_part_out = db_part;
+  if (db_rows_out) *db_rows_out = shards;
   return 0;
 }
 
 static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
-                     const float *dout, int *status, void *ws, size_t ws_bytes, hipStream_t stream) {
+                     const float *dout, int *status, void *ws, size_t ws_bytes, float *db_part, int *shard_base,
+                     hipStream_t stream) {
   PersistArgs a;
   { const char *e = getenv("NABU_PERSIST_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   int BS = pick_bs(B, H);
@@ -851,6 +877,8 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
   a.len = len;
   for (int i = 0; i < 2; ++i) { a.kernel[i] = kernel[i]; a.gates[i] = gates[i]; a.cs[i] = cs[i]; }
   a.out = out; a.dout = dout;
+  a.db_part = db_part; a.shard_base = *shard_base;
+  *shard_base += a.nshard;
   a.status = status;
   a.table = static_cast<unsigned *>(ws);
   a.xbuf = static_cast<char *>(ws) + TABLE_BYTES;
@@ -882,13 +910,16 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
 int lstm_persist_fwd(int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2],
                      float *out, int *status, void *ws, size_t ws_bytes, hipStream_t stream) {
-  return run(true, B, T, D, H, max_len, len, kernel, gates, cs, out, nullptr, status, ws, ws_bytes, stream);
+  return run(true, B, T, D, H, max_len, len, kernel, gates, cs, out, nullptr, status, ws, ws_bytes, nullptr, nullptr,
+             stream);
 }
 
 int lstm_persist_bwd(int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2],
-                     const float *dout, int *status, void *ws, size_t ws_bytes, hipStream_t stream) {
-  return run(false, B, T, D, H, max_len, len, kernel, gates, cs, nullptr, dout, status, ws, ws_bytes, stream);
+                     const float *dout, int *status, void *ws, size_t ws_bytes, float **db_part, int *db_rows,
+                     hipStream_t stream) {
+  return run(false, B, T, D, H, max_len, len, kernel, gates, cs, nullptr, dout, status, ws, ws_bytes, db_part, db_rows,
+             stream);
 }
 
 }  // namespace nabu
