@@ -21,6 +21,10 @@
 
 namespace nabu {
 
+// k-tile of gemm_f32_fast_kernel: 16 (2 x 2 x 8.25 KiB of LDS) lets three workgroups share a CU;
+// measured 2-3 % faster than 32 on the NT / TN products
+constexpr int FKT = 16;
+
 // ---- "k-contiguous" operand: element (r,k) at base[r*ld + k] ----------------
 __device__ __forceinline__ void load_kc(float4 (&v)[2], const float *base, int ld, int r0,
                                         int rmax, int k0, int kend, int vec, int tid) {
@@ -178,11 +182,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
+  constexpr int KT = FKT, KQ = KT / 4;   // k-tile, 16-byte pieces per row
   // double-buffered operand tiles (2 x 2 x 16.5 KiB = 66 KiB: two workgroups per CU)
   extern __shared__ __attribute__((aligned(16))) float fsm[];
   typedef float (*Tile)[LDT];
-#define NABU_ATILE(buf) reinterpret_cast<Tile>(fsm + (buf) * (2 * FBK * LDT))
-#define NABU_BTILE(buf) reinterpret_cast<Tile>(fsm + (buf) * (2 * FBK * LDT) + FBK * LDT)
+#define NABU_ATILE(buf) reinterpret_cast<Tile>(fsm + (buf) * (2 * KT * LDT))
+#define NABU_BTILE(buf) reinterpret_cast<Tile>(fsm + (buf) * (2 * KT * LDT) + KT * LDT)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -216,10 +221,10 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
                                     : (size_t)k * a.lda;                                         \
       pa##j = a.A + off + min(m0 + 4 * (idx & 31), a.M - 4);                                     \
     } else {                                                                                     \
-      pa##j = a.A + (size_t)min(m0 + (idx >> 3), a.M - 1) * a.lda + (k0_) + 4 * (idx & 7);       \
+      pa##j = a.A + (size_t)min(m0 + (idx / KQ), a.M - 1) * a.lda + (k0_) + 4 * (idx % KQ);       \
     }                                                                                            \
     if (TB) {                                                                                    \
-      pb##j = a.B + (size_t)min(n0 + (idx >> 3), a.N - 1) * a.ldb + (k0_) + 4 * (idx & 7);       \
+      pb##j = a.B + (size_t)min(n0 + (idx / KQ), a.N - 1) * a.ldb + (k0_) + 4 * (idx % KQ);       \
     } else {                                                                                     \
       const int k = (k0_) + (idx >> 5);                                                          \
       const size_t off = a.kseg > 0 ? (size_t)(k / a.kseg) * (size_t)a.b_seg +                   \
@@ -228,9 +233,9 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
       pb##j = a.B + off + min(n0 + 4 * (idx & 31), a.N - 4);                                     \
     }                                                                                            \
   }
-#define NABU_GADDR(k0_) { NABU_GADDR1(0, k0_) NABU_GADDR1(1, k0_) NABU_GADDR1(2, k0_) NABU_GADDR1(3, k0_) }
-  const size_t stepA = TA ? (size_t)FBK * a.lda : (size_t)FBK;
-  const size_t stepB = TB ? (size_t)FBK : (size_t)FBK * a.ldb;
+#define NABU_GADDR(k0_) { NABU_GADDR1(0, k0_) NABU_GADDR1(1, k0_) if (KT > 16) { NABU_GADDR1(2, k0_) NABU_GADDR1(3, k0_) } }
+  const size_t stepA = TA ? (size_t)KT * a.lda : (size_t)KT;
+  const size_t stepB = TB ? (size_t)KT : (size_t)KT * a.ldb;
 #define NABU_GLOAD1(j, k0_)                                                                      \
   {                                                                                              \
     ra##j = *reinterpret_cast<const float4 *>(pa##j);                                            \
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
 #define NABU_GLOAD(k0_)                                                                          \
   {                                                                                              \
     if (a.kseg > 0) NABU_GADDR(k0_)                                                              \
-    NABU_GLOAD1(0, k0_) NABU_GLOAD1(1, k0_) NABU_GLOAD1(2, k0_) NABU_GLOAD1(3, k0_)              \
+    NABU_GLOAD1(0, k0_) NABU_GLOAD1(1, k0_) if (KT > 16) { NABU_GLOAD1(2, k0_) NABU_GLOAD1(3, k0_) }  \
   }
 #define NABU_SSTORE1(j)                                                                          \
   {                                                                                              \
@@ -250,17 +255,17 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
     if (TA) {                                                                                    \
       *reinterpret_cast<float4 *>(&As[idx >> 5][4 * (idx & 31)]) = ra##j;                        \
     } else {                                                                                     \
-      const int r = idx >> 3, k = 4 * (idx & 7);                                                 \
+      const int r = idx / KQ, k = 4 * (idx % KQ);                                                 \
       As[k + 0][r] = ra##j.x; As[k + 1][r] = ra##j.y; As[k + 2][r] = ra##j.z; As[k + 3][r] = ra##j.w; \
     }                                                                                            \
     if (TB) {                                                                                    \
-      const int r = idx >> 3, k = 4 * (idx & 7);                                                 \
+      const int r = idx / KQ, k = 4 * (idx % KQ);                                                 \
       Bs[k + 0][r] = rb##j.x; Bs[k + 1][r] = rb##j.y; Bs[k + 2][r] = rb##j.z; Bs[k + 3][r] = rb##j.w; \
     } else {                                                                                     \
       *reinterpret_cast<float4 *>(&Bs[idx >> 5][4 * (idx & 31)]) = rb##j;                        \
     }                                                                                            \
   }
-#define NABU_SSTORE() { NABU_SSTORE1(0) NABU_SSTORE1(1) NABU_SSTORE1(2) NABU_SSTORE1(3) }
+#define NABU_SSTORE() { NABU_SSTORE1(0) NABU_SSTORE1(1) if (KT > 16) { NABU_SSTORE1(2) NABU_SSTORE1(3) } }
 
   // Pipeline, ONE barrier per k-tile: while tile i is multiplied out of LDS buffer i%2, the
   // registers holding tile i+1 (loaded during the previous iteration) are written to the other
@@ -270,23 +275,23 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
   NABU_GADDR(kbeg);
   NABU_GLOAD(kbeg);
   NABU_SSTORE();
-  const bool two = kbeg + FBK < kend && !(a.vecA & 2);   // vecA bit 1: timing experiment (no staging)
-  if (two) NABU_GLOAD(kbeg + FBK);
+  const bool two = kbeg + KT < kend && !(a.vecA & 2);   // vecA bit 1: timing experiment (no staging)
+  if (two) NABU_GLOAD(kbeg + KT);
   __syncthreads();
   const int li = lane & 31, lk = lane >> 5;
   int cur = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += FBK) {
-    const bool have_next = k0 + FBK < kend && !(a.vecA & 2);       // registers hold tile k0+FBK
-    const bool load_next2 = k0 + 2 * FBK < kend && !(a.vecA & 2);
+  for (int k0 = kbeg; k0 < kend; k0 += KT) {
+    const bool have_next = k0 + KT < kend && !(a.vecA & 2);       // registers hold tile k0+KT
+    const bool load_next2 = k0 + 2 * KT < kend && !(a.vecA & 2);
     Tile As = NABU_ATILE(cur), Bs = NABU_BTILE(cur);
     // operands of k-step kk+2 are read from LDS before the MFMAs of k-step kk are issued (left to
     // itself hipcc reads them after, and the wave then waits out the LDS latency with an empty pipe)
     float a0n = As[lk][wm * 64 + li], a1n = As[lk][wm * 64 + 32 + li];
     float b0n = Bs[lk][wn * 64 + li], b1n = Bs[lk][wn * 64 + 32 + li];
 #pragma unroll
-    for (int kk = 0; kk < FBK; kk += 2) {
+    for (int kk = 0; kk < KT; kk += 2) {
       const float a0 = a0n, a1 = a1n, b0 = b0n, b1 = b1n;
-      if (kk + 2 < FBK) {
+      if (kk + 2 < KT) {
         a0n = As[kk + 2 + lk][wm * 64 + li];
         a1n = As[kk + 2 + lk][wm * 64 + 32 + li];
         b0n = Bs[kk + 2 + lk][wn * 64 + li];
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
           sbuf = cur ^ 1;
           NABU_SSTORE();
         }
-        if (load_next2 && !(a.vecA & 4)) NABU_GLOAD(k0 + 2 * FBK);
+        if (load_next2 && !(a.vecA & 4)) NABU_GLOAD(k0 + 2 * KT);
       }
     }
     __syncthreads();
@@ -460,7 +465,7 @@ extern "C" int nabu_gemm_ex(int precision, int transA, int transB, int M, int N,
     if (int e = gemm_bf16_launch(a, transA != 0, transB != 0, precision - NABU_GEMM_BF16 + 1, grid, s)) return e;
   } else
   if (fast) {
-    const size_t lds = 4 * (size_t)FBK * LDT * sizeof(float);
+    const size_t lds = 4 * (size_t)FKT * LDT * sizeof(float);
     static bool configured = false;
     if (!configured) {
       const void *fns[4] = {reinterpret_cast<const void *>(gemm_f32_fast_kernel<true, true>),
