@@ -1,12 +1,11 @@
-"""StandardTrainer (reference: nabu/neuralnetworks/trainers/standard_trainer.py:6-41)."""
+"""The plain trainer: Trainer without an extra loss term or hooks (the role of
+nabu/neuralnetworks/trainers/standard_trainer.py:6-41)."""
 from nabu_amd.neuralnetworks.trainers import trainer
 
 
 class StandardTrainer(trainer.Trainer):
-    '''a trainer with no added functionality'''
 
-    def aditional_loss(self):
-        '''an additional loss term, or None'''
+    def aditional_loss(self):            # (sic: the reference's spelling of the hook)
         return None
 
     def chief_only_hooks(self, outputs):

@@ -1,10 +1,6 @@
-"""Trainer factory (reference: nabu/neuralnetworks/trainers/trainer_factory.py:4-17)."""
+"""Trainer classes by recipe name (the role of nabu/neuralnetworks/trainers/trainer_factory.py:4-17)."""
+from nabu_amd.tools.registry import Registry
 
-
-def factory(trainer):
-    '''get a Trainer class by its recipe name'''
-    if trainer == 'standard':
-        from nabu_amd.neuralnetworks.trainers import standard_trainer
-        return standard_trainer.StandardTrainer
-    else:
-        raise Exception('Undefined trainer type: %s' % trainer)
+factory = Registry('trainer', {
+    'standard': 'nabu_amd.neuralnetworks.trainers.standard_trainer:StandardTrainer',
+}, undefined='Undefined %s type: %s')

@@ -1,5 +1,6 @@
-"""General TFRecord writer (reference: nabu/processing/tfwriters/tfwriter.py:9-55): one file per
-utterance under <datadir>/data/file<N>, and a line `name<TAB>filename` in <datadir>/pointers.scp."""
+"""Base of the per-utterance TFRecord writers (on-disk layout of nabu/processing/tfwriters/tfwriter.py:9-55):
+utterance number N goes to <datadir>/data/fileN, and <datadir>/pointers.scp gains one line
+``name<TAB>path`` so that readers and `get_filenames` can find it."""
 import os
 from abc import ABCMeta, abstractmethod
 
@@ -7,24 +8,21 @@ from nabu_amd.processing import tfrecord
 
 
 class TfWriter(object, metaclass=ABCMeta):
-    '''a general class for writing utterances as TFRecord files'''
+    """Subclasses turn one utterance into a serialized tf.train.Example (`_get_example`)."""
 
     def __init__(self, datadir):
-        if not os.path.exists(datadir):
-            os.makedirs(datadir)
-        self.scp_file = os.path.join(datadir, 'pointers.scp')
         self.write_dir = os.path.join(datadir, 'data')
-        os.makedirs(self.write_dir)
+        os.makedirs(self.write_dir)                     # also creates datadir; refuses to overwrite a set
+        self.scp_file = os.path.join(datadir, 'pointers.scp')
         self.filenum = 0
 
     def write(self, data, name):
-        example = self._get_example(data)
-        filename = os.path.join(self.write_dir, 'file%d' % self.filenum)
+        path = os.path.join(self.write_dir, 'file%d' % self.filenum)
+        tfrecord.write_records(path, [self._get_example(data)])
+        with open(self.scp_file, 'a') as scp:
+            scp.write(name + '\t' + path + '\n')
         self.filenum += 1
-        tfrecord.write_records(filename, [example])
-        with open(self.scp_file, 'a') as fid:
-            fid.write('%s\t%s\n' % (name, filename))
 
     @abstractmethod
     def _get_example(self, data):
-        '''the serialized tf.train.Example of one utterance'''
+        """bytes of the tf.train.Example holding `data`"""

@@ -1,15 +1,8 @@
-"""TfWriter factory (reference: nabu/processing/tfwriters/tfwriter_factory.py)."""
+"""Writers by name (the role of nabu/processing/tfwriters/tfwriter_factory.py)."""
+from nabu_amd.tools.registry import Registry
 
-
-def factory(writer_type):
-    '''Args: writer_type: 'array' or 'string' (the types on the hot path's data contract)'''
-    if writer_type == 'array':
-        from nabu_amd.processing.tfwriters import array_writer
-        return array_writer.ArrayWriter
-    elif writer_type == 'string':
-        from nabu_amd.processing.tfwriters import string_writer
-        return string_writer.StringWriter
-    elif writer_type in ('binary', 'alignment'):
-        raise Exception('%s writers belong to recipes outside the hot path' % writer_type)
-    else:
-        raise Exception('unknown writer type: %s' % writer_type)
+_PKG = 'nabu_amd.processing.tfwriters.'
+factory = Registry('writer', {
+    'array': _PKG + 'array_writer:ArrayWriter',
+    'string': _PKG + 'string_writer:StringWriter',
+}, outside=('binary', 'alignment'), undefined='unknown %s type: %s')
