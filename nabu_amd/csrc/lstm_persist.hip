@@ -145,6 +145,16 @@ struct SpinGuard {
   unsigned spins;
   __device__ __forceinline__ void start() { t0 = wall_clock64(); spins = 0; }
   __device__ __forceinline__ bool expired(const PersistArgs &p) {
+    // back off between polls: 512 workgroups re-reading 8 KiB each as fast as the L2 answers
+    // (one way latency is ~50 ns, scratch/ub/pingpong.hip) would saturate the L2 they wait on
+    switch ((p.dbg >> 8) & 7) {
+      case 1: __builtin_amdgcn_s_sleep(1); break;
+      case 2: __builtin_amdgcn_s_sleep(2); break;
+      case 3: __builtin_amdgcn_s_sleep(4); break;
+      case 4: __builtin_amdgcn_s_sleep(8); break;
+      case 5: __builtin_amdgcn_s_sleep(16); break;
+      default: break;
+    }
     if ((++spins & 31u) != 0) return false;
     __builtin_amdgcn_s_sleep(1);
     if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
@@ -214,15 +224,18 @@ __device__ __forceinline__ bool unit_handshake(const PersistArgs &p, int unit, i
 // wave-private LDS region), the waves' partial sums meet in a double-buffered LDS tile.
 template <int KPL, int BS>
 struct FwdLds {
-  static constexpr int NKS = 4 * BS;             // k-slices (4 per wave)
-  static constexpr int H = NKS * KPL;
-  static constexpr int SLICE = KPL * BS + 4;     // padded k-slice of the h vector
+  static constexpr int NW = BS, RG = BS / 4;     // waves, groups of 4 batch rows
+  static constexpr int KW = 4 * KPL;             // k values multiplied by one wave
+  static constexpr int H = NW * KW;
+  static constexpr int ROW = KW + 4;             // padded row of the staged h: [RG][4 rows][KW] per wave
   static constexpr int HS = 0;
-  static constexpr int PART = HS + NKS * SLICE;  // [2][BS waves][64*BS]
-  static constexpr int XST = PART + 2 * BS * 64 * BS;   // [2][64*BS] prefetched x-projection
+  static constexpr int PART = HS + NW * RG * 4 * ROW;   // [2][NW][RG][64 lanes][4 rows]
+  static constexpr int XST = PART + 2 * NW * RG * 256;  // [2][64*BS] prefetched x-projection
   static constexpr int FLAG = XST + 2 * 64 * BS;
   static constexpr int TOTAL = FLAG + 4;
 };
+
+typedef float mf32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float row_shl_f(float v, const int n) {   // lane i <- lane i+n of its 16-lane row
   const int x = __builtin_bit_cast(int, v);
@@ -238,7 +251,7 @@ __device__ __forceinline__ float row_shl_f(float v, const int n) {   // lane i <
 template <int KPL, int BS>
 __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_fwd_kernel(PersistArgs p) {
   using L = FwdLds<KPL, BS>;
-  constexpr int PT = 64 * BS, NW = BS, RPL = BS / 4;   // threads, waves, rows handed off per lane
+  constexpr int PT = 64 * BS, NW = BS;   // threads, waves
   constexpr int H = L::H;
   constexpr int P = H / UC;
   constexpr int WP = H / 4;                        // 16-byte pieces of h gathered by one wave
@@ -251,27 +264,31 @@ __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_fwd_kernel(PersistArg
   const int NU = 2 * p.nshard;
   int unit, slot;
   block_identity(NU, &unit, &slot);
+  // The two workgroups of a CU (units u and u + NU/2) must not multiply at the same time: the product
+  // of one alone takes 0.5 us, two at once take 1 us each, and the slowest workgroup sets the step of
+  // its whole unit.  The lower unit's product runs at raised wave priority: it is never slowed, the
+  // other one is pushed back whenever they overlap and so slides into the gaps (self-stabilising).
+  const bool hi_prio = BS == 4 && unit < NU / 2 && !(p.dbg & 2048);
   const int dir = unit & 1, shard = unit >> 1;
   const int U0 = slot * UC, b0 = shard * BS;
   const int T = p.T;
-  // matrix-phase identity: (hidden unit, k-slice); 4 adjacent lanes = 4 k-slices
-  const int fu = (tid >> 2) & 15, fq = tid & 3, ks = 4 * w + fq;
+  // matrix-phase identity (v_mfma_f32_4x4x1_16b_f32: 16 blocks of [4 rows] x [4 columns]): lane =
+  // (hidden unit mu = block, gate mg = column); the A operand of a lane is h[row = lane & 3][k]
+  const int mu = lane >> 2, mg = lane & 3;
   // gate-phase identity: (gate, batch row, hidden unit); 4 adjacent lanes = 4 gates.  Loads and
   // stores of the per-step tensors use it directly (16-byte runs per gate and row).
   const int gg = tid & 3, gb = (tid >> 2) & (BS - 1), gu = tid / (4 * BS);
   const int gbg = b0 + gb;
   const int n_g = gbg < p.B ? p.len[gbg] : 0;
 
-  // this lane's slice of W_h stays in registers for the whole sequence (gate pairs packed)
-  f32x2 Wr[KPL][2];
+  // this lane's slice of W_h stays in registers for the whole sequence: column (gate mg, unit mu),
+  // the KW rows k of this wave
+  constexpr int KW = L::KW, RG = L::RG;
+  float Wr[KW];
   {
-    const float *Wh = p.kernel[dir] + (size_t)p.D * 4 * H + U0 + fu;
+    const float *Wh = p.kernel[dir] + ((size_t)p.D + (size_t)w * KW) * 4 * H + (size_t)mg * H + U0 + mu;
 #pragma unroll
-    for (int j = 0; j < KPL; ++j) {
-      const float *row = Wh + (size_t)(ks * KPL + j) * 4 * H;
-      Wr[j][0] = (f32x2){row[0], row[H]};
-      Wr[j][1] = (f32x2){row[2 * H], row[3 * H]};
-    }
+    for (int j = 0; j < KW; ++j) Wr[j] = Wh[(size_t)j * 4 * H];
   }
   float c_state = 0.f, h_state = 0.f;
   if (!unit_handshake(p, unit, slot, NU, P, flag)) return;
@@ -309,6 +326,8 @@ __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_fwd_kernel(PersistArg
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), visible to the compiler's bookkeeping
   float xnext = xst[tid];
 
+  if (hi_prio) __builtin_amdgcn_s_setprio(2);   // for the whole sequence (a change inside the loop body
+                                                // split its basic blocks and cost the FMA loop its registers)
   for (int s = 0; s < p.max_len; ++s) {
     NABU_STAMP(0, 0);
     // (a) wait for h_{s-1}: wave w gathers the k range it multiplies, nothing else
@@ -336,93 +355,72 @@ __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_fwd_kernel(PersistArg
           break;
         }
       }
+      // stage transposed: piece qr = (k, row group) -> [row group][row][k], k contiguous, so that the
+      // A operands of 4 consecutive k are one 16-byte read
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
         const int qr = lane + i * 64;
         if (qr < WP) {
-          const int q = w * WP + qr, k = (q * 4) / BS;
-          *reinterpret_cast<u32x4 *>(hs + q * 4 + (k / KPL) * 4) = v[i];
+          const f32x4 fv = __builtin_bit_cast(f32x4, v[i]);
+          float *d = hs + ((size_t)(w * RG + qr % RG) * 4) * L::ROW + qr / RG;
+          d[0] = fv.x; d[L::ROW] = fv.y; d[2 * L::ROW] = fv.z; d[3 * L::ROW] = fv.w;
         }
       }
     }
     NABU_STAMP(0, 1);
+    if ((p.dbg & 4096) && (unit == 0 || unit == NU / 2) && tid == 0 && s == p.max_len / 2 + 1)
+      p.status[384 + 64 * (unit != 0) + 2 * slot + 1] = (int)wall_clock64();   // poll done (wave 0)
     const float xg = xnext;
     fetch_x(s + 1);
 
-    // (b) recurrent product on the VALU (packed FMAs): acc[b][g] += h[b][k] * W[k][g].
-    // The staged h is read back by the wave that wrote it: LDS operations of one wave execute
-    // in order, no barrier.
-    f32x2 acc[BS][2];
+    // (b) recurrent product on the matrix pipe, exact fp32: v_mfma_f32_4x4x1_16b_f32 multiplies, for
+    // each of 16 hidden units, [4 rows x 1] (h) by [1 x 4 gates] (W): no padding waste at 4 batch
+    // rows, the k reduction stays inside the accumulators (no cross-lane sum), and the VALU is free
+    // for the other workgroup of the CU.  Two accumulators per row group hide the dependent-issue
+    // latency.  The staged h is read back by the wave that wrote it (in-order LDS, no barrier).
+    mf32x4 acc[RG][2];
 #pragma unroll
-    for (int b = 0; b < BS; ++b) acc[b][0] = acc[b][1] = (f32x2){0.f, 0.f};
+    for (int g = 0; g < RG; ++g) acc[g][0] = acc[g][1] = (mf32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0 && !(p.dbg & 2)) {
-      const float *hrow = hs + ks * L::SLICE;
-      // software pipeline: the LDS broadcast reads of chunk c+1 (CH k values) are issued before
-      // the FMAs of chunk c
-      constexpr int RQ = BS / 4, CHW = 4 / RQ > 0 ? 4 / RQ : 1;   // 4 reads (16 VGPRs) per chunk
-      constexpr int CH = KPL < CHW ? KPL : CHW, NCH = KPL / CH;
-      float4 hq[2][CH * RQ];
+      const float *hrow = hs + ((size_t)w * RG * 4 + (lane & 3)) * L::ROW;
+      constexpr int NCH = KW / 4;
+      float4 hq[2][RG];
 #pragma unroll
-      for (int i = 0; i < CH * RQ; ++i) hq[0][i] = *reinterpret_cast<const float4 *>(hrow + 4 * i);
+      for (int g = 0; g < RG; ++g) hq[0][g] = *reinterpret_cast<const float4 *>(hrow + (size_t)g * 4 * L::ROW);
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
         if (ch + 1 < NCH) {
 #pragma unroll
-          for (int i = 0; i < CH * RQ; ++i)
-            hq[(ch + 1) & 1][i] = *reinterpret_cast<const float4 *>(hrow + (ch + 1) * CH * BS + 4 * i);
+          for (int g = 0; g < RG; ++g)
+            hq[(ch + 1) & 1][g] = *reinterpret_cast<const float4 *>(hrow + (size_t)g * 4 * L::ROW + 4 * (ch + 1));
         }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int jj = 0; jj < CH; ++jj) {
-          const int j = ch * CH + jj;
-#pragma unroll
-          for (int i = 0; i < RQ; ++i) {
-            const float4 h4 = hq[ch & 1][jj * RQ + i];
-            const float hb[4] = {h4.x, h4.y, h4.z, h4.w};
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-              const int b = 4 * i + bb;
-              const f32x2 hh = {hb[bb], hb[bb]};
-              acc[b][0] = __builtin_elementwise_fma(hh, Wr[j][0], acc[b][0]);
-              acc[b][1] = __builtin_elementwise_fma(hh, Wr[j][1], acc[b][1]);
-            }
-          }
+        for (int g = 0; g < RG; ++g) {
+          const float4 h4 = hq[ch & 1][g];
+          acc[g][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.x, Wr[4 * ch + 0], acc[g][0], 0, 0, 0);
+          acc[g][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.y, Wr[4 * ch + 1], acc[g][1], 0, 0, 0);
+          acc[g][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.z, Wr[4 * ch + 2], acc[g][0], 0, 0, 0);
+          acc[g][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.w, Wr[4 * ch + 3], acc[g][1], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
-      // sum the 4 k-slices of the quad (all lanes get the total)
-#pragma unroll
-      for (int b = 0; b < BS; ++b)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float v = acc[b][g >> 1][g & 1];
-          v += QUAD_XOR1(v);
-          v += QUAD_XOR2(v);
-          acc[b][g >> 1][g & 1] = v;
-        }
     }
     NABU_STAMP(0, 2);
-    float *const pbuf = part + (s & 1) * (NW * PT);
-    {  // lane fq hands rows fq*RPL .. fq*RPL+RPL-1 of its wave's partial to the gate phase
-      float *dst = pbuf + w * PT + (fu * BS + fq * RPL) * 4;
+    // hand the wave's partial sums to the gate phase: [wave][row group][lane][4 rows]
+    float *const pbuf = part + (s & 1) * (NW * RG * 256);
 #pragma unroll
-      for (int i = 0; i < RPL; ++i) {
-        float4 r;
-        r.x = sel4(fq, acc[i][0].x, acc[RPL + i][0].x, acc[2 * RPL + i][0].x, acc[3 * RPL + i][0].x);
-        r.y = sel4(fq, acc[i][0].y, acc[RPL + i][0].y, acc[2 * RPL + i][0].y, acc[3 * RPL + i][0].y);
-        r.z = sel4(fq, acc[i][1].x, acc[RPL + i][1].x, acc[2 * RPL + i][1].x, acc[3 * RPL + i][1].x);
-        r.w = sel4(fq, acc[i][1].y, acc[RPL + i][1].y, acc[2 * RPL + i][1].y, acc[3 * RPL + i][1].y);
-        *reinterpret_cast<float4 *>(dst + 4 * i) = r;
-      }
+    for (int g = 0; g < RG; ++g) {
+      const mf32x4 t = acc[g][0] + acc[g][1];
+      *reinterpret_cast<mf32x4 *>(pbuf + ((size_t)(w * RG + g) * 64 + lane) * 4) = t;
     }
     __syncthreads();                                            // the step's only barrier
     if (flag[0]) return;
     NABU_STAMP(0, 3);
 
-    // (c) gates: thread = (gate gg, row gb, unit gu); pbuf[w][tid] are its partials
+    // (c) gates: thread = (gate gg, row gb, unit gu); its partials sit at lane (gu, gg), row gb of
+    // every wave's tile
     float z = xg;
 #pragma unroll
-    for (int ww = 0; ww < NW; ++ww) z += pbuf[ww * PT + tid];
+    for (int ww = 0; ww < NW; ++ww) z += pbuf[((size_t)(ww * RG + (gb >> 2)) * 64 + gu * 4 + gg) * 4 + (gb & 3)];
     const float a = (gg == 1) ? fast_tanh(z) : fast_sigmoid(gg == 2 ? z + 1.0f : z);
     const float gi = QUAD_BCAST(a, 0), gj = QUAD_BCAST(a, 1), gf = QUAD_BCAST(a, 2), go = QUAD_BCAST(a, 3);
     const bool act_g = s < n_g;
@@ -453,6 +451,8 @@ __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_fwd_kernel(PersistArg
     wait_vm<2>();
     xnext = xst[((s + 1) & 1) * PT + tid];
     NABU_STAMP(0, 4);
+    if ((p.dbg & 4096) && (unit == 0 || unit == NU / 2) && tid == 0 && s == p.max_len / 2)
+      p.status[384 + 64 * (unit != 0) + 2 * slot] = (int)wall_clock64();
 
     // (e) off the critical path: activations (in place over the x-projection), cell state, output
     if (gbg < p.B && !(p.dbg & 128)) {
@@ -474,9 +474,10 @@ __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_fwd_kernel(PersistArg
 // transpose), dz meets in a double-buffered LDS tile.
 template <int BS>
 struct BwdLds {
-  static constexpr int QS = 16 * BS + 4;           // padded gate quarter of dz [16 cols][BS rows]
-  static constexpr int DZ = 0;                     // [2][4 quarters]
-  static constexpr int RED = DZ + 2 * 4 * QS;      // [16 groups][16*BS] partial dh sums
+  static constexpr int RG = BS / 4;                // groups of 4 batch rows
+  static constexpr int DROW = 64 + 4;              // padded row of dz: [RG][4 rows][64 gate columns]
+  static constexpr int DZ = 0;                     // double buffered
+  static constexpr int RED = DZ + 2 * RG * 4 * DROW;   // [16 groups][16*BS] partial dh sums
   static constexpr int XST = RED + 16 * 16 * BS;   // [2][3][64*BS] prefetched saved values
   static constexpr int FLAG = XST + 2 * 3 * 64 * BS;
   static constexpr int TOTAL = FLAG + 4;
@@ -487,12 +488,12 @@ __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_bwd_kernel(PersistArg
   using L = BwdLds<BS>;
   constexpr int PT = 64 * BS;
   constexpr int P = H / UC;
-  constexpr int KQ = H / 4;                         // k-quads of the product's output
-  constexpr int LQ = PT / 4;                        // lanes along the k-quad axis
-  constexpr int NKQ = (KQ + LQ - 1) / LQ;           // k-quads per lane (1 or 2)
+  constexpr int NW = BS, RG = L::RG;
+  constexpr int NG = H / 64;                        // output groups of 64 k (one MFMA covers 16 x 4 k)
+  constexpr int GPW = NG >= NW ? NG / NW : 1;       // groups per wave (waves >= NG idle in the product)
   constexpr int PPB = UC * BS / 4;                  // 16-byte pieces per source piece
   constexpr int NQ = (P + 15) / 16;                 // sources per lane (16 source groups per wave)
-  static_assert(NKQ <= 2, "backward kernel supports H <= 512");
+  static_assert(GPW * 64 <= 128, "backward kernel holds at most 128 weight registers per lane");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *dzs = smem + L::DZ, *red = smem + L::RED, *xst = smem + L::XST;
   int *flag = reinterpret_cast<int *>(smem + L::FLAG);
@@ -501,10 +502,17 @@ __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_bwd_kernel(PersistArg
   const int NU = 2 * p.nshard;
   int unit, slot;
   block_identity(NU, &unit, &slot);
+  // The two workgroups of a CU (units u and u + NU/2) must not multiply at the same time: the product
+  // of one alone takes 0.5 us, two at once take 1 us each, and the slowest workgroup sets the step of
+  // its whole unit.  The lower unit's product runs at raised wave priority: it is never slowed, the
+  // other one is pushed back whenever they overlap and so slides into the gaps (self-stabilising).
+  const bool hi_prio = BS == 4 && unit < NU / 2 && !(p.dbg & 2048);
   const int dir = unit & 1, shard = unit >> 1;
   const int U0 = slot * UC, b0 = shard * BS;
   const int T = p.T;
-  const int cq = tid & 3, kq0 = tid >> 2;
+  // matrix-phase identity (v_mfma_f32_4x4x1_16b_f32): lane = one output k of a 64-k group; its A
+  // operand is dz[row = lane & 3][column c]
+  const bool mfma_wave = w * GPW < NG;
   // gate-phase identity as in the forward kernel; also used for every per-step load and store
   const int gg = tid & 3, gb = (tid >> 2) & (BS - 1), gu = tid / (4 * BS);
   const int gbg = b0 + gb;
@@ -513,22 +521,14 @@ __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_bwd_kernel(PersistArg
   // consume; lane = (source group, piece)
   const int xgrp = lane >> 2, xpos = 4 * w + (lane & 3);
 
-  // Wr[m][c][jp] = (W_h[4kq+2jp][cq*H + U0 + c], W_h[4kq+2jp+1][...]), kq = kq0 + m*LQ
-  f32x2 Wr[NKQ][16][2];
+  // Wr[m][c] = W_h[k][column c of my workgroup], k = (w*GPW + m)*64 + lane, c = gate*16 + unit
+  float Wr[GPW][64];
 #pragma unroll
-  for (int m = 0; m < NKQ; ++m) {
-    const int kq = kq0 + m * LQ;
-    if (kq < KQ) {
-      const float *Wh = p.kernel[dir] + (size_t)p.D * 4 * H + (size_t)cq * H + U0;
+  for (int m = 0; m < GPW; ++m) {
+    const int k = min((w * GPW + m) * 64 + lane, H - 1);
+    const float *Wh = p.kernel[dir] + ((size_t)p.D + k) * 4 * H + U0;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        Wr[m][c][0] = (f32x2){Wh[(size_t)(4 * kq + 0) * 4 * H + c], Wh[(size_t)(4 * kq + 1) * 4 * H + c]};
-        Wr[m][c][1] = (f32x2){Wh[(size_t)(4 * kq + 2) * 4 * H + c], Wh[(size_t)(4 * kq + 3) * 4 * H + c]};
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) Wr[m][c][0] = Wr[m][c][1] = (f32x2){0.f, 0.f};
-    }
+    for (int c = 0; c < 64; ++c) Wr[m][c] = Wh[(size_t)(c >> 4) * H + (c & 15)];
   }
   float dc_state = 0.f;
   float db_acc = 0.f;   // bias gradient: my (gate, row, unit) dz summed over the sequence
@@ -579,6 +579,7 @@ __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_bwd_kernel(PersistArg
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see the forward kernel
   fetched(p.max_len - 1, av_next, xv_next);
 
+  if (hi_prio) __builtin_amdgcn_s_setprio(2);
   for (int s = p.max_len - 1; s >= 0; --s) {
     NABU_STAMP(1, 0);
     // (a) reduce-scatter input: the partial products of step s+1 addressed to me
@@ -647,8 +648,8 @@ __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_bwd_kernel(PersistArg
       dc_state = dct * gf;
     }
     db_acc += dz;
-    float *const dzb = dzs + (s & 1) * (4 * L::QS);
-    dzb[gg * L::QS + gu * BS + gb] = dz;
+    float *const dzb = dzs + (s & 1) * (RG * 4 * L::DROW);
+    dzb[(size_t)gb * L::DROW + gg * 16 + gu] = dz;      // [row group][row][gate*16 + unit] = [gb][c]
     NABU_STAMP(1, 2);
     __syncthreads();                                            // the step's only barrier
     if (flag[0]) return;
@@ -662,79 +663,60 @@ __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_bwd_kernel(PersistArg
     }
     if (s > 0) fetch(s - 1);
 
-    // (c) partial product for step s-1: acc[m][b][j] = sum_c dz[b][cq,c] * W[4kq_m+j][cq,c]
+    // (c) partial product for step s-1 on the matrix pipe (exact fp32, see the forward kernel):
+    // block = 4 consecutive k, D[row][k] += dz[row][c] * W[k][c] over my 64 gate columns c.  A lane
+    // ends with the 4 rows of ITS k: exactly one 16-byte piece of the reduce-scatter — no cross-lane sum.
     if (s > 0) {
-      f32x2 acc[NKQ][BS][2];
+      mf32x4 acc[GPW][RG][2];
 #pragma unroll
-      for (int m = 0; m < NKQ; ++m)
+      for (int m = 0; m < GPW; ++m)
 #pragma unroll
-        for (int b = 0; b < BS; ++b) acc[m][b][0] = acc[m][b][1] = (f32x2){0.f, 0.f};
-      const float *dq = dzb + cq * L::QS;
-      if (!(p.dbg & 2)) {
-        // all 16 column reads of this lane's gate quarter are issued up front (<= 32 VGPRs)
-        constexpr int RQ = BS / 4;
-        float4 dqv[16 * RQ];
+        for (int g = 0; g < RG; ++g) acc[m][g][0] = acc[m][g][1] = (mf32x4){0.f, 0.f, 0.f, 0.f};
+      if (!(p.dbg & 2) && mfma_wave) {
+        const float *drow = dzb + (size_t)(lane & 3) * L::DROW;
+        float4 dq[2][RG];
 #pragma unroll
-        for (int i = 0; i < 16 * RQ; ++i) dqv[i] = *reinterpret_cast<const float4 *>(dq + 4 * i);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int g = 0; g < RG; ++g) dq[0][g] = *reinterpret_cast<const float4 *>(drow + (size_t)g * 4 * L::DROW);
 #pragma unroll
-        for (int c2 = 0; c2 < 16; ++c2)
+        for (int ch = 0; ch < 16; ++ch) {
+          if (ch + 1 < 16) {
 #pragma unroll
-          for (int i = 0; i < RQ; ++i) {
-            const float4 d4 = dqv[c2 * RQ + i];
-            const float db[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-            for (int m = 0; m < NKQ; ++m)
-#pragma unroll
-              for (int bb = 0; bb < 4; ++bb) {
-                const int b = 4 * i + bb;
-                const f32x2 dd = {db[bb], db[bb]};
-                acc[m][b][0] = __builtin_elementwise_fma(dd, Wr[m][c2][0], acc[m][b][0]);
-                acc[m][b][1] = __builtin_elementwise_fma(dd, Wr[m][c2][1], acc[m][b][1]);
-              }
+            for (int g = 0; g < RG; ++g)
+              dq[(ch + 1) & 1][g] = *reinterpret_cast<const float4 *>(drow + (size_t)g * 4 * L::DROW + 4 * (ch + 1));
           }
-      }
-      // quad all-reduce over the 4 gate quarters; lane cq then keeps k = 4kq + cq, all rows
-      float r[NKQ][BS];
 #pragma unroll
-      for (int m = 0; m < NKQ; ++m)
+          for (int g = 0; g < RG; ++g) {
+            const float4 d4 = dq[ch & 1][g];
 #pragma unroll
-        for (int b = 0; b < BS; ++b) {
-          float t[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float x = acc[m][b][j >> 1][j & 1];
-            x += QUAD_XOR1(x);
-            x += QUAD_XOR2(x);
-            t[j] = x;
+            for (int m = 0; m < GPW; ++m) {
+              acc[m][g][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(d4.x, Wr[m][4 * ch + 0], acc[m][g][0], 0, 0, 0);
+              acc[m][g][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(d4.y, Wr[m][4 * ch + 1], acc[m][g][1], 0, 0, 0);
+              acc[m][g][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(d4.z, Wr[m][4 * ch + 2], acc[m][g][0], 0, 0, 0);
+              acc[m][g][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(d4.w, Wr[m][4 * ch + 3], acc[m][g][1], 0, 0, 0);
+            }
           }
-          r[m][b] = sel4(cq, t[0], t[1], t[2], t[3]);
         }
+      }
       NABU_STAMP(1, 4);
       // publish.  My slot resets of this slot's previous use were issued three steps ago and
       // exchange loads issued after them have been consumed: they are performed (in-order
       // completion of vector memory operations).
 #pragma unroll
-      for (int m = 0; m < NKQ; ++m) {
-        const int kq = kq0 + m * LQ;
-        const int k = 4 * kq + cq;
+      for (int m = 0; m < GPW; ++m) {
+        const int k = (w * GPW + m) * 64 + lane;
         const int dest = k / UC, ul = k % UC;
         const unsigned off = (unsigned)((s % RING) * slot_bytes + (size_t)dest * block_bytes +
                                         (size_t)slot * piece_bytes + (size_t)ul * BS * 4);
 #pragma unroll
-        for (int i = 0; i < BS / 4; ++i) {
-          u32x4 pv;
-          pv.x = __builtin_bit_cast(unsigned, r[m][4 * i]);
-          pv.y = __builtin_bit_cast(unsigned, r[m][4 * i + 1]);
-          pv.z = __builtin_bit_cast(unsigned, r[m][4 * i + 2]);
-          pv.w = __builtin_bit_cast(unsigned, r[m][4 * i + 3]);
-          xstore(pv, rs, kq < KQ ? off + 16 * i : OOB, coloc);
+        for (int g = 0; g < RG; ++g) {
+          const mf32x4 t = acc[m][g][0] + acc[m][g][1];
+          xstore(__builtin_bit_cast(u32x4, t), rs, (mfma_wave && k < H) ? off + 16 * g : OOB, coloc);
         }
       }
     }
     // claim the prefetched values here, in front of the dz store (see the forward kernel)
     if (s > 0) {
-      wait_vm<NKQ * (BS / 4)>();   // N = the publish stores above
+      wait_vm<GPW * RG>();   // N = the publish stores above
       fetched(s - 1, av_next, xv_next);
     }
     NABU_STAMP(1, 5);
