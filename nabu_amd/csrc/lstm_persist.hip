@@ -11,10 +11,7 @@
 // a [H x 64] slice of W_h (128 KiB at H=512) held in VGPRs for the whole sequence.
 // Two geometries (template parameter BS):
 //   BS = 4: 256-thread workgroups (one wave per SIMD, 128 weight registers per
-//           lane), TWO workgroups per CU that belong to different units.  While one
-//           waits for its exchange the other multiplies: the hardware interleaves
-//           the two waves of a SIMD, which hides the hand-off latency.  cfg2:
-//           16 units x 32 workgroups = 512 = 2 per CU.
+//           lane), two workgroups per CU (cfg2: 16 units x 32 workgroups = 512);
 //   BS = 8: 512-thread workgroups (two waves per SIMD, 64 weight registers per
 //           lane), one per CU; used when the batch is too large for BS = 4.
 // Block b belongs to unit b % NU, so with the observed round-robin block->XCD
@@ -43,9 +40,15 @@
 //   Every spin is bounded by a wall-clock timeout; a timeout sets a status
 //   word, makes every workgroup leave, and is reported to the host.
 //
-// MATH per workgroup and step: [BS x H] x [H x 64] on the fp32 VALU with packed
-// FMAs (v_pk_fma_f32): lanes are (hidden unit, k-slice) / (k-quad, gate) register
-// tiles so that one 16-byte LDS broadcast read feeds 8-16 FMAs.
+// MATH per workgroup and step: [BS x H] x [H x 64] in exact fp32 on the MATRIX pipe with
+// v_mfma_f32_4x4x1_16b_f32: one instruction multiplies, for 16 blocks, a [4 x 1] column by a
+// [1 x 4] row.  Forward: block = hidden unit, A = h[4 rows][k], B = W[k][4 gates of the unit];
+// backward: block = 4 consecutive k, A = dz[4 rows][c], B = W[4 k][c].  Four batch rows fill
+// the instruction exactly (the 16x16 / 32x32 shapes would waste 3/4 of it), the k reduction
+// stays inside the accumulators, a lane ends with the 4 rows of one (unit, gate) resp. one k —
+// the layout the gate phase resp. the exchange wants — and the VALU only does the gate math.
+// (The first versions ran the product as 256 v_pk_fma_f32 per lane plus DPP reductions: at the
+// same FLOP rate, but ~3x the VALU instructions, fighting the other workgroup of the CU.)
 #include "lstm_persist.h"
 
 #include <stdlib.h>
@@ -176,10 +179,10 @@ struct SpinGuard {
 // every CU once before it places a second workgroup), so the second wave of blocks is rotated by
 // NU/2 units: the two workgroups of a CU then belong to DIFFERENT units of the same XCD and can
 // interleave (same-unit workgroups are in lockstep and would always collide on the VALU).
-__device__ __forceinline__ void block_identity(int NU, int *unit, int *slot) {
+__device__ __forceinline__ void block_identity(int NU, int *unit, int *slot, bool rotate) {
   const int b = blockIdx.x;
   int u = b % NU;
-  if (b >= NCU && NCU % NU == 0) u = (u + NU / 2) % NU;
+  if (rotate && b >= NCU && NCU % NU == 0) u = (u + NU / 2) % NU;
   *unit = u;
   *slot = b / NU;
 }
@@ -263,12 +266,12 @@ __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_fwd_kernel(PersistArg
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const int NU = 2 * p.nshard;
   int unit, slot;
-  block_identity(NU, &unit, &slot);
-  // The two workgroups of a CU (units u and u + NU/2) must not multiply at the same time: the product
-  // of one alone takes 0.5 us, two at once take 1 us each, and the slowest workgroup sets the step of
-  // its whole unit.  The lower unit's product runs at raised wave priority: it is never slowed, the
-  // other one is pushed back whenever they overlap and so slides into the gaps (self-stabilising).
-  const bool hi_prio = BS == 4 && unit < NU / 2 && !(p.dbg & 2048);
+  block_identity(NU, &unit, &slot, (p.dbg & 8192) != 0);
+  // Experiments kept behind NABU_PERSIST_DEBUG: 8192 = the two workgroups of a CU belong to different
+  // units (rotation in block_identity) and 2048 = one of them runs at raised wave priority.  With the
+  // product on the matrix pipe neither beats the plain layout (same unit, lockstep) by more than
+  // run-to-run noise, so both are off.
+  const bool hi_prio = BS == 4 && unit < NU / 2 && (p.dbg & 2048) && (p.dbg & 8192);
   const int dir = unit & 1, shard = unit >> 1;
   const int U0 = slot * UC, b0 = shard * BS;
   const int T = p.T;
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_fwd_kernel(PersistArg
   const bool coloc = flag[1] != 0;
   // Two workgroups of different units share a CU (BS = 4): start the upper half of the
   // units half a step late so that one multiplies while the other waits for its exchange.
-  if (BS == 4 && unit >= NU / 2 && !(p.dbg & 32)) {
+  if (BS == 4 && unit >= NU / 2 && (p.dbg & 8192) && !(p.dbg & 32)) {
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < 100) __builtin_amdgcn_s_sleep(4);
   }
@@ -501,12 +504,12 @@ __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_bwd_kernel(PersistArg
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const int NU = 2 * p.nshard;
   int unit, slot;
-  block_identity(NU, &unit, &slot);
+  block_identity(NU, &unit, &slot, (p.dbg & 8192) != 0);
   // The two workgroups of a CU (units u and u + NU/2) must not multiply at the same time: the product
   // of one alone takes 0.5 us, two at once take 1 us each, and the slowest workgroup sets the step of
   // its whole unit.  The lower unit's product runs at raised wave priority: it is never slowed, the
   // other one is pushed back whenever they overlap and so slides into the gaps (self-stabilising).
-  const bool hi_prio = BS == 4 && unit < NU / 2 && !(p.dbg & 2048);
+  const bool hi_prio = BS == 4 && unit < NU / 2 && (p.dbg & 2048) && (p.dbg & 8192);
   const int dir = unit & 1, shard = unit >> 1;
   const int U0 = slot * UC, b0 = shard * BS;
   const int T = p.T;
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(64 * BS, 2) void lstm_persist_bwd_kernel(PersistArg
   float db_acc = 0.f;   // bias gradient: my (gate, row, unit) dz summed over the sequence
   if (!unit_handshake(p, unit, slot, NU, P, flag)) return;
   const bool coloc = flag[1] != 0;
-  if (BS == 4 && unit >= NU / 2 && !(p.dbg & 32)) {   // see the forward kernel
+  if (BS == 4 && unit >= NU / 2 && (p.dbg & 8192) && !(p.dbg & 32)) {   // see the forward kernel
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < 100) __builtin_amdgcn_s_sleep(4);
   }
