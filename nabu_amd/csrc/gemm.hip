@@ -363,8 +363,8 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs a) {
 static int choose_split(int M, int N, int K, int *ksplit) {
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   int ns = 1;
-  if (tiles < 512 && K >= 1024) {   // aim at >= 2 workgroups per CU (256 CUs)
-    ns = (512 + tiles - 1) / tiles;
+  if (tiles < 768 && K >= 1024) {   // aim at 3 workgroups per CU (256 CUs; the 16-wide k-tile fits three)
+    ns = (768 + tiles - 1) / tiles;
     const int maxs = K / (K >= 4096 ? 512 : 256);
     if (ns > maxs) ns = maxs;
     if (ns < 1) ns = 1;
