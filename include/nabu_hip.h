@@ -349,6 +349,71 @@ int nabu_layer_norm_bwd(int B, int N, int F, const float *x, const float *gamma,
                         const float *mean, const float *rstd, float *dx, float *dgamma_part,
                         float *dbeta_part, nabu_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Inference decoders — nabu/neuralnetworks/decoders.
+ *
+ * nabu_ctc_beam_search: CTCDecoder.__call__ (decoders/ctc_decoder.py:44-68) =
+ * tf.nn.ctc_beam_search_decoder(logits, seq_len) with its defaults top_paths = 1,
+ * beam_width = 100, merge_repeated = 1: CTC prefix beam search (prefix tree with per-node
+ * (total, blank, label) log-probabilities, bounded beam of the beam_width best prefixes per
+ * frame, blank = C-1), one workgroup per utterance over all its frames; merge_repeated also
+ * collapses equal neighbours of the OUTPUT labelling, as TF's BeamEntry::LabelSeq does.
+ *   logits [B,T,C] batch-major (softmax is taken inside), logit_len [B];
+ *   out_ids [B,T] (entries >= out_len are -1), out_len [B], out_logprob [B] (may be NULL):
+ *   log P(best prefix) under the per-frame normalised posteriors.
+ * The workspace holds the prefix trees; it is initialised by the call. */
+size_t nabu_ctc_beam_ws_bytes(int B, int T, int C, int beam_width);
+int nabu_ctc_beam_search(int B, int T, int C, int beam_width, int merge_repeated, const float *logits,
+                         const int32_t *logit_len, int32_t *out_ids, int32_t *out_len,
+                         float *out_logprob, void *ws, size_t ws_bytes, nabu_stream_t stream);
+
+/* tf.edit_distance(hyp, truth, normalize=False) per utterance (ctc_decoder.py:112-118,
+ * decoders/beam_search_decoder.py:176-179): Levenshtein distance of hyp[b,:hyp_len[b]] and
+ * truth[b,:truth_len[b]] (negative lengths count as 0); dist [B] int32. */
+int nabu_edit_distance(int B, const int32_t *hyp, int ldh, const int32_t *hyp_len, const int32_t *truth,
+                       int ldt, const int32_t *truth_len, int32_t *dist, nabu_stream_t stream);
+
+/* Attention beam search — BeamSearchDecoder.__call__ (decoders/beam_search_decoder.py:31-114)
+ * over components/beam_search_decoder.py:141-451 driven by dynamic_decode(maximum_iterations =
+ * max_steps): the encoder output is tiled beam_width times, every step runs the Speller cell
+ * (same kernels as nabu_speller_fwd) on B*beam_width rows, then
+ *   nabu_beam_prune: candidates = every (beam, label) expansion plus one "stay" hypothesis per
+ *     finished beam; log-softmax(logits / temperature); score = logprob / ((5+len)/6)^length_penalty;
+ *     the beam_width best by score (ties: lower candidate index, as tf.nn.top_k) survive;
+ *   nabu_beam_gather: survivors take the new cell state of their parent, "stay" hypotheses keep
+ *     the state they had.
+ * The search ends when every beam slot has been finished at some step (dynamic_decode ORs
+ * `finished` over steps: the reference's decoder does not track it itself) or after max_steps.
+ * Then the backwards search through the parent pointers (finalize, :341-451).
+ *   values [B,Te,E] (rows >= enc_len zero), params as nabu_speller_fwd;
+ *   sequences [B,W,max_steps] int32 (valid [:, :, :*num_steps]), lengths [B,W] (labels before
+ *   the end token C-1), scores [B,W], alignments [B,W,max_steps,Te] or NULL.
+ * SYNCHRONISES the stream once per step (the stop test) — an inference-time API.
+ * Where the reference derives the parent slot of a "stay" hypothesis as idx % C (valid while
+ * beam_width <= C), the slot idx - beam_width*C is used, so wider beams also work. */
+typedef struct {
+  uint32_t size;
+  int32_t B, Te, E, U, C, num_layers;
+  int32_t kind, K, F;                 /* attention: see nabu_attn_desc */
+  int32_t beam_width, max_steps;
+  float length_penalty, temperature;
+} nabu_beam_desc;
+size_t nabu_speller_beam_ws_bytes(const nabu_beam_desc *d);
+int nabu_speller_beam_search(const nabu_beam_desc *d, const float *values, const int32_t *enc_len,
+                             const nabu_speller_params *p, int32_t *sequences, int32_t *lengths,
+                             float *scores, float *alignments, int32_t *num_steps, void *ws,
+                             size_t ws_bytes, nabu_stream_t stream);
+/* One pruning step on its own (testable without a model).  logits [B*W,C]; logprobs, lengths,
+ * finished, seen [B,W] are updated in place; pred_ids, parent, stay [B,W] and all_seen [B] are
+ * written; scratch [B, W*C+W] floats. */
+int nabu_beam_prune(int B, int W, int C, const float *logits, float temperature, float length_penalty,
+                    float *logprobs, int32_t *lengths, int32_t *finished, int32_t *seen,
+                    int32_t *pred_ids, int32_t *parent, int32_t *stay, int32_t *all_seen,
+                    float *scratch, nabu_stream_t stream);
+/* dst[b,w,:] = (stay[b,w] ? old : fresh)[b, parent[b,w], :]  for [B,W,F] float rows */
+int nabu_beam_gather(int B, int W, int F, const float *fresh, const float *old, const int32_t *parent,
+                     const int32_t *stay, float *dst, nabu_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

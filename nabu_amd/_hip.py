@@ -66,6 +66,13 @@ SIGNATURES = {
     'nabu_sum_f32': (_i, [_sz, _vp, _f, _vp, _vp]),
     'nabu_axpy_f32': (_i, [_sz, _f, _vp, _vp, _vp]),
     'nabu_ceil_div_i32': (_i, [_i, _vp, _i, _vp, _vp]),
+    'nabu_ctc_beam_ws_bytes': (_sz, [_i, _i, _i, _i]),
+    'nabu_ctc_beam_search': (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'nabu_edit_distance': (_i, [_i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    'nabu_speller_beam_ws_bytes': (_sz, [_vp]),
+    'nabu_speller_beam_search': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'nabu_beam_prune': (_i, [_i, _i, _i, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'nabu_beam_gather': (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'nabu_relu_f32': (_i, [_sz, _vp, _vp, _vp]),
     'nabu_relu_bwd_f32': (_i, [_sz, _vp, _vp, _vp, _vp]),
     'nabu_layer_norm_fwd': (_i, [_i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
@@ -144,6 +151,13 @@ class SpellerDesc(_c.Structure):
                                           ('B', 'Te', 'E', 'U', 'C', 'L', 'num_layers', 'kind', 'K', 'F')] + \
                [('keep_prob', _c.c_float), ('seed', _c.c_ulonglong), ('seed_offset', _c.c_ulonglong),
                 ('sample_prob', _c.c_float), ('sample_seed', _c.c_ulonglong), ('sample_offset', _c.c_ulonglong)]
+
+
+class BeamDesc(_c.Structure):
+    _fields_ = [('size', _c.c_uint32)] + [(n, _c.c_int32) for n in
+                                          ('B', 'Te', 'E', 'U', 'C', 'num_layers', 'kind', 'K', 'F',
+                                           'beam_width', 'max_steps')] + \
+               [('length_penalty', _c.c_float), ('temperature', _c.c_float)]
 
 
 class SpellerPtrs(_c.Structure):

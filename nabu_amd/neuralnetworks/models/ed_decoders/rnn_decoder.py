@@ -39,13 +39,10 @@ def _ptrs(named, lstm, grad):
     return s
 
 
-def dynamic_decode(cell, encoded, encoded_seq_length, targets, target_seq_length, sample_prob,
-                   is_training):
-    """Run the projected attention cell over the target sequence.
-
-    encoded [B,Te,E] (rows >= length zero), targets [B,Lt] int32 (already holding EOS
-    where the recipe uses it), target_seq_length [B].  Returns logits [B,L,C] with
-    L = max(target_seq_length); rows of finished utterances are zero."""
+def cell_parameters(cell, E):
+    """The variables of a projected attention cell (created on first use in the current scope,
+    TF-style names) in the form the C ABI takes them.  Returns (attention mechanism, LSTM cells,
+    number of layers, num_units, output dim, {name: Variable}, [(kernel, bias) per layer])."""
     wrapper = cell._cell
     mech = wrapper.attention_mechanism
     cells = wrapper.cells
@@ -55,14 +52,7 @@ def dynamic_decode(cell, encoded, encoded_seq_length, targets, target_seq_length
         raise NotImplementedError('all speller layers must have the same num_units')
     if nl > _hip.SPELLER_MAX_LAYERS:
         raise NotImplementedError('at most %d speller layers' % _hip.SPELLER_MAX_LAYERS)
-    dev = encoded.device
-    B, Te, E = encoded.shape
     C = cell.output_size
-    tlen = SeqLen.wrap(target_seq_length, dev)
-    elen = SeqLen.wrap(encoded_seq_length, dev)
-    L = tlen.max()
-
-    # ---- variables (created in the decoder's scope, TF-style names) -------------
     with vs.variable_scope('decoder'):
         av = mech.variables()
         with vs.variable_scope('attention_wrapper'):
@@ -71,6 +61,22 @@ def dynamic_decode(cell, encoded, encoded_seq_length, targets, target_seq_length
     named = dict(memory_kernel=av['memory_kernel'], query_kernel=av['query_kernel'],
                  attention_v=av['attention_v'], conv_kernel=av.get('conv_kernel'),
                  conv_proj=av.get('conv_proj'), out_kernel=Wout, out_bias=bout)
+    return mech, cells, nl, U, C, named, lstm
+
+
+def dynamic_decode(cell, encoded, encoded_seq_length, targets, target_seq_length, sample_prob,
+                   is_training):
+    """Run the projected attention cell over the target sequence.
+
+    encoded [B,Te,E] (rows >= length zero), targets [B,Lt] int32 (already holding EOS
+    where the recipe uses it), target_seq_length [B].  Returns logits [B,L,C] with
+    L = max(target_seq_length); rows of finished utterances are zero."""
+    dev = encoded.device
+    B, Te, E = encoded.shape
+    mech, cells, nl, U, C, named, lstm = cell_parameters(cell, E)
+    tlen = SeqLen.wrap(target_seq_length, dev)
+    elen = SeqLen.wrap(encoded_seq_length, dev)
+    L = tlen.max()
 
     keep = cells[0].output_keep_prob
     seed, offset = nops.global_rng().next() if keep < 1 else (0, 0)
@@ -121,6 +127,41 @@ def dynamic_decode(cell, encoded, encoded_seq_length, targets, target_seq_length
     dynamic_decode.last = (desc, reserve)           # for decoder_inputs() below (tests, diagnostics)
     return logits, tlen
 
+
+
+def beam_search(cell, encoded, encoded_seq_length, beam_width, max_steps, length_penalty=0.0,
+                temperature=1.0, with_alignments=True):
+    """Beam search over the projected attention cell (components/beam_search_decoder.py:68-451
+    under dynamic_decode): ONE call into the C ABI (nabu_speller_beam_search), whose C++ driver runs
+    the cell kernels on B*beam_width rows, prunes and gathers on the device, and stops as the
+    reference's dynamic_decode does.  encoded [B,Te,E] (rows >= length zero).
+    Returns (sequences [B,W,time] int32, lengths [B,W] int32, scores [B,W], alignments
+    [B,W,time,Te] or None)."""
+    dev = encoded.device
+    B, Te, E = encoded.shape
+    mech, cells, nl, U, C, named, lstm = cell_parameters(cell, E)
+    elen = SeqLen.wrap(encoded_seq_length, dev)
+    W, S = int(beam_width), int(max_steps)
+    desc = _hip.BeamDesc(ctypes.sizeof(_hip.BeamDesc), B, Te, E, U, C, nl, mech.kind, mech.filtersize,
+                         mech.numfilt, W, S, float(length_penalty), float(temperature))
+    lib = _hip.lib()
+    ws_bytes = lib.nabu_speller_beam_ws_bytes(ctypes.byref(desc))
+    if ws_bytes == 0:
+        raise _hip.NabuHipError('beam search: unsupported shape: %s' % lib.nabu_last_error().decode())
+    values = encoded if encoded.is_contiguous() else encoded.contiguous()
+    seq = torch.empty((B, W, S), dtype=torch.int32, device=dev)
+    lengths = torch.empty((B, W), dtype=torch.int32, device=dev)
+    scores = torch.empty((B, W), dtype=torch.float32, device=dev)
+    align = torch.empty((B, W, S, Te), dtype=torch.float32, device=dev) if with_alignments else None
+    ws = _hip.Workspace.get(ws_bytes, dev, 'beam_search')
+    params = _ptrs(named, lstm, grad=False)
+    steps = ctypes.c_int32(0)
+    _hip.check(lib.nabu_speller_beam_search(ctypes.byref(desc), _hip.ptr(values), _hip.ptr(elen.dev),
+                                            ctypes.byref(params), _hip.ptr(seq), _hip.ptr(lengths),
+                                            _hip.ptr(scores), _hip.ptr(align), ctypes.byref(steps),
+                                            _hip.ptr(ws), ws_bytes, _hip.stream()), 'nabu_speller_beam_search')
+    n = steps.value
+    return seq[:, :, :n], lengths, scores, (align[:, :, :n] if with_alignments else None)
 
 def decoder_inputs():
     """[L,B] int32 labels the last dynamic_decode fed to the cell (row 0 = SOS; later rows are the

@@ -350,3 +350,57 @@ def ceil_div_i32(x, d):
     out = torch.empty_like(x)
     check(_hip.lib().nabu_ceil_div_i32(x.numel(), ptr(x), int(d), ptr(out), stream()), 'nabu_ceil_div_i32')
     return out
+
+
+# --------------------------------------------------------------------------
+# inference decoders (decode.hip)
+def ctc_beam_search(logits, logit_len, beam_width=100, merge_repeated=True):
+    """tf.nn.ctc_beam_search_decoder(top_paths=1) on batch-major logits [B,T,C]:
+    returns (ids [B,T] int32 padded with -1, lengths [B] int32, log-probabilities [B])"""
+    B, T, C = logits.shape
+    logits = logits.contiguous()
+    lib = _hip.lib()
+    nbytes = lib.nabu_ctc_beam_ws_bytes(B, T, C, int(beam_width))
+    ws = _hip.Workspace.get(nbytes, logits.device, 'ctc_beam')
+    ids = torch.empty((B, T), dtype=torch.int32, device=logits.device)
+    lens = torch.empty((B,), dtype=torch.int32, device=logits.device)
+    lp = torch.empty((B,), dtype=torch.float32, device=logits.device)
+    check(lib.nabu_ctc_beam_search(B, T, C, int(beam_width), int(bool(merge_repeated)), ptr(logits),
+                                   ptr(logit_len), ptr(ids), ptr(lens), ptr(lp), ptr(ws), nbytes, stream()),
+          'nabu_ctc_beam_search')
+    return ids, lens, lp
+
+
+def edit_distance(hyp, hyp_len, truth, truth_len):
+    """Levenshtein distance per row: hyp [B,Lh], truth [B,Lt] int32 with their lengths -> [B] int32"""
+    B = hyp.shape[0]
+    hyp, truth = hyp.contiguous(), truth.contiguous()
+    dist = torch.empty((B,), dtype=torch.int32, device=hyp.device)
+    check(_hip.lib().nabu_edit_distance(B, ptr(hyp) if hyp.numel() else None, hyp.shape[1], ptr(hyp_len),
+                                        ptr(truth) if truth.numel() else None, truth.shape[1],
+                                        ptr(truth_len), ptr(dist), stream()), 'nabu_edit_distance')
+    return dist
+
+
+def beam_prune(logits, logprobs, lengths, finished, seen, temperature=1.0, length_penalty=0.0):
+    """one expand+prune step of the attention beam search; logits [B,W,C]; the [B,W] state tensors
+    are updated in place.  Returns (pred_ids, parent, stay, all_seen)"""
+    B, W, C = logits.shape
+    dev = logits.device
+    pred = torch.empty((B, W), dtype=torch.int32, device=dev)
+    parent, stay = torch.empty_like(pred), torch.empty_like(pred)
+    all_seen = torch.empty((B,), dtype=torch.int32, device=dev)
+    scratch = torch.empty((B, W * C + W), dtype=torch.float32, device=dev)
+    check(_hip.lib().nabu_beam_prune(B, W, C, ptr(logits.contiguous()), float(temperature), float(length_penalty),
+                                     ptr(logprobs), ptr(lengths), ptr(finished), ptr(seen), ptr(pred),
+                                     ptr(parent), ptr(stay), ptr(all_seen), ptr(scratch), stream()),
+          'nabu_beam_prune')
+    return pred, parent, stay, all_seen
+
+
+def beam_gather(fresh, old, parent, stay):
+    B, W, F = fresh.shape
+    dst = torch.empty_like(fresh)
+    check(_hip.lib().nabu_beam_gather(B, W, F, ptr(fresh.contiguous()), ptr(old.contiguous()), ptr(parent),
+                                      ptr(stay), ptr(dst), stream()), 'nabu_beam_gather')
+    return dst
