@@ -38,7 +38,10 @@ struct Best {
 // larger value wins, equal values go to the smaller index; NaN never wins
 __device__ __forceinline__ Best better(Best a, Best b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
 
-__device__ __forceinline__ Best block_best(Best x, Best *red) {
+// `red` holds two sets of per-wave results used alternately (parity = round & 1), so that one
+// barrier per round suffices: round k+1 writes the other set while stragglers still read set k.
+__device__ __forceinline__ Best block_best(Best x, Best *red, int parity) {
+  red += parity * (DT / 64);
 #pragma unroll
   for (int o = 32; o; o >>= 1) {
     Best y;
@@ -51,7 +54,6 @@ __device__ __forceinline__ Best block_best(Best x, Best *red) {
   Best r = red[0];
 #pragma unroll
   for (int w = 1; w < DT / 64; ++w) r = better(r, red[w]);
-  __syncthreads();
   return r;
 }
 
@@ -80,7 +82,7 @@ struct CtcBeamArgs {
 
 __global__ __launch_bounds__(DT) void ctc_beam_kernel(CtcBeamArgs p) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
-  __shared__ Best red[DT / 64];
+  __shared__ Best red[2 * (DT / 64)];
   __shared__ int s_nl, s_nnodes;
   const int b = blockIdx.x, tid = threadIdx.x, W = p.W, C = p.C, C1 = p.C - 1, blank = p.C - 1;
   float *inp = dsm;                                 // [C]   log-softmax of the frame
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(DT) void ctc_beam_kernel(CtcBeamArgs p) {
     for (int idx = tid; idx < n; idx += DT) mine = better(mine, Best{keys[idx], idx});
     int nsel = 0;
     for (int k = 0; k < W; ++k) {
-      const Best g = block_best(mine, red);
+      const Best g = block_best(mine, red, k & 1);
       if (!(g.v > -INFINITY)) break;                      // uniform: fewer live candidates than W
       if (tid == 0) sel[k] = g.i;
       if ((g.i % DT) == tid) {
@@ -277,7 +279,7 @@ __device__ __forceinline__ float length_penalty(int len, float w, float pen6) {
 
 __global__ __launch_bounds__(DT) void beam_prune_kernel(PruneArgs p) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
-  __shared__ Best red[DT / 64];
+  __shared__ Best red[2 * (DT / 64)];
   __shared__ int s_all;
   const int b = blockIdx.x, tid = threadIdx.x, W = p.W, C = p.C, end = p.C - 1;
   const int n = W * C + W;
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(DT) void beam_prune_kernel(PruneArgs p) {
   Best mine = {-INFINITY, INT_MAX};
   for (int idx = tid; idx < n; idx += DT) mine = better(mine, Best{sc[idx], idx});
   for (int k = 0; k < W; ++k) {
-    Best g = block_best(mine, red);
+    Best g = block_best(mine, red, k & 1);
     if (g.i == INT_MAX) g.i = k;                         // only NaNs left (NaN logits): any slot
     if (tid == 0) sel[k] = g.i;
     if ((g.i % DT) == tid) {

@@ -85,6 +85,7 @@ class VariableStore(object):
         self.device = device
         self.flat = None
         self.flat_grad = None
+        self.restore = {}          # name -> array: values variables take when they are created
 
     def _dev(self):
         if self.device is None:
@@ -105,6 +106,8 @@ class VariableStore(object):
         if self.flat is not None:
             raise Exception('variable %s created after the store was flattened' % full)
         value = initializer(self.rng, tuple(shape))
+        if full in self.restore:                        # a loaded checkpoint wins over the initialiser
+            value = np.asarray(self.restore.pop(full), np.float32).reshape(tuple(shape))
         var = Variable(full, torch.from_numpy(np.ascontiguousarray(value)).to(self._dev()), trainable)
         self.vars[full] = var
         self.order.append(full)
@@ -150,6 +153,15 @@ class VariableStore(object):
             if n not in self.vars:
                 raise Exception('unknown variable %s' % n)
             self.vars[n].data.copy_(torch.from_numpy(np.ascontiguousarray(value, np.float32)))
+
+    def restore_from(self, state):
+        '''LoadAtBegin (components/hooks.py:6-28) for a store whose variables are created on first
+        use: existing variables are overwritten now, the others when they come into existence'''
+        for n, value in state.items():
+            if n in self.vars:
+                self.vars[n].data.copy_(torch.from_numpy(np.ascontiguousarray(value, np.float32)))
+            else:
+                self.restore[n] = np.asarray(value)
 
 
 _default = [None]

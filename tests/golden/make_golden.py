@@ -298,8 +298,54 @@ def make_components():
     np.savez_compressed(os.path.join(HERE, 'components.npz'), **out)
 
 
+def make_decode():
+    """inference, from oracle/decode_oracle.py: CTC beam search at the default
+    beam on posteriors of cfg2's logit shape statistics, edit distances, and an attention beam
+    search on a small Speller (weights by the reference's variable names)"""
+    from oracle import decode_oracle as DO
+    rng = np.random.default_rng(4321)
+    out = {}
+    B, T, C = 6, 40, 40
+    logits = rng.normal(0, 1, (B, T, C)).astype(np.float32)
+    path = rng.integers(0, C, (B, T))
+    logits[np.arange(B)[:, None], np.arange(T)[None, :], path] += 3.0
+    lens = np.array([40, 33, 0, 25, 40, 12], np.int32)
+    for merge in (1, 0):
+        hyps = DO.ctc_decode_batch(logits, lens, 100, bool(merge))
+        ids = np.full((B, T), -1, np.int32)
+        for b, h in enumerate(hyps):
+            ids[b, :len(h)] = h
+        out['ctc_ids_merge%d' % merge] = ids
+        out['ctc_len_merge%d' % merge] = np.array([len(h) for h in hyps], np.int32)
+    refs = rng.integers(0, C - 1, (B, 30)).astype(np.int32)
+    ref_len = rng.integers(0, 31, B).astype(np.int32)
+    hyps = DO.ctc_decode_batch(logits, lens, 100, True)
+    out.update(ctc_logits=logits, ctc_lens=lens, ed_ref=refs, ed_ref_len=ref_len,
+               ed_dist=np.array([DO.edit_distance(h, list(refs[b, :ref_len[b]])) for b, h in enumerate(hyps)], np.int32))
+    # attention beam search
+    Bs, Te, E, U, Cs, W, S = 3, 11, 24, 32, 9, 6, 12
+    for attention, K, F in (('vanilla', 0, 0), ('location_aware', 5, 3)):
+        names = speller_names(E, U, Cs, 1, attention, K, F)
+        w = draw_weights(names)
+        w[SP + 'dense/kernel'] = (w[SP + 'dense/kernel'] * 6.0).astype(np.float32)    # well separated hypotheses
+        w[SP + 'dense/bias'][Cs - 1] = 1.0                                             # ... some of which end
+        enc_len = np.array([11, 6, 9], np.int32)
+        enc = rng.normal(size=(Bs, Te, E)).astype(np.float32)
+        enc *= (np.arange(Te)[None, :, None] < enc_len[:, None, None])
+        res = DO.speller_beam_search(enc.astype(np.float64), enc_len, speller_view(w, 1, attention), W, S, 1.0, 1.0,
+                                     attention)
+        pre = 'bs_%s_' % attention
+        out.update(pack(pre + 'w_', w))
+        out.update({pre + 'enc': enc, pre + 'enc_len': enc_len, pre + 'seq': res['sequences'].astype(np.int32),
+                    pre + 'len': res['lengths'].astype(np.int32), pre + 'scores': res['scores'].astype(np.float32),
+                    pre + 'align': res['alignments'].astype(np.float32)})
+    np.savez_compressed(os.path.join(HERE, 'decode.npz'), **out)
+    return out['ctc_len_merge1'].tolist()
+
+
 if __name__ == '__main__':
     make_components()
+    print('decode        ', make_decode())
     print('cfg1_exact    ', make_cfg1_exact())
     print('cfg1_small    ', make_small_ctc('cfg1_small', 'DBLSTM', 2, 32, 4, 40, 1, 1234))
     print('cfg2_small    ', make_small_ctc('cfg2_small', 'Listener', 3, 32, 4, 64, 8, 2234))

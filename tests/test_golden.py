@@ -141,3 +141,25 @@ def test_cfg1_exact_fixture_matches_oracle():
         key = k.replace('/', '|')
         assert abs(np.sqrt((flat ** 2).sum()) - fx['gnorm:' + key]) < 1e-9 * max(1.0, fx['gnorm:' + key])
         np.testing.assert_allclose(flat[G.sample_index(k, flat.size)], fx['gsample:' + key], atol=1e-12)
+
+
+def test_decode_fixture_matches_the_decode_oracle():
+    """tests/golden/decode.npz (inference) is what oracle/decode_oracle.py gives"""
+    from oracle import decode_oracle as DO
+    fx = load('decode')
+    for merge in (1, 0):
+        hyps = DO.ctc_decode_batch(fx['ctc_logits'], fx['ctc_lens'], 100, bool(merge))
+        for b, h in enumerate(hyps):
+            n = fx['ctc_len_merge%d' % merge][b]
+            assert list(fx['ctc_ids_merge%d' % merge][b, :n]) == h
+    hyps = DO.ctc_decode_batch(fx['ctc_logits'], fx['ctc_lens'], 100, True)
+    for b, h in enumerate(hyps):
+        assert DO.edit_distance(h, list(fx['ed_ref'][b, :fx['ed_ref_len'][b]])) == fx['ed_dist'][b]
+    for attention in ('vanilla', 'location_aware'):
+        pre = 'bs_%s_' % attention
+        w = unpack(fx, pre + 'w_')
+        res = DO.speller_beam_search(fx[pre + 'enc'].astype(np.float64), fx[pre + 'enc_len'],
+                                     G.speller_view(w, 1, attention), 6, 12, 1.0, 1.0, attention)
+        np.testing.assert_array_equal(res['sequences'], fx[pre + 'seq'])
+        np.testing.assert_array_equal(res['lengths'], fx[pre + 'len'])
+        np.testing.assert_allclose(res['scores'], fx[pre + 'scores'], rtol=1e-6)

@@ -264,3 +264,78 @@ def test_beam_search_decoder_and_evaluator_through_the_recipe_api(tmp_path):
     ev.decoder.write(out, str(tmp_path), ['u%d' % b for b in range(4)])
     assert len(open(tmp_path / 'u0').read().strip().split('\n')) == 4
     assert np.load(tmp_path / 'u0_alignments.npy').shape[0] == 4
+
+
+def test_train_then_test_and_decode_scripts(tmp_path):
+    """the reference's run train -> run test -> run decode cycle on an experiment directory with
+    TFRecord data sets: the trained variables come back from model/network.ckpt.npz, `test` writes
+    the label error rate of the CTC decoder to <expdir>/result and `decode` one line per utterance"""
+    import os
+    from tests.test_data_path import make_dataset
+    from nabu_amd.neuralnetworks.trainers import trainer_factory
+    from nabu_amd.scripts import test as test_script, decode as decode_script
+    expdir = str(tmp_path / 'exp')
+    os.makedirs(expdir)
+    conf, feats, texts, alphabet = make_dataset(str(tmp_path / 'train'), n=16, dim=40, min_frames=14)
+    tst, tfeats, ttexts, _ = make_dataset(str(tmp_path / 'test'), n=7, dim=40, seed=9, min_frames=14)
+    conf.read_dict({'testfbank': dict(tst.items('trainfbank')), 'testtext': dict(tst.items('traintext'))})
+    mc, tc, ec = recipes.load_recipe('cfg1_dblstm_ctc', **{
+        'encoder.num_units': 16, 'trainer.batch_size': 4, 'trainer.num_epochs': 2, 'io.output_dims': 4})
+    tc.set('trainer', 'features', 'trainfbank')
+    tc.set('trainer', 'targets', 'text')
+    tc.set('trainer', 'text', 'traintext')
+    tc.set('trainer', 'valid_frequency', '1000')
+    ec.read_dict({'evaluator': {'evaluator': 'None'}})
+    for name, c in (('database.conf', conf), ('model.cfg', mc), ('trainer.cfg', tc)):
+        with open(os.path.join(expdir, name), 'w') as fid:
+            c.write(fid)
+    te = configparser.ConfigParser()
+    te.read_dict({'evaluator': {'evaluator': 'decoder_evaluator', 'batch_size': '3', 'features': 'testfbank',
+                                'targets': 'text', 'text': 'testtext'},
+                  'decoder': {'decoder': 'ctc_decoder', 'text_alphabet': ' '.join(alphabet)}})
+    rc = configparser.ConfigParser()
+    rc.read_dict({'recognizer': {'batch_size': '3', 'features': 'testfbank'},
+                  'decoder': {'decoder': 'ctc_decoder', 'text_alphabet': ' '.join(alphabet)}})
+    for name, c in (('test_evaluator.cfg', te), ('recognizer.cfg', rc)):
+        with open(os.path.join(expdir, name), 'w') as fid:
+            c.write(fid)
+    tr = trainer_factory.factory('standard')(conf=tc, dataconf=conf, modelconf=mc, evaluatorconf=ec,
+                                             expdir=expdir, server=None, task_index=0)
+    tr.train()
+    trained = tr.model.store.state_dict()
+    # run test
+    ler = test_script.test(expdir)
+    assert 0.0 <= ler and float(open(os.path.join(expdir, 'result')).read()) == ler
+    model = test_script.load_model(expdir)
+    x = torch.zeros((1, 20, 40), device=DEV)
+    with torch.no_grad():
+        model({'features': x}, {'features': np.array([20], np.int32)}, [], [], False)
+    loaded = model.store.state_dict()
+    assert set(loaded) == set(trained) and not model.store.restore
+    for k in trained:
+        np.testing.assert_array_equal(loaded[k], trained[k])
+    # the error rate over the first 6 of 7 test utterances (7 // 3 batches of 3), recomputed with the oracle
+    from nabu_amd.autodiff import SeqLen
+    errors = targets = 0
+    names = sorted(tfeats)
+    rd = te  # noqa
+    from nabu_amd.processing import input_pipeline
+    src = input_pipeline.from_sections(conf, ['features'], [['testfbank']], ['text'], [['testtext']],
+                                       batch_size=3, numbuckets=1, shuffle=False)
+    for i in range(2):
+        b = src.batch(i)
+        with torch.no_grad():
+            lg, ll = model({'features': torch.tensor(b['inputs']['features'], device=DEV)},
+                           {'features': SeqLen(b['input_seq_length']['features'], DEV)}, [], [], False)
+        hyps = D.ctc_decode_batch(lg['text'].cpu().numpy(), ll['text'].host, 100, True)
+        for j, h in enumerate(hyps):
+            tl = b['target_seq_length']['text'][j]
+            errors += D.edit_distance(h, list(b['targets']['text'][j, :tl]))
+            targets += tl
+    assert abs(ler - errors / targets) < 1e-9
+    # run decode: every test utterance, the last batch smaller
+    out = decode_script.decode(expdir)
+    lines = open(os.path.join(out, 'text')).read().strip('\n').split('\n')
+    assert sorted(l.split(' ')[0] for l in lines) == names
+    for l in lines:
+        assert all(s in alphabet for s in l.split(' ')[1:] if s)

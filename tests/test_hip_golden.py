@@ -143,3 +143,42 @@ def test_cfg5_recipe_with_its_bf16_input_gemms_stays_within_the_north_star_toler
     losses = [float(tr.step(tr.to_device(batch_of(fx, s))).item()) for s in range(steps)]
     rel = np.abs(np.array(losses) - fx['losses']) / fx['losses']
     assert rel.max() < 1e-3, (losses, fx['losses'])
+
+
+def test_decoders_against_the_golden_decode_fixture():
+    """inference kernels (decode.hip) against committed vectors: CTC beam search with and without
+    merge_repeated, edit distance, attention beam search (vanilla and location-aware)"""
+    from nabu_amd import ops
+    from nabu_amd import variables as vs
+    from nabu_amd.autodiff import SeqLen
+    from nabu_amd.neuralnetworks.models.ed_decoders import ed_decoder_factory, rnn_decoder
+    fx = load('decode')
+    dev = 'cuda'
+    lg, ln = torch.tensor(fx['ctc_logits'], device=dev), torch.tensor(fx['ctc_lens'], device=dev)
+    for merge in (1, 0):
+        ids, out_len, _ = ops.ctc_beam_search(lg, ln, 100, bool(merge))
+        np.testing.assert_array_equal(out_len.cpu().numpy(), fx['ctc_len_merge%d' % merge])
+        np.testing.assert_array_equal(ids.cpu().numpy(), fx['ctc_ids_merge%d' % merge])
+    ids, out_len, _ = ops.ctc_beam_search(lg, ln, 100, True)
+    dist = ops.edit_distance(ids, out_len, torch.tensor(fx['ed_ref'], device=dev),
+                             torch.tensor(fx['ed_ref_len'], device=dev))
+    np.testing.assert_array_equal(dist.cpu().numpy(), fx['ed_dist'])
+    for attention, K, F in (('vanilla', 0, 0), ('location_aware', 5, 3)):
+        pre = 'bs_%s_' % attention
+        w = unpack(fx, pre + 'w_')
+        over = {'decoder.num_layers': 1, 'decoder.num_units': 32, 'decoder.attention': attention}
+        if K:
+            over.update({'decoder.numfilt': F, 'decoder.filtersize': K})
+        mc, _, _ = recipes.load_recipe('cfg3_las_vanilla', **over)
+        dec = ed_decoder_factory.factory('speller')(mc, {'text': 9}, None)
+        store = vs.VariableStore(seed=0)
+        store.restore_from(w)
+        enc, enc_len = torch.tensor(fx[pre + 'enc'], device=dev), SeqLen(fx[pre + 'enc_len'], dev)
+        with torch.no_grad(), vs.as_default(store), vs.variable_scope(dec.scope):
+            cell = dec.create_cell({'features': enc}, {'features': enc_len}, False)
+            seqs, lengths, scores, aligns = rnn_decoder.beam_search(cell, enc, enc_len, 6, 12, 1.0, 1.0)
+        assert not store.restore, 'variable names differ from the reference names: %s' % sorted(store.restore)
+        np.testing.assert_array_equal(seqs.cpu().numpy(), fx[pre + 'seq'])
+        np.testing.assert_array_equal(lengths.cpu().numpy(), fx[pre + 'len'])
+        np.testing.assert_allclose(scores.cpu().numpy(), fx[pre + 'scores'], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(aligns.cpu().numpy(), fx[pre + 'align'], atol=2e-5)

@@ -97,3 +97,41 @@ def test_synthetic_batch_contract():
     for i in range(4):
         lab = p['targets']['text'][i, :p['target_seq_length']['text'][i]]
         assert len(lab) + np.sum(lab[1:] == lab[:-1]) <= -(-p['input_seq_length']['features'][i] // 8)
+
+
+def test_decoder_and_evaluator_factories_cover_the_inference_path():
+    """decoder_factory.py:4-37 / evaluator_factory.py:4-24: names of the reference dispatch to classes,
+    decoders outside the hot path say so, unknown names raise 'Undefined'"""
+    import configparser
+    from nabu_amd.neuralnetworks.decoders import decoder_factory, decoder as decoder_mod
+    from nabu_amd.neuralnetworks.evaluators import evaluator_factory
+    assert decoder_factory.factory('ctc_decoder').__name__ == 'CTCDecoder'
+    assert decoder_factory.factory('beam_search_decoder').__name__ == 'BeamSearchDecoder'
+    assert evaluator_factory.factory('decoder_evaluator').__name__ == 'DecoderEvaluator'
+    with pytest.raises(Exception, match='outside the MI355X hot path'):
+        decoder_factory.factory('max_decoder')
+    with pytest.raises(Exception, match='Undefined decoder type'):
+        decoder_factory.factory('nope')
+
+    class FakeModel(object):
+        output_names = ['text']
+        output_dims = {'text': 5}
+    conf = configparser.ConfigParser()
+    conf.read_dict({'decoder': {'decoder': 'beam_search_decoder', 'alphabet': 'a b c d'}})
+    with pytest.raises(Exception, match='max_steps'):                  # required field (empty default)
+        decoder_factory.factory('beam_search_decoder')(conf, FakeModel())
+    conf.set('decoder', 'max_steps', '7')
+    dec = decoder_factory.factory('beam_search_decoder')(conf, FakeModel())
+    assert dec.conf['beam_width'] == '16' and dec.conf['length_penalty'] == '1' and dec.alphabet == list('abcd')
+    conf2 = configparser.ConfigParser()
+    conf2.read_dict({'decoder': {'decoder': 'ctc_decoder', 'text_alphabet': 'x y'}})
+    ctc = decoder_factory.factory('ctc_decoder')(conf2, FakeModel())
+    assert ctc.alphabets == {'text': ['x', 'y']}
+    # the running error rate: (loss*num_targets + errors) / (num_targets + batch_targets)
+    loss = [0.0]
+    ctc._fold(loss, 3, 10)
+    ctc._fold(loss, 1, 30)
+    assert abs(loss[0] - 4.0 / 40.0) < 1e-12
+    ctc.reset()
+    assert ctc.num_targets == 0.0
+    assert list(decoder_mod.host_lengths([1, 2])) == [1, 2]
