@@ -206,12 +206,16 @@ int nabu_lstm_cell_bwd(int B, int U, int step, const int32_t *seq_len, const flo
  * [B,K,F] (the caller zeroes them before the first step and column-sums them
  * afterwards), writes dq [B,U] and dalign_out [B,Te] (gradient w.r.t. align_prev;
  * location only).  dalign_in (may be NULL) is the gradient that reaches this
- * step's alignments through the next step's location features. */
+ * step's alignments through the next step's location features.
+ * 'windowed' (WindowedAttention, attention.py:294-396) is the vanilla score restricted to the
+ * frames [m - left - 1, m + right), m = the first frame at which the cumulated PREVIOUS alignment
+ * exceeds 0.5 (Te if none does); the initial alignment is one-hot at frame 0 (the decoder drivers
+ * set it).  The window is a constant of the step: the backward kernel is the vanilla one. */
 typedef struct {
   uint32_t size;       /* sizeof(nabu_attn_desc) */
   int32_t B, Te, E, U;
-  int32_t kind;        /* 0 = vanilla (Bahdanau), 1 = location_aware */
-  int32_t K, F;        /* filtersize, numfilt (location_aware) */
+  int32_t kind;        /* 0 = vanilla (Bahdanau), 1 = location_aware, 2 = windowed */
+  int32_t K, F;        /* location_aware: filtersize, numfilt; windowed: left_window_width, right_window_width */
 } nabu_attn_desc;
 int nabu_attn_fwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
                   const int32_t *enc_len, const float *keys, const float *values,

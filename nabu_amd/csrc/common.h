@@ -33,6 +33,9 @@ int fail(int code, const char *fmt, ...);
                           __LINE__, hipGetErrorString(e_));                   \
   } while (0)
 
+// speller.hip: x[r*ld] = 1 for r < rows (initial alignments of the windowed attention)
+int first_col_one(int rows, int ld, float *x, hipStream_t s);
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }

@@ -612,6 +612,7 @@ extern "C" int nabu_speller_beam_search(const nabu_beam_desc *d, const float *va
   }
   NABU_HIP(hipMemsetAsync(w + L.ctx[cur], 0, (size_t)N * E * 4, s));
   NABU_HIP(hipMemsetAsync(w + L.align[cur], 0, (size_t)N * Te * 4, s));
+  if (d->kind == 2) DEC_TRY(first_col_one(N, Te, w + L.align[cur], s));
   float *z = w + L.z, *lg = w + L.logits;
   const int32_t *big = wi + L.big, *lenT = wi + L.lenT;
   int32_t *par = wi + L.parent, *stay = wi + L.stay;

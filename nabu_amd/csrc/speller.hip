@@ -133,6 +133,34 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
     conv_features(p, alp, cf, n);
     __syncthreads();
   }
+  // WindowedAttention (attention.py:294-396): only frames in [m - left - 1, m + right) may be attended,
+  // m = first frame at which the cumulated previous alignment exceeds 0.5 (Te if it never does)
+  int w_lo = 0, w_hi = Te;
+  if (!KIND && p.kind == 2) {
+    if (w == 0) {
+      float carry = 0.f;
+      int m = Te;
+      for (int base = 0; base < Te && m == Te; base += 64) {
+        const int t = base + lane;
+        float c = t < Te ? p.align_prev[(size_t)b * Te + t] : 0.f;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const float up = __shfl_up(c, o);
+          if (lane >= o) c += up;
+        }
+        c += carry;
+        const unsigned long long hit = __ballot(t < Te && c > 0.5f);
+        if (hit) m = base + __ffsll((long long)hit) - 1;
+        carry = __shfl(c, 63);
+      }
+      if (lane == 0) { red[0] = __int_as_float(m); }
+    }
+    __syncthreads();
+    const int m = __float_as_int(red[0]);
+    w_lo = max(m - p.K - 1, 0);
+    w_hi = min(m + p.F, Te);
+    __syncthreads();
+  }
   // scores: waves over encoder frames (4 frames of a wave in flight), lanes over 16-byte groups of
   // units — the keys are streamed once with coalesced 1 KiB wave loads
   {
@@ -200,6 +228,11 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
     }
   }
   __syncthreads();
+  if (!KIND && p.kind == 2) {
+    for (int t = tid; t < n; t += AT)
+      if (t < w_lo || t >= w_hi) sc[t] = -INFINITY;
+    __syncthreads();
+  }
   // softmax over the valid frames (score_mask_value = -inf past the length)
   float m = -3.0e38f;
   for (int t = tid; t < n; t += AT) m = fmaxf(m, sc[t]);
@@ -585,13 +618,24 @@ static int transpose(int R, int C, const float *in, int ldin, float *out, hipStr
   return 0;
 }
 
+// x[r, 0] = 1 for every row: WindowedAttention.initial_alignments (attention.py:352-359)
+__global__ __launch_bounds__(256) void first_col_one_kernel(int rows, int ld, float *__restrict__ x) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < rows) x[(size_t)r * ld] = 1.f;
+}
+int first_col_one(int rows, int ld, float *x, hipStream_t s) {
+  hipLaunchKernelGGL(first_col_one_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, rows, ld, x);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
 static int grid1(size_t n) {
   size_t b = (n + 255) / 256;
   return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
 }
 
 static size_t attn_lds(const nabu_attn_desc *d, bool bwd) {
-  size_t f = 2 * (size_t)d->Te + (d->kind ? (size_t)d->Te * d->F * (bwd ? 2 : 1) : 0);
+  size_t f = 2 * (size_t)d->Te + (d->kind == 1 ? (size_t)d->Te * d->F * (bwd ? 2 : 1) : 0);
   f += bwd ? 4 + (size_t)(AT / 64) * d->U : 64 + 4 + 4 * (size_t)AT;
   return f * sizeof(float);
 }
@@ -601,8 +645,9 @@ static int check_attn(const nabu_attn_desc *d) {
   if (d->B <= 0 || d->Te <= 0 || d->E <= 0 || d->U <= 0) return fail(NABU_EINVAL, "attention: bad dimensions");
   if (d->U > 1024) return fail(NABU_EUNSUP, "attention: num_units > 1024");
   if (d->U % 4 || d->E % 4) return fail(NABU_EUNSUP, "attention: num_units and encoder dim must be multiples of 4");
-  if (d->kind != 0 && d->kind != 1) return fail(NABU_EINVAL, "attention: unknown kind");
-  if (d->kind && (d->K <= 0 || d->F <= 0 || d->F > 16)) return fail(NABU_EUNSUP, "attention: numfilt must be 1..16");
+  if (d->kind < 0 || d->kind > 2) return fail(NABU_EINVAL, "attention: unknown kind");
+  if (d->kind == 1 && (d->K <= 0 || d->F <= 0 || d->F > 16)) return fail(NABU_EUNSUP, "attention: numfilt must be 1..16");
+  if (d->kind == 2 && (d->K < 0 || d->F < 1)) return fail(NABU_EINVAL, "attention: windowed needs left_window_width >= 0, right_window_width >= 1");
   if (attn_lds(d, true) > 150 * 1024) return fail(NABU_EUNSUP, "attention: encoder length too large for LDS");
   return 0;
 }
@@ -646,7 +691,7 @@ extern "C" int nabu_attn_fwd(const nabu_attn_desc *d, int step, const int32_t *d
   if (int e = check_attn(d)) return e;
   NABU_CHECK_ARG(dec_len && enc_len && keys && values && q && v && align_prev && ctx_prev && align && ctx,
                  "attn_fwd: null pointer");
-  NABU_CHECK_ARG(!d->kind || (conv_kernel && conv_proj), "attn_fwd: location-aware attention needs its kernels");
+  NABU_CHECK_ARG(d->kind != 1 || (conv_kernel && conv_proj), "attn_fwd: location-aware attention needs its kernels");
   AttnArgs p = {};
   p.B = d->B; p.Te = d->Te; p.E = d->E; p.U = d->U; p.kind = d->kind; p.K = d->K; p.F = d->F; p.step = step;
   p.dec_len = dec_len; p.enc_len = enc_len; p.keys = keys; p.values = values; p.q = q; p.v = v;
@@ -654,8 +699,8 @@ extern "C" int nabu_attn_fwd(const nabu_attn_desc *d, int step, const int32_t *d
   p.align = align; p.ctx = ctx;
   const size_t shm = attn_lds(d, false);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool reg = d->kind && d->U <= 256 * RJ && d->F <= RF;
-  auto kern = !d->kind ? attn_fwd_kernel<0> : reg ? attn_fwd_kernel<2> : attn_fwd_kernel<1>;
+  const bool reg = d->kind == 1 && d->U <= 256 * RJ && d->F <= RF;
+  auto kern = d->kind != 1 ? attn_fwd_kernel<0> : reg ? attn_fwd_kernel<2> : attn_fwd_kernel<1>;
   if (shm > 64 * 1024)
     NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
@@ -674,7 +719,7 @@ extern "C" int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *d
   if (int e = check_attn(d)) return e;
   NABU_CHECK_ARG(dec_len && enc_len && keys && values && q && v && align && dctx && dq && dkeys && dv_part,
                  "attn_bwd: null pointer");
-  NABU_CHECK_ARG(!d->kind || (conv_kernel && conv_proj && align_prev && dconv_proj_part &&
+  NABU_CHECK_ARG(d->kind != 1 || (conv_kernel && conv_proj && align_prev && dconv_proj_part &&
                               dconv_kernel_part && dalign_out),
                  "attn_bwd: location-aware attention needs its kernels and gradient buffers");
   AttnArgs p = {};
@@ -686,8 +731,8 @@ extern "C" int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *d
   p.dwf_part = dconv_proj_part; p.dck_part = dconv_kernel_part; p.dalign_out = dalign_out;
   const size_t shm = attn_lds(d, true);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool reg = d->kind && d->U <= 256 * RJ && d->F <= RF;
-  auto kern = !d->kind ? attn_bwd_kernel<0> : reg ? attn_bwd_kernel<2> : attn_bwd_kernel<1>;
+  const bool reg = d->kind == 1 && d->U <= 256 * RJ && d->F <= RF;
+  auto kern = d->kind != 1 ? attn_bwd_kernel<0> : reg ? attn_bwd_kernel<2> : attn_bwd_kernel<1>;
   if (shm > 64 * 1024)
     NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
@@ -870,6 +915,7 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
   }
   NABU_HIP(hipMemsetAsync(r + R.ctx, 0, (size_t)B * E * 4, s));
   NABU_HIP(hipMemsetAsync(r + R.align, 0, (size_t)B * Te * 4, s));
+  if (d->kind == 2) SP_TRY(first_col_one(B, Te, r + R.align, s));
   // decoder inputs actually used (scheduled sampling replaces entries of rows 1..L-1 below)
   int32_t *ids_used = reinterpret_cast<int32_t *>(r + R.ids);
   NABU_HIP(hipMemcpyAsync(ids_used, ids, (size_t)L * B * 4, hipMemcpyDeviceToDevice, s));
@@ -953,7 +999,7 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   SP_TRY(mm(false, true, BL, E, C, dl, C, p->out_kernel + (size_t)U * C, C, 0.f, dCtx, E, nullptr, gw, gwb, stream));
   NABU_HIP(hipMemsetAsync(dkeys, 0, (size_t)B * Te * U * 4, s));
   NABU_HIP(hipMemsetAsync(w + W.dv, 0, (size_t)B * U * 4, s));
-  if (d->kind) {
+  if (d->kind == 1) {
     NABU_HIP(hipMemsetAsync(w + W.dwf, 0, (size_t)B * F * U * 4, s));
     NABU_HIP(hipMemsetAsync(w + W.dck, 0, (size_t)B * K * F * 4, s));
   }
@@ -979,12 +1025,12 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   for (int t = L - 1; t >= 0; --t) {
     float *dCt = dCtx + (size_t)t * B * E;
     if (dctx_carry) SP_TRY(nabu_axpy_f32((size_t)B * E, 1.f, dctx_carry, dCt, stream));
-    float *dal_out = d->kind ? w + W.dal[t & 1] : nullptr;
+    float *dal_out = d->kind == 1 ? w + W.dal[t & 1] : nullptr;
     float *dqt = dq + (size_t)t * B * U;
     SP_TRY(nabu_attn_bwd(&ad, t, dec_len, enc_len, r + R.keys, values, r + R.q + (size_t)t * B * U, p->attention_v,
                          p->conv_kernel, p->conv_proj, r + R.align + (size_t)t * B * Te,
                          r + R.align + (size_t)(t + 1) * B * Te, dCt, dal_carry, dqt, dkeys, w + W.dv,
-                         d->kind ? w + W.dwf : nullptr, d->kind ? w + W.dck : nullptr, dal_out, stream));
+                         d->kind == 1 ? w + W.dwf : nullptr, d->kind == 1 ? w + W.dck : nullptr, dal_out, stream));
     dal_carry = dal_out;
     float *dHt = dH + (size_t)t * B * U;
     SP_TRY(mm(false, false, B, U, U, dqt, U, w + W.wqT, U, 1.f, dHt, U, nullptr, gw, gwb, stream));
@@ -1030,7 +1076,7 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
     SP_TRY(nabu_colsum_f32(BL, 4 * U, dzn, 4 * U, 0.f, g->lstm_bias[n], gw, gwb, stream));
   }
   SP_TRY(nabu_colsum_f32(B, U, w + W.dv, U, 0.f, g->attention_v, gw, gwb, stream));
-  if (d->kind) {
+  if (d->kind == 1) {
     SP_TRY(nabu_colsum_f32(B, F * U, w + W.dwf, F * U, 0.f, g->conv_proj, gw, gwb, stream));
     SP_TRY(nabu_colsum_f32(B, K * F, w + W.dck, K * F, 0.f, g->conv_kernel, gw, gwb, stream));
   }

@@ -1,12 +1,12 @@
 """Attention mechanisms (reference: nabu/neuralnetworks/components/attention.py).
 
 The factory keeps the reference's keys ('vanilla' -> tf BahdanauAttention,
-'location_aware' -> LocationAwareAttention); a mechanism object only owns its
+'location_aware' -> LocationAwareAttention, 'windowed' -> WindowedAttention); a mechanism object only owns its
 variables — the arithmetic of a decoder step is the fused kernel nabu_attn_fwd /
 nabu_attn_bwd driven by rnn_decoder.dynamic_decode."""
 from nabu_amd import variables as vs
 
-KINDS = {'vanilla': 0, 'location_aware': 1}
+KINDS = {'vanilla': 0, 'location_aware': 1, 'windowed': 2}
 
 
 def factory(conf, num_units, encoded, encoded_seq_length):
@@ -23,7 +23,9 @@ def factory(conf, num_units, encoded, encoded_seq_length):
         return BahdanauAttention(num_units=num_units, memory=encoded,
                                  memory_sequence_length=encoded_seq_length)
     elif conf['attention'] == 'windowed':
-        raise Exception('windowed attention is outside the MI355X hot path (SURVEY.md 2.1 row 3)')
+        return WindowedAttention(num_units=num_units, left_window_width=int(conf['left_window_width']),
+                                 right_window_width=int(conf['right_window_width']), memory=encoded,
+                                 memory_sequence_length=encoded_seq_length)
     raise Exception('unknown attention type %s' % conf['attention'])
 
 
@@ -66,3 +68,18 @@ class LocationAwareAttention(BahdanauAttention):
             v['conv_kernel'] = vs.get_variable('conv1d/kernel', [self.filtersize, 1, self.numfilt])
             v['conv_proj'] = vs.get_variable('process_conv_features/kernel', [self.numfilt, self.num_units])
         return v
+
+
+class WindowedAttention(BahdanauAttention):
+    '''Bahdanau attention restricted to a window around the median of the previous alignments
+    (reference attention.py:294-396); initial alignments are one-hot at the first frame.  The C ABI
+    carries the window widths in the descriptor fields location-aware attention uses for
+    filtersize / numfilt.'''
+    kind = 2
+    scope = 'windowed_attention'             # tf.variable_scope(None, 'windowed_attention', ...), attention.py:374
+
+    def __init__(self, num_units, left_window_width, right_window_width, memory, memory_sequence_length):
+        super(WindowedAttention, self).__init__(num_units, memory, memory_sequence_length)
+        if int(right_window_width) < 1 or int(left_window_width) < 0:
+            raise Exception('windowed attention needs left_window_width >= 0 and right_window_width >= 1')
+        self.filtersize, self.numfilt = int(left_window_width), int(right_window_width)

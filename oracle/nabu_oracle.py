@@ -456,8 +456,22 @@ def _prob_bwd(dalpha, alpha, score, mask, kind):
     return np.where(mask, dsg * sg * (1 - sg), 0)
 
 
+def attention_window(prev_align, left, right):
+    """WindowedAttention.__call__ (attention.py:376-390): boolean [B,Te] window from the previous
+    alignments — cumsum > 0.5 shifted left by left+1 (padded True) XOR shifted right by `right`
+    (padded False), i.e. frames [m-left-1, m+right) around the median frame m."""
+    B, Te = prev_align.shape
+    half = np.cumsum(prev_align, 1) > 0.5
+    sl = np.ones((B, Te), bool)
+    if left + 1 < Te:
+        sl[:, :Te - left - 1] = half[:, left + 1:]
+    sr = np.zeros((B, Te), bool)
+    sr[:, right:] = half[:, :Te - right]
+    return np.logical_xor(sl, sr)
+
+
 def speller_fwd(enc, enc_len, targets, target_len, p, attention='vanilla',
-                probability_fn='softmax', dec_inputs=None):
+                probability_fn='softmax', dec_inputs=None, window=None):
     """RNNDecoder._decode (rnn_decoder.py:13-82) with Speller.create_cell
     (speller.py:13-69), sample_prob=0, dropout=1.
 
@@ -488,6 +502,8 @@ def speller_fwd(enc, enc_len, targets, target_len, p, attention='vanilla',
     cs = [np.zeros((B, U), dt) for _ in range(nl)]
     ctx = np.zeros((B, E), dt)
     align = np.zeros((B, Te), dt)
+    if attention == 'windowed':
+        align[:, 0] = 1                                            # initial_alignments, attention.py:352-359
     sos = C - 1                                                    # rnn_decoder.py:46-47
     inp_ids = np.concatenate([np.full((B, 1), sos, np.int64),
                               np.asarray(targets)[:, :L].astype(np.int64)], 1)
@@ -520,11 +536,14 @@ def speller_fwd(enc, enc_len, targets, target_len, p, attention='vanilla',
             cf = conv1d_same(align, p['conv_kernel'])
             s = s + cf @ p['conv_proj']
             st['cf'] = cf
+        elif attention == 'windowed':
+            wmask = attention_window(align, window[0], window[1])
+            st['wmask'] = wmask
         elif attention != 'vanilla':
             raise ValueError(attention)
         th = np.tanh(s)
         score = th @ p['attention_v']
-        al = _prob_fwd(score, mask, probability_fn)
+        al = _prob_fwd(score, mask & wmask if attention == 'windowed' else mask, probability_fn)
         cx = np.einsum('bt,bte->be', al, values)
         lg = np.concatenate([query, cx], 1) @ p['out_kernel'] + p['out_bias']
         st.update(query=query, th=th, score=score, al=al, cx=cx)

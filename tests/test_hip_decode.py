@@ -143,6 +143,8 @@ def _speller(attention, nl, U, C, E, K=5, F=3, seed=5):
     over = {'decoder.num_layers': nl, 'decoder.num_units': U, 'decoder.attention': attention}
     if attention == 'location_aware':
         over.update({'decoder.numfilt': F, 'decoder.filtersize': K})
+    if attention == 'windowed':
+        over.update({'decoder.left_window_width': 1, 'decoder.right_window_width': 3})
     mc, _, _ = recipes.load_recipe('cfg3_las_vanilla', **over)
     dec = ed_decoder_factory.factory('speller')(mc, {'text': C}, None)
     return dec, vs.VariableStore(seed=seed)
@@ -150,7 +152,7 @@ def _speller(attention, nl, U, C, E, K=5, F=3, seed=5):
 
 @pytest.mark.parametrize('attention,nl,U,W,lpw,temp', [
     ('vanilla', 1, 32, 4, 0.0, 1.0), ('vanilla', 2, 16, 8, 1.0, 1.0),
-    ('location_aware', 1, 32, 6, 1.0, 1.5), ('vanilla', 1, 32, 16, 1.0, 1.0)])
+    ('location_aware', 1, 32, 6, 1.0, 1.5), ('vanilla', 1, 32, 16, 1.0, 1.0), ('windowed', 1, 32, 5, 1.0, 1.0)])
 def test_speller_beam_search_matches_oracle(attention, nl, U, W, lpw, temp):
     from nabu_amd import variables as vs
     from nabu_amd.autodiff import SeqLen
@@ -170,7 +172,8 @@ def test_speller_beam_search_matches_oracle(attention, nl, U, W, lpw, temp):
         store.vars['Speller/decoder/dense/kernel'].data.mul_(6.0)
         seqs, lengths, scores, aligns = rnn_decoder.beam_search(cell, enc_d, SeqLen(enc_len, DEV), W, S, lpw, temp)
     p = speller_params(store.state_dict(), nl, attention)
-    ref = D.speller_beam_search(enc.astype(np.float64), enc_len, p, W, S, lpw, temp, attention)
+    ref = D.speller_beam_search(enc.astype(np.float64), enc_len, p, W, S, lpw, temp, attention,
+                                window=(1, 3) if attention == 'windowed' else None)
     seqs, lengths, scores, aligns = (x.cpu().numpy() for x in (seqs, lengths, scores, aligns))
     assert seqs.shape[2] == ref['sequences'].shape[2]
     live = np.isfinite(ref['scores']) & (ref['scores'] > -1e30)

@@ -14,8 +14,12 @@ pytestmark = pytest.mark.gpu
 PRE = 'Speller/decoder/'
 
 
+SCOPES = {'vanilla': 'bahdanau_attention', 'location_aware': 'location_aware_attention',
+          'windowed': 'windowed_attention'}
+
+
 def speller_params(st, nl, attention):
-    sc = 'bahdanau_attention' if attention == 'vanilla' else 'location_aware_attention'
+    sc = SCOPES[attention]
     p = dict(memory_kernel=st[PRE + 'memory_layer/kernel'],
              query_kernel=st[PRE + sc + '/query_layer/kernel'],
              attention_v=st[PRE + sc + '/attention_v'],
@@ -38,7 +42,7 @@ def speller_params(st, nl, attention):
 
 
 def grad_names(nl, attention):
-    sc = 'bahdanau_attention' if attention == 'vanilla' else 'location_aware_attention'
+    sc = SCOPES[attention]
     m = {'memory_kernel': PRE + 'memory_layer/kernel', 'query_kernel': PRE + sc + '/query_layer/kernel',
          'attention_v': PRE + sc + '/attention_v', 'out_kernel': PRE + 'dense/kernel',
          'out_bias': PRE + 'dense/bias'}
@@ -51,7 +55,8 @@ def grad_names(nl, attention):
 @pytest.mark.parametrize('attention,nl,U,K,F', [
     ('vanilla', 1, 32, 0, 0), ('vanilla', 2, 16, 0, 0),
     ('location_aware', 1, 32, 5, 3), ('location_aware', 2, 16, 4, 2), ('location_aware', 1, 64, 11, 10),
-    ('location_aware', 1, 32, 5, 14)])          # numfilt > 12: the generic location-aware kernels
+    ('location_aware', 1, 32, 5, 14),           # numfilt > 12: the generic location-aware kernels
+    ('windowed', 1, 32, 1, 2), ('windowed', 2, 16, 0, 3)])     # K, F = left / right window width
 def test_speller_step_matches_oracle(attention, nl, U, K, F):
     """decoder alone on a given 'encoded' tensor: logits, loss and every gradient"""
     from nabu_amd import variables as vs
@@ -63,6 +68,8 @@ def test_speller_step_matches_oracle(attention, nl, U, K, F):
     over = {'decoder.num_layers': nl, 'decoder.num_units': U, 'decoder.attention': attention}
     if attention == 'location_aware':
         over.update({'decoder.numfilt': F, 'decoder.filtersize': K})
+    if attention == 'windowed':
+        over.update({'decoder.left_window_width': K, 'decoder.right_window_width': F})
     mc, _, _ = recipes.load_recipe('cfg3_las_vanilla', **over)
     dec = ed_decoder_factory.factory('speller')(mc, {'text': C}, None)
     enc_len = np.array([13, 9, 13, 4, 7], np.int32)
@@ -93,7 +100,8 @@ def test_speller_step_matches_oracle(attention, nl, U, K, F):
     tape.backward(loss)
     st = store.state_dict()
     p = speller_params(st, nl, attention)
-    rl, rll, cache = O.speller_fwd(enc.astype(np.float64), enc_len, tg, tlen, p, attention)
+    rl, rll, cache = O.speller_fwd(enc.astype(np.float64), enc_len, tg, tlen, p, attention,
+                                   window=(K, F) if attention == 'windowed' else None)
     np.testing.assert_array_equal(rll, lsl['text'].host)
     lg = logits['text'].cpu().numpy()
     assert np.abs(lg - rl).max() < 2e-5

@@ -257,7 +257,8 @@ def _speller_params(rng, E, U, C, nl, attention, K=5, F=3):
 @pytest.mark.parametrize('attention,prob_fn,nl,K', [
     ('vanilla', 'softmax', 1, 0), ('vanilla', 'softmax', 2, 0),
     ('location_aware', 'softmax', 1, 5), ('location_aware', 'softmax', 2, 4),
-    ('vanilla', 'sigmoid', 1, 0), ('location_aware', 'normalized_sigmoid', 1, 3)])
+    ('vanilla', 'sigmoid', 1, 0), ('location_aware', 'normalized_sigmoid', 1, 3),
+    ('windowed', 'softmax', 1, 0), ('windowed', 'softmax', 2, 1)])
 def test_speller_matches_torch_autograd(attention, prob_fn, nl, K):
     rng = _rng(11)
     B, Te, E, U, C = 3, 7, 6, 5, 6
@@ -268,11 +269,17 @@ def test_speller_matches_torch_autograd(attention, prob_fn, nl, K):
     for b in range(B):
         targets[b, tl[b] - 1] = C - 1       # eos
     p = _speller_params(rng, E, U, C, nl, attention, K=K)
-    lg, ll, cache = O.speller_fwd(enc, enc_len, targets, tl, p, attention, prob_fn)
+    window = (K, 2) if attention == 'windowed' else None      # (left_window_width, right_window_width)
+    lg, ll, cache = O.speller_fwd(enc, enc_len, targets, tl, p, attention, prob_fn, window=window)
+    if window:
+        # the window moves and really masks something
+        masks = np.array([st['wmask'] for st in cache['steps']])
+        assert masks[0, :, :2].all() and not masks[0, :, 2:].any()      # one-hot start: frames [0, right)
+        assert (masks[1:] != masks[:1]).any()
     loss, dlg = O.average_cross_entropy(lg, targets, ll, tl)
     denc, g = O.speller_bwd(dlg, cache)
     et, pt = _t(enc), _t(p)
-    lg2 = R.speller(et, enc_len, targets, tl, pt, attention, prob_fn)
+    lg2 = R.speller(et, enc_len, targets, tl, pt, attention, prob_fn, window)
     np.testing.assert_allclose(lg, lg2.detach().numpy(), atol=1e-11)
     l2 = R.avg_xent(lg2, targets, tl, tl)
     np.testing.assert_allclose(loss, l2.item(), rtol=1e-11)

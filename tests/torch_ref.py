@@ -79,7 +79,7 @@ def avg_xent(logits, targets, logit_len, target_len):
     return (ce.sum(1) / torch.as_tensor(target_len).to(logits.dtype)).mean()
 
 
-def speller(enc, enc_len, targets, target_len, p, attention, prob_fn):
+def speller(enc, enc_len, targets, target_len, p, attention, prob_fn, window=None):
     B, Te, E = enc.shape
     C = p['out_bias'].shape[0]
     U = p['attention_v'].shape[0]
@@ -93,6 +93,8 @@ def speller(enc, enc_len, targets, target_len, p, attention, prob_fn):
         cs = [enc.new_zeros(U) for _ in p['lstm']]
         ctx = enc.new_zeros(E)
         al = enc.new_zeros(Te)
+        if attention == 'windowed':
+            al[0] = 1.0
         prev = C - 1
         row = []
         for t in range(L):
@@ -117,6 +119,13 @@ def speller(enc, enc_len, targets, target_len, p, attention, prob_fn):
                 s = s + cf @ p['conv_proj']
             score = torch.tanh(s) @ p['attention_v']
             valid = torch.arange(Te) < n
+            if attention == 'windowed':
+                # interval form of the reference's shift/xor window: [m - left - 1, m + right) around the
+                # first frame m whose cumulated previous alignment exceeds one half
+                over = (torch.cumsum(al.detach(), 0) > 0.5).nonzero()
+                m = int(over[0]) if len(over) else Te
+                idx = torch.arange(Te)
+                valid = valid & (idx >= m - window[0] - 1) & (idx < m + window[1])
             if prob_fn == 'softmax':
                 al = torch.softmax(torch.where(valid, score, torch.full_like(score, -float('inf'))), 0)
             else:
