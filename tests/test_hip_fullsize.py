@@ -1,0 +1,210 @@
+"""GPU: the hot path at BASELINE.json's FULL sizes, where the float64 oracle would take hours.
+Checked through size-independent properties instead:
+
+  * the persistent recurrence (one launch per layer and pass) against the step-wise kernels (one
+    launch per frame) — two independent implementations of the same layer, each pinned against the
+    oracle at small sizes — on the cfg2 / cfg5 layer shapes with ragged lengths;
+  * time reversal: the backward direction of a BLSTM is the forward direction on per-utterance
+    reversed input, so reversing the input and swapping the two directions' weights must give the
+    time-reversed output with swapped halves (reference layer.py:35-49 via reverse_sequence);
+  * GEMM checksums: (A·B)·v = A·(B·v) and uᵀ·(A·B) = (uᵀ·A)·B in float64 on the host;
+  * the whole cfg2 training step: utterance permutation leaves loss and gradients unchanged, and the
+    gradient of the batch is the mean of the gradients of its halves (the loss is a mean over
+    utterances, loss_functions.py:206-212) — which also exercises another shard geometry;
+  * clip + Adam at cfg2's parameter count against the closed form in NumPy."""
+import numpy as np
+import pytest
+import torch
+
+from nabu_amd import recipes
+from nabu_amd.processing.synthetic import SyntheticData
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _layer(B, T, D, H, lens, mode, x, p, dout, need_dx=True):
+    from nabu_amd import ops
+    plan = ops.BlstmPlan(B, T, D, H, int(max(lens)), mode)
+    ld = torch.tensor(np.asarray(lens), dtype=torch.int32, device=DEV)
+    out = torch.full((B, T, 2 * H), float('nan'), device=DEV)
+    reserve = torch.empty(plan.reserve_bytes, dtype=torch.uint8, device=DEV)
+    ops.blstm_fwd(plan, x, ld, p['fw_kernel'], p['fw_bias'], p['bw_kernel'], p['bw_bias'], out, reserve)
+    dx = torch.full((B, T, D), float('nan'), device=DEV) if need_dx else None
+    g = {k: torch.full(v.shape, float('nan'), device=DEV) for k, v in p.items()}
+    ops.blstm_bwd(plan, x, ld, p['fw_kernel'], p['bw_kernel'], out, dout, reserve, dx,
+                  g['fw_kernel'], g['fw_bias'], g['bw_kernel'], g['bw_bias'])
+    ops.check_persist_status()
+    return out, dx, g
+
+
+def _layer_case(B, T, D, H, seed, ragged=True):
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    lens = np.full(B, T)
+    if ragged:
+        lens = np.random.default_rng(seed).integers(T // 2, T + 1, B)
+        lens[0] = T
+    x = torch.randn((B, T, D), generator=gen, device=DEV)
+    mask = (torch.arange(T, device=DEV)[None, :] < torch.tensor(lens, device=DEV)[:, None])
+    x = x * mask[:, :, None]
+    s = 1.0 / np.sqrt(D + H)
+    p = {k: torch.randn(shape, generator=gen, device=DEV) * s
+         for k, shape in (('fw_kernel', (D + H, 4 * H)), ('fw_bias', (4 * H,)),
+                          ('bw_kernel', (D + H, 4 * H)), ('bw_bias', (4 * H,)))}
+    dout = torch.randn((B, T, 2 * H), generator=gen, device=DEV) * mask[:, :, None]
+    return lens, x, p, dout
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-20))
+
+
+@pytest.mark.parametrize('B,T,D,H', [
+    (32, 1000, 40, 512),        # cfg2 layer 0
+    (32, 500, 2048, 512),       # cfg2 layer 1
+    (32, 125, 2048, 512),       # cfg2 final layer
+    (8, 200, 40, 256),          # cfg1 layer 0
+    (64, 400, 2048, 512),       # cfg5 layer 2 (two launches of 32 rows)
+])
+def test_persistent_recurrence_equals_stepwise_at_full_size(B, T, D, H):
+    from nabu_amd import ops
+    lens, x, p, dout = _layer_case(B, T, D, H, seed=T + D)
+    need_dx = D != 40
+    out_p, dx_p, g_p = _layer(B, T, D, H, lens, ops.LSTM_PERSISTENT, x, p, dout, need_dx)
+    out_s, dx_s, g_s = _layer(B, T, D, H, lens, ops.LSTM_STEPWISE, x, p, dout, need_dx)
+    assert torch.isfinite(out_p).all()
+    # same arithmetic in a different order (MFMA k-blocks vs. a GEMM): rounding-level agreement that
+    # must not grow with T — an error in the exchange or the masking would be O(1)
+    assert float((out_p - out_s).abs().max()) < 2e-4
+    for b in range(B):
+        assert torch.all(out_p[b, lens[b]:] == 0)
+    if need_dx:
+        assert _rel(dx_p, dx_s) < 5e-4
+    for k in g_p:
+        assert _rel(g_p[k], g_s[k]) < 5e-4, k
+
+
+@pytest.mark.parametrize('B,T,D,H', [(32, 1000, 40, 512), (32, 250, 2048, 512)])
+def test_time_reversal_swaps_the_directions(B, T, D, H):
+    from nabu_amd import ops
+    lens, x, p, dout = _layer_case(B, T, D, H, seed=3 * T)
+    out, dx, g = _layer(B, T, D, H, lens, ops.LSTM_PERSISTENT, x, p, dout)
+    # reverse_sequence along time within each utterance's length
+    idx = torch.arange(T, device=DEV)[None, :].repeat(B, 1)
+    ln = torch.tensor(lens, device=DEV)[:, None]
+    ridx = torch.where(idx < ln, ln - 1 - idx, idx)
+    rev = lambda a: torch.gather(a, 1, ridx[:, :, None].expand_as(a))
+    swap = lambda a: torch.cat([a[..., H:], a[..., :H]], -1)
+    q = dict(fw_kernel=p['bw_kernel'], fw_bias=p['bw_bias'], bw_kernel=p['fw_kernel'], bw_bias=p['fw_bias'])
+    out2, dx2, g2 = _layer(B, T, D, H, lens, ops.LSTM_PERSISTENT, rev(x).contiguous(), q,
+                           swap(rev(dout)).contiguous())
+    assert float((swap(rev(out2)) - out).abs().max()) < 1e-5      # identical arithmetic, other slots
+    assert _rel(rev(dx2), dx) < 1e-5
+    assert _rel(g2['fw_kernel'], g['bw_kernel']) < 1e-4 and _rel(g2['bw_bias'], g['fw_bias']) < 1e-4
+
+
+@pytest.mark.parametrize('ta,tb,M,N,K', [
+    (0, 0, 32000, 4096, 40), (0, 0, 16000, 4096, 2048),      # x·[Wx_fw | Wx_bw] of cfg2 layers 0 / 1
+    (0, 1, 16000, 2048, 4096),                                # dx = dz·Wxᵀ
+    (1, 0, 2048, 2048, 16000), (1, 0, 512, 2048, 32000)])     # dWx = xᵀ·dz, dWh = hᵀ·dz
+def test_gemm_checksums_at_cfg2_sizes(ta, tb, M, N, K):
+    from nabu_amd import ops
+    gen = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=gen, device=DEV)
+    b = torch.randn((N, K) if tb else (K, N), generator=gen, device=DEV)
+    c = torch.full((M, N), float('nan'), device=DEV)
+    ops.gemm(a, b, c, trans_a=bool(ta), trans_b=bool(tb))
+    A = a.cpu().numpy().astype(np.float64)
+    Bm = b.cpu().numpy().astype(np.float64)
+    A = A.T if ta else A
+    Bm = Bm.T if tb else Bm
+    C = c.cpu().numpy().astype(np.float64)
+    rng = np.random.default_rng(1)
+    v, u = rng.normal(size=N), rng.normal(size=M)
+    # |C v| ~ sqrt(K N): fp32 accumulation over K and the checksum over N give ~1e-6 relative
+    cv, want = C @ v, A @ (Bm @ v)
+    assert np.abs(cv - want).max() / np.abs(want).max() < 2e-5
+    uc, want = u @ C, (u @ A) @ Bm
+    assert np.abs(uc - want).max() / np.abs(want).max() < 2e-5
+    # and a sample of entries exactly
+    ii, jj = rng.integers(0, M, 64), rng.integers(0, N, 64)
+    want = np.einsum('ik,ki->i', A[ii], Bm[:, jj])
+    assert np.abs(C[ii, jj] - want).max() < 1e-3 * np.sqrt(K / 2048 + 1)
+
+
+def _cfg2_step_grads(tr, batch):
+    from nabu_amd.autodiff import Tape
+    from nabu_amd.neuralnetworks.trainers import loss_functions
+    b = tr.to_device(batch)
+    for v in tr.model.variables:
+        if v.grad is not None:
+            v.grad.zero_()
+    with Tape() as tape:
+        logits, ll = tr.model(b['inputs'], b['input_seq_length'], b['targets'], b['target_seq_length'], True)
+        loss = loss_functions.factory('CTC')(b['targets'], logits, ll, b['target_seq_length'])
+    tape.backward(loss)
+    loss_functions.check_status()
+    return float(loss.item()), {v.name: v.grad.clone() for v in tr.model.variables}
+
+
+def _take(batch, idx):
+    out = {}
+    for k, d in batch.items():
+        out[k] = {n: np.ascontiguousarray(a[idx]) for n, a in d.items()}
+    return out
+
+
+def test_cfg2_full_size_step_is_permutation_invariant_and_linear_in_the_batch():
+    """BASELINE.json configs[1] exactly: Listener 3+1 x 512, batch 32 x 1000 x 40, CTC"""
+    from tests.test_hip_model import make_trainer
+    data = SyntheticData(32, 1000, 40, min_frames=600, min_labels=20, max_labels=60, time_reduction=8, seed=2234)
+    tr = make_trainer('cfg2_listener_ctc', data)
+    batch = data.batch(0)
+    assert batch['inputs']['features'].shape == (32, 1000, 40)
+    loss, g = _cfg2_step_grads(tr, batch)
+    assert np.isfinite(loss) and 50 < loss < 1000               # ~ L * log(40) for random weights
+    assert tr.model.store.num_params() == 33734656 + 41000
+    perm = np.random.default_rng(0).permutation(32)
+    loss_p, g_p = _cfg2_step_grads(tr, _take(batch, perm))
+    assert abs(loss_p - loss) / loss < 2e-6
+    for k in g:
+        assert _rel(g_p[k], g[k]) < 2e-4, k
+    la, ga = _cfg2_step_grads(tr, _take(batch, np.arange(16)))
+    lb, gb = _cfg2_step_grads(tr, _take(batch, np.arange(16, 32)))
+    assert abs(0.5 * (la + lb) - loss) / loss < 2e-6
+    for k in g:
+        assert _rel(0.5 * (ga[k] + gb[k]), g[k]) < 2e-4, k
+    # zero-padding the time axis beyond the longest utterance changes nothing
+    padded = _take(batch, np.arange(32))
+    padded['inputs']['features'] = np.concatenate(
+        [padded['inputs']['features'], np.zeros((32, 24, 40), np.float32)], 1)
+    loss_z, g_z = _cfg2_step_grads(tr, padded)
+    assert abs(loss_z - loss) / loss < 2e-6
+    for k in g:
+        assert _rel(g_z[k], g[k]) < 2e-4, k
+
+
+def test_clip_adam_at_cfg2_parameter_count():
+    from nabu_amd import ops
+    n = 33734656 + 41000
+    rng = np.random.default_rng(5)
+    theta = rng.normal(size=n).astype(np.float32)
+    grad = (rng.normal(size=n) * 1.5).astype(np.float32)         # a third of the entries get clipped
+    m = (rng.normal(size=n) * 0.1).astype(np.float32)
+    v = (rng.uniform(size=n) * 0.01).astype(np.float32)
+    t, lr, b1, b2, eps = 7, 1e-3, 0.9, 0.999, 1e-8
+    td, gd, md, vd = (torch.tensor(a, device=DEV) for a in (theta, grad, m, v))
+    lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)          # tf.train.AdamOptimizer's step size
+    ops.adam_clip_step(td, gd, md, vd, lr_t, b1, b2, eps, 1.0)
+    g64 = np.clip(grad.astype(np.float64), -1, 1)
+    # the hyper-parameters reach the kernel as float32 scalars (as they reach TF's ApplyAdam), so
+    # 1 - beta is the float32 difference: 1 - 0.999f is 1.3e-5 off 0.001
+    omb1 = float(np.float32(1) - np.float32(b1))
+    omb2 = float(np.float32(1) - np.float32(b2))
+    lr_t = float(np.float32(lr_t))
+    m64 = m + (g64 - m) * omb1
+    v64 = v + (g64 * g64 - v) * omb2
+    th64 = theta - lr_t * m64 / (np.sqrt(v64) + eps)
+    np.testing.assert_allclose(md.cpu().numpy(), m64, rtol=2e-6, atol=1e-7)     # fp32 rounding of O(0.1) terms
+    np.testing.assert_allclose(vd.cpu().numpy(), v64, rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(td.cpu().numpy(), th64, rtol=0, atol=2e-6)
