@@ -10,9 +10,11 @@
 //     that stays L2-resident.
 //   * attention: the per-step cell kernels of speller.hip on B*beam_width rows, then one
 //     pruning workgroup per utterance and row gathers of the cell state.
-// Selecting the k best of n candidates is k rounds of a workgroup-wide arg-max in which every
-// thread caches the best of its own strided share and only the owner of the removed candidate
-// rescans (n/256 elements) — exact, deterministic, ties to the lower candidate index.
+// Selecting the k best of n candidates, exact and deterministic with ties to the lower candidate
+// index: CTC (k = 100 of ~4000 per frame) uses a radix select of the k-th largest key + compaction +
+// rank sort (select_best); the attention search (k = 16) uses k rounds of a workgroup-wide arg-max
+// in which every thread caches the best of its own strided share and only the owner of the removed
+// candidate rescans.
 #include <float.h>
 #include <limits.h>
 
@@ -68,6 +70,104 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+
+// order-preserving map float -> uint32 (larger float = larger integer); -inf and NaN map to 0 = "dead"
+__device__ __forceinline__ unsigned key_image(float x) {
+  if (!(x > -INFINITY)) return 0u;
+  const unsigned b = __float_as_uint(x);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// The `want` best of keys[0..n) by (value desc, index asc), dead keys (-inf/NaN) never: writes their
+// indices best-first to sel[] and returns how many there are (uniform).  One barrier-synchronised
+// routine for the whole workgroup; scratch: hist[256], list_u/list_i[want], ties[n], sc[8].
+__device__ int select_best(const float *keys, int n, int want, int *hist, unsigned *list_u, int *list_i,
+                           int *ties, int *sel, int *sc) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  unsigned prefix = 0;
+  int need = want;             // rank of the threshold key among the keys matching the prefix so far
+  bool all_live = false;       // fewer live keys than `want`: take them all
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    const unsigned himask = pass ? (0xFFFFFFFFu << (shift + 8)) : 0u;
+    for (int i = tid; i < 256; i += DT) hist[i] = 0;
+    __syncthreads();
+    for (int idx = tid; idx < n; idx += DT) {
+      const unsigned u = key_image(keys[idx]);
+      if (u && (u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+      const int s4 = h0 + h1 + h2 + h3;
+      int inc = s4;                                  // inclusive suffix sum over lanes >= this one
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_down(inc, o);
+        if (lane + o < 64) inc += t;
+      }
+      if (lane == 0) sc[2] = inc;                    // keys matching the prefix
+      int a = inc - s4;                              // keys in higher bins
+      const int hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+      for (int b = 3; b >= 0; --b) {
+        if (a < need && need <= a + hh[b]) { sc[0] = 4 * lane + b; sc[1] = need - a; }
+        a += hh[b];
+      }
+    }
+    __syncthreads();
+    if (sc[2] < need) { all_live = true; break; }    // only possible in pass 0 (uniform)
+    prefix |= (unsigned)sc[0] << shift;
+    need = sc[1];
+    __syncthreads();
+  }
+  // compaction
+  if (tid == 0) { sc[3] = 0; sc[4] = 0; }
+  __syncthreads();
+  const unsigned thr = all_live ? 0u : prefix;
+  for (int idx = tid; idx < n; idx += DT) {
+    const unsigned u = key_image(keys[idx]);
+    if (!u) continue;
+    if (u > thr) {
+      const int pos = atomicAdd(&sc[3], 1);
+      list_u[pos] = u; list_i[pos] = idx;
+    } else if (u == thr) {
+      ties[atomicAdd(&sc[4], 1)] = idx;
+    }
+  }
+  __syncthreads();
+  const int above = sc[3], nties = all_live ? 0 : sc[4];
+  // of the keys equal to the threshold the `need` lowest indices survive
+  for (int t = tid; t < nties; t += DT) {
+    const int me = ties[t];
+    int rank = 0;
+    if (nties > need)
+      for (int j = 0; j < nties; ++j) rank += ties[j] < me;
+    else
+      rank = 0;
+    if (nties <= need || rank < need) {
+      const int pos = atomicAdd(&sc[3], 1);
+      list_u[pos] = thr; list_i[pos] = me;
+    }
+  }
+  __syncthreads();
+  const int m = sc[3];
+  (void)above;
+  // rank sort (keys descending, equal keys by ascending index)
+  for (int t = tid; t < m; t += DT) {
+    const unsigned u = list_u[t];
+    const int i = list_i[t];
+    int rank = 0;
+    for (int j = 0; j < m; ++j) {
+      const unsigned uj = list_u[j];
+      rank += (uj > u) || (uj == u && list_i[j] < i);
+    }
+    sel[rank] = i;
+  }
+  __syncthreads();
+  return m;
+}
+
 // ===========================================================================
 // CTC prefix beam search
 struct CtcBeamArgs {
@@ -82,7 +182,6 @@ struct CtcBeamArgs {
 
 __global__ __launch_bounds__(DT) void ctc_beam_kernel(CtcBeamArgs p) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
-  __shared__ Best red[2 * (DT / 64)];
   __shared__ int s_nl, s_nnodes;
   const int b = blockIdx.x, tid = threadIdx.x, W = p.W, C = p.C, C1 = p.C - 1, blank = p.C - 1;
   float *inp = dsm;                                 // [C]   log-softmax of the frame
@@ -93,6 +192,11 @@ __global__ __launch_bounds__(DT) void ctc_beam_kernel(CtcBeamArgs p) {
   int *s_node = reinterpret_cast<int *>(n_lab + W); // [W]   tree node of a beam slot
   int *s_lbl = s_node + W, *n_node = s_lbl + W, *n_lbl = n_node + W, *sel = n_lbl + W;
   float *keys = reinterpret_cast<float *>(sel + W); // [W*C] selection keys: leaves, then expansions
+  int *ties = reinterpret_cast<int *>(keys + W * C);   // [W*C] candidates equal to the W-th key
+  unsigned *list_u = reinterpret_cast<unsigned *>(ties + W * C);   // [W] survivors: key image, index
+  int *list_i = reinterpret_cast<int *>(list_u + W);
+  int *hist = list_i + W;                              // [256]
+  __shared__ int s_sc[8];
   int32_t *parent = p.nodes + (size_t)b * p.per_utt, *label = parent + p.NN, *slot = label + p.NN,
           *child = slot + p.NN;
   int Tb = p.len[b];
@@ -151,22 +255,10 @@ __global__ __launch_bounds__(DT) void ctc_beam_kernel(CtcBeamArgs p) {
       keys[nl + idx] = sc;
     }
     __syncthreads();
-    // (3) the beam_width best
-    Best mine = {-INFINITY, INT_MAX};
-    for (int idx = tid; idx < n; idx += DT) mine = better(mine, Best{keys[idx], idx});
-    int nsel = 0;
-    for (int k = 0; k < W; ++k) {
-      const Best g = block_best(mine, red, k & 1);
-      if (!(g.v > -INFINITY)) break;                      // uniform: fewer live candidates than W
-      if (tid == 0) sel[k] = g.i;
-      if ((g.i % DT) == tid) {
-        keys[g.i] = -INFINITY;
-        mine = Best{-INFINITY, INT_MAX};
-        for (int idx = tid; idx < n; idx += DT) mine = better(mine, Best{keys[idx], idx});
-      }
-      ++nsel;
-    }
-    __syncthreads();
+    // (3) the beam_width best: radix select of the W-th largest key (4 passes over 8-bit digits of
+    // the order-preserving integer image of the floats, 256-bin histograms in LDS), compaction of
+    // everything above it plus the lowest-index ties, then a rank sort of the <= W survivors
+    const int nsel = select_best(keys, n, W, hist, list_u, list_i, ties, sel, s_sc);
     // (4) the new beam, best first; prefixes entering the tree get a node
     if (tid < nl) slot[s_node[tid]] = -1;
     __syncthreads();
@@ -226,7 +318,7 @@ __global__ __launch_bounds__(DT) void ctc_beam_kernel(CtcBeamArgs p) {
   for (int k = s_len + tid; k < p.T; k += DT) p.out_ids[(size_t)b * p.T + k] = -1;
 }
 
-static size_t ctc_beam_lds(int C, int W) { return ((size_t)C + 13 * (size_t)W + (size_t)W * C) * 4; }
+static size_t ctc_beam_lds(int C, int W) { return ((size_t)C + 15 * (size_t)W + 2 * (size_t)W * C + 256) * 4; }
 
 // ===========================================================================
 // Levenshtein distance, one workgroup per pair, anti-diagonal wavefront in LDS

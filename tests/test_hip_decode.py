@@ -342,3 +342,19 @@ def test_train_then_test_and_decode_scripts(tmp_path):
     assert sorted(l.split(' ')[0] for l in lines) == names
     for l in lines:
         assert all(s in alphabet for s in l.split(' ')[1:] if s)
+
+
+def test_ctc_beam_search_ties_go_to_the_earlier_candidate():
+    """uniform posteriors: every expansion of a frame ties exactly; the beam keeps the earlier
+    candidates (existing leaves before expansions, lower leaf, lower label), like a bounded top-N
+    container with a strict admission test — the radix select + lowest-index tie rule"""
+    for T, C, W in ((6, 4, 8), (9, 6, 20), (5, 40, 100)):
+        logits = np.zeros((2, T, C), np.float32)
+        logits[1] = 0.5                                          # any constant: still uniform
+        lens = np.array([T, T - 1], np.int32)
+        for merge in (True, False):
+            ids, out_len, _ = ops.ctc_beam_search(torch.tensor(logits, device=DEV), torch.tensor(lens, device=DEV),
+                                                  W, merge)
+            want = D.ctc_decode_batch(logits, lens, W, merge)
+            for b in range(2):
+                assert list(ids[b, :out_len[b]].cpu().numpy()) == want[b], (T, C, W, merge, b)
