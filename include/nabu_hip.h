@@ -207,6 +207,9 @@ int nabu_lstm_cell_bwd(int B, int U, int step, const int32_t *seq_len, const flo
  * afterwards), writes dq [B,U] and dalign_out [B,Te] (gradient w.r.t. align_prev;
  * location only).  dalign_in (may be NULL) is the gradient that reaches this
  * step's alignments through the next step's location features.
+ * probability_fn: alignments = softmax(score) | sigmoid(score) | sigmoid(score) / sum_t sigmoid(score)
+ * over the unmasked frames (masked frames get 0).  normalized_sigmoid keeps its normaliser per
+ * utterance in znorm [B] (written by the forward kernel, read by the backward kernel; NULL otherwise).
  * 'windowed' (WindowedAttention, attention.py:294-396) is the vanilla score restricted to the
  * frames [m - left - 1, m + right), m = the first frame at which the cumulated PREVIOUS alignment
  * exceeds 0.5 (Te if none does); the initial alignment is one-hot at frame 0 (the decoder drivers
@@ -216,19 +219,20 @@ typedef struct {
   int32_t B, Te, E, U;
   int32_t kind;        /* 0 = vanilla (Bahdanau), 1 = location_aware, 2 = windowed */
   int32_t K, F;        /* location_aware: filtersize, numfilt; windowed: left_window_width, right_window_width */
+  int32_t prob_fn;     /* probability_fn (attention.py:9-13): 0 softmax, 1 sigmoid, 2 normalized_sigmoid */
 } nabu_attn_desc;
 int nabu_attn_fwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
                   const int32_t *enc_len, const float *keys, const float *values,
                   const float *q, const float *v, const float *conv_kernel,
                   const float *conv_proj, const float *align_prev, const float *ctx_prev,
-                  float *align, float *ctx, nabu_stream_t stream);
+                  float *align, float *ctx, float *znorm, nabu_stream_t stream);
 int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
                   const int32_t *enc_len, const float *keys, const float *values,
                   const float *q, const float *v, const float *conv_kernel,
                   const float *conv_proj, const float *align_prev, const float *align,
                   const float *dctx, const float *dalign_in, float *dq, float *dkeys,
                   float *dv_part, float *dconv_proj_part, float *dconv_kernel_part,
-                  float *dalign_out, nabu_stream_t stream);
+                  float *dalign_out, const float *znorm, nabu_stream_t stream);
 
 /* Whole-sequence decoder driver: RNNDecoder._decode over all L = max(dec_len)
  * steps in one call (rnn_decoder.py:59-82: ScheduledEmbeddingTrainingHelper,
@@ -247,7 +251,7 @@ int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
 typedef struct {
   uint32_t size;
   int32_t B, Te, E, U, C, L, num_layers;
-  int32_t kind, K, F;                 /* attention: see nabu_attn_desc */
+  int32_t kind, K, F, prob_fn;        /* attention: see nabu_attn_desc */
   float keep_prob;                    /* output dropout of every LSTM layer; 1 = off */
   unsigned long long seed, seed_offset;
   float sample_prob;                  /* scheduled sampling probability (speller.cfg sample_prob); 0 = off */
@@ -398,7 +402,7 @@ int nabu_edit_distance(int B, const int32_t *hyp, int ldh, const int32_t *hyp_le
 typedef struct {
   uint32_t size;
   int32_t B, Te, E, U, C, num_layers;
-  int32_t kind, K, F;                 /* attention: see nabu_attn_desc */
+  int32_t kind, K, F, prob_fn;        /* attention: see nabu_attn_desc */
   int32_t beam_width, max_steps;
   float length_penalty, temperature;
 } nabu_beam_desc;

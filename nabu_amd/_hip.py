@@ -48,8 +48,8 @@ SIGNATURES = {
     'nabu_xent_loss_grad': (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     'nabu_lstm_cell_fwd': (_i, [_i, _i, _i] + [_vp] * 10 + [_vp]),
     'nabu_lstm_cell_bwd': (_i, [_i, _i, _i] + [_vp] * 9 + [_vp]),
-    'nabu_attn_fwd': (_i, [_vp, _i] + [_vp] * 12 + [_vp]),
-    'nabu_attn_bwd': (_i, [_vp, _i] + [_vp] * 18 + [_vp]),
+    'nabu_attn_fwd': (_i, [_vp, _i] + [_vp] * 13 + [_vp]),
+    'nabu_attn_bwd': (_i, [_vp, _i] + [_vp] * 19 + [_vp]),
     'nabu_sample_ids': (_i, [_i, _i, _vp, _f, _c.c_ulonglong, _c.c_ulonglong, _vp, _vp, _vp]),
     'nabu_speller_decoder_inputs': (_i, [_vp, _vp, _vp, _vp]),
     'nabu_speller_reserve_bytes': (_sz, [_vp]),
@@ -148,14 +148,14 @@ GEMM_PRECISIONS = {'default': 0, 'f32': 1, 'bf16': 2, 'bf16x3': 3, 'bf16x6': 4}
 
 class SpellerDesc(_c.Structure):
     _fields_ = [('size', _c.c_uint32)] + [(n, _c.c_int32) for n in
-                                          ('B', 'Te', 'E', 'U', 'C', 'L', 'num_layers', 'kind', 'K', 'F')] + \
+                                          ('B', 'Te', 'E', 'U', 'C', 'L', 'num_layers', 'kind', 'K', 'F', 'prob_fn')] + \
                [('keep_prob', _c.c_float), ('seed', _c.c_ulonglong), ('seed_offset', _c.c_ulonglong),
                 ('sample_prob', _c.c_float), ('sample_seed', _c.c_ulonglong), ('sample_offset', _c.c_ulonglong)]
 
 
 class BeamDesc(_c.Structure):
     _fields_ = [('size', _c.c_uint32)] + [(n, _c.c_int32) for n in
-                                          ('B', 'Te', 'E', 'U', 'C', 'num_layers', 'kind', 'K', 'F',
+                                          ('B', 'Te', 'E', 'U', 'C', 'num_layers', 'kind', 'K', 'F', 'prob_fn',
                                            'beam_width', 'max_steps')] + \
                [('length_penalty', _c.c_float), ('temperature', _c.c_float)]
 
@@ -169,4 +169,5 @@ class SpellerPtrs(_c.Structure):
 
 class AttnDesc(_c.Structure):
     _fields_ = [('size', _c.c_uint32), ('B', _c.c_int32), ('Te', _c.c_int32), ('E', _c.c_int32),
-                ('U', _c.c_int32), ('kind', _c.c_int32), ('K', _c.c_int32), ('F', _c.c_int32)]
+                ('U', _c.c_int32), ('kind', _c.c_int32), ('K', _c.c_int32), ('F', _c.c_int32),
+                ('prob_fn', _c.c_int32)]

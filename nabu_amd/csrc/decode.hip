@@ -677,7 +677,7 @@ extern "C" int nabu_speller_beam_search(const nabu_beam_desc *d, const float *va
             S = d->max_steps;
   float *gw = w + L.gemm;
   const size_t gwb = L.gemm_bytes;
-  const nabu_attn_desc ad = {sizeof(nabu_attn_desc), N, Te, E, U, d->kind, d->K, d->F};
+  const nabu_attn_desc ad = {sizeof(nabu_attn_desc), N, Te, E, U, d->kind, d->K, d->F, d->prob_fn};
   auto tile = [&](const void *src, void *dst, size_t F) {
     size_t gy = (F + DT * 4 - 1) / (DT * 4);
     hipLaunchKernelGGL(tile_rows_kernel, dim3(N, gy > 64 ? 64 : (unsigned)gy), dim3(DT), 0, s, W, F,
@@ -729,7 +729,8 @@ extern "C" int nabu_speller_beam_search(const nabu_beam_desc *d, const float *va
     const float *htop = w + L.h[fresh][nl - 1];
     DEC_TRY(bmm(N, U, U, htop, U, p->query_kernel, U, 0.f, w + L.q, U, nullptr, gw, gwb, stream));
     DEC_TRY(nabu_attn_fwd(&ad, 0, big, lenT, w + L.keysT, w + L.valuesT, w + L.q, p->attention_v, p->conv_kernel,
-                          p->conv_proj, w + L.align[cur], w + L.ctx[cur], w + L.align[fresh], w + L.ctx[fresh], stream));
+                          p->conv_proj, w + L.align[cur], w + L.ctx[cur], w + L.align[fresh], w + L.ctx[fresh],
+                          w + L.acts /* normaliser scratch: the saved gate activations are not used at inference */, stream));
     // AttentionProjectionWrapper: [h, context of this step]·W + b (rnn_cell.py:145-155)
     DEC_TRY(bmm(N, C, U, htop, U, p->out_kernel, C, 0.f, lg, C, p->out_bias, gw, gwb, stream));
     DEC_TRY(bmm(N, C, E, w + L.ctx[fresh], E, p->out_kernel + (size_t)U * C, C, 1.f, lg, C, nullptr, gw, gwb, stream));

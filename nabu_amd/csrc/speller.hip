@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
 
 // ---------------------------------------------------------------------------
 struct AttnArgs {
-  int B, Te, E, U, kind, K, F, step;
+  int B, Te, E, U, kind, K, F, step, prob_fn;
+  float *znorm;      // [B] normaliser of normalized_sigmoid (forward writes, backward reads)
   const int32_t *dec_len, *enc_len;
   const float *keys, *values, *q, *v, *ck, *wf, *align_prev;
   // forward
@@ -233,6 +234,28 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
       if (t < w_lo || t >= w_hi) sc[t] = -INFINITY;
     __syncthreads();
   }
+  if (p.prob_fn != 0) {
+    // sigmoid / normalized_sigmoid (attention.py:9-13, 41-55): masked frames (score -inf) give 0
+    float z = 0.f;
+    for (int t = tid; t < n; t += AT) {
+      const float e = 1.0f / (1.0f + expf(-sc[t]));
+      sc[t] = e;
+      z += e;
+    }
+    z = wave_sum(z);
+    if (lane == 0) red[w] = z;
+    __syncthreads();
+    z = 0.f;
+    for (int i = 0; i < AT / 64; ++i) z += red[i];
+    const float inv = p.prob_fn == 2 ? 1.0f / z : 1.0f;
+    if (p.prob_fn == 2 && tid == 0 && p.znorm) p.znorm[b] = z;
+    for (int t = tid; t < Te; t += AT) {
+      const float a = t < n ? sc[t] * inv : 0.f;
+      sc[t] = a;
+      align[t] = a;
+    }
+    __syncthreads();
+  } else {
   // softmax over the valid frames (score_mask_value = -inf past the length)
   float m = -3.0e38f;
   for (int t = tid; t < n; t += AT) m = fmaxf(m, sc[t]);
@@ -261,6 +284,7 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
     align[t] = a;
   }
   __syncthreads();
+  }
   // context = alignments^T · values: threads over 16-byte column groups, the frames split over
   // the AT / (E/4) thread groups (8 frames of a thread in flight), partial sums through LDS
   {
@@ -377,7 +401,14 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
   r = 0.f;
   for (int i = 0; i < NW; ++i) r += red[i];
   __syncthreads();
-  for (int t = tid; t < Te; t += AT) ds[t] = t < n ? al[t] * (ds[t] - r) : 0.f;
+  if (p.prob_fn == 0) {
+    for (int t = tid; t < Te; t += AT) ds[t] = t < n ? al[t] * (ds[t] - r) : 0.f;
+  } else if (p.prob_fn == 1) {        // a = sigmoid(s): ds = da a (1 - a)
+    for (int t = tid; t < Te; t += AT) ds[t] = t < n ? ds[t] * al[t] * (1.f - al[t]) : 0.f;
+  } else {                            // a = sg / z, sg = sigmoid(s): ds = (da - sum a da) a (1 - a z)
+    const float z = p.znorm[b];
+    for (int t = tid; t < Te; t += AT) ds[t] = t < n ? (ds[t] - r) * al[t] * (1.f - al[t] * z) : 0.f;
+  }
   __syncthreads();
   // through v·tanh(keys + q + f): lanes own 16-byte groups of units (u4 = lane + 64 j), waves split
   // the frames (2 frames of a wave in flight); keys are read and dkeys updated with 1 KiB wave accesses
@@ -646,6 +677,7 @@ static int check_attn(const nabu_attn_desc *d) {
   if (d->U > 1024) return fail(NABU_EUNSUP, "attention: num_units > 1024");
   if (d->U % 4 || d->E % 4) return fail(NABU_EUNSUP, "attention: num_units and encoder dim must be multiples of 4");
   if (d->kind < 0 || d->kind > 2) return fail(NABU_EINVAL, "attention: unknown kind");
+  if (d->prob_fn < 0 || d->prob_fn > 2) return fail(NABU_EINVAL, "attention: unknown probability_fn");
   if (d->kind == 1 && (d->K <= 0 || d->F <= 0 || d->F > 16)) return fail(NABU_EUNSUP, "attention: numfilt must be 1..16");
   if (d->kind == 2 && (d->K < 0 || d->F < 1)) return fail(NABU_EINVAL, "attention: windowed needs left_window_width >= 0, right_window_width >= 1");
   if (attn_lds(d, true) > 150 * 1024) return fail(NABU_EUNSUP, "attention: encoder length too large for LDS");
@@ -687,7 +719,7 @@ extern "C" int nabu_attn_fwd(const nabu_attn_desc *d, int step, const int32_t *d
                              const int32_t *enc_len, const float *keys, const float *values,
                              const float *q, const float *v, const float *conv_kernel,
                              const float *conv_proj, const float *align_prev, const float *ctx_prev,
-                             float *align, float *ctx, nabu_stream_t stream) {
+                             float *align, float *ctx, float *znorm, nabu_stream_t stream) {
   if (int e = check_attn(d)) return e;
   NABU_CHECK_ARG(dec_len && enc_len && keys && values && q && v && align_prev && ctx_prev && align && ctx,
                  "attn_fwd: null pointer");
@@ -696,7 +728,7 @@ extern "C" int nabu_attn_fwd(const nabu_attn_desc *d, int step, const int32_t *d
   p.B = d->B; p.Te = d->Te; p.E = d->E; p.U = d->U; p.kind = d->kind; p.K = d->K; p.F = d->F; p.step = step;
   p.dec_len = dec_len; p.enc_len = enc_len; p.keys = keys; p.values = values; p.q = q; p.v = v;
   p.ck = conv_kernel; p.wf = conv_proj; p.align_prev = align_prev; p.ctx_prev = ctx_prev;
-  p.align = align; p.ctx = ctx;
+  p.align = align; p.ctx = ctx; p.prob_fn = d->prob_fn; p.znorm = znorm;
   const size_t shm = attn_lds(d, false);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool reg = d->kind == 1 && d->U <= 256 * RJ && d->F <= RF;
@@ -715,7 +747,7 @@ extern "C" int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *d
                              const float *conv_proj, const float *align_prev, const float *align,
                              const float *dctx, const float *dalign_in, float *dq, float *dkeys,
                              float *dv_part, float *dconv_proj_part, float *dconv_kernel_part,
-                             float *dalign_out, nabu_stream_t stream) {
+                             float *dalign_out, const float *znorm, nabu_stream_t stream) {
   if (int e = check_attn(d)) return e;
   NABU_CHECK_ARG(dec_len && enc_len && keys && values && q && v && align && dctx && dq && dkeys && dv_part,
                  "attn_bwd: null pointer");
@@ -729,6 +761,8 @@ extern "C" int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *d
   p.align = const_cast<float *>(align);
   p.dctx = dctx; p.dalign_in = dalign_in; p.dq = dq; p.dkeys = dkeys; p.dv_part = dv_part;
   p.dwf_part = dconv_proj_part; p.dck_part = dconv_kernel_part; p.dalign_out = dalign_out;
+  p.prob_fn = d->prob_fn; p.znorm = const_cast<float *>(znorm);
+  NABU_CHECK_ARG(d->prob_fn != 2 || znorm, "attn_bwd: normalized_sigmoid needs the normalisers of the forward pass");
   const size_t shm = attn_lds(d, true);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool reg = d->kind == 1 && d->U <= 256 * RJ && d->F <= RF;
@@ -775,7 +809,7 @@ namespace nabu {
 struct SpLayout {
   size_t H[NABU_SPELLER_MAX_LAYERS], Cs[NABU_SPELLER_MAX_LAYERS], Ho[NABU_SPELLER_MAX_LAYERS],
       acts[NABU_SPELLER_MAX_LAYERS];
-  size_t ctx, align, q, keys, logits_tm, ids, total;   // offsets in floats (ids: [L,B] int32)
+  size_t ctx, align, q, keys, logits_tm, ids, znorm, total;   // offsets in floats (ids: [L,B] int32)
 };
 
 static SpLayout sp_layout(const nabu_speller_desc *d) {
@@ -795,6 +829,7 @@ static SpLayout sp_layout(const nabu_speller_desc *d) {
   s.keys = take(B * Te * U);
   s.logits_tm = take(L * B * C);
   s.ids = take(L * B);
+  s.znorm = take(L * B);
   s.total = o;
   return s;
 }
@@ -860,7 +895,7 @@ static int check_sp(const nabu_speller_desc *d) {
   if (d->U % 4 || d->E % 4) return fail(NABU_EUNSUP, "speller: num_units and encoder dim must be multiples of 4");
   if (!(d->keep_prob > 0.f && d->keep_prob <= 1.f)) return fail(NABU_EINVAL, "speller: keep_prob out of (0,1]");
   if (!(d->sample_prob >= 0.f && d->sample_prob <= 1.f)) return fail(NABU_EINVAL, "speller: sample_prob out of [0,1]");
-  nabu_attn_desc a = {sizeof(nabu_attn_desc), d->B, d->Te, d->E, d->U, d->kind, d->K, d->F};
+  nabu_attn_desc a = {sizeof(nabu_attn_desc), d->B, d->Te, d->E, d->U, d->kind, d->K, d->F, d->prob_fn};
   return check_attn(&a);
 }
 
@@ -905,7 +940,7 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
   const int B = d->B, L = d->L, U = d->U, E = d->E, Te = d->Te, C = d->C, nl = d->num_layers;
   float *gw = w + W.gemm;
   const size_t gwb = W.gemm_bytes;
-  const nabu_attn_desc ad = {sizeof(nabu_attn_desc), B, Te, E, U, d->kind, d->K, d->F};
+  const nabu_attn_desc ad = {sizeof(nabu_attn_desc), B, Te, E, U, d->kind, d->K, d->F, d->prob_fn};
   const bool drop = d->keep_prob < 1.f;
   // zero initial state (index 0 of every time-major array)
   for (int n = 0; n < nl; ++n) {
@@ -948,7 +983,8 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
     SP_TRY(mm(false, false, B, U, U, htop, U, p->query_kernel, U, 0.f, qt, U, nullptr, gw, gwb, stream));
     SP_TRY(nabu_attn_fwd(&ad, t, dec_len, enc_len, r + R.keys, values, qt, p->attention_v, p->conv_kernel,
                          p->conv_proj, r + R.align + (size_t)t * B * Te, r + R.ctx + (size_t)t * B * E,
-                         r + R.align + (size_t)(t + 1) * B * Te, r + R.ctx + (size_t)(t + 1) * B * E, stream));
+                         r + R.align + (size_t)(t + 1) * B * Te, r + R.ctx + (size_t)(t + 1) * B * E,
+                         r + R.znorm + (size_t)t * B, stream));
     if (sampling && t + 1 < L) {
       // ScheduledEmbeddingTrainingHelper: the step's logits decide the next input of selected rows
       float *lt = r + R.logits_tm + (size_t)t * B * C;
@@ -984,7 +1020,7 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   const int B = d->B, L = d->L, U = d->U, E = d->E, Te = d->Te, C = d->C, nl = d->num_layers, F = d->F, K = d->K;
   float *gw = w + W.gemm;
   const size_t gwb = W.gemm_bytes;
-  const nabu_attn_desc ad = {sizeof(nabu_attn_desc), B, Te, E, U, d->kind, d->K, d->F};
+  const nabu_attn_desc ad = {sizeof(nabu_attn_desc), B, Te, E, U, d->kind, d->K, d->F, d->prob_fn};
   const bool drop = d->keep_prob < 1.f;
   const int BL = B * L;
   float *dl = w + W.dl, *dH = w + W.dH, *dCtx = w + W.dCtx, *dkeys = w + W.dkeys, *dq = w + W.dq;
@@ -1030,7 +1066,8 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
     SP_TRY(nabu_attn_bwd(&ad, t, dec_len, enc_len, r + R.keys, values, r + R.q + (size_t)t * B * U, p->attention_v,
                          p->conv_kernel, p->conv_proj, r + R.align + (size_t)t * B * Te,
                          r + R.align + (size_t)(t + 1) * B * Te, dCt, dal_carry, dqt, dkeys, w + W.dv,
-                         d->kind == 1 ? w + W.dwf : nullptr, d->kind == 1 ? w + W.dck : nullptr, dal_out, stream));
+                         d->kind == 1 ? w + W.dwf : nullptr, d->kind == 1 ? w + W.dck : nullptr, dal_out,
+                         r + R.znorm + (size_t)t * B, stream));
     dal_carry = dal_out;
     float *dHt = dH + (size_t)t * B * U;
     SP_TRY(mm(false, false, B, U, U, dqt, U, w + W.wqT, U, 1.f, dHt, U, nullptr, gw, gwb, stream));

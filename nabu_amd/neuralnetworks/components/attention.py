@@ -7,14 +7,19 @@ nabu_attn_bwd driven by rnn_decoder.dynamic_decode."""
 from nabu_amd import variables as vs
 
 KINDS = {'vanilla': 0, 'location_aware': 1, 'windowed': 2}
+PROB_FNS = {'softmax': 0, 'sigmoid': 1, 'normalized_sigmoid': 2}
 
 
 def factory(conf, num_units, encoded, encoded_seq_length):
     '''create the attention mechanism (reference attention.py:6-39)'''
-    if conf['probability_fn'] != 'softmax':
-        raise NotImplementedError(
-            'probability_fn = %s: only softmax runs on the HIP path (the oracle also covers sigmoid and '
-            'normalized_sigmoid)' % conf['probability_fn'])
+    if conf['probability_fn'] not in PROB_FNS:
+        raise KeyError(conf['probability_fn'])              # the reference indexes a dict (attention.py:9-13)
+    mech = _mechanism(conf, num_units, encoded, encoded_seq_length)
+    mech.prob_fn = PROB_FNS[conf['probability_fn']]
+    return mech
+
+
+def _mechanism(conf, num_units, encoded, encoded_seq_length):
     if conf['attention'] == 'location_aware':
         return LocationAwareAttention(num_units=num_units, numfilt=int(conf['numfilt']),
                                       filtersize=int(conf['filtersize']), memory=encoded,
@@ -33,6 +38,7 @@ class BahdanauAttention(object):
     '''additive attention: score = v . tanh(keys + query_layer(query)), normalize=False
     (tf.contrib.seq2seq.BahdanauAttention as used at attention.py:24-30)'''
     kind = 0
+    prob_fn = 0                                  # softmax
     scope = 'bahdanau_attention'
 
     def __init__(self, num_units, memory, memory_sequence_length):

@@ -89,7 +89,7 @@ def dynamic_decode(cell, encoded, encoded_seq_length, targets, target_seq_length
     if sprob > 0:
         nops.global_rng().offset += L
     desc = _hip.SpellerDesc(ctypes.sizeof(_hip.SpellerDesc), B, Te, E, U, C, L, nl, mech.kind,
-                            mech.filtersize, mech.numfilt, keep, seed, offset * 1000003,
+                            mech.filtersize, mech.numfilt, mech.prob_fn, keep, seed, offset * 1000003,
                             sprob, sseed, soffset * 1000003)
     lib = _hip.lib()
     reserve_bytes = lib.nabu_speller_reserve_bytes(ctypes.byref(desc))
@@ -143,7 +143,7 @@ def beam_search(cell, encoded, encoded_seq_length, beam_width, max_steps, length
     elen = SeqLen.wrap(encoded_seq_length, dev)
     W, S = int(beam_width), int(max_steps)
     desc = _hip.BeamDesc(ctypes.sizeof(_hip.BeamDesc), B, Te, E, U, C, nl, mech.kind, mech.filtersize,
-                         mech.numfilt, W, S, float(length_penalty), float(temperature))
+                         mech.numfilt, mech.prob_fn, W, S, float(length_penalty), float(temperature))
     lib = _hip.lib()
     ws_bytes = lib.nabu_speller_beam_ws_bytes(ctypes.byref(desc))
     if ws_bytes == 0:

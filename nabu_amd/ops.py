@@ -270,23 +270,26 @@ def lstm_cell_bwd(step, seq_len_dev, acts, c_new, c_prev, dh, dh2, dc_in, dz, dc
           'nabu_lstm_cell_bwd')
 
 
-def attn_desc(B, Te, E, U, kind, K=0, F=0):
-    return _hip.AttnDesc(ctypes.sizeof(_hip.AttnDesc), B, Te, E, U, kind, K, F)
+PROB_FNS = {'softmax': 0, 'sigmoid': 1, 'normalized_sigmoid': 2}
+
+
+def attn_desc(B, Te, E, U, kind, K=0, F=0, prob_fn=0):
+    return _hip.AttnDesc(ctypes.sizeof(_hip.AttnDesc), B, Te, E, U, kind, K, F, prob_fn)
 
 
 def attn_fwd(desc, step, dec_len, enc_len, keys, values, q, v, conv_kernel, conv_proj, align_prev,
-             ctx_prev, align, ctx):
+             ctx_prev, align, ctx, znorm=None):
     check(_hip.lib().nabu_attn_fwd(ctypes.byref(desc), step, ptr(dec_len), ptr(enc_len), ptr(keys), ptr(values),
                                    ptr(q), ptr(v), ptr(conv_kernel), ptr(conv_proj), ptr(align_prev),
-                                   ptr(ctx_prev), ptr(align), ptr(ctx), stream()), 'nabu_attn_fwd')
+                                   ptr(ctx_prev), ptr(align), ptr(ctx), ptr(znorm), stream()), 'nabu_attn_fwd')
 
 
 def attn_bwd(desc, step, dec_len, enc_len, keys, values, q, v, conv_kernel, conv_proj, align_prev, align,
-             dctx, dalign_in, dq, dkeys, dv_part, dcp_part, dck_part, dalign_out):
+             dctx, dalign_in, dq, dkeys, dv_part, dcp_part, dck_part, dalign_out, znorm=None):
     check(_hip.lib().nabu_attn_bwd(ctypes.byref(desc), step, ptr(dec_len), ptr(enc_len), ptr(keys), ptr(values),
                                    ptr(q), ptr(v), ptr(conv_kernel), ptr(conv_proj), ptr(align_prev),
                                    ptr(align), ptr(dctx), ptr(dalign_in), ptr(dq), ptr(dkeys), ptr(dv_part),
-                                   ptr(dcp_part), ptr(dck_part), ptr(dalign_out), stream()), 'nabu_attn_bwd')
+                                   ptr(dcp_part), ptr(dck_part), ptr(dalign_out), ptr(znorm), stream()), 'nabu_attn_bwd')
 
 
 def mask_time_(x, len_dev):

@@ -184,7 +184,8 @@ def edit_distance(hyp, truth):
 # --------------------------------------------------------------------------
 # Attention beam search (components/beam_search_decoder.py)
 # --------------------------------------------------------------------------
-def speller_cell_step(p, ids, state, values, keys, mask, attention='vanilla', window=None):
+def speller_cell_step(p, ids, state, values, keys, mask, attention='vanilla', window=None,
+                      probability_fn='softmax'):
     """One AttentionProjectionWrapper(AttentionWrapper(MultiRNNCell)) step on N rows
     (speller.py:13-69, rnn_cell.py:145-155) — the body of nabu_oracle.speller_fwd's loop.
     state = (hs, cs, ctx, align); returns logits [N,C], new state."""
@@ -210,7 +211,7 @@ def speller_cell_step(p, ids, state, values, keys, mask, attention='vanilla', wi
     score = np.tanh(s) @ p['attention_v']
     if attention == 'windowed':
         mask = mask & no.attention_window(align, window[0], window[1])
-    al = no._prob_fwd(score, mask, 'softmax')
+    al = no._prob_fwd(score, mask, probability_fn)
     cx = np.einsum('bt,bte->be', al, values)
     lg = np.concatenate([x, cx], 1) @ p['out_kernel'] + p['out_bias']
     return lg, (nh, nc, cx, al)
@@ -229,7 +230,7 @@ def _log_softmax(x):
 
 
 def speller_beam_search(enc, enc_len, p, beam_width, max_steps, length_penalty=1.0, temperature=1.0,
-                        attention='vanilla', dtype=np.float64, window=None):
+                        attention='vanilla', dtype=np.float64, window=None, probability_fn='softmax'):
     """decoders/beam_search_decoder.py:31-114 + components/beam_search_decoder.py:141-451.
 
     enc [B,Te,E].  Returns dict(sequences [B,W,time] int, lengths [B,W], scores [B,W],
@@ -267,7 +268,8 @@ def speller_beam_search(enc, enc_len, p, beam_width, max_steps, length_penalty=1
         return v[bi, idx].reshape(a.shape)
 
     for time in range(int(max_steps)):
-        lg, new_state = speller_cell_step(pp, ids.reshape(N), state, values, keys, mask, attention, window)
+        lg, new_state = speller_cell_step(pp, ids.reshape(N), state, values, keys, mask, attention, window,
+                                          probability_fn)
         out = lg.reshape(B, W, C) / temperature
         new_lp = _log_softmax(out)
         new_lp = np.where(finished[:, :, None], -FMAX, new_lp)

@@ -543,7 +543,9 @@ def speller_fwd(enc, enc_len, targets, target_len, p, attention='vanilla',
             raise ValueError(attention)
         th = np.tanh(s)
         score = th @ p['attention_v']
-        al = _prob_fwd(score, mask & wmask if attention == 'windowed' else mask, probability_fn)
+        pmask = mask & wmask if attention == 'windowed' else mask
+        st['pmask'] = pmask
+        al = _prob_fwd(score, pmask, probability_fn)
         cx = np.einsum('bt,bte->be', al, values)
         lg = np.concatenate([query, cx], 1) @ p['out_kernel'] + p['out_bias']
         st.update(query=query, th=th, score=score, al=al, cx=cx)
@@ -587,7 +589,7 @@ def speller_bwd(dlogits, cache):
         dcx = dqc[:, U:] + np.where(act, dctx, 0)
         dal = np.einsum('be,bte->bt', dcx, values) + np.where(act, dalign, 0)
         dvalues += st['al'][:, :, None] * dcx[:, None, :]
-        dscore = _prob_bwd(dal, st['al'], st['score'], mask, pf)
+        dscore = _prob_bwd(dal, st['al'], st['score'], st['pmask'], pf)
         dscore = np.where(act, dscore, 0)
         g['attention_v'] += np.einsum('bt,btu->u', dscore, st['th'])
         ds = dscore[:, :, None] * p['attention_v'] * (1 - st['th'] ** 2)

@@ -56,16 +56,22 @@ def grad_names(nl, attention):
     ('vanilla', 1, 32, 0, 0), ('vanilla', 2, 16, 0, 0),
     ('location_aware', 1, 32, 5, 3), ('location_aware', 2, 16, 4, 2), ('location_aware', 1, 64, 11, 10),
     ('location_aware', 1, 32, 5, 14),           # numfilt > 12: the generic location-aware kernels
-    ('windowed', 1, 32, 1, 2), ('windowed', 2, 16, 0, 3)])     # K, F = left / right window width
+    ('windowed', 1, 32, 1, 2), ('windowed', 2, 16, 0, 3),      # K, F = left / right window width
+    ('vanilla:sigmoid', 1, 32, 0, 0), ('vanilla:normalized_sigmoid', 2, 16, 0, 0),      # probability_fn
+    ('location_aware:normalized_sigmoid', 1, 32, 5, 3), ('location_aware:sigmoid', 1, 32, 5, 14),
+    ('windowed:normalized_sigmoid', 1, 32, 1, 3)])
 def test_speller_step_matches_oracle(attention, nl, U, K, F):
     """decoder alone on a given 'encoded' tensor: logits, loss and every gradient"""
     from nabu_amd import variables as vs
     from nabu_amd.autodiff import Tape, SeqLen
     from nabu_amd.neuralnetworks.models.ed_decoders import ed_decoder_factory
     from nabu_amd.neuralnetworks.trainers import loss_functions
+    attention, _, prob_fn = attention.partition(':')
+    prob_fn = prob_fn or 'softmax'
     rng = np.random.default_rng(U + K)
     B, Te, E, C = 5, 13, 24, 8
-    over = {'decoder.num_layers': nl, 'decoder.num_units': U, 'decoder.attention': attention}
+    over = {'decoder.num_layers': nl, 'decoder.num_units': U, 'decoder.attention': attention,
+            'decoder.probability_fn': prob_fn}
     if attention == 'location_aware':
         over.update({'decoder.numfilt': F, 'decoder.filtersize': K})
     if attention == 'windowed':
@@ -100,7 +106,7 @@ def test_speller_step_matches_oracle(attention, nl, U, K, F):
     tape.backward(loss)
     st = store.state_dict()
     p = speller_params(st, nl, attention)
-    rl, rll, cache = O.speller_fwd(enc.astype(np.float64), enc_len, tg, tlen, p, attention,
+    rl, rll, cache = O.speller_fwd(enc.astype(np.float64), enc_len, tg, tlen, p, attention, prob_fn,
                                    window=(K, F) if attention == 'windowed' else None)
     np.testing.assert_array_equal(rll, lsl['text'].host)
     lg = logits['text'].cpu().numpy()

@@ -258,7 +258,8 @@ def _speller_params(rng, E, U, C, nl, attention, K=5, F=3):
     ('vanilla', 'softmax', 1, 0), ('vanilla', 'softmax', 2, 0),
     ('location_aware', 'softmax', 1, 5), ('location_aware', 'softmax', 2, 4),
     ('vanilla', 'sigmoid', 1, 0), ('location_aware', 'normalized_sigmoid', 1, 3),
-    ('windowed', 'softmax', 1, 0), ('windowed', 'softmax', 2, 1)])
+    ('windowed', 'softmax', 1, 0), ('windowed', 'softmax', 2, 1), ('windowed', 'normalized_sigmoid', 1, 1),
+    ('windowed', 'sigmoid', 1, 0)])
 def test_speller_matches_torch_autograd(attention, prob_fn, nl, K):
     rng = _rng(11)
     B, Te, E, U, C = 3, 7, 6, 5, 6
