@@ -20,7 +20,9 @@ def factory(loss_function):
         return average_cross_entropy
     elif loss_function == 'CTC':
         return CTC
-    elif loss_function in ('sum_cross_entropy', 'average_sigmoid_cross_entropy', 'marigin'):
+    elif loss_function == 'sum_cross_entropy':
+        return sum_cross_entropy
+    elif loss_function in ('average_sigmoid_cross_entropy', 'marigin'):
         raise Exception('loss function %s is outside the MI355X hot path' % loss_function)
     else:
         raise Exception('unknown loss function %s' % loss_function)
@@ -65,6 +67,23 @@ def average_cross_entropy(targets, logits, logit_seq_length, target_seq_length):
         B = lg.shape[0]
         lsl, tsl = SeqLen.wrap(logit_seq_length[t], lg.device), SeqLen.wrap(target_seq_length[t], lg.device)
         per_utt, dlogits = hip.xent_loss_grad(lg.contiguous(), _labels(targets[t]), lsl.dev, tsl.dev, 1.0 / B)
+        loss = hip.sum_(per_utt, 1.0 / B)
+        record([lg], [loss], lambda g, d=dlogits: [d])
+        losses.append(loss)
+    return _total(losses)
+
+
+def sum_cross_entropy(targets, logits, logit_seq_length, target_seq_length):
+    '''cross entropy summed over timesteps (reference loss_functions.py:142-153): the mask is the
+    TARGET length here and nothing is divided: mean_b( sum_{t<target_len} xent ), summed over the
+    outputs.  Same kernel as average_cross_entropy with a divisor of one.'''
+    losses = []
+    for t in targets:
+        lg = logits[t]
+        B = lg.shape[0]
+        tsl = SeqLen.wrap(target_seq_length[t], lg.device)
+        ones = torch.ones_like(tsl.dev)
+        per_utt, dlogits = hip.xent_loss_grad(lg.contiguous(), _labels(targets[t]), tsl.dev, ones, 1.0 / B)
         loss = hip.sum_(per_utt, 1.0 / B)
         record([lg], [loss], lambda g, d=dlogits: [d])
         losses.append(loss)

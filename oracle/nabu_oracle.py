@@ -399,6 +399,12 @@ def average_cross_entropy(logits, targets, logit_len, target_len):
     return loss, g
 
 
+def sum_cross_entropy(logits, targets, target_len):
+    """loss_functions.py:142-153: mean_b( sum_{t<target_len} xent(logits[b,t], targets[b,t]) ) — the
+    mask is the target length and nothing is divided."""
+    return average_cross_entropy(logits, targets, target_len, np.ones(len(target_len)))
+
+
 # --------------------------------------------------------------------------
 # Speller (RNNDecoder + AttentionWrapper + AttentionProjectionWrapper)
 # --------------------------------------------------------------------------

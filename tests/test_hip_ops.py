@@ -338,3 +338,36 @@ def test_gemm_skinny_rows(M, N, K):
     ops.gemm(torch.tensor(a, device='cuda'), torch.tensor(b, device='cuda'), c2, alpha=0.5, beta=2.0,
              bias=torch.tensor(bias, device='cuda'))
     assert torch.equal(c, c2)
+
+
+def test_cross_entropy_losses_match_oracle():
+    """average_cross_entropy (loss_functions.py:155-165) and sum_cross_entropy (:142-153) on ragged
+    lengths: loss and the gradient the tape receives"""
+    from nabu_amd.autodiff import Tape, SeqLen, record
+    from nabu_amd.neuralnetworks.trainers import loss_functions
+    rng = np.random.default_rng(8)
+    B, L, C = 6, 9, 7
+    logits = rng.normal(0, 2, (B, L, C))
+    tl = np.array([9, 4, 1, 7, 9, 2], np.int32)
+    ll = np.array([9, 4, 1, 6, 8, 2], np.int32)              # logit lengths may be shorter than targets
+    tg = rng.integers(0, C, (B, L)).astype(np.int32)
+    for name, want in (('average_cross_entropy', O.average_cross_entropy(logits, tg, ll, tl)),
+                       ('sum_cross_entropy', O.sum_cross_entropy(logits, tg, tl))):
+        src = dev(logits)
+        lg = dev(logits)
+        got = {}
+
+        def capture(g):
+            got['g'] = g
+            return [None]
+        with Tape() as tape:
+            record([src], [lg], capture)             # makes the logits an interior node of the tape
+            loss = loss_functions.factory(name)({'text': dev(tg, torch.int32)}, {'text': lg},
+                                                {'text': SeqLen(ll, 'cuda')}, {'text': SeqLen(tl, 'cuda')})
+        tape.backward(loss)
+        assert abs(float(loss.item()) - want[0]) / abs(want[0]) < 1e-6, name
+        assert rel_err(host(got['g']), want[1]) < 1e-5, name
+    with pytest.raises(Exception, match='outside the MI355X hot path'):
+        loss_functions.factory('marigin')
+    with pytest.raises(Exception, match='unknown loss function'):
+        loss_functions.factory('nope')
