@@ -573,6 +573,8 @@ static int check_beam(const nabu_beam_desc *d) {
   if (d->B <= 0 || d->Te <= 0 || d->E <= 0 || d->U <= 0 || d->C <= 1) return fail(NABU_EINVAL, "beam search: bad dimensions");
   if (d->beam_width <= 0 || d->max_steps <= 0) return fail(NABU_EINVAL, "beam search: beam_width and max_steps must be positive");
   if (!(d->temperature > 0.f)) return fail(NABU_EINVAL, "beam search: temperature must be positive");
+  if (d->kind < 0 || d->kind > 2 || d->prob_fn < 0 || d->prob_fn > 2)
+    return fail(NABU_EINVAL, "beam search: unknown attention kind or probability_fn");
   if (d->num_layers < 1 || d->num_layers > NABU_SPELLER_MAX_LAYERS) return fail(NABU_EUNSUP, "beam search: 1..%d layers", NABU_SPELLER_MAX_LAYERS);
   if (d->U % 4 || d->E % 4) return fail(NABU_EUNSUP, "beam search: num_units and encoder dim must be multiples of 4");
   if ((long long)d->B * d->beam_width > (1 << 20)) return fail(NABU_EUNSUP, "beam search: B*beam_width too large");

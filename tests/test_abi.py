@@ -60,3 +60,32 @@ def test_product_path_has_no_cpu_fallback():
             if f.endswith('.py'):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle', txt, flags=re.M), f
+
+
+def test_decoder_entry_points_validate_on_the_host():
+    """size queries and argument errors of the inference entry points (decode.hip), no GPU"""
+    import ctypes
+    from nabu_amd import _hip
+    lib = _hip.lib()
+    # prefix trees: (1 + T*W) nodes x (parent, label, slot, C-1 children) int32 per utterance
+    assert lib.nabu_ctc_beam_ws_bytes(32, 125, 40, 100) == 32 * (1 + 125 * 100) * (3 + 39) * 4
+    assert lib.nabu_ctc_beam_ws_bytes(0, 125, 40, 100) == 0
+    one = ctypes.c_void_p(16)          # any non-null pointer: validation happens before it is touched
+    assert lib.nabu_ctc_beam_search(2, 5, 4, 300, 1, one, one, one, one, None, one, 1 << 30, None) == -2
+    assert b'beam_width' in lib.nabu_last_error()
+    assert lib.nabu_ctc_beam_search(2, 5, 4, 8, 1, one, one, one, one, None, one, 16, None) == -3    # workspace
+    assert lib.nabu_ctc_beam_search(2, 5, 4, 8, 1, None, one, one, one, None, one, 1 << 30, None) == -1
+    d = _hip.BeamDesc(ctypes.sizeof(_hip.BeamDesc), 32, 125, 1024, 512, 40, 1, 0, 0, 0, 0, 16, 100, 1.0, 1.0)
+    assert lib.nabu_speller_beam_ws_bytes(ctypes.byref(d)) > 32 * 16 * 125 * 1024 * 4      # tiled encoder output
+    d.temperature = 0.0
+    assert lib.nabu_speller_beam_ws_bytes(ctypes.byref(d)) == 0 and b'temperature' in lib.nabu_last_error()
+    d.temperature, d.prob_fn = 1.0, 7
+    assert lib.nabu_speller_beam_ws_bytes(ctypes.byref(d)) == 0 and b'probability_fn' in lib.nabu_last_error()
+    a = _hip.AttnDesc(ctypes.sizeof(_hip.AttnDesc), 4, 10, 8, 8, 2, 1, 0, 0)    # windowed, right width 0
+    assert lib.nabu_attn_fwd(ctypes.byref(a), 0, one, one, one, one, one, one, None, None, one, one, one, one,
+                             None, None) == -1
+    assert b'right_window_width' in lib.nabu_last_error()
+    a = _hip.AttnDesc(ctypes.sizeof(_hip.AttnDesc), 4, 10, 8, 8, 0, 0, 0, 3)    # unknown probability_fn
+    assert lib.nabu_attn_fwd(ctypes.byref(a), 0, one, one, one, one, one, one, None, None, one, one, one, one,
+                             None, None) == -1
+    assert b'probability_fn' in lib.nabu_last_error()
