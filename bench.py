@@ -85,6 +85,54 @@ def cpu_baseline(seconds_budget=30.0):
                       'the reference TF-1.8 trainer itself cannot run here' % (reps, Ts, Ts)}
 
 
+def gemm_roofline(B, T, D, H, precision):
+    """Second roofline object: the dense products of one cfg2 step (input projections, dz·Wxᵀ, xᵀ·dz,
+    hᵀ·dz of every layer, both directions) launched back to back on the current stream and timed
+    with events — MFMA-bound, fp32 peak from MI355X_MICROARCH.md."""
+    import torch
+    from nabu_amd import ops
+    shapes = []
+    Dl = D
+    for l in range(4):
+        BT = B * (T >> l)
+        shapes.append((0, 0, BT, 8 * H, Dl))                     # x · [Wx_fw | Wx_bw]
+        if l:
+            shapes.append((0, 1, BT, Dl, 8 * H))                 # dx = dz · Wx^T
+        shapes += [(1, 0, Dl, 4 * H, BT)] * 2 + [(1, 0, H, 4 * H, BT)] * 2     # dWx, dWh per direction
+        Dl = 4 * H
+    bufs = {}
+    def buf(n):
+        if n not in bufs:
+            bufs[n] = torch.randn(n, device='cuda')
+        return bufs[n]
+    calls = []
+    for ta, tb, M, N, K in shapes:
+        a = buf(M * K).view((K, M) if ta else (M, K))
+        b = buf(K * N).view((N, K) if tb else (K, N))
+        c = torch.empty((M, N), device='cuda')
+        calls.append((a, b, c, bool(ta), bool(tb)))
+    def run():
+        for a, b, c, ta, tb in calls:
+            ops.gemm(a, b, c, trans_a=ta, trans_b=tb, precision=precision)
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = sum(2.0 * M * N * K for _, _, M, N, K in shapes)
+    tf = flops / ms / 1e9
+    return {'bound': 'mfma', 'achieved': round(tf, 1), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(tf / 157.3, 4),
+            'traffic': None, 'kernel': 'gemm_f32_fast_kernel<*> (+ split-K reduce)', 'ms_per_step': round(ms, 3),
+            'flops_per_step': int(flops),
+            'note': 'every dense product of a cfg2 step at its real shape, back to back, timed with events on the '
+                    'launch stream; peak = dense fp32 MFMA (v_mfma_f32_32x32x2_f32) at 2.4 GHz'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -222,6 +270,8 @@ def main():
                                   'bf16x3': 'f32 operands split into 2 bf16 pieces, 3 bf16 MFMA products, f32 accumulate',
                                   'bf16': 'operands rounded to bf16, f32 accumulate'}[args.gemm_precision]},
         'roofline': roofline,
+        'roofline_gemm': (gemm_roofline(B, T, D, H, args.gemm_precision)
+                          if args.workload == 'cfg2' and args.gemm_precision == 'f32' else None),
         'hbm_roofline_frac_whole_step': round(step_bytes_total / (dt / args.steps) / (HBM_PEAK_GBS * 1e9), 4),
         'final_loss': round(final_loss, 4),
     }
