@@ -190,7 +190,9 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
 #define NABU_BTILE(buf) reinterpret_cast<Tile>(fsm + (buf) * (2 * KT * LDT) + KT * LDT)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int tile_m, tile_n;
+  tile_of_block(a.swz, &tile_m, &tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kbeg = blockIdx.z * a.ksplit;
   const int kend = min(a.K, kbeg + a.ksplit);
 
@@ -454,6 +456,9 @@ extern "C" int nabu_gemm_ex(int precision, int transA, int transB, int M, int N,
   auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   a.vecA = al16(A) && lda % 4 == 0 && (a_seg_stride % 4 == 0);
   a.vecB = al16(B) && ldb % 4 == 0 && (b_seg_stride % 4 == 0);
+  static int swz_env = -2;
+  if (swz_env == -2) { const char *e = getenv("NABU_GEMM_SWIZZLE"); swz_env = e ? atoi(e) : -1; }
+  a.swz = swz_env >= 0 ? swz_env : 0;
   if (const char *e = getenv("NABU_GEMM_NOSTAGE")) a.vecA |= 2 * atoi(e);   // timing experiments: 1 nothing, 2 no loads, 4 no LDS stores
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, a.nsplit), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -20,7 +20,26 @@ struct GemmArgs {
   int ksplit;  // k-range per z-slice (multiple of FBK)
   int nsplit;
   int vecA, vecB;  // 16-byte vector loads allowed
+  int swz;         // tile order: 0 = blockIdx as is, g > 0 = XCD-aware with groups of g row tiles
 };
+
+// Workgroup -> output tile.  The dispatcher deals workgroups round-robin over the 8 XCDs (linear id
+// % 8), each with its own 4 MiB L2.  With swz > 0 every XCD walks a CONTIGUOUS range of the tile
+// sequence, and the sequence itself goes column-major through bands of `swz` row tiles, so that the
+// ~96 workgroups resident on an XCD share few operand panels (each panel is then fetched into that
+// L2 once instead of once per XCD).
+__device__ __forceinline__ void tile_of_block(int swz, int *tm, int *tn) {
+  const int nbx = gridDim.x, nby = gridDim.y;
+  if (swz <= 0) { *tm = blockIdx.y; *tn = blockIdx.x; return; }
+  const int total = nbx * nby, pid = blockIdx.y * nbx + blockIdx.x;
+  const int per = (total + 7) / 8, tall = total % 8 ? total % 8 : 8;
+  const int xcd = pid % 8, local = pid / 8;
+  const int t = xcd < tall ? xcd * per + local : tall * per + (xcd - tall) * (per - 1) + local;
+  const int band = swz * nbx, g = t / band, first = g * swz;
+  const int rows = min(nby - first, swz), r = t - g * band;
+  *tm = first + r % rows;
+  *tn = r / rows;
+}
 
 // skinny products (gemm_skinny.hip): M <= 64, no transposes
 int gemm_skinny_chunk(int M, int N, int K);
