@@ -202,9 +202,9 @@ int nabu_lstm_cell_bwd(int B, int U, int step, const int32_t *seq_len, const flo
  * (rows >= enc_len are zero), q [B,U] (= h·query_kernel).  Rows with
  * step >= dec_len[b] are finished: align/ctx copy align_prev/ctx_prev.
  * The backward kernel recomputes tanh, ACCUMULATES into dkeys [B,Te,U] and into the
- * per-utterance partials dv_part [B,U], dconv_proj_part [B,F,U], dconv_kernel_part
+ * partials dv_part [B*S,U], dconv_proj_part [B*S,F,U], dconv_kernel_part
  * [B,K,F] (the caller zeroes them before the first step and column-sums them
- * afterwards), writes dq [B,U] and dalign_out [B,Te] (gradient w.r.t. align_prev;
+ * afterwards; S below), writes dq [B,U] and dalign_out [B,Te] (gradient w.r.t. align_prev;
  * location only).  dalign_in (may be NULL) is the gradient that reaches this
  * step's alignments through the next step's location features.
  * probability_fn: alignments = softmax(score) | sigmoid(score) | sigmoid(score) / sum_t sigmoid(score)
@@ -226,13 +226,21 @@ int nabu_attn_fwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
                   const float *q, const float *v, const float *conv_kernel,
                   const float *conv_proj, const float *align_prev, const float *ctx_prev,
                   float *align, float *ctx, float *znorm, nabu_stream_t stream);
+/* The backward pass cuts every utterance into S = nabu_attn_bwd_slices(d) slices of encoder frames
+ * (one workgroup each, so that a step fills the chip at small batch sizes): dv_part and
+ * dconv_proj_part have B*S rows; ctx is THIS step's context (the forward output: it turns the
+ * softmax's sum over all frames into a dot product, which is what makes the slices independent);
+ * ws (nabu_attn_bwd_ws_bytes) holds the per-slice dq and the d location features. */
+int nabu_attn_bwd_slices(const nabu_attn_desc *d);
+size_t nabu_attn_bwd_ws_bytes(const nabu_attn_desc *d);
 int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
                   const int32_t *enc_len, const float *keys, const float *values,
                   const float *q, const float *v, const float *conv_kernel,
                   const float *conv_proj, const float *align_prev, const float *align,
-                  const float *dctx, const float *dalign_in, float *dq, float *dkeys,
-                  float *dv_part, float *dconv_proj_part, float *dconv_kernel_part,
-                  float *dalign_out, const float *znorm, nabu_stream_t stream);
+                  const float *ctx, const float *dctx, const float *dalign_in, float *dq,
+                  float *dkeys, float *dv_part, float *dconv_proj_part,
+                  float *dconv_kernel_part, float *dalign_out, const float *znorm, void *ws,
+                  size_t ws_bytes, nabu_stream_t stream);
 
 /* Whole-sequence decoder driver: RNNDecoder._decode over all L = max(dec_len)
  * steps in one call (rnn_decoder.py:59-82: ScheduledEmbeddingTrainingHelper,

@@ -90,18 +90,22 @@ struct AttnArgs {
   // backward
   const float *dctx, *dalign_in;
   float *dq, *dkeys, *dv_part, *dwf_part, *dck_part, *dalign_out;
+  float *dq_part, *dcf_g;   // [B,S,U] per-slice dq, [B,Te,F] d location features (backward scratch)
 };
 
 // LDS carve for the attention kernels (floats): al[Te] prev alignment (padded conv input),
 // sc[Te] scores / alignments, cf[Te*F] location features, red[...] reductions
-__device__ __forceinline__ void conv_features(const AttnArgs &p, const float *al_prev, float *cf, int n) {
-  // cf[t,f] = sum_d a[t + d - pb] ck[d,f], 'same' padding, pb = (K-1)/2 (tf.layers.conv1d)
+// the conv kernel [K*F] is staged at the start of the dynamic LDS (ck_floats, 16-byte multiple)
+__device__ __forceinline__ int ck_floats(const AttnArgs &p) { return p.kind == 1 ? (p.K * p.F + 3) & ~3 : 0; }
+__device__ __forceinline__ void conv_features(const AttnArgs &p, const float *al_prev, float *cf, int lo, int hi,
+                                              const float *ck_s) {
+  // cf[t,f] = sum_d a[t + d - pb] ck[d,f], 'same' padding, pb = (K-1)/2 (tf.layers.conv1d); frames [lo,hi)
   const int pb = (p.K - 1) / 2;
-  for (int i = threadIdx.x; i < p.Te * p.F; i += AT) {
+  for (int i = lo * p.F + threadIdx.x; i < hi * p.F; i += AT) {
     const int t = i / p.F, f = i % p.F;
     float s = 0.f;
     const int d0 = max(0, pb - t), d1 = min(p.K, p.Te + pb - t);
-    for (int d = d0; d < d1; ++d) s = fmaf(al_prev[t + d - pb], p.ck[d * p.F + f], s);
+    for (int d = d0; d < d1; ++d) s = fmaf(al_prev[t + d - pb], ck_s[d * p.F + f], s);
     cf[i] = s;
   }
 }
@@ -116,7 +120,8 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int Te = p.Te, U = p.U, E = p.E;
-  float *alp = smem, *sc = alp + Te, *cf = sc + Te, *red = cf + (KIND ? Te * p.F : 0);
+  float *base = smem + ck_floats(p);
+  float *alp = base, *sc = alp + Te, *cf = sc + Te, *red = cf + (KIND ? Te * p.F : 0);
   float *align = p.align + (size_t)b * Te;
   float *ctx = p.ctx + (size_t)b * E;
   if (p.step >= p.dec_len[b]) {   // finished row: state frozen
@@ -130,8 +135,9 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
   const float *q = p.q + (size_t)b * U;
   if (KIND) {
     for (int t = tid; t < Te; t += AT) alp[t] = p.align_prev[(size_t)b * Te + t];
+    for (int i = tid; i < p.K * p.F; i += AT) smem[i] = p.ck[i];
     __syncthreads();
-    conv_features(p, alp, cf, n);
+    conv_features(p, alp, cf, 0, Te, smem);
     __syncthreads();
   }
   // WindowedAttention (attention.py:294-396): only frames in [m - left - 1, m + right) may be attended,
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
     const int nsp = max(1, min(AT / max(E4, 1), 8));    // frame partitions
     const float4 *vals4 = reinterpret_cast<const float4 *>(vals);
     // [nsp][AT / nsp] partial sums behind the scalars of `red`, 16-byte aligned
-    float4 *part = reinterpret_cast<float4 *>(smem + ((2 * Te + (KIND ? Te * p.F : 0) + 64 + 3) & ~3));
+    float4 *part = reinterpret_cast<float4 *>(base + ((2 * Te + (KIND ? Te * p.F : 0) + 64 + 3) & ~3));
     for (int c0 = 0; c0 < E4; c0 += AT / nsp) {
       const int e4 = c0 + tid % (AT / nsp), pt = tid / (AT / nsp);
       if (e4 < E4 && pt < nsp) {
@@ -332,24 +338,24 @@ template <int MODE>
 __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
   constexpr bool REG = MODE == 2, KIND = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // grid (B, S): workgroup (b, s) owns the encoder frames [lo, hi) of utterance b — the per-utterance
+  // sums over frames (dq, dv, d conv_proj) leave as per-slice partials, the location features' gradient
+  // goes to HBM, and attn_bwd_finish_kernel does what needs all frames of an utterance
+  const int b = blockIdx.x, sl = blockIdx.y, S = gridDim.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int Te = p.Te, U = p.U, E = p.E, F = p.F;
   constexpr int NW = AT / 64;
-  float *alp = smem;                       // [Te] previous alignment
+  float *base = smem + ck_floats(p);
+  float *alp = base;                       // [Te] previous alignment
   float *ds = alp + Te;                    // [Te] d score
   float *cf = ds + Te;                     // [Te*F]
-  float *dcf = cf + (KIND ? Te * F : 0); // [Te*F]
   // [NW * U] cross-wave partials (dq / dv), also scalars; 16-byte aligned
-  float *red = smem + ((2 * Te + (KIND ? 2 * Te * F : 0) + 3) & ~3);
-  float *dq = p.dq + (size_t)b * U;
-  float *dal_out = p.dalign_out ? p.dalign_out + (size_t)b * Te : nullptr;
-  if (p.step >= p.dec_len[b]) {
-    for (int u = tid; u < U; u += AT) dq[u] = 0.f;
-    if (dal_out)
-      for (int t = tid; t < Te; t += AT) dal_out[t] = p.dalign_in ? p.dalign_in[(size_t)b * Te + t] : 0.f;
-    return;
-  }
+  float *red = base + ((2 * Te + (KIND ? Te * F : 0) + 3) & ~3);
+  float *dq = p.dq_part + ((size_t)b * S + sl) * U;
+  if (p.step >= p.dec_len[b]) return;      // finished row: the finish kernel writes its zeros
   const int n = min(max(p.enc_len[b], 0), Te);
+  const int per = (Te + S - 1) / S, lo = min(sl * per, n), hi = min(lo + per, n);
+  float *dcf = p.dcf_g + (size_t)b * Te * F;   // [Te*F] in HBM
   const float *keys = p.keys + (size_t)b * Te * U;
   const float *vals = p.values + (size_t)b * Te * E;
   const float *q = p.q + (size_t)b * U;
@@ -358,8 +364,9 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
   float *dkeys = p.dkeys + (size_t)b * Te * U;
   if (KIND) {
     for (int t = tid; t < Te; t += AT) alp[t] = p.align_prev[(size_t)b * Te + t];
+    for (int i = tid; i < p.K * F; i += AT) smem[i] = p.ck[i];
     __syncthreads();
-    conv_features(p, alp, cf, n);
+    conv_features(p, alp, cf, lo, hi, smem);
   }
   // d alignment[t] = dctx · values[t] (+ the gradient arriving through next step's location features):
   // waves over frames (4 in flight), lanes over 16-byte groups of the encoder dimension
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
     constexpr int FR = 4;
     const float4 *vals4 = reinterpret_cast<const float4 *>(vals);
     const float4 *dctx4 = reinterpret_cast<const float4 *>(dctx);
-    for (int t0 = w; t0 < n; t0 += FR * NW) {
+    for (int t0 = lo + w; t0 < hi; t0 += FR * NW) {
       float s[FR];
 #pragma unroll
       for (int i = 0; i < FR; ++i) s[i] = 0.f;
@@ -376,7 +383,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
         const float4 dc = dctx4[e4];
         float4 vv[FR];
 #pragma unroll
-        for (int i = 0; i < FR; ++i) vv[i] = vals4[(size_t)min(t0 + i * NW, n - 1) * E4 + e4];
+        for (int i = 0; i < FR; ++i) vv[i] = vals4[(size_t)min(t0 + i * NW, hi - 1) * E4 + e4];
 #pragma unroll
         for (int i = 0; i < FR; ++i) {
           s[i] = fmaf(dc.x, vv[i].x, s[i]); s[i] = fmaf(dc.y, vv[i].y, s[i]);
@@ -387,14 +394,21 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
       for (int i = 0; i < FR; ++i) {
         const int t = t0 + i * NW;
         const float tot = wave_sum(s[i]);
-        if (lane == 0 && t < n) ds[t] = tot + (p.dalign_in ? p.dalign_in[(size_t)b * Te + t] : 0.f);
+        if (lane == 0 && t < hi) ds[t] = tot + (p.dalign_in ? p.dalign_in[(size_t)b * Te + t] : 0.f);
       }
     }
   }
   __syncthreads();
   // softmax backward: dscore = a * (da - sum a*da)
+  // sum_t a[t] da[t] over ALL frames of the utterance without visiting them:
+  //   da[t] = dctx·values[t] + dalign_in[t]  =>  sum_t a[t] da[t] = dctx·context + sum_t a[t] dalign_in[t]
   float r = 0.f;
-  for (int t = tid; t < n; t += AT) r = fmaf(al[t], ds[t], r);
+  {
+    const float *cx = p.ctx + (size_t)b * E;
+    for (int e = tid; e < E; e += AT) r = fmaf(dctx[e], cx[e], r);
+    if (p.dalign_in)
+      for (int t = tid; t < n; t += AT) r = fmaf(al[t], p.dalign_in[(size_t)b * Te + t], r);
+  }
   r = wave_sum(r);
   if (lane == 0) red[w] = r;
   __syncthreads();
@@ -402,12 +416,12 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
   for (int i = 0; i < NW; ++i) r += red[i];
   __syncthreads();
   if (p.prob_fn == 0) {
-    for (int t = tid; t < Te; t += AT) ds[t] = t < n ? al[t] * (ds[t] - r) : 0.f;
+    for (int t = lo + tid; t < hi; t += AT) ds[t] = al[t] * (ds[t] - r);
   } else if (p.prob_fn == 1) {        // a = sigmoid(s): ds = da a (1 - a)
-    for (int t = tid; t < Te; t += AT) ds[t] = t < n ? ds[t] * al[t] * (1.f - al[t]) : 0.f;
+    for (int t = lo + tid; t < hi; t += AT) ds[t] = ds[t] * al[t] * (1.f - al[t]);
   } else {                            // a = sg / z, sg = sigmoid(s): ds = (da - sum a da) a (1 - a z)
     const float z = p.znorm[b];
-    for (int t = tid; t < Te; t += AT) ds[t] = t < n ? (ds[t] - r) * al[t] * (1.f - al[t] * z) : 0.f;
+    for (int t = lo + tid; t < hi; t += AT) ds[t] = (ds[t] - r) * al[t] * (1.f - al[t] * z);
   }
   __syncthreads();
   // through v·tanh(keys + q + f): lanes own 16-byte groups of units (u4 = lane + 64 j), waves split
@@ -430,7 +444,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
     float4 *dkeys4 = reinterpret_cast<float4 *>(dkeys);
     const float4 *q4 = reinterpret_cast<const float4 *>(q), *v4 = reinterpret_cast<const float4 *>(p.v);
     constexpr int FR = KIND ? 1 : 2;         // frames of a wave in flight (registers!)
-    for (int t0 = w; t0 < n; t0 += FR * NW) {
+    for (int t0 = lo + w; t0 < hi; t0 += FR * NW) {
       float dcf_l[FR][NF];
 #pragma unroll
       for (int i = 0; i < FR; ++i)
@@ -444,14 +458,14 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
           float4 kx[FR], dk[FR];
 #pragma unroll
           for (int i = 0; i < FR; ++i) {
-            const size_t o = (size_t)min(t0 + i * NW, n - 1) * U4 + u4;
+            const size_t o = (size_t)min(t0 + i * NW, hi - 1) * U4 + u4;
             kx[i] = keys4[o];
             dk[i] = dkeys4[o];
           }
 #pragma unroll
           for (int i = 0; i < FR; ++i) {
             const int t = t0 + i * NW;
-            if (t < n) {
+            if (t < hi) {
               const float g = ds[t];
               float x[4] = {kx[i].x + qq.x, kx[i].y + qq.y, kx[i].z + qq.z, kx[i].w + qq.w};
               if (KIND)
@@ -495,7 +509,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
           for (int f = 0; f < NF; ++f)
             if (f < F) {
               const float tot = wave_sum(dcf_l[i][f]);
-              if (lane == 0 && t0 + i * NW < n) dcf[(t0 + i * NW) * F + f] = tot;
+              if (lane == 0 && t0 + i * NW < hi) dcf[(t0 + i * NW) * F + f] = tot;
             }
       }
     }
@@ -522,14 +536,10 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
   for (int u = tid; u < U; u += AT) {
     float s = 0.f;
     for (int i = 0; i < NW; ++i) s += red[i * U + u];
-    p.dv_part[(size_t)b * U + u] += s;
+    p.dv_part[((size_t)b * S + sl) * U + u] += s;
   }
   if (KIND) {
     __syncthreads();
-    // frames past the length (and frames no wave visited) carry no gradient
-    for (int i = tid + n * F; i < Te * F; i += AT) dcf[i] = 0.f;
-    __syncthreads();
-    const int pb = (p.K - 1) / 2;
     if (REG) {
       // d conv_proj[f,u] += sum_t cf[t,f] * d[t,u]: the per-wave register sums, reduced across waves
       // one feature at a time (fixed order)
@@ -545,7 +555,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
           for (int u = tid; u < U; u += AT) {
             float sm = 0.f;
             for (int i = 0; i < NW; ++i) sm += red[i * U + u];
-            p.dwf_part[((size_t)b * F + f) * U + u] += sm;
+            p.dwf_part[(((size_t)b * S + sl) * F + f) * U + u] += sm;
           }
           __syncthreads();
         }
@@ -556,7 +566,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
       float acc[16];
 #pragma unroll
       for (int f = 0; f < 16; ++f) acc[f] = 0.f;
-      for (int t = 0; t < n; ++t) {
+      for (int t = lo; t < hi; ++t) {
         float x = keys[(size_t)t * U + u] + q[u];
         for (int f = 0; f < F; ++f) x = fmaf(cf[t * F + f], p.wf[f * U + u], x);
         const float th = tanhf_(x);
@@ -567,30 +577,69 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
       }
 #pragma unroll
       for (int f = 0; f < 16; ++f)
-        if (f < F) p.dwf_part[((size_t)b * F + f) * U + u] += acc[f];
+        if (f < F) p.dwf_part[(((size_t)b * S + sl) * F + f) * U + u] += acc[f];
     }
-    // d previous alignment and d conv kernel
-    for (int t = tid; t < Te; t += AT) {
+  }
+}
+
+// What needs every frame of an utterance: dq = sum of the slices' partials; for location-aware
+// attention the gradient w.r.t. the previous alignments and the conv kernel, from the d location
+// features the slices left in HBM.  grid (B, 2) for location-aware attention (y = 0: dq and d previous
+// alignment, y = 1: d conv kernel), else (B, 1); 256 threads; previous alignment, d features and the
+// conv kernel are staged in LDS: alp[Te], dcf[Te*F], ck[K*F].
+__global__ __launch_bounds__(256) void attn_bwd_finish_kernel(AttnArgs p, int S) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+  const int Te = p.Te, U = p.U, F = p.F;
+  const bool loc = p.kind == 1;
+  float *dq = p.dq + (size_t)b * U;
+  float *dal_out = p.dalign_out ? p.dalign_out + (size_t)b * Te : nullptr;
+  if (p.step >= p.dec_len[b]) {            // finished row: no gradient of its own, pass dalign through
+    if (part == 0) {
+      for (int u = tid; u < U; u += 256) dq[u] = 0.f;
+      if (dal_out)
+        for (int t = tid; t < Te; t += 256) dal_out[t] = p.dalign_in ? p.dalign_in[(size_t)b * Te + t] : 0.f;
+    }
+    return;
+  }
+  if (part == 0)
+    for (int u = tid; u < U; u += 256) {
       float s = 0.f;
-      // out frame to = t - d + pb receives a[t] * ck[d,f]
-      for (int d = 0; d < p.K; ++d) {
-        const int to = t - d + pb;
-        if (to >= 0 && to < n)
-          for (int f = 0; f < F; ++f) s = fmaf(dcf[to * F + f], p.ck[d * F + f], s);
+      for (int i = 0; i < S; ++i) s += p.dq_part[((size_t)b * S + i) * U + u];
+      dq[u] = s;
+    }
+  if (!loc) {
+    if (dal_out)
+      for (int t = tid; t < Te; t += 256) dal_out[t] = 0.f;
+    return;
+  }
+  const int n = min(max(p.enc_len[b], 0), Te);
+  float *alp = smem, *dcf = alp + Te, *ck = dcf + Te * F;
+  for (int t = tid; t < Te; t += 256) alp[t] = p.align_prev[(size_t)b * Te + t];
+  // frames past the length carry no gradient
+  for (int i = tid; i < Te * F; i += 256) dcf[i] = i < n * F ? p.dcf_g[(size_t)b * Te * F + i] : 0.f;
+  for (int i = tid; i < p.K * F; i += 256) ck[i] = p.ck[i];
+  __syncthreads();
+  const int pb = (p.K - 1) / 2;
+  if (part == 0) {
+    // out frame to = t - d + pb receives a[t] * ck[d,f]
+    for (int t = tid; t < Te; t += 256) {
+      float s = 0.f;
+      const int d0 = max(0, t + pb - (n - 1)), d1 = min(p.K, t + pb + 1);
+      for (int d = d0; d < d1; ++d) {
+        const float *g = dcf + (t - d + pb) * F, *c = ck + d * F;
+        for (int f = 0; f < F; ++f) s = fmaf(g[f], c[f], s);
       }
       dal_out[t] = s;
     }
-    for (int i = tid; i < p.K * F; i += AT) {
+  } else {
+    for (int i = tid; i < p.K * F; i += 256) {
       const int d = i / F, f = i % F;
       float s = 0.f;
-      for (int to = 0; to < n; ++to) {
-        const int t = to + d - pb;
-        if (t >= 0 && t < Te) s = fmaf(alp[t], dcf[to * F + f], s);
-      }
+      const int to0 = max(0, pb - d), to1 = min(n, Te + pb - d);
+      for (int to = to0; to < to1; ++to) s = fmaf(alp[to + d - pb], dcf[to * F + f], s);
       p.dck_part[(size_t)b * p.K * F + i] += s;
     }
-  } else if (dal_out) {
-    for (int t = tid; t < Te; t += AT) dal_out[t] = 0.f;
   }
 }
 
@@ -668,7 +717,18 @@ static int grid1(size_t n) {
 static size_t attn_lds(const nabu_attn_desc *d, bool bwd) {
   size_t f = 2 * (size_t)d->Te + (d->kind == 1 ? (size_t)d->Te * d->F * (bwd ? 2 : 1) : 0);
   f += bwd ? 4 + (size_t)(AT / 64) * d->U : 64 + 4 + 4 * (size_t)AT;
+  if (d->kind == 1) f += ((size_t)d->K * d->F + 3) & ~(size_t)3;     // the staged conv kernel
   return f * sizeof(float);
+}
+
+// Backward: frame slices per utterance so that the launch has ~256 workgroups (one per CU); a slice
+// keeps at least 16 encoder frames (8 waves x 2 frames in flight)
+static int attn_bwd_nslices(const nabu_attn_desc *d) {
+  int S = (256 + d->B - 1) / d->B;
+  const int cap = (d->Te + 15) / 16;
+  if (S > cap) S = cap;
+  if (S > 8) S = 8;
+  return S < 1 ? 1 : S;
 }
 
 static int check_attn(const nabu_attn_desc *d) {
@@ -741,27 +801,44 @@ extern "C" int nabu_attn_fwd(const nabu_attn_desc *d, int step, const int32_t *d
   return 0;
 }
 
+extern "C" int nabu_attn_bwd_slices(const nabu_attn_desc *d) {
+  if (check_attn(d)) return 0;
+  return attn_bwd_nslices(d);
+}
+
+extern "C" size_t nabu_attn_bwd_ws_bytes(const nabu_attn_desc *d) {
+  if (check_attn(d)) return 0;
+  const size_t S = attn_bwd_nslices(d);
+  return ((size_t)d->B * S * d->U + (d->kind == 1 ? (size_t)d->B * d->Te * d->F : 0) + 4) * sizeof(float);
+}
+
 extern "C" int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
                              const int32_t *enc_len, const float *keys, const float *values,
                              const float *q, const float *v, const float *conv_kernel,
                              const float *conv_proj, const float *align_prev, const float *align,
-                             const float *dctx, const float *dalign_in, float *dq, float *dkeys,
-                             float *dv_part, float *dconv_proj_part, float *dconv_kernel_part,
-                             float *dalign_out, const float *znorm, nabu_stream_t stream) {
+                             const float *ctx, const float *dctx, const float *dalign_in, float *dq,
+                             float *dkeys, float *dv_part, float *dconv_proj_part,
+                             float *dconv_kernel_part, float *dalign_out, const float *znorm, void *ws,
+                             size_t ws_bytes, nabu_stream_t stream) {
   if (int e = check_attn(d)) return e;
-  NABU_CHECK_ARG(dec_len && enc_len && keys && values && q && v && align && dctx && dq && dkeys && dv_part,
+  NABU_CHECK_ARG(dec_len && enc_len && keys && values && q && v && align && ctx && dctx && dq && dkeys && dv_part && ws,
                  "attn_bwd: null pointer");
   NABU_CHECK_ARG(d->kind != 1 || (conv_kernel && conv_proj && align_prev && dconv_proj_part &&
                               dconv_kernel_part && dalign_out),
                  "attn_bwd: location-aware attention needs its kernels and gradient buffers");
+  if (ws_bytes < nabu_attn_bwd_ws_bytes(d)) return fail(NABU_EWS, "attn_bwd: workspace too small");
+  const int S = attn_bwd_nslices(d);
   AttnArgs p = {};
   p.B = d->B; p.Te = d->Te; p.E = d->E; p.U = d->U; p.kind = d->kind; p.K = d->K; p.F = d->F; p.step = step;
   p.dec_len = dec_len; p.enc_len = enc_len; p.keys = keys; p.values = values; p.q = q; p.v = v;
   p.ck = conv_kernel; p.wf = conv_proj; p.align_prev = align_prev;
   p.align = const_cast<float *>(align);
+  p.ctx = const_cast<float *>(ctx);
   p.dctx = dctx; p.dalign_in = dalign_in; p.dq = dq; p.dkeys = dkeys; p.dv_part = dv_part;
   p.dwf_part = dconv_proj_part; p.dck_part = dconv_kernel_part; p.dalign_out = dalign_out;
   p.prob_fn = d->prob_fn; p.znorm = const_cast<float *>(znorm);
+  p.dq_part = static_cast<float *>(ws);
+  p.dcf_g = p.dq_part + (size_t)d->B * S * d->U;
   NABU_CHECK_ARG(d->prob_fn != 2 || znorm, "attn_bwd: normalized_sigmoid needs the normalisers of the forward pass");
   const size_t shm = attn_lds(d, true);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -770,7 +847,13 @@ extern "C" int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *d
   if (shm > 64 * 1024)
     NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  hipLaunchKernelGGL(kern, dim3(d->B), dim3(AT), shm, s, p);
+  hipLaunchKernelGGL(kern, dim3(d->B, S), dim3(AT), shm, s, p);
+  NABU_LAUNCH_CHECK();
+  const size_t shm2 = ((size_t)d->Te + (d->kind == 1 ? (size_t)d->Te * d->F + (size_t)d->K * d->F : 0) + 4) * sizeof(float);
+  if (shm2 > 64 * 1024)
+    NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_finish_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2));
+  hipLaunchKernelGGL(attn_bwd_finish_kernel, dim3(d->B, d->kind == 1 ? 2 : 1), dim3(256), shm2, s, p, S);
   NABU_LAUNCH_CHECK();
   return 0;
 }
@@ -835,7 +918,7 @@ static SpLayout sp_layout(const nabu_speller_desc *d) {
 }
 
 struct SpWs {
-  size_t z, dl, dH, dCtx, dkeys, dv, dwf, dck, dq, dz[NABU_SPELLER_MAX_LAYERS], dh[2][NABU_SPELLER_MAX_LAYERS],
+  size_t z, dl, dH, dCtx, dkeys, dv, dwf, dck, attn, dq, dz[NABU_SPELLER_MAX_LAYERS], dh[2][NABU_SPELLER_MAX_LAYERS],
       dc[2][NABU_SPELLER_MAX_LAYERS], dctx[2], dal[2], dx, tmp, gemm, gemm_bytes, total;
   size_t wqT, kxT[NABU_SPELLER_MAX_LAYERS], khT[NABU_SPELLER_MAX_LAYERS];   // transposed weights (backward)
 };
@@ -850,8 +933,11 @@ static SpWs sp_ws(const nabu_speller_desc *d) {
   s.dH = take(L * B * U);
   s.dCtx = take(L * B * E);
   s.dkeys = take(B * Te * U);
-  s.dv = take(B * U);
-  s.dwf = take(B * F * U + 4);
+  const nabu_attn_desc adesc = {sizeof(nabu_attn_desc), d->B, d->Te, d->E, d->U, d->kind, d->K, d->F, d->prob_fn};
+  const size_t S = attn_bwd_nslices(&adesc);
+  s.dv = take(B * S * U);
+  s.dwf = take(B * S * F * U + 4);
+  s.attn = take(nabu_attn_bwd_ws_bytes(&adesc) / 4 + 4);
   s.dck = take(B * K * F + 4);
   s.dq = take(L * B * U);
   for (int n = 0; n < d->num_layers; ++n) {
@@ -880,7 +966,7 @@ static SpWs sp_ws(const nabu_speller_desc *d) {
   mx(nabu_gemm_ws_bytes(BL, (int)U, (int)C)); mx(nabu_gemm_ws_bytes(BL, (int)E, (int)C));
   mx(nabu_gemm_ws_bytes((int)U, (int)U, BL)); mx(nabu_gemm_ws_bytes((int)E, (int)(4 * U), BL));
   mx(nabu_gemm_ws_bytes((int)U, (int)(4 * U), BL)); mx(nabu_gemm_ws_bytes((int)Te, (int)E, (int)L));
-  mx(nabu_colsum_ws_bytes(BL, (int)(4 * U))); mx(nabu_colsum_ws_bytes((int)B, (int)(F * U + K * F + U)));
+  mx(nabu_colsum_ws_bytes(BL, (int)(4 * U))); mx(nabu_colsum_ws_bytes((int)(B * 8), (int)(F * U + K * F + U)));
   s.gemm_bytes = (g + 255) / 256 * 256;
   s.gemm = take(s.gemm_bytes / 4 + 4);
   s.total = o;
@@ -1034,9 +1120,11 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   SP_TRY(mm(false, true, BL, U, C, dl, C, p->out_kernel, C, 0.f, dH, U, nullptr, gw, gwb, stream));
   SP_TRY(mm(false, true, BL, E, C, dl, C, p->out_kernel + (size_t)U * C, C, 0.f, dCtx, E, nullptr, gw, gwb, stream));
   NABU_HIP(hipMemsetAsync(dkeys, 0, (size_t)B * Te * U * 4, s));
-  NABU_HIP(hipMemsetAsync(w + W.dv, 0, (size_t)B * U * 4, s));
+  const int S = nabu_attn_bwd_slices(&ad);          // per-slice partial rows of the attention backward
+  const size_t attn_wsb = nabu_attn_bwd_ws_bytes(&ad);
+  NABU_HIP(hipMemsetAsync(w + W.dv, 0, (size_t)B * S * U * 4, s));
   if (d->kind == 1) {
-    NABU_HIP(hipMemsetAsync(w + W.dwf, 0, (size_t)B * F * U * 4, s));
+    NABU_HIP(hipMemsetAsync(w + W.dwf, 0, (size_t)B * S * F * U * 4, s));
     NABU_HIP(hipMemsetAsync(w + W.dck, 0, (size_t)B * K * F * 4, s));
   }
   for (int n = 0; n < nl; ++n) {
@@ -1065,9 +1153,10 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
     float *dqt = dq + (size_t)t * B * U;
     SP_TRY(nabu_attn_bwd(&ad, t, dec_len, enc_len, r + R.keys, values, r + R.q + (size_t)t * B * U, p->attention_v,
                          p->conv_kernel, p->conv_proj, r + R.align + (size_t)t * B * Te,
-                         r + R.align + (size_t)(t + 1) * B * Te, dCt, dal_carry, dqt, dkeys, w + W.dv,
-                         d->kind == 1 ? w + W.dwf : nullptr, d->kind == 1 ? w + W.dck : nullptr, dal_out,
-                         r + R.znorm + (size_t)t * B, stream));
+                         r + R.align + (size_t)(t + 1) * B * Te, r + R.ctx + (size_t)(t + 1) * B * E, dCt, dal_carry,
+                         dqt, dkeys, w + W.dv, d->kind == 1 ? w + W.dwf : nullptr,
+                         d->kind == 1 ? w + W.dck : nullptr, dal_out, r + R.znorm + (size_t)t * B, w + W.attn,
+                         attn_wsb, stream));
     dal_carry = dal_out;
     float *dHt = dH + (size_t)t * B * U;
     SP_TRY(mm(false, false, B, U, U, dqt, U, w + W.wqT, U, 1.f, dHt, U, nullptr, gw, gwb, stream));
@@ -1112,9 +1201,9 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
     }
     SP_TRY(nabu_colsum_f32(BL, 4 * U, dzn, 4 * U, 0.f, g->lstm_bias[n], gw, gwb, stream));
   }
-  SP_TRY(nabu_colsum_f32(B, U, w + W.dv, U, 0.f, g->attention_v, gw, gwb, stream));
+  SP_TRY(nabu_colsum_f32(B * S, U, w + W.dv, U, 0.f, g->attention_v, gw, gwb, stream));
   if (d->kind == 1) {
-    SP_TRY(nabu_colsum_f32(B, F * U, w + W.dwf, F * U, 0.f, g->conv_proj, gw, gwb, stream));
+    SP_TRY(nabu_colsum_f32(B * S, F * U, w + W.dwf, F * U, 0.f, g->conv_proj, gw, gwb, stream));
     SP_TRY(nabu_colsum_f32(B, K * F, w + W.dck, K * F, 0.f, g->conv_kernel, gw, gwb, stream));
   }
   // keys = values·Wmem ; context_t = align_t^T·values

@@ -284,12 +284,21 @@ def attn_fwd(desc, step, dec_len, enc_len, keys, values, q, v, conv_kernel, conv
                                    ptr(ctx_prev), ptr(align), ptr(ctx), ptr(znorm), stream()), 'nabu_attn_fwd')
 
 
-def attn_bwd(desc, step, dec_len, enc_len, keys, values, q, v, conv_kernel, conv_proj, align_prev, align,
+def attn_bwd(desc, step, dec_len, enc_len, keys, values, q, v, conv_kernel, conv_proj, align_prev, align, ctx,
              dctx, dalign_in, dq, dkeys, dv_part, dcp_part, dck_part, dalign_out, znorm=None):
-    check(_hip.lib().nabu_attn_bwd(ctypes.byref(desc), step, ptr(dec_len), ptr(enc_len), ptr(keys), ptr(values),
-                                   ptr(q), ptr(v), ptr(conv_kernel), ptr(conv_proj), ptr(align_prev),
-                                   ptr(align), ptr(dctx), ptr(dalign_in), ptr(dq), ptr(dkeys), ptr(dv_part),
-                                   ptr(dcp_part), ptr(dck_part), ptr(dalign_out), ptr(znorm), stream()), 'nabu_attn_bwd')
+    """dv_part / dcp_part have B * attn_bwd_slices(desc) rows; ctx = this step's context"""
+    L = _hip.lib()
+    nbytes = L.nabu_attn_bwd_ws_bytes(ctypes.byref(desc))
+    ws = Workspace.get(nbytes, keys.device, 'attn_bwd')
+    check(L.nabu_attn_bwd(ctypes.byref(desc), step, ptr(dec_len), ptr(enc_len), ptr(keys), ptr(values),
+                          ptr(q), ptr(v), ptr(conv_kernel), ptr(conv_proj), ptr(align_prev),
+                          ptr(align), ptr(ctx), ptr(dctx), ptr(dalign_in), ptr(dq), ptr(dkeys), ptr(dv_part),
+                          ptr(dcp_part), ptr(dck_part), ptr(dalign_out), ptr(znorm), ptr(ws), nbytes, stream()),
+          'nabu_attn_bwd')
+
+
+def attn_bwd_slices(desc):
+    return _hip.lib().nabu_attn_bwd_slices(ctypes.byref(desc))
 
 
 def mask_time_(x, len_dev):
