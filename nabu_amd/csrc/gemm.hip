@@ -386,6 +386,10 @@ extern "C" size_t nabu_gemm_ws_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   int ks;
   int ns = choose_split(M, N, K, &ks);
+  if (K % FKT && K > FKT) {             // the K-tail split runs the fast kernel on K - K % 16
+    const int nm = choose_split(M, N, K - K % FKT, &ks);
+    if (nm > ns) ns = nm;
+  }
   const int kc = gemm_skinny_chunk(M, N, K);
   if (kc && K / kc > ns) ns = K / kc;
   return ns > 1 ? (size_t)ns * M * N * sizeof(float) : 0;
@@ -421,6 +425,22 @@ extern "C" int nabu_gemm_f32(int transA, int transB, int M, int N, int K, float 
                       a_seg_stride, b_seg_stride, ws, ws_bytes, stream);
 }
 
+static int gemm_run(int precision, int transA, int transB, int M, int N, int K, float alpha,
+                    const float *A, int lda, const float *B, int ldb, float beta,
+                    float *C, int ldc, const float *bias, int kseg,
+                    long long a_seg_stride, long long b_seg_stride, void *ws,
+                    size_t ws_bytes, nabu_stream_t stream);
+
+// Shapes the fast fp32 kernel takes: reduction length a multiple of its 16-wide k-tile, 16-byte
+// vector loads along the contiguous dimension of each operand (so only THAT dimension must be a
+// multiple of 4; the other one is clamped at the edges).
+static bool fast_f32_ok(bool ta, bool tb, int M, int N, int K, const void *A, int lda, const void *B, int ldb,
+                        long long a_seg, long long b_seg) {
+  auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return K > 0 && K % FKT == 0 && al16(A) && lda % 4 == 0 && a_seg % 4 == 0 && al16(B) && ldb % 4 == 0 &&
+         b_seg % 4 == 0 && (!ta || M % 4 == 0) && (tb || N % 4 == 0);
+}
+
 extern "C" int nabu_gemm_ex(int precision, int transA, int transB, int M, int N, int K, float alpha,
                             const float *A, int lda, const float *B, int ldb, float beta,
                             float *C, int ldc, const float *bias, int kseg,
@@ -433,6 +453,32 @@ extern "C" int nabu_gemm_ex(int precision, int transA, int transB, int M, int N,
   NABU_CHECK_ARG(A && B && C, "gemm: null pointer");
   NABU_CHECK_ARG(kseg == 0 || (transA && !transB && K % kseg == 0),
                  "gemm: segmented K needs transA=1, transB=0 and K %% kseg == 0");
+  // Reduction lengths that are not a multiple of the fast kernel's k-tile (B*T of real batches): the
+  // fast kernel takes the first K - K % 16 indices, the generic kernel adds the rest.  With segmented K
+  // the rest must lie inside the last segment (it does unless a segment is shorter than 16).
+  const int Kt = K % FKT, Km = K - Kt;
+  if (precision == NABU_GEMM_F32 && Kt != 0 && Km >= 4 * FKT && !(M <= 64 && !transA && !transB) &&
+      (kseg == 0 || Km / kseg == (K - 1) / kseg) &&
+      fast_f32_ok(transA != 0, transB != 0, M, N, Km, A, lda, B, ldb, a_seg_stride, b_seg_stride)) {
+    if (int e = gemm_run(precision, transA, transB, M, N, Km, alpha, A, lda, B, ldb, beta, C, ldc, bias, kseg,
+                         a_seg_stride, b_seg_stride, ws, ws_bytes, stream))
+      return e;
+    auto off = [&](bool kmajor, int ld, long long seg) -> size_t {     // offset of reduction index Km
+      if (!kmajor) return (size_t)Km;
+      return kseg > 0 ? (size_t)(Km / kseg) * (size_t)seg + (size_t)(Km % kseg) * ld : (size_t)Km * ld;
+    };
+    return gemm_run(precision, transA, transB, M, N, Kt, alpha, A + off(transA != 0, lda, a_seg_stride), lda,
+                    B + off(transB == 0, ldb, b_seg_stride), ldb, 1.f, C, ldc, nullptr, 0, 0, 0, ws, ws_bytes, stream);
+  }
+  return gemm_run(precision, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, kseg,
+                  a_seg_stride, b_seg_stride, ws, ws_bytes, stream);
+}
+
+static int gemm_run(int precision, int transA, int transB, int M, int N, int K, float alpha,
+                    const float *A, int lda, const float *B, int ldb, float beta,
+                    float *C, int ldc, const float *bias, int kseg,
+                    long long a_seg_stride, long long b_seg_stride, void *ws,
+                    size_t ws_bytes, nabu_stream_t stream) {
   GemmArgs a;
   a.A = A; a.B = B; a.C = C; a.bias = bias;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
@@ -462,14 +508,15 @@ extern "C" int nabu_gemm_ex(int precision, int transA, int transB, int M, int N,
   if (const char *e = getenv("NABU_GEMM_NOSTAGE")) a.vecA |= 2 * atoi(e);   // timing experiments: 1 nothing, 2 no loads, 4 no LDS stores
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, a.nsplit), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool fast = M % 4 == 0 && N % 4 == 0 && K > 0 && K % FBK == 0 && a.vecA && a.vecB;
+  const bool fast = M % 4 == 0 && N % 4 == 0 && K > 0 && K % FBK == 0 && a.vecA && a.vecB;      // bf16 kernels
+  const bool fast32 = fast_f32_ok(transA != 0, transB != 0, M, N, K, A, lda, B, ldb, a_seg_stride, b_seg_stride);
   if (skinny_kc) {
     if (int e = gemm_skinny_launch(a, s)) return e;
   } else
   if (fast && precision != NABU_GEMM_F32) {
     if (int e = gemm_bf16_launch(a, transA != 0, transB != 0, precision - NABU_GEMM_BF16 + 1, grid, s)) return e;
   } else
-  if (fast) {
+  if (fast32) {
     const size_t lds = 4 * (size_t)FKT * LDT * sizeof(float);
     static bool configured = false;
     if (!configured) {

@@ -26,7 +26,10 @@ def rel_err(a, b):
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize('ta,tb', [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize('M,N,K', [(128, 128, 16), (200, 136, 40), (37, 40, 1024), (1, 5, 3),
-                                   (40, 256, 4100), (300, 40, 48)])
+                                   (40, 256, 4100), (300, 40, 48),
+                                   # real batches: B*T is rarely a multiple of anything — odd row counts and a
+                                   # reduction length with a tail beyond the fast kernel's 16-wide k-tile
+                                   (1003, 136, 1592), (512, 2048, 1001), (129, 516, 88)])
 def test_gemm_matches_float64(ta, tb, M, N, K):
     from nabu_amd import ops
     rng = np.random.default_rng(M * 7 + N * 3 + K)
@@ -66,6 +69,26 @@ def test_gemm_segmented_k_shifted_product():
     ops.gemm(o.view(-1)[H + 2 * H:], d, c, True, False, M=H, N=4 * H, K=B * (T - 1), lda=2 * H,
              ldb=4 * H, ldc=4 * H, kseg=T - 1, a_seg=T * 2 * H, b_seg=T * 4 * H)
     assert rel_err(host(c), ref_bw) < 2e-6
+
+
+def test_gemm_segmented_k_with_a_tail():
+    """cfg1's dWh: 8 segments of 199 frames — K = 1592 = 99 k-tiles of 16 + 8; the tail lies inside the
+    last segment and is added by the generic kernel"""
+    from nabu_amd import ops
+    rng = np.random.default_rng(14)
+    B, T, H = 8, 200, 64
+    out = rng.normal(size=(B, T, 2 * H)); dz = rng.normal(size=(B, T, 4 * H))
+    ref_fw = np.einsum('bth,btg->hg', out[:, :-1, :H], dz[:, 1:])
+    o, d = dev(out), dev(dz)
+    c = torch.full((H, 4 * H), float('nan'), device='cuda')
+    ops.gemm(o, d.view(-1)[4 * H:], c, True, False, M=H, N=4 * H, K=B * (T - 1), lda=2 * H, ldb=4 * H,
+             ldc=4 * H, kseg=T - 1, a_seg=T * 2 * H, b_seg=T * 4 * H)
+    assert rel_err(host(c), ref_fw) < 4e-6
+    bias = rng.normal(size=4 * H)
+    c2 = dev(np.ones((H, 4 * H)))
+    ops.gemm(o, d.view(-1)[4 * H:], c2, True, False, M=H, N=4 * H, K=B * (T - 1), lda=2 * H, ldb=4 * H,
+             ldc=4 * H, kseg=T - 1, a_seg=T * 2 * H, b_seg=T * 4 * H, alpha=0.5, beta=3.0, bias=dev(bias))
+    assert rel_err(host(c2), 0.5 * ref_fw + 3.0 + bias) < 4e-6
 
 
 def test_colsum():
