@@ -141,6 +141,8 @@ def main():
     ap.add_argument('--mode', default='auto', choices=['auto', 'stepwise', 'persistent'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the informational bf16x6 measurement')
+    ap.add_argument('--no-gemm-roofline', action='store_true',
+                    help='skip the roofline_gemm measurement (keeps a kernel trace of this command to the training steps)')
     ap.add_argument('--gemm-precision', default='f32', choices=['f32', 'bf16x6', 'bf16x3', 'bf16'],
                     help='arithmetic of the dense products (include/nabu_hip.h nabu_gemm_ex); the BASELINE metric '
                          'is fp32 = the default; the others are reported as such in config.gemm_arith')
@@ -271,7 +273,8 @@ def main():
                                   'bf16': 'operands rounded to bf16, f32 accumulate'}[args.gemm_precision]},
         'roofline': roofline,
         'roofline_gemm': (gemm_roofline(B, T, D, H, args.gemm_precision)
-                          if args.workload == 'cfg2' and args.gemm_precision == 'f32' else None),
+                          if args.workload == 'cfg2' and args.gemm_precision == 'f32' and not args.no_gemm_roofline
+                          else None),
         'hbm_roofline_frac_whole_step': round(step_bytes_total / (dt / args.steps) / (HBM_PEAK_GBS * 1e9), 4),
         'final_loss': round(final_loss, 4),
     }
