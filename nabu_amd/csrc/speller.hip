@@ -666,16 +666,38 @@ __global__ __launch_bounds__(256) void swap01_kernel(int L, int B, int F, const 
   }
 }
 
-// dK[c,:] = sum over (l,b) with ids[l,b] == c of dz[l,b,:]  (gradient of the one-hot rows)
+// dK[c,:] = sum over (l,b) with ids[l,b] == c of dz[l,b,:]  (gradient of the one-hot rows).
+// Workgroup (column block, class c): the ids are scanned 256 at a time through LDS (one coalesced load
+// per chunk instead of a dependent global load per row), matching rows are added in increasing row
+// order (deterministic).
 __global__ __launch_bounds__(256) void scatter_rows_kernel(int C, int N, int W, const int32_t *__restrict__ ids,
                                                            const float *__restrict__ dz, float *__restrict__ dK) {
-  const int c = blockIdx.y;
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= W) return;
+  __shared__ int hit[256];
+  __shared__ int nhit;
+  const int c = blockIdx.y, tid = threadIdx.x;
+  const int col = blockIdx.x * 256 + tid;
   float s = 0.f;
-  for (int i = 0; i < N; ++i)
-    if (ids[i] == c) s += dz[(size_t)i * W + col];
-  dK[(size_t)c * W + col] = s;
+  for (int base = 0; base < N; base += 256) {
+    if (tid == 0) nhit = 0;
+    __syncthreads();
+    const int i = base + tid;
+    const bool m = i < N && ids[i] == c;
+    // order-preserving compaction: matches of wave w go after those of the waves before it
+    const unsigned long long bal = __ballot(m);
+    __shared__ int wcount[4];
+    if ((tid & 63) == 0) wcount[tid >> 6] = __popcll(bal);
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < (tid >> 6); ++w) off += wcount[w];
+    if (m) hit[off + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = i;
+    if (tid == 0) nhit = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    __syncthreads();
+    const int n = nhit;
+    if (col < W)
+      for (int j = 0; j < n; ++j) s += dz[(size_t)hit[j] * W + col];
+    __syncthreads();
+  }
+  if (col < W) dK[(size_t)c * W + col] = s;
 }
 
 // out[c][r] = in[r][c] (32x32 LDS tiles); used once per backward pass to turn the per-step
