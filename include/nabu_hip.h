@@ -225,7 +225,11 @@ int nabu_attn_fwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
                   const int32_t *enc_len, const float *keys, const float *values,
                   const float *q, const float *v, const float *conv_kernel,
                   const float *conv_proj, const float *align_prev, const float *ctx_prev,
-                  float *align, float *ctx, float *znorm, nabu_stream_t stream);
+                  float *align, float *ctx, float *znorm, void *ws, size_t ws_bytes,
+                  nabu_stream_t stream);
+/* bytes of ws the forward pass needs (0 when the batch alone fills the chip): small batches are cut
+ * into slices of encoder frames like the backward pass, partial softmax sums / contexts meet in ws */
+size_t nabu_attn_fwd_ws_bytes(const nabu_attn_desc *d);
 /* The backward pass cuts every utterance into S = nabu_attn_bwd_slices(d) slices of encoder frames
  * (one workgroup each, so that a step fills the chip at small batch sizes): dv_part and
  * dconv_proj_part have B*S rows; ctx is THIS step's context (the forward output: it turns the

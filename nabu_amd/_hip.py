@@ -48,7 +48,8 @@ SIGNATURES = {
     'nabu_xent_loss_grad': (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     'nabu_lstm_cell_fwd': (_i, [_i, _i, _i] + [_vp] * 10 + [_vp]),
     'nabu_lstm_cell_bwd': (_i, [_i, _i, _i] + [_vp] * 9 + [_vp]),
-    'nabu_attn_fwd': (_i, [_vp, _i] + [_vp] * 13 + [_vp]),
+    'nabu_attn_fwd': (_i, [_vp, _i] + [_vp] * 14 + [_sz, _vp]),
+    'nabu_attn_fwd_ws_bytes': (_sz, [_vp]),
     'nabu_attn_bwd': (_i, [_vp, _i] + [_vp] * 21 + [_sz, _vp]),
     'nabu_attn_bwd_slices': (_i, [_vp]),
     'nabu_attn_bwd_ws_bytes': (_sz, [_vp]),

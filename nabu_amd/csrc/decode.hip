@@ -548,7 +548,11 @@ static BeamWs beam_ws(const nabu_beam_desc *d) {
   s.z = take(N * 4 * U); s.q = take(N * U); s.logits = take(N * C); s.acts = take(N * 4 * U);
   s.ids = take(N); s.logprobs = take(N); s.lengths = take(N); s.finished = take(N); s.seen = take(N);
   s.parent = take(N); s.stay = take(N); s.all_seen = take(B);
-  s.scratch = take(B * (W * C + W));
+  {
+    const nabu_attn_desc ad = {sizeof(nabu_attn_desc), (int32_t)N, d->Te, d->E, d->U, d->kind, d->K, d->F, d->prob_fn};
+    const size_t need = nabu_attn_fwd_ws_bytes(&ad) / 4, prune = B * (W * C + W);
+    s.scratch = take(need > prune ? need : prune);
+  }
   s.hist_pred = take(S * N); s.hist_parent = take(S * N);
   s.hist_align = take(S * N * Te);
   s.src = take(N * S);
@@ -680,6 +684,7 @@ extern "C" int nabu_speller_beam_search(const nabu_beam_desc *d, const float *va
   float *gw = w + L.gemm;
   const size_t gwb = L.gemm_bytes;
   const nabu_attn_desc ad = {sizeof(nabu_attn_desc), N, Te, E, U, d->kind, d->K, d->F, d->prob_fn};
+  const size_t attn_wsb = nabu_attn_fwd_ws_bytes(&ad);   // sliced forward (small B*W): partials in the pruning scratch
   auto tile = [&](const void *src, void *dst, size_t F) {
     size_t gy = (F + DT * 4 - 1) / (DT * 4);
     hipLaunchKernelGGL(tile_rows_kernel, dim3(N, gy > 64 ? 64 : (unsigned)gy), dim3(DT), 0, s, W, F,
@@ -732,7 +737,8 @@ extern "C" int nabu_speller_beam_search(const nabu_beam_desc *d, const float *va
     DEC_TRY(bmm(N, U, U, htop, U, p->query_kernel, U, 0.f, w + L.q, U, nullptr, gw, gwb, stream));
     DEC_TRY(nabu_attn_fwd(&ad, 0, big, lenT, w + L.keysT, w + L.valuesT, w + L.q, p->attention_v, p->conv_kernel,
                           p->conv_proj, w + L.align[cur], w + L.ctx[cur], w + L.align[fresh], w + L.ctx[fresh],
-                          w + L.acts /* normaliser scratch: the saved gate activations are not used at inference */, stream));
+                          w + L.acts /* normaliser scratch: the saved gate activations are not used at inference */,
+                          w + L.scratch, attn_wsb, stream));
     // AttentionProjectionWrapper: [h, context of this step]·W + b (rnn_cell.py:145-155)
     DEC_TRY(bmm(N, C, U, htop, U, p->out_kernel, C, 0.f, lg, C, p->out_bias, gw, gwb, stream));
     DEC_TRY(bmm(N, C, E, w + L.ctx[fresh], E, p->out_kernel + (size_t)U * C, C, 1.f, lg, C, nullptr, gw, gwb, stream));

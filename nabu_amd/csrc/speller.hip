@@ -91,6 +91,7 @@ struct AttnArgs {
   const float *dctx, *dalign_in;
   float *dq, *dkeys, *dv_part, *dwf_part, *dck_part, *dalign_out;
   float *dq_part, *dcf_g;   // [B,S,U] per-slice dq, [B,Te,F] d location features (backward scratch)
+  float *fwd_part;          // [B,S,E+4] per-slice context + (local max, local sum) (forward scratch)
 };
 
 // LDS carve for the attention kernels (floats): al[Te] prev alignment (padded conv input),
@@ -118,18 +119,24 @@ template <int MODE>   // 0 vanilla, 1 location-aware (generic), 2 location-aware
 __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
   constexpr bool REG = MODE == 2, KIND = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // grid (B, S).  S = 1: the workgroup does the whole utterance.  S > 1 (small batches: fill the chip):
+  // workgroup (b, sl) scores the frames [lo, n) only and leaves exp(score - local max), the local
+  // max / sum and its part of the context; attn_fwd_finish_kernel rescales and combines them.
+  const int b = blockIdx.x, sl = blockIdx.y, S = gridDim.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int Te = p.Te, U = p.U, E = p.E;
   float *base = smem + ck_floats(p);
   float *alp = base, *sc = alp + Te, *cf = sc + Te, *red = cf + (KIND ? Te * p.F : 0);
   float *align = p.align + (size_t)b * Te;
-  float *ctx = p.ctx + (size_t)b * E;
+  float *ctx = S > 1 ? p.fwd_part + ((size_t)b * S + sl) * (E + 4) : p.ctx + (size_t)b * E;
   if (p.step >= p.dec_len[b]) {   // finished row: state frozen
+    if (S > 1) return;            // ... by the finish kernel
     for (int t = tid; t < Te; t += AT) align[t] = p.align_prev[(size_t)b * Te + t];
     for (int e = tid; e < E; e += AT) ctx[e] = p.ctx_prev[(size_t)b * E + e];
     return;
   }
-  const int n = min(max(p.enc_len[b], 0), Te);
+  const int nfull = min(max(p.enc_len[b], 0), Te);
+  const int per = (Te + S - 1) / S, lo = min(sl * per, nfull), n = min(lo + per, nfull);   // my frames [lo, n)
   const float *keys = p.keys + (size_t)b * Te * U;
   const float *vals = p.values + (size_t)b * Te * E;
   const float *q = p.q + (size_t)b * U;
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
     for (int t = tid; t < Te; t += AT) alp[t] = p.align_prev[(size_t)b * Te + t];
     for (int i = tid; i < p.K * p.F; i += AT) smem[i] = p.ck[i];
     __syncthreads();
-    conv_features(p, alp, cf, 0, Te, smem);
+    conv_features(p, alp, cf, lo, n, smem);
     __syncthreads();
   }
   // WindowedAttention (attention.py:294-396): only frames in [m - left - 1, m + right) may be attended,
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
                                           : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    for (int t0 = w; t0 < n; t0 += FR * NW) {
+    for (int t0 = lo + w; t0 < n; t0 += FR * NW) {
       float s[FR];
 #pragma unroll
       for (int i = 0; i < FR; ++i) s[i] = 0.f;
@@ -236,10 +243,39 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
   }
   __syncthreads();
   if (!KIND && p.kind == 2) {
-    for (int t = tid; t < n; t += AT)
+    for (int t = lo + tid; t < n; t += AT)
       if (t < w_lo || t >= w_hi) sc[t] = -INFINITY;
     __syncthreads();
   }
+  if (S > 1) {
+    // partial result of this slice: e[t] = exp(score - local max) (softmax) or sigmoid(score), the
+    // local max and sum; the context loop below then accumulates e[t] * values[t] over my frames
+    float m = -3.0e38f;
+    if (p.prob_fn == 0) {
+      for (int t = lo + tid; t < n; t += AT) m = fmaxf(m, sc[t]);
+      m = fmaxf(m, __shfl_xor(m, 32)); m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 8));
+      m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 1));
+      if (lane == 0) red[w] = m;
+      __syncthreads();
+      m = red[0];
+      for (int i = 1; i < AT / 64; ++i) m = fmaxf(m, red[i]);
+      __syncthreads();
+    }
+    float z = 0.f;
+    for (int t = lo + tid; t < n; t += AT) {
+      const float e = p.prob_fn == 0 ? expf(sc[t] - m) : 1.0f / (1.0f + expf(-sc[t]));
+      sc[t] = e;
+      align[t] = e;
+      z += e;
+    }
+    z = wave_sum(z);
+    if (lane == 0) red[w] = z;
+    __syncthreads();
+    z = 0.f;
+    for (int i = 0; i < AT / 64; ++i) z += red[i];
+    if (tid == 0) { ctx[E] = m; ctx[E + 1] = z; }
+    __syncthreads();
+  } else
   if (p.prob_fn != 0) {
     // sigmoid / normalized_sigmoid (attention.py:9-13, 41-55): masked frames (score -inf) give 0
     float z = 0.f;
@@ -303,7 +339,7 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
       const int e4 = c0 + tid % (AT / nsp), pt = tid / (AT / nsp);
       if (e4 < E4 && pt < nsp) {
         float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-        int t = pt;
+        int t = lo + pt;
         for (; t + 3 * nsp < n; t += 4 * nsp) {
           const float4 a0 = vals4[(size_t)t * E4 + e4], a1 = vals4[(size_t)(t + nsp) * E4 + e4];
           const float4 a2 = vals4[(size_t)(t + 2 * nsp) * E4 + e4], a3 = vals4[(size_t)(t + 3 * nsp) * E4 + e4];
@@ -331,6 +367,43 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
       }
       __syncthreads();
     }
+  }
+}
+
+// Combines the slices of a sliced forward pass (flash-style): M = max of the local maxima, every
+// slice's weights and partial context are rescaled by exp(m_s - M) / Z.  grid B, 256 threads.
+__global__ __launch_bounds__(256) void attn_fwd_finish_kernel(AttnArgs p, int S) {
+  __shared__ float fac[8];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int Te = p.Te, E = p.E;
+  float *align = p.align + (size_t)b * Te;
+  float *ctx = p.ctx + (size_t)b * E;
+  if (p.step >= p.dec_len[b]) {   // finished row: state frozen
+    for (int t = tid; t < Te; t += 256) align[t] = p.align_prev[(size_t)b * Te + t];
+    for (int e = tid; e < E; e += 256) ctx[e] = p.ctx_prev[(size_t)b * E + e];
+    return;
+  }
+  const int n = min(max(p.enc_len[b], 0), Te);
+  const int per = (Te + S - 1) / S;
+  const float *part = p.fwd_part + (size_t)b * S * (E + 4);
+  if (tid == 0) {
+    float M = -3.0e38f, Z = 0.f;
+    for (int i = 0; i < S; ++i) M = fmaxf(M, part[(size_t)i * (E + 4) + E]);
+    for (int i = 0; i < S; ++i) {
+      const float sc = p.prob_fn == 0 ? expf(part[(size_t)i * (E + 4) + E] - M) : 1.0f;
+      fac[i] = sc;
+      Z += sc * part[(size_t)i * (E + 4) + E + 1];
+    }
+    const float inv = p.prob_fn == 1 ? 1.0f : 1.0f / Z;
+    for (int i = 0; i < S; ++i) fac[i] *= inv;
+    if (p.prob_fn == 2 && p.znorm) p.znorm[b] = Z;
+  }
+  __syncthreads();
+  for (int t = tid; t < Te; t += 256) align[t] = t < n ? align[t] * fac[t / per] : 0.f;
+  for (int e = tid; e < E; e += 256) {
+    float c = 0.f;
+    for (int i = 0; i < S; ++i) c = fmaf(fac[i], part[(size_t)i * (E + 4) + e], c);
+    ctx[e] = c;
   }
 }
 
@@ -801,16 +874,20 @@ extern "C" int nabu_attn_fwd(const nabu_attn_desc *d, int step, const int32_t *d
                              const int32_t *enc_len, const float *keys, const float *values,
                              const float *q, const float *v, const float *conv_kernel,
                              const float *conv_proj, const float *align_prev, const float *ctx_prev,
-                             float *align, float *ctx, float *znorm, nabu_stream_t stream) {
+                             float *align, float *ctx, float *znorm, void *ws, size_t ws_bytes,
+                             nabu_stream_t stream) {
   if (int e = check_attn(d)) return e;
   NABU_CHECK_ARG(dec_len && enc_len && keys && values && q && v && align_prev && ctx_prev && align && ctx,
                  "attn_fwd: null pointer");
+  const int S = attn_bwd_nslices(d);     // frame slices per utterance (1 for batches that fill the chip)
+  if (S > 1 && (!ws || ws_bytes < nabu_attn_fwd_ws_bytes(d))) return fail(NABU_EWS, "attn_fwd: workspace too small");
   NABU_CHECK_ARG(d->kind != 1 || (conv_kernel && conv_proj), "attn_fwd: location-aware attention needs its kernels");
   AttnArgs p = {};
   p.B = d->B; p.Te = d->Te; p.E = d->E; p.U = d->U; p.kind = d->kind; p.K = d->K; p.F = d->F; p.step = step;
   p.dec_len = dec_len; p.enc_len = enc_len; p.keys = keys; p.values = values; p.q = q; p.v = v;
   p.ck = conv_kernel; p.wf = conv_proj; p.align_prev = align_prev; p.ctx_prev = ctx_prev;
   p.align = align; p.ctx = ctx; p.prob_fn = d->prob_fn; p.znorm = znorm;
+  p.fwd_part = static_cast<float *>(ws);
   const size_t shm = attn_lds(d, false);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool reg = d->kind == 1 && d->U <= 256 * RJ && d->F <= RF;
@@ -818,9 +895,19 @@ extern "C" int nabu_attn_fwd(const nabu_attn_desc *d, int step, const int32_t *d
   if (shm > 64 * 1024)
     NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  hipLaunchKernelGGL(kern, dim3(d->B), dim3(AT), shm, s, p);
+  hipLaunchKernelGGL(kern, dim3(d->B, S), dim3(AT), shm, s, p);
   NABU_LAUNCH_CHECK();
+  if (S > 1) {
+    hipLaunchKernelGGL(attn_fwd_finish_kernel, dim3(d->B), dim3(256), 0, s, p, S);
+    NABU_LAUNCH_CHECK();
+  }
   return 0;
+}
+
+extern "C" size_t nabu_attn_fwd_ws_bytes(const nabu_attn_desc *d) {
+  if (check_attn(d)) return 0;
+  const size_t S = attn_bwd_nslices(d);
+  return S > 1 ? (size_t)d->B * S * ((size_t)d->E + 4) * sizeof(float) : 0;
 }
 
 extern "C" int nabu_attn_bwd_slices(const nabu_attn_desc *d) {
@@ -959,7 +1046,8 @@ static SpWs sp_ws(const nabu_speller_desc *d) {
   const size_t S = attn_bwd_nslices(&adesc);
   s.dv = take(B * S * U);
   s.dwf = take(B * S * F * U + 4);
-  s.attn = take(nabu_attn_bwd_ws_bytes(&adesc) / 4 + 4);
+  s.attn = take((nabu_attn_bwd_ws_bytes(&adesc) > nabu_attn_fwd_ws_bytes(&adesc) ? nabu_attn_bwd_ws_bytes(&adesc)
+                                                                                   : nabu_attn_fwd_ws_bytes(&adesc)) / 4 + 4);
   s.dck = take(B * K * F + 4);
   s.dq = take(L * B * U);
   for (int n = 0; n < d->num_layers; ++n) {
@@ -1049,6 +1137,7 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
   float *gw = w + W.gemm;
   const size_t gwb = W.gemm_bytes;
   const nabu_attn_desc ad = {sizeof(nabu_attn_desc), B, Te, E, U, d->kind, d->K, d->F, d->prob_fn};
+  const size_t attn_fwd_wsb = nabu_attn_fwd_ws_bytes(&ad);
   const bool drop = d->keep_prob < 1.f;
   // zero initial state (index 0 of every time-major array)
   for (int n = 0; n < nl; ++n) {
@@ -1092,7 +1181,7 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
     SP_TRY(nabu_attn_fwd(&ad, t, dec_len, enc_len, r + R.keys, values, qt, p->attention_v, p->conv_kernel,
                          p->conv_proj, r + R.align + (size_t)t * B * Te, r + R.ctx + (size_t)t * B * E,
                          r + R.align + (size_t)(t + 1) * B * Te, r + R.ctx + (size_t)(t + 1) * B * E,
-                         r + R.znorm + (size_t)t * B, stream));
+                         r + R.znorm + (size_t)t * B, w + W.attn, attn_fwd_wsb, stream));
     if (sampling && t + 1 < L) {
       // ScheduledEmbeddingTrainingHelper: the step's logits decide the next input of selected rows
       float *lt = r + R.logits_tm + (size_t)t * B * C;

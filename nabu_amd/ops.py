@@ -279,9 +279,12 @@ def attn_desc(B, Te, E, U, kind, K=0, F=0, prob_fn=0):
 
 def attn_fwd(desc, step, dec_len, enc_len, keys, values, q, v, conv_kernel, conv_proj, align_prev,
              ctx_prev, align, ctx, znorm=None):
-    check(_hip.lib().nabu_attn_fwd(ctypes.byref(desc), step, ptr(dec_len), ptr(enc_len), ptr(keys), ptr(values),
-                                   ptr(q), ptr(v), ptr(conv_kernel), ptr(conv_proj), ptr(align_prev),
-                                   ptr(ctx_prev), ptr(align), ptr(ctx), ptr(znorm), stream()), 'nabu_attn_fwd')
+    L = _hip.lib()
+    nbytes = L.nabu_attn_fwd_ws_bytes(ctypes.byref(desc))
+    ws = Workspace.get(nbytes, keys.device, 'attn_fwd') if nbytes else None
+    check(L.nabu_attn_fwd(ctypes.byref(desc), step, ptr(dec_len), ptr(enc_len), ptr(keys), ptr(values),
+                          ptr(q), ptr(v), ptr(conv_kernel), ptr(conv_proj), ptr(align_prev),
+                          ptr(ctx_prev), ptr(align), ptr(ctx), ptr(znorm), ptr(ws), nbytes, stream()), 'nabu_attn_fwd')
 
 
 def attn_bwd(desc, step, dec_len, enc_len, keys, values, q, v, conv_kernel, conv_proj, align_prev, align, ctx,

@@ -83,9 +83,9 @@ def test_decoder_entry_points_validate_on_the_host():
     assert lib.nabu_speller_beam_ws_bytes(ctypes.byref(d)) == 0 and b'probability_fn' in lib.nabu_last_error()
     a = _hip.AttnDesc(ctypes.sizeof(_hip.AttnDesc), 4, 10, 8, 8, 2, 1, 0, 0)    # windowed, right width 0
     assert lib.nabu_attn_fwd(ctypes.byref(a), 0, one, one, one, one, one, one, None, None, one, one, one, one,
-                             None, None) == -1
+                             None, None, 0, None) == -1
     assert b'right_window_width' in lib.nabu_last_error()
     a = _hip.AttnDesc(ctypes.sizeof(_hip.AttnDesc), 4, 10, 8, 8, 0, 0, 0, 3)    # unknown probability_fn
     assert lib.nabu_attn_fwd(ctypes.byref(a), 0, one, one, one, one, one, one, None, None, one, one, one, one,
-                             None, None) == -1
+                             None, None, 0, None) == -1
     assert b'probability_fn' in lib.nabu_last_error()

@@ -154,18 +154,20 @@ def _speller(attention, nl, U, C, E, K=5, F=3, seed=5, prob_fn='softmax'):
 @pytest.mark.parametrize('attention,nl,U,W,lpw,temp', [
     ('vanilla', 1, 32, 4, 0.0, 1.0), ('vanilla', 2, 16, 8, 1.0, 1.0),
     ('location_aware', 1, 32, 6, 1.0, 1.5), ('vanilla', 1, 32, 16, 1.0, 1.0), ('windowed', 1, 32, 5, 1.0, 1.0),
-    ('vanilla:normalized_sigmoid', 1, 32, 5, 1.0, 1.0)])
+    ('vanilla:normalized_sigmoid', 1, 32, 5, 1.0, 1.0),
+    ('vanilla@40', 1, 32, 4, 1.0, 1.0), ('location_aware@40', 1, 32, 3, 0.0, 1.0)])   # 40 frames: sliced attention
 def test_speller_beam_search_matches_oracle(attention, nl, U, W, lpw, temp):
     from nabu_amd import variables as vs
     from nabu_amd.autodiff import SeqLen
     from nabu_amd.neuralnetworks.models.ed_decoders import rnn_decoder
     from tests.test_hip_speller import speller_params
+    attention, _, frames = attention.partition('@')
     attention, _, prob_fn = attention.partition(':')
     prob_fn = prob_fn or 'softmax'
     rng = np.random.default_rng(U + W)
-    B, Te, E, C, S = 3, 11, 24, 9, 12
+    B, Te, E, C, S = 3, int(frames or 11), 24, 9, 12
     dec, store = _speller(attention, nl, U, C, E, prob_fn=prob_fn)
-    enc_len = np.array([11, 6, 9], np.int32)
+    enc_len = np.array([11, 6, 9], np.int32) if Te == 11 else np.array([Te, Te // 2, Te - 7], np.int32)
     enc = rng.normal(size=(B, Te, E)).astype(np.float32)
     enc *= (np.arange(Te)[None, :, None] < enc_len[:, None, None])
     enc_d = torch.tensor(enc, device=DEV)

@@ -52,6 +52,7 @@ def grad_names(nl, attention):
     return m
 
 
+@pytest.mark.parametrize('Te', [13, 70])      # 70 frames: 5 frame slices per utterance in both attention passes
 @pytest.mark.parametrize('attention,nl,U,K,F', [
     ('vanilla', 1, 32, 0, 0), ('vanilla', 2, 16, 0, 0),
     ('location_aware', 1, 32, 5, 3), ('location_aware', 2, 16, 4, 2), ('location_aware', 1, 64, 11, 10),
@@ -60,7 +61,7 @@ def grad_names(nl, attention):
     ('vanilla:sigmoid', 1, 32, 0, 0), ('vanilla:normalized_sigmoid', 2, 16, 0, 0),      # probability_fn
     ('location_aware:normalized_sigmoid', 1, 32, 5, 3), ('location_aware:sigmoid', 1, 32, 5, 14),
     ('windowed:normalized_sigmoid', 1, 32, 1, 3)])
-def test_speller_step_matches_oracle(attention, nl, U, K, F):
+def test_speller_step_matches_oracle(attention, nl, U, K, F, Te):
     """decoder alone on a given 'encoded' tensor: logits, loss and every gradient"""
     from nabu_amd import variables as vs
     from nabu_amd.autodiff import Tape, SeqLen
@@ -69,7 +70,7 @@ def test_speller_step_matches_oracle(attention, nl, U, K, F):
     attention, _, prob_fn = attention.partition(':')
     prob_fn = prob_fn or 'softmax'
     rng = np.random.default_rng(U + K)
-    B, Te, E, C = 5, 13, 24, 8
+    B, E, C = 5, 24, 8
     over = {'decoder.num_layers': nl, 'decoder.num_units': U, 'decoder.attention': attention,
             'decoder.probability_fn': prob_fn}
     if attention == 'location_aware':
@@ -78,7 +79,7 @@ def test_speller_step_matches_oracle(attention, nl, U, K, F):
         over.update({'decoder.left_window_width': K, 'decoder.right_window_width': F})
     mc, _, _ = recipes.load_recipe('cfg3_las_vanilla', **over)
     dec = ed_decoder_factory.factory('speller')(mc, {'text': C}, None)
-    enc_len = np.array([13, 9, 13, 4, 7], np.int32)
+    enc_len = np.array([13, 9, 13, 4, 7], np.int32) if Te == 13 else np.array([70, 33, 70, 15, 52], np.int32)
     enc = rng.normal(size=(B, Te, E)).astype(np.float32)
     enc *= (np.arange(Te)[None, :, None] < enc_len[:, None, None])
     tlen = np.array([6, 3, 5, 6, 1], np.int32)
