@@ -104,10 +104,18 @@ __device__ __forceinline__ void conv_features(const AttnArgs &p, const float *al
   const int pb = (p.K - 1) / 2;
   for (int i = lo * p.F + threadIdx.x; i < hi * p.F; i += AT) {
     const int t = i / p.F, f = i % p.F;
-    float s = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;     // independent chains: the loop is LDS-latency bound
     const int d0 = max(0, pb - t), d1 = min(p.K, p.Te + pb - t);
-    for (int d = d0; d < d1; ++d) s = fmaf(al_prev[t + d - pb], ck_s[d * p.F + f], s);
-    cf[i] = s;
+    const float *a = al_prev + t - pb, *c = ck_s + f;
+    int d = d0;
+    for (; d + 3 < d1; d += 4) {
+      s0 = fmaf(a[d], c[d * p.F], s0);
+      s1 = fmaf(a[d + 1], c[(d + 1) * p.F], s1);
+      s2 = fmaf(a[d + 2], c[(d + 2) * p.F], s2);
+      s3 = fmaf(a[d + 3], c[(d + 3) * p.F], s3);
+    }
+    for (; d < d1; ++d) s0 = fmaf(a[d], c[d * p.F], s0);
+    cf[i] = (s0 + s1) + (s2 + s3);
   }
 }
 
@@ -658,60 +666,85 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
 // What needs every frame of an utterance: dq = sum of the slices' partials; for location-aware
 // attention the gradient w.r.t. the previous alignments and the conv kernel, from the d location
 // features the slices left in HBM.  grid (B, 2) for location-aware attention (y = 0: dq and d previous
-// alignment, y = 1: d conv kernel), else (B, 1); 256 threads; previous alignment, d features and the
-// conv kernel are staged in LDS: alp[Te], dcf[Te*F], ck[K*F].
-__global__ __launch_bounds__(256) void attn_bwd_finish_kernel(AttnArgs p, int S) {
+// alignment, y = 1: d conv kernel), else (B, 1); FT threads; previous alignment, d features and the
+// conv kernel are staged in LDS: alp[Te], dcf[Te*F], ck[K*F].  Both sums are LDS-latency bound when
+// written as one dependent load + fma per iteration, so the work is spread over 1024 threads (four
+// threads per output frame, one per conv-kernel entry) with independent accumulator chains.
+constexpr int FT = 1024;
+__global__ __launch_bounds__(FT) void attn_bwd_finish_kernel(AttnArgs p, int S) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int b = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+  const int b = blockIdx.x, part = blockIdx.y, tid = threadIdx.x, NT = blockDim.x;
   const int Te = p.Te, U = p.U, F = p.F;
   const bool loc = p.kind == 1;
   float *dq = p.dq + (size_t)b * U;
   float *dal_out = p.dalign_out ? p.dalign_out + (size_t)b * Te : nullptr;
   if (p.step >= p.dec_len[b]) {            // finished row: no gradient of its own, pass dalign through
     if (part == 0) {
-      for (int u = tid; u < U; u += 256) dq[u] = 0.f;
+      for (int u = tid; u < U; u += NT) dq[u] = 0.f;
       if (dal_out)
-        for (int t = tid; t < Te; t += 256) dal_out[t] = p.dalign_in ? p.dalign_in[(size_t)b * Te + t] : 0.f;
+        for (int t = tid; t < Te; t += NT) dal_out[t] = p.dalign_in ? p.dalign_in[(size_t)b * Te + t] : 0.f;
     }
     return;
   }
   if (part == 0)
-    for (int u = tid; u < U; u += 256) {
+    for (int u = tid; u < U; u += NT) {
       float s = 0.f;
       for (int i = 0; i < S; ++i) s += p.dq_part[((size_t)b * S + i) * U + u];
       dq[u] = s;
     }
   if (!loc) {
     if (dal_out)
-      for (int t = tid; t < Te; t += 256) dal_out[t] = 0.f;
+      for (int t = tid; t < Te; t += NT) dal_out[t] = 0.f;
     return;
   }
   const int n = min(max(p.enc_len[b], 0), Te);
   float *alp = smem, *dcf = alp + Te, *ck = dcf + Te * F;
-  for (int t = tid; t < Te; t += 256) alp[t] = p.align_prev[(size_t)b * Te + t];
+  for (int t = tid; t < Te; t += NT) alp[t] = p.align_prev[(size_t)b * Te + t];
   // frames past the length carry no gradient
-  for (int i = tid; i < Te * F; i += 256) dcf[i] = i < n * F ? p.dcf_g[(size_t)b * Te * F + i] : 0.f;
-  for (int i = tid; i < p.K * F; i += 256) ck[i] = p.ck[i];
+  for (int i = tid; i < Te * F; i += NT) dcf[i] = i < n * F ? p.dcf_g[(size_t)b * Te * F + i] : 0.f;
+  for (int i = tid; i < p.K * F; i += NT) ck[i] = p.ck[i];
   __syncthreads();
   const int pb = (p.K - 1) / 2;
   if (part == 0) {
-    // out frame to = t - d + pb receives a[t] * ck[d,f]
-    for (int t = tid; t < Te; t += 256) {
-      float s = 0.f;
-      const int d0 = max(0, t + pb - (n - 1)), d1 = min(p.K, t + pb + 1);
-      for (int d = d0; d < d1; ++d) {
-        const float *g = dcf + (t - d + pb) * F, *c = ck + d * F;
-        for (int f = 0; f < F; ++f) s = fmaf(g[f], c[f], s);
+    // out frame to = t - d + pb receives a[t] * ck[d,f]; thread (t, q) takes the taps d = d0 + q, +4, ...
+    for (int t0 = 0; t0 < Te; t0 += NT / 4) {
+      const int t = t0 + (tid >> 2), q = tid & 3;
+      float s0 = 0.f, s1 = 0.f;
+      if (t < Te) {
+        const int d0 = max(0, t + pb - (n - 1)), d1 = min(p.K, t + pb + 1);
+        int d = d0 + q;
+        for (; d + 4 < d1; d += 8) {
+          const float *g = dcf + (t - d + pb) * F, *c = ck + d * F;
+          for (int f = 0; f < F; ++f) {
+            s0 = fmaf(g[f], c[f], s0);
+            s1 = fmaf(g[f - 4 * F], c[f + 4 * F], s1);
+          }
+        }
+        for (; d < d1; d += 4) {
+          const float *g = dcf + (t - d + pb) * F, *c = ck + d * F;
+          for (int f = 0; f < F; ++f) s0 = fmaf(g[f], c[f], s0);
+        }
       }
-      dal_out[t] = s;
+      float s = s0 + s1;
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      if (t < Te && q == 0) dal_out[t] = s;
     }
   } else {
-    for (int i = tid; i < p.K * F; i += 256) {
+    for (int i = tid; i < p.K * F; i += NT) {
       const int d = i / F, f = i % F;
-      float s = 0.f;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
       const int to0 = max(0, pb - d), to1 = min(n, Te + pb - d);
-      for (int to = to0; to < to1; ++to) s = fmaf(alp[to + d - pb], dcf[to * F + f], s);
-      p.dck_part[(size_t)b * p.K * F + i] += s;
+      const float *a = alp + d - pb, *g = dcf + f;
+      int to = to0;
+      for (; to + 3 < to1; to += 4) {
+        s0 = fmaf(a[to], g[to * F], s0);
+        s1 = fmaf(a[to + 1], g[(to + 1) * F], s1);
+        s2 = fmaf(a[to + 2], g[(to + 2) * F], s2);
+        s3 = fmaf(a[to + 3], g[(to + 3) * F], s3);
+      }
+      for (; to < to1; ++to) s0 = fmaf(a[to], g[to * F], s0);
+      p.dck_part[(size_t)b * p.K * F + i] += (s0 + s1) + (s2 + s3);
     }
   }
 }
@@ -819,7 +852,7 @@ static size_t attn_lds(const nabu_attn_desc *d, bool bwd) {
 // Backward: frame slices per utterance so that the launch has ~256 workgroups (one per CU); a slice
 // keeps at least 16 encoder frames (8 waves x 2 frames in flight)
 static int attn_bwd_nslices(const nabu_attn_desc *d) {
-  int S = (256 + d->B - 1) / d->B;
+  int S = (512 + d->B - 1) / d->B;      // two 512-thread workgroups per CU: four waves per SIMD hide the frame latency
   const int cap = (d->Te + 15) / 16;
   if (S > cap) S = cap;
   if (S > 8) S = 8;
@@ -962,7 +995,7 @@ extern "C" int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *d
   if (shm2 > 64 * 1024)
     NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_finish_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2));
-  hipLaunchKernelGGL(attn_bwd_finish_kernel, dim3(d->B, d->kind == 1 ? 2 : 1), dim3(256), shm2, s, p, S);
+  hipLaunchKernelGGL(attn_bwd_finish_kernel, dim3(d->B, d->kind == 1 ? 2 : 1), dim3(d->kind == 1 ? FT : 256), shm2, s, p, S);
   NABU_LAUNCH_CHECK();
   return 0;
 }
