@@ -252,7 +252,7 @@ __device__ __forceinline__ float row_shl_f(float v, const int n) {   // lane i <
 }
 
 template <int KPL, int BS>
-__global__ __launch_bounds__(64 * BS, 2) void lstm_persist_fwd_kernel(PersistArgs p) {
+__global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8 ? 4 : 2))) void lstm_persist_fwd_kernel(PersistArgs p) {
   using L = FwdLds<KPL, BS>;
   constexpr int PT = 64 * BS, NW = BS;   // threads, waves
   constexpr int H = L::H;
@@ -487,7 +487,7 @@ struct BwdLds {
 };
 
 template <int H, int BS>
-__global__ __launch_bounds__(64 * BS, 2) void lstm_persist_bwd_kernel(PersistArgs p) {
+__global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8 ? 4 : 2))) void lstm_persist_bwd_kernel(PersistArgs p) {
   using L = BwdLds<BS>;
   constexpr int PT = 64 * BS;
   constexpr int P = H / UC;
@@ -758,28 +758,32 @@ static int cu_count() {
 }
 
 // geometry: BS = 4 (two 256-thread workgroups per CU) when the batch fits, else BS = 8
-static int pick_bs(int B, int H) {
+static int pick_bs(int B, int H, bool fwd) {
   const int P = H / UC;
   if (2 * ((B + 3) / 4) * P <= 2 * NCU) return 4;
-  if (2 * ((B + 7) / 8) * P <= NCU) return 8;
+  if (2 * ((B + 7) / 8) * P <= NCU) return 8;          // one 512-thread workgroup per CU
+  // two 512-thread workgroups per CU (<= 128 VGPRs): cfg5's B = 64 at H = 512 in ONE launch.  Forward
+  // only: measured 4.04 us per step against 2 x 2.41 for two launches of 32 rows; the backward kernel,
+  // whose reduce-scatter volume doubles with the rows, takes 5.69 against 2 x 2.47 and stays chunked.
+  if (fwd && 2 * ((B + 7) / 8) * P <= 2 * NCU) return 8;
   return 0;
 }
 
 // Batches that need more workgroups than the chip holds run as consecutive launches over
-// chunks of batch rows (the tensors are batch-major, a chunk is a contiguous slab): cfg5's
-// B = 64 at H = 512 is two launches of 32 rows.
-static int chunk_rows(int B, int H) {
-  if (pick_bs(B, H)) return B;
-  int c = 4 * (2 * NCU / (2 * (H / UC)));   // largest BS = 4 batch
+// chunks of batch rows (the tensors are batch-major, a chunk is a contiguous slab): at H = 512 a
+// launch takes up to 64 rows (BS = 8, two workgroups per CU), B = 96 is a launch of 64 and one of 32.
+static int chunk_rows(int B, int H, bool fwd) {
+  if (pick_bs(B, H, fwd)) return B;
+  int c = (fwd ? 8 : 4) * (2 * NCU / (2 * (H / UC)));   // largest batch of one launch
   return c < 4 ? 4 : c;
 }
 
 bool lstm_persist_supported(int B, int T, int H) {
   if (!(H == 64 || H == 128 || H == 256 || H == 512)) return false;
   if (B <= 0 || T <= 0) return false;
-  if ((size_t)B * T * 4 * H * 4 >= 0x80000000ull && (size_t)chunk_rows(B, H) * T * 4 * H * 4 >= 0x80000000ull)
+  if ((size_t)B * T * 4 * H * 4 >= 0x80000000ull && (size_t)chunk_rows(B, H, true) * T * 4 * H * 4 >= 0x80000000ull)
     return false;   // 32-bit buffer offsets inside one launch
-  return pick_bs(chunk_rows(B, H), H) != 0;
+  return pick_bs(chunk_rows(B, H, true), H, true) != 0 && pick_bs(chunk_rows(B, H, false), H, false) != 0;
 }
 
 // bias-gradient partials of the backward kernel: one row of 2 x 4H per shard (BS = 4 gives the most)
@@ -792,11 +796,11 @@ static size_t ring_bytes(bool fwd, int BS, int nshard, int H) {
 
 size_t lstm_persist_ws_bytes(int B, int T, int H) {
   if (!lstm_persist_supported(B, T, H)) return 0;
-  const int Bc = chunk_rows(B, H);
   size_t m = 0;
   for (int BS = 4; BS <= 8; BS += 4) {   // either geometry may be selected at run time
-    const int ns = (Bc + BS - 1) / BS;
     for (int f = 0; f < 2; ++f) {
+      const int Bc = chunk_rows(B, H, f != 0);
+      const int ns = (Bc + BS - 1) / BS;
       const size_t r = ring_bytes(f != 0, BS, ns, H);
       if (r > m) m = r;
     }
@@ -834,7 +838,7 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
   if (ws_bytes < need) return fail(NABU_EWS, "persistent LSTM: workspace %zu < %zu", ws_bytes, need);
   float *db_part = reinterpret_cast<float *>(static_cast<char *>(ws) + need - db_part_bytes(B, H));
   int shards = 0;
-  const int Bc = chunk_rows(B, H);
+  const int Bc = chunk_rows(B, H, fwd);
   for (int b0 = 0; b0 < B; b0 += Bc) {
     const int nb = B - b0 < Bc ? B - b0 : Bc;
     float *g2[2] = {gates[0] + (size_t)b0 * T * 4 * H, gates[1] + (size_t)b0 * T * 4 * H};
@@ -856,7 +860,7 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
                      hipStream_t stream) {
   PersistArgs a;
   { const char *e = getenv("NABU_PERSIST_DEBUG"); a.dbg = e ? atoi(e) : 0; }
-  int BS = pick_bs(B, H);
+  int BS = pick_bs(B, H, fwd);
   if ((a.dbg & 16) && 2 * ((B + 7) / 8) * (H / UC) <= NCU) BS = 8;
   a.B = B; a.T = T; a.D = D; a.H = H; a.max_len = max_len; a.nshard = (B + BS - 1) / BS;
   a.len = len;
@@ -870,12 +874,12 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
   a.timeout_ticks = 20000000ull;   // 0.2 s at 100 MHz: a step takes microseconds
   const int NU = 2 * a.nshard, P = H / UC;
   const int grid = NU * P;
-  const int per_cu = BS == 4 ? 2 : 1;
+  const int per_cu = (BS == 4 || grid > NCU) ? 2 : 1;
   if (grid > per_cu * cu_count())
     return fail(NABU_EUNSUP, "persistent LSTM: %d workgroups > %d x %d CUs", grid, per_cu, cu_count());
   NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + ring_bytes(fwd, BS, a.nshard, H), stream));
   // dynamic LDS chosen so that exactly `per_cu` workgroups fit on a CU (160 KiB)
-  const size_t lds = BS == 4 ? 64 * 1024 : 96 * 1024;
+  const size_t lds = BS == 4 ? 64 * 1024 : (grid > NCU ? 72 * 1024 : 96 * 1024);
 #define NABU_PERSIST_CASE(h)                                                                         \
   case h:                                                                                            \
     if (BS == 4)                                                                                     \
