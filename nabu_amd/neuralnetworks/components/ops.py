@@ -1,6 +1,5 @@
 """Tensor plumbing ops of the hot path (reference: nabu/neuralnetworks/components/ops.py)."""
 import numpy as np
-import torch
 
 from nabu_amd import ops as hip
 from nabu_amd.autodiff import record, SeqLen
