@@ -95,10 +95,11 @@ def gemm_roofline(B, T, D, H, precision):
     Dl = D
     for l in range(4):
         BT = B * (T >> l)
-        shapes.append((0, 0, BT, 8 * H, Dl))                     # x · [Wx_fw | Wx_bw]
+        # the calls nabu_blstm_fwd / _bwd make, one set per direction (lstm.hip)
+        shapes += [(0, 0, BT, 4 * H, Dl)] * 2                    # gates_d = x · Wx_d
         if l:
-            shapes.append((0, 1, BT, Dl, 8 * H))                 # dx = dz · Wx^T
-        shapes += [(1, 0, Dl, 4 * H, BT)] * 2 + [(1, 0, H, 4 * H, BT)] * 2     # dWx, dWh per direction
+            shapes += [(0, 1, BT, Dl, 4 * H)] * 2                # dx (+)= dz_d · Wx_d^T
+        shapes += [(1, 0, Dl, 4 * H, BT)] * 2 + [(1, 0, H, 4 * H, BT)] * 2     # dWx_d, dWh_d
         Dl = 4 * H
     bufs = {}
     def buf(n):
