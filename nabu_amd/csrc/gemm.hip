@@ -183,11 +183,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
   constexpr int KT = FKT, KQ = KT / 4;   // k-tile, 16-byte pieces per row
-  // double-buffered operand tiles (2 x 2 x 16.5 KiB = 66 KiB: two workgroups per CU)
+  // double-buffered operand tiles.  An operand whose contiguous dimension is the row/column index
+  // (A with TA, B with !TB) is staged k-major [KT][LDT] with 16-byte stores; an operand whose contiguous
+  // dimension is k (A with !TA, B with TB) is staged row-major [128][LDK = KT + 2] with two 8-byte
+  // stores per 16-byte piece (the k-major layout needs four scalar stores with bank conflicts for it:
+  // 8-16 ds_write_b32 per thread and k-tile made the NN / NT variants LDS-store bound).  Both layouts
+  // give conflict-free ds_read_b32 MFMA operands (32 consecutive floats, resp. stride 18 = 16 even banks
+  // for the 32 rows of one k, the odd banks for the other k of the pair).
   extern __shared__ __attribute__((aligned(16))) float fsm[];
-  typedef float (*Tile)[LDT];
-#define NABU_ATILE(buf) reinterpret_cast<Tile>(fsm + (buf) * (2 * KT * LDT))
-#define NABU_BTILE(buf) reinterpret_cast<Tile>(fsm + (buf) * (2 * KT * LDT) + KT * LDT)
+  constexpr int LDK = KT + 2;
+  constexpr int TILE_F = KT * LDT > 128 * LDK ? KT * LDT : 128 * LDK;     // floats per operand tile
+#define NABU_ATILE(buf) (fsm + (buf) * (2 * TILE_F))
+#define NABU_BTILE(buf) (fsm + (buf) * (2 * TILE_F) + TILE_F)
+#define NABU_AEL(t, r, kx) (TA ? (t)[(kx) * LDT + (r)] : (t)[(r) * LDK + (kx)])
+#define NABU_BEL(t, c, kx) (TB ? (t)[(c) * LDK + (kx)] : (t)[(kx) * LDT + (c)])
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
   int tile_m, tile_n;
@@ -252,19 +261,21 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
   }
 #define NABU_SSTORE1(j)                                                                          \
   {                                                                                              \
-    Tile As = NABU_ATILE(sbuf), Bs = NABU_BTILE(sbuf);                                           \
+    float *As = NABU_ATILE(sbuf), *Bs = NABU_BTILE(sbuf);                                        \
     const int idx = tid + 256 * j;                                                               \
     if (TA) {                                                                                    \
-      *reinterpret_cast<float4 *>(&As[idx >> 5][4 * (idx & 31)]) = ra##j;                        \
+      *reinterpret_cast<float4 *>(&As[(idx >> 5) * LDT + 4 * (idx & 31)]) = ra##j;               \
     } else {                                                                                     \
-      const int r = idx / KQ, k = 4 * (idx % KQ);                                                 \
-      As[k + 0][r] = ra##j.x; As[k + 1][r] = ra##j.y; As[k + 2][r] = ra##j.z; As[k + 3][r] = ra##j.w; \
+      float *d_ = &As[(idx / KQ) * LDK + 4 * (idx % KQ)];                                         \
+      *reinterpret_cast<float2 *>(d_) = make_float2(ra##j.x, ra##j.y);                           \
+      *reinterpret_cast<float2 *>(d_ + 2) = make_float2(ra##j.z, ra##j.w);                       \
     }                                                                                            \
     if (TB) {                                                                                    \
-      const int r = idx / KQ, k = 4 * (idx % KQ);                                                 \
-      Bs[k + 0][r] = rb##j.x; Bs[k + 1][r] = rb##j.y; Bs[k + 2][r] = rb##j.z; Bs[k + 3][r] = rb##j.w; \
+      float *d_ = &Bs[(idx / KQ) * LDK + 4 * (idx % KQ)];                                         \
+      *reinterpret_cast<float2 *>(d_) = make_float2(rb##j.x, rb##j.y);                           \
+      *reinterpret_cast<float2 *>(d_ + 2) = make_float2(rb##j.z, rb##j.w);                       \
     } else {                                                                                     \
-      *reinterpret_cast<float4 *>(&Bs[idx >> 5][4 * (idx & 31)]) = rb##j;                        \
+      *reinterpret_cast<float4 *>(&Bs[(idx >> 5) * LDT + 4 * (idx & 31)]) = rb##j;               \
     }                                                                                            \
   }
 #define NABU_SSTORE() { NABU_SSTORE1(0) NABU_SSTORE1(1) if (KT > 16) { NABU_SSTORE1(2) NABU_SSTORE1(3) } }
@@ -285,19 +296,19 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
   for (int k0 = kbeg; k0 < kend; k0 += KT) {
     const bool have_next = k0 + KT < kend && !(a.vecA & 2);       // registers hold tile k0+KT
     const bool load_next2 = k0 + 2 * KT < kend && !(a.vecA & 2);
-    Tile As = NABU_ATILE(cur), Bs = NABU_BTILE(cur);
+    const float *As = NABU_ATILE(cur), *Bs = NABU_BTILE(cur);
     // operands of k-step kk+2 are read from LDS before the MFMAs of k-step kk are issued (left to
     // itself hipcc reads them after, and the wave then waits out the LDS latency with an empty pipe)
-    float a0n = As[lk][wm * 64 + li], a1n = As[lk][wm * 64 + 32 + li];
-    float b0n = Bs[lk][wn * 64 + li], b1n = Bs[lk][wn * 64 + 32 + li];
+    float a0n = NABU_AEL(As, wm * 64 + li, lk), a1n = NABU_AEL(As, wm * 64 + 32 + li, lk);
+    float b0n = NABU_BEL(Bs, wn * 64 + li, lk), b1n = NABU_BEL(Bs, wn * 64 + 32 + li, lk);
 #pragma unroll
     for (int kk = 0; kk < KT; kk += 2) {
       const float a0 = a0n, a1 = a1n, b0 = b0n, b1 = b1n;
       if (kk + 2 < KT) {
-        a0n = As[kk + 2 + lk][wm * 64 + li];
-        a1n = As[kk + 2 + lk][wm * 64 + 32 + li];
-        b0n = Bs[kk + 2 + lk][wn * 64 + li];
-        b1n = Bs[kk + 2 + lk][wn * 64 + 32 + li];
+        a0n = NABU_AEL(As, wm * 64 + li, kk + 2 + lk);
+        a1n = NABU_AEL(As, wm * 64 + 32 + li, kk + 2 + lk);
+        b0n = NABU_BEL(Bs, wn * 64 + li, kk + 2 + lk);
+        b1n = NABU_BEL(Bs, wn * 64 + 32 + li, kk + 2 + lk);
       }
       __builtin_amdgcn_sched_barrier(0);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
@@ -317,6 +328,8 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
   }
 #undef NABU_ATILE
 #undef NABU_BTILE
+#undef NABU_AEL
+#undef NABU_BEL
 #undef NABU_GADDR
 #undef NABU_GADDR1
 #undef NABU_GLOAD
@@ -517,7 +530,7 @@ static int gemm_run(int precision, int transA, int transB, int M, int N, int K, 
     if (int e = gemm_bf16_launch(a, transA != 0, transB != 0, precision - NABU_GEMM_BF16 + 1, grid, s)) return e;
   } else
   if (fast32) {
-    const size_t lds = 4 * (size_t)FKT * LDT * sizeof(float);
+    const size_t lds = 4 * (size_t)(FKT * LDT > 128 * (FKT + 2) ? FKT * LDT : 128 * (FKT + 2)) * sizeof(float);
     static bool configured = false;
     if (!configured) {
       const void *fns[4] = {reinterpret_cast<const void *>(gemm_f32_fast_kernel<true, true>),
