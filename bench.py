@@ -147,7 +147,7 @@ def main():
     ap.add_argument('--gemm-precision', default='f32', choices=['f32', 'bf16x6', 'bf16x3', 'bf16'],
                     help='arithmetic of the dense products (include/nabu_hip.h nabu_gemm_ex); the BASELINE metric '
                          'is fp32 = the default; the others are reported as such in config.gemm_arith')
-    ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg3', 'cfg5'],
+    ap.add_argument('--workload', default='cfg2', choices=['cfg1', 'cfg2', 'cfg3', 'cfg5'],
                     help='cfg2 (default) is the BASELINE.json metric; cfg3 = same encoder + Speller; cfg5 = '
                          'location-aware LAS, batch 64x1600x80, bf16 input GEMMs (BASELINE.json configs[2]/[4]), '
                          'for information')
@@ -173,8 +173,15 @@ def main():
     layer.LSTM_MODE[0] = {'auto': ops.LSTM_AUTO, 'stepwise': ops.LSTM_STEPWISE,
                           'persistent': ops.LSTM_PERSISTENT}[args.mode]
 
-    global B, T, D
-    if args.workload == 'cfg5':
+    global B, T, D, H
+    layer_t = None
+    if args.workload == 'cfg1':
+        # BASELINE.json configs[0]: DBLSTM 2 x 256 + CTC, 8 x 200 x 40 (the reference's CPU-runnable case)
+        B, T, D, H = 8, 200, 40, 256
+        layer_t = [T, T]
+        mc, tc, ec = recipes.load_recipe('cfg1_dblstm_ctc')
+        data = SyntheticData(B, T, D, min_frames=T, min_labels=10, max_labels=40, seed=1234 + rank)
+    elif args.workload == 'cfg5':
         B, T, D = 64, 1600, 80
         mc, tc, ec = recipes.load_recipe('cfg5_las_location')
         data = SyntheticData(B, T, D, min_frames=T, min_labels=40, max_labels=159, eos=True, time_reduction=8,
@@ -248,10 +255,12 @@ def main():
                 'recurrent_ms_per_step': round(tot_ms / args.steps, 3),
                 'note': 'algorithmic bytes (W_h streamed per timestep model, SURVEY.md 8(d)); '
                         'events recorded by the library around the recurrent launches'}
-    layer_t = [T >> i for i in range(4)]
+    if layer_t is None:
+        layer_t = [T >> i for i in range(4)]
     step_bytes_total = 2 * 2 * sum(layer_t) * step_bytes(B, H)
     out = {
-        'metric': {'cfg2': 'utterances/sec training step, 4x512 Listener+CTC, batch 32x1000x40 fbank',
+        'metric': {'cfg1': 'utterances/sec training step, 2x256 DBLSTM+CTC, batch 8x200x40 fbank',
+                   'cfg2': 'utterances/sec training step, 4x512 Listener+CTC, batch 32x1000x40 fbank',
                    'cfg3': 'utterances/sec training step, Listener-512 + Speller (vanilla attention), batch 32x1000x40',
                    'cfg5': 'utterances/sec training step, Listener-512 + Speller (location-aware attention), '
                            'bf16 input GEMMs, batch 64x1600x80'}[args.workload],
@@ -260,7 +269,8 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32' if args.gemm_precision in ('f32', 'bf16x6') else 'f32 state / %s products' % args.gemm_precision,
         'data': 'synthetic',
-        'config': {'workload': {'cfg2': 'cfg2: Listener 3 pyramidal + 1 BLSTM x512, DNNDecoder, CTC, Adam+clip; '
+        'config': {'workload': {'cfg1': 'cfg1: DBLSTM 2 x 256, DNNDecoder, CTC, Adam+clip; 8 utt x 200 frames x 40 fbank per GPU',
+                                'cfg2': 'cfg2: Listener 3 pyramidal + 1 BLSTM x512, DNNDecoder, CTC, Adam+clip; '
                                         '32 utt x 1000 frames x 40 fbank per GPU',
                                 'cfg3': 'cfg3: cfg2 encoder + Speller (1x512 LSTMCell, Bahdanau attention), '
                                         'average cross-entropy; 32 utt x 1000 frames x 40 fbank per GPU',
