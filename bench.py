@@ -2,8 +2,13 @@
 """bench.py — utterances/sec of the Nabu training step on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N
-          --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+  N > 1 either way:
+    * python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+      --master-port P bench.py --gpus N ...      (ranks are given: RANK/WORLD_SIZE in the env)
+    * python bench.py --gpus N ...               (no WORLD_SIZE in the env: bench.py starts its own
+      N ranks on this node through torch.distributed.run over 127.0.0.1 — the analogue of the
+      reference's single_machine local cluster, nabu/scripts/prepare_train.py:107-123,
+      nabu/computing/local_cluster.py:22-41)
 
 Workload (BASELINE.json configs[1]/[3], "cfg2"): 4-layer Listener-512 (3 pyramidal
 BLSTM layers + 1 BLSTM) + DNNDecoder + CTC, batch 32 x 1000 frames x 40 fbank per
@@ -18,13 +23,17 @@ One JSON line is printed by rank 0.  Extra objects:
                  gate activations + h/c state) / duration measured with HIP events
                  recorded by the library around the recurrent launches, inside the
                  timed region, on the launch stream.
-  cpu_baseline — the oracle (NumPy float32 restatement of the reference graph at
-                 TF op granularity, "port") timed on the host cores on a bounded
-                 sample.  The reference's own TF-1.8 trainer cannot run here.
+  cpu_baseline — oracle/cpu_baseline.py: the reference graph restated at TF op
+                 granularity with PyTorch-CPU float32 ("port"), SURVEY.md 8(d)
+                 protocol (full T, warm-ups, median), cfg1 and cfg2, plus the
+                 torch.nn.LSTM upper baseline.  The reference's own TF-1.8 trainer
+                 cannot run here.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,47 +51,31 @@ def step_bytes(batch, hidden):
     return 4 * (hidden * 4 * hidden + batch * 4 * hidden + batch * 4 * hidden + 4 * batch * hidden)
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """Time the oracle (float32) for one full training step of the cfg2 model on a
-    bounded sample: all 32 utterances, the first T_s frames (cost is linear in T)."""
-    import numpy as np
-    from oracle import nabu_oracle as O
-    from nabu_amd.processing.synthetic import SyntheticData
-    Ts = 200
-    rng = np.random.default_rng(99)
-    dims = [D, 4 * H, 4 * H, 4 * H]
-    layers = [{k: O.glorot_uniform(rng, (d + H, 4 * H)) if 'kernel' in k else O.glorot_uniform(rng, (4 * H,))
-               for k in ('fw_kernel', 'fw_bias', 'bw_kernel', 'bw_bias')} for d in dims]
-    W = O.glorot_uniform(rng, (2 * H, C)); bo = np.zeros(C, np.float32)
-    data = SyntheticData(B, Ts, D, min_frames=Ts, min_labels=4, max_labels=12, time_reduction=8, seed=2234)
-    batch = data.batch(0)
-    x = batch['inputs']['features']
-
-    def one_step():
-        enc, el, caches = O.listener_fwd(x, batch['input_seq_length']['features'], layers)
-        lg = O.linear_fwd(enc, W, bo)
-        nll, dlg = O.ctc_loss(lg, el, batch['targets']['text'], batch['target_seq_length']['text'])
-        de, dW, db = O.linear_bwd((dlg / B).astype(np.float32), enc, W)
-        _, grads = O.listener_bwd(de, caches)
-        for l, g in zip(layers, grads):
-            for k in l:
-                l[k], _, _ = O.clip_adam_update(l[k], g[k], np.zeros_like(l[k]), np.zeros_like(l[k]), 1, 1e-3)
-        return float(nll.mean())
-    t0 = time.time()
-    one_step()
-    dt = time.time() - t0
-    reps = 1
-    if dt * 3 < seconds_budget:          # a second repetition if it is cheap
-        t0 = time.time()
-        one_step()
-        dt = min(dt, time.time() - t0)
-        reps = 2
-    utt_s = B / (dt * (T / float(Ts)))
-    return {'value': round(utt_s, 3), 'unit': 'utterances/sec', 'cores': os.cpu_count(), 'kind': 'port',
-            'sample': '%d step(s) of the cfg2 model, 32 utterances x first %d of 1000 frames, NumPy float32 '
-                      'oracle at TF op granularity (one [B,in+H]x[in+H,4H] matmul per timestep per '
-                      'direction), BLAS threads = all host cores; utt/s scaled by %d/1000 (cost linear in T); '
-                      'the reference TF-1.8 trainer itself cannot run here' % (reps, Ts, Ts)}
+def cpu_baseline(budget_s=45.0):
+    """PyTorch-CPU float32 at TF op granularity (one [B,in+H]x[in+H,4H] matmul per
+    frame per direction over the FULL T, autograd backward, per-variable clip + Adam),
+    torch.set_num_threads(physical cores).  cfg1: 2 warm-ups + median of 5 steps.  cfg2 (the
+    headline workload): 1 warm-up + >= 2 FULL steps within the time budget — no extrapolation from
+    shorter sequences.  torch.nn.LSTM's fused kernel is the upper baseline."""
+    from oracle import cpu_baseline as cb
+    cores = cb.physical_cores()
+    c1 = cb.time_config('cfg1', 2, 5, threads=cores)
+    c1f = cb.time_config('cfg1', 2, 5, fused=True, threads=cores)
+    c2 = cb.time_config('cfg2', 1, 5, threads=cores, budget_s=budget_s)
+    c2f = cb.time_config('cfg2', 1, 5, fused=True, threads=cores, budget_s=budget_s / 2)
+    return {'value': c2['utt_per_s'], 'unit': 'utterances/sec', 'cores': cores, 'kind': 'port',
+            'sample': 'cfg2 (32 x 1000 x 40, 4x512 Listener + CTC), full T: %d warm-up + median of %d complete '
+                      'training steps (%s s each) of the reference graph restated at TF op granularity in '
+                      'PyTorch-CPU float32 (per-frame [B,in+H]x[in+H,4H] matmul per direction, autograd, '
+                      'per-variable clip+Adam), torch.set_num_threads(%d) = physical cores of this host '
+                      '(%d logical); the reference TF-1.8 trainer itself cannot run here'
+                      % (c2['warmup'], c2['steps_timed'], c2['seconds_per_step'], cores, os.cpu_count()),
+            'cfg1': {'value': c1['utt_per_s'], 'median_s': c1['median_s'], 'warmup': 2, 'steps': c1['steps_timed']},
+            'upper_baseline_torch_nn_lstm': {
+                'cfg1': {'value': c1f['utt_per_s'], 'median_s': c1f['median_s'], 'steps': c1f['steps_timed']},
+                'cfg2': {'value': c2f['utt_per_s'], 'median_s': c2f['median_s'], 'steps': c2f['steps_timed']},
+                'note': 'same step with torch.nn.LSTM\'s fused CPU kernel on packed sequences instead of the '
+                        'per-frame loop: faster than anything TF-1.8 dynamic_rnn could do'}}
 
 
 def gemm_roofline(B, T, D, H, precision):
@@ -134,7 +127,25 @@ def gemm_roofline(B, T, D, H, precision):
                     'launch stream; peak = dense fp32 MFMA (v_mfma_f32_32x32x2_f32) at 2.4 GHz'}
 
 
-def main():
+METRICS = {'cfg1': 'utterances/sec training step, 2x256 DBLSTM+CTC, batch 8x200x40 fbank',
+           'cfg2': 'utterances/sec training step, 4x512 Listener+CTC, batch 32x1000x40 fbank',
+           'cfg3': 'utterances/sec training step, Listener-512 + Speller (vanilla attention), batch 32x1000x40',
+           'cfg5': 'utterances/sec training step, Listener-512 + Speller (location-aware attention), '
+                   'bf16 input GEMMs, batch 64x1600x80'}
+WORKLOADS = {'cfg1': 'cfg1: DBLSTM 2 x 256, DNNDecoder, CTC, Adam+clip; 8 utt x 200 frames x 40 fbank per GPU',
+             'cfg2': 'cfg2: Listener 3 pyramidal + 1 BLSTM x512, DNNDecoder, CTC, Adam+clip; '
+                     '32 utt x 1000 frames x 40 fbank per GPU',
+             'cfg3': 'cfg3: cfg2 encoder + Speller (1x512 LSTMCell, Bahdanau attention), '
+                     'average cross-entropy; 32 utt x 1000 frames x 40 fbank per GPU',
+             'cfg5': 'cfg5: Listener-512 (bf16 input GEMMs) + Speller (location-aware attention); '
+                     '64 utt x 1600 frames x 80 fbank per GPU'}
+GEMM_ARITH = {'f32': 'f32 (v_mfma_f32_32x32x2_f32, exact fp32)',
+              'bf16x6': 'f32 operands split into 3 bf16 pieces, 6 bf16 MFMA products, f32 accumulate',
+              'bf16x3': 'f32 operands split into 2 bf16 pieces, 3 bf16 MFMA products, f32 accumulate',
+              'bf16': 'operands rounded to bf16, f32 accumulate'}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
@@ -151,160 +162,277 @@ def main():
                     help='cfg2 (default) is the BASELINE.json metric; cfg3 = same encoder + Speller; cfg5 = '
                          'location-aware LAS, batch 64x1600x80, bf16 input GEMMs (BASELINE.json configs[2]/[4]), '
                          'for information')
-    args = ap.parse_args()
+    ap.add_argument('--allreduce', default='flat', choices=['flat', 'bucketed'],
+                    help='gradient exchange of the data-parallel mode (trainer cfg key allreduce_buckets)')
+    return ap.parse_args(argv)
 
-    import torch
-    from nabu_amd import recipes, ops, _hip
+
+# ------------------------------------------------------------------ launching the ranks
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_command(argv, nproc, script=None, port=None):
+    """the command that runs `script argv` as nproc ranks on this node (one process per GPU)"""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc),
+            '--master-addr', '127.0.0.1', '--master-port', str(port or free_port()),
+            script or os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(argv, nproc, script=None):
+    """`python bench.py --gpus N` without ranks in the environment: start them (the local
+    'cluster' of the reference's single_machine mode).  Rank 0's JSON line reaches our stdout
+    through the inherited descriptors.  Returns the launcher's exit code."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC for RCCL on this driver
+    env.setdefault('OMP_NUM_THREADS', '4')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    return subprocess.call(launch_command(argv, nproc, script), env=env)
+
+
+def make_server():
     from nabu_amd.computing import dist
-    from nabu_amd.neuralnetworks.components import layer
-    from nabu_amd.neuralnetworks.trainers import trainer_factory, loss_functions
-    from nabu_amd.processing.synthetic import SyntheticData
+    return dist.create_server()
 
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
-    server = dist.create_server()
+
+# ------------------------------------------------------------------ the workload on the GPU
+class HipWorkload(object):
+    """the BASELINE workload on this rank's GPU through the recipe API"""
+
+    def __init__(self, args, server):
+        import torch
+        from nabu_amd import recipes, ops, _hip
+        from nabu_amd.neuralnetworks.components import layer
+        from nabu_amd.neuralnetworks.trainers import trainer_factory
+        from nabu_amd.processing.synthetic import SyntheticData
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+        if server.world_size == 1:
+            torch.cuda.set_device(0)
+        self.torch, self.ops, self._hip, self.layer = torch, ops, _hip, layer
+        self.args, self.server = args, server
+        rank = server.rank
+        _hip.lib()
+        ops.set_gemm_precision(args.gemm_precision)
+        layer.LSTM_MODE[0] = {'auto': ops.LSTM_AUTO, 'stepwise': ops.LSTM_STEPWISE,
+                              'persistent': ops.LSTM_PERSISTENT}[args.mode]
+        self.B, self.T, self.D, self.H = B, T, D, H
+        self.layer_t = None
+        over = {'trainer.allreduce_buckets': 'True' if args.allreduce == 'bucketed' else 'False'}
+        if args.workload == 'cfg1':
+            # BASELINE.json configs[0]: DBLSTM 2 x 256 + CTC, 8 x 200 x 40 (the reference's CPU-runnable case)
+            self.B, self.T, self.D, self.H = 8, 200, 40, 256
+            self.layer_t = [200, 200]
+            mc, tc, ec = recipes.load_recipe('cfg1_dblstm_ctc', **over)
+            data = SyntheticData(8, 200, 40, min_frames=200, min_labels=10, max_labels=40, seed=1234 + rank)
+        elif args.workload == 'cfg5':
+            self.B, self.T, self.D = 64, 1600, 80
+            mc, tc, ec = recipes.load_recipe('cfg5_las_location', **over)
+            data = SyntheticData(64, 1600, 80, min_frames=1600, min_labels=40, max_labels=159, eos=True,
+                                 time_reduction=8, seed=5234 + rank)
+        elif args.workload == 'cfg3':
+            mc, tc, ec = recipes.load_recipe('cfg3_las_vanilla', **over)
+            data = SyntheticData(B, T, D, min_frames=T, min_labels=20, max_labels=79, eos=True, time_reduction=8,
+                                 seed=3234 + rank)
+        else:
+            mc, tc, ec = recipes.load_recipe('cfg2_listener_ctc', **over)
+            data = SyntheticData(B, T, D, min_frames=T, min_labels=20, max_labels=60, time_reduction=8,
+                                 seed=4234 + rank)
+        if self.layer_t is None:
+            self.layer_t = [self.T >> i for i in range(4)]
+        self.tr = trainer_factory.factory('standard')(conf=tc, dataconf=data, modelconf=mc, evaluatorconf=ec,
+                                                      expdir=None, server=server, task_index=rank)
+        self.tr.time_allreduce = server.world_size > 1
+        self.batches = [self.tr.to_device(data.batch(i)) for i in range(2)]      # resident in HBM
+        # the event profiler is armed during the warm-up as well: its first use (event pool creation
+        # inside the HIP runtime) stalls the queue for tens of milliseconds once
+        self.prof = ops.enable_profiler()
+        self.loss = None
+
+    units_per_step = property(lambda self: self.B)
+
+    def step(self, i):
+        self.loss = self.tr.step(self.batches[i % 2])
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def check(self):
+        from nabu_amd.neuralnetworks.trainers import loss_functions
+        loss_functions.check_status()
+        self.ops.check_persist_status()
+
+    def start_timed_region(self):
+        self.prof.collect()                                         # drop the warm-up records
+        self.tr.allreduce_ms = []
+
+    def end_timed_region(self):
+        self.prof.enabled = False
+        self.recs = self.prof.collect()
+        self.final_loss = float(self.loss.item())
+
+    def reduce_max(self, values):
+        t = self.torch.tensor(values, dtype=self.torch.float64, device='cuda')
+        if self.server.world_size > 1:
+            self.torch.distributed.all_reduce(t, op=self.torch.distributed.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
+    def gather(self, value):
+        t = self.torch.tensor([value], dtype=self.torch.float64, device='cuda')
+        if self.server.world_size == 1:
+            return [float(value)]
+        out = [self.torch.zeros_like(t) for _ in range(self.server.world_size)]
+        self.torch.distributed.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
+    def allreduce_ms_per_step(self):
+        ev = getattr(self.tr, 'allreduce_ms', [])
+        if not ev:
+            return None
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+    def alt(self, steps):
+        if self.args.gemm_precision != 'f32' or self.args.workload != 'cfg2' or self.args.no_alt:
+            return None
+        return alt_gemm_arith(self.tr, self.batches, self.server, steps)
+
+    def describe(self, dt):
+        """workload-specific part of the JSON line (rank 0)"""
+        import ctypes
+        args, _hip, layer = self.args, self._hip, self.layer
+        B_, T_, D_, H_ = self.B, self.T, self.D, self.H
+        # roofline of the dominant kernel: recurrent step(s), per launch
+        desc = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), B_, T_, D_, H_, T_, layer.LSTM_MODE[0], 0)
+        persistent = bool(_hip.lib().nabu_blstm_uses_persistent(ctypes.byref(desc)))
+        recs = self.recs
+        tot_ms = sum(r[4] for r in recs)
+        tot_steps = sum(r[2] for r in recs)                   # timesteps covered (both directions each)
+        tot_bytes = sum(2 * r[2] * step_bytes(r[1], r[3]) for r in recs)
+        launches = len(recs) if persistent else tot_steps
+        per_launch_bytes = tot_bytes / max(launches, 1)
+        per_launch_s = tot_ms * 1e-3 / max(launches, 1)
+        achieved = per_launch_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
+        # HBM traffic per launch of the same kernels from the PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, separate runs of this command; summarised by tools/pmc_summary.py with the
+        # gfx950 corrections of MI355X_MICROARCH.md).  null when this workload was not profiled.
+        traffic = None
+        for name in ('r02_cfg2_pmc_traffic.json', 'r01_cfg2_pmc_traffic.json'):
+            pmc = os.path.join(ROOT, 'profiles', name)
+            if persistent and args.workload == 'cfg2' and os.path.exists(pmc):
+                with open(pmc) as fid:
+                    traffic = int(json.load(fid)['lstm_persist_traffic_bytes_per_launch'])
+                break
+        step_bytes_total = 2 * 2 * sum(self.layer_t) * step_bytes(B_, H_)
+        frac_step = step_bytes_total / (dt / args.steps) / (HBM_PEAK_GBS * 1e9)
+        roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                    'kernel': 'lstm_persist_{fwd,bwd}' if persistent else 'lstm_step_{fwd,bwd}_kernel',
+                    'bytes_per_launch': int(per_launch_bytes), 'us_per_launch': round(per_launch_s * 1e6, 3),
+                    'launches_timed': launches,
+                    'recurrent_ms_per_step': round(tot_ms / args.steps, 3),
+                    'frac_step': round(frac_step, 4),
+                    'note': 'algorithmic bytes (W_h streamed per timestep model, SURVEY.md 8(d)); '
+                            'events recorded by the library around the recurrent launches; frac = the recurrent '
+                            'kernels alone, frac_step = the same bytes over the WHOLE step time (the SURVEY.md '
+                            '8(d) definition, which also pays for the MFMA-bound GEMMs of the step)'}
+        return {
+            'metric': METRICS[args.workload],
+            'dtype': 'f32' if args.gemm_precision in ('f32', 'bf16x6') else 'f32 state / %s products' % args.gemm_precision,
+            'config': {'workload': WORKLOADS[args.workload], 'frames': T_,
+                       'recurrent_path': 'persistent' if persistent else 'stepwise',
+                       'gemm_arith': GEMM_ARITH[args.gemm_precision]},
+            'roofline': roofline,
+            'roofline_gemm': (gemm_roofline(B_, T_, D_, H_, args.gemm_precision)
+                              if args.workload == 'cfg2' and args.gemm_precision == 'f32' and not args.no_gemm_roofline
+                              else None),
+            'hbm_roofline_frac_whole_step': round(frac_step, 4),
+            'final_loss': round(self.final_loss, 4),
+        }
+
+    def wants_cpu_baseline(self):
+        return self.args.workload == 'cfg2'
+
+
+def make_workload(args, server):
+    return HipWorkload(args, server)
+
+
+# ------------------------------------------------------------------ the protocol
+def run(args, server, wl):
+    """W untimed warm-up steps, then EXACTLY K steps bracketed by device sync + barrier on both
+    sides; the time is the MAX over ranks; rank 0 returns the JSON object (others None)."""
     rank, world = server.rank, server.world_size
-    if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    if world == 1:
-        torch.cuda.set_device(0)
-    _hip.lib()
-    ops.set_gemm_precision(args.gemm_precision)
-    layer.LSTM_MODE[0] = {'auto': ops.LSTM_AUTO, 'stepwise': ops.LSTM_STEPWISE,
-                          'persistent': ops.LSTM_PERSISTENT}[args.mode]
-
-    global B, T, D, H
-    layer_t = None
-    if args.workload == 'cfg1':
-        # BASELINE.json configs[0]: DBLSTM 2 x 256 + CTC, 8 x 200 x 40 (the reference's CPU-runnable case)
-        B, T, D, H = 8, 200, 40, 256
-        layer_t = [T, T]
-        mc, tc, ec = recipes.load_recipe('cfg1_dblstm_ctc')
-        data = SyntheticData(B, T, D, min_frames=T, min_labels=10, max_labels=40, seed=1234 + rank)
-    elif args.workload == 'cfg5':
-        B, T, D = 64, 1600, 80
-        mc, tc, ec = recipes.load_recipe('cfg5_las_location')
-        data = SyntheticData(B, T, D, min_frames=T, min_labels=40, max_labels=159, eos=True, time_reduction=8,
-                             seed=5234 + rank)
-    elif args.workload == 'cfg3':
-        mc, tc, ec = recipes.load_recipe('cfg3_las_vanilla')
-        data = SyntheticData(B, T, D, min_frames=T, min_labels=20, max_labels=79, eos=True, time_reduction=8,
-                             seed=3234 + rank)
-    else:
-        mc, tc, ec = recipes.load_recipe('cfg2_listener_ctc')
-        data = SyntheticData(B, T, D, min_frames=T, min_labels=20, max_labels=60, time_reduction=8,
-                             seed=4234 + rank)
-    tr = trainer_factory.factory('standard')(conf=tc, dataconf=data, modelconf=mc, evaluatorconf=ec,
-                                             expdir=None, server=server, task_index=rank)
-    batches = [tr.to_device(data.batch(i)) for i in range(2)]      # resident in HBM
-    # the event profiler is armed during the warm-up as well: its first use (event pool creation
-    # inside the HIP runtime) stalls the queue for tens of milliseconds once
-    prof = ops.enable_profiler()
     for i in range(max(args.warmup, 1)):
-        tr.step(batches[i % 2])
-    loss_functions.check_status()
-    torch.cuda.synchronize()
-    prof.collect()                                                 # drop the warm-up records
+        wl.step(i)
+    wl.check()
+    wl.sync()
+    wl.start_timed_region()
     server.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = tr.step(batches[i % 2])
-    torch.cuda.synchronize()
+        wl.step(i)
+    wl.sync()
     server.barrier()
-    dt = time.perf_counter() - t0
-    prof.enabled = False
-    recs = prof.collect()
-    final_loss = float(loss.item())
-    loss_functions.check_status()
-    alt = None
-    if args.gemm_precision == 'f32' and args.workload == 'cfg2' and not args.no_alt:
-        alt = alt_gemm_arith(tr, batches, server, min(args.steps, 5))
-    tmax = torch.tensor([dt, alt[0] if alt else 0.0], dtype=torch.float64, device='cuda')
-    if world > 1:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax[0].item())
-    if alt:
-        alt = (float(tmax[1].item()), alt[1])
+    dt_rank = time.perf_counter() - t0
+    wl.end_timed_region()
+    wl.check()
+    alt = wl.alt(min(args.steps, 5))
+    red = wl.reduce_max([dt_rank, alt[0] if alt else 0.0])
+    per_rank = wl.gather(dt_rank)
+    ar_ms = wl.allreduce_ms_per_step()
+    ar_ranks = wl.gather(ar_ms if ar_ms is not None else 0.0)
+    dt = red[0]
     if rank != 0:
-        return
-
-    # roofline of the dominant kernel: recurrent step(s), per launch
-    import ctypes
-    desc = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), B, T, D, H, T, layer.LSTM_MODE[0], 0)
-    persistent = bool(_hip.lib().nabu_blstm_uses_persistent(ctypes.byref(desc)))
-    tot_ms = sum(r[4] for r in recs)
-    tot_steps = sum(r[2] for r in recs)                   # timesteps covered (both directions each)
-    tot_bytes = sum(2 * r[2] * step_bytes(r[1], r[3]) for r in recs)
-    launches = len(recs) if persistent else tot_steps
-    per_launch_bytes = tot_bytes / max(launches, 1)
-    per_launch_s = tot_ms * 1e-3 / max(launches, 1)
-    achieved = per_launch_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
-    # HBM traffic per launch of the same kernels from the PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    # WRITE_SIZE, separate runs of this command; summarised by tools/pmc_summary.py with the
-    # gfx950 corrections of MI355X_MICROARCH.md).  null when this workload was not profiled.
-    traffic = None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_cfg2_pmc_traffic.json')
-    if persistent and args.workload == 'cfg2' and os.path.exists(pmc):
-        with open(pmc) as fid:
-            traffic = int(json.load(fid)['lstm_persist_traffic_bytes_per_launch'])
-    roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                'kernel': 'lstm_persist_{fwd,bwd}' if persistent else 'lstm_step_{fwd,bwd}_kernel',
-                'bytes_per_launch': int(per_launch_bytes), 'us_per_launch': round(per_launch_s * 1e6, 3),
-                'launches_timed': launches,
-                'recurrent_ms_per_step': round(tot_ms / args.steps, 3),
-                'note': 'algorithmic bytes (W_h streamed per timestep model, SURVEY.md 8(d)); '
-                        'events recorded by the library around the recurrent launches'}
-    if layer_t is None:
-        layer_t = [T >> i for i in range(4)]
-    step_bytes_total = 2 * 2 * sum(layer_t) * step_bytes(B, H)
-    out = {
-        'metric': {'cfg1': 'utterances/sec training step, 2x256 DBLSTM+CTC, batch 8x200x40 fbank',
-                   'cfg2': 'utterances/sec training step, 4x512 Listener+CTC, batch 32x1000x40 fbank',
-                   'cfg3': 'utterances/sec training step, Listener-512 + Speller (vanilla attention), batch 32x1000x40',
-                   'cfg5': 'utterances/sec training step, Listener-512 + Speller (location-aware attention), '
-                           'bf16 input GEMMs, batch 64x1600x80'}[args.workload],
-        'value': round(world * B * args.steps / dt, 2), 'unit': 'utterances/sec', 'n_gpus': world,
-        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32' if args.gemm_precision in ('f32', 'bf16x6') else 'f32 state / %s products' % args.gemm_precision,
-        'data': 'synthetic',
-        'config': {'workload': {'cfg1': 'cfg1: DBLSTM 2 x 256, DNNDecoder, CTC, Adam+clip; 8 utt x 200 frames x 40 fbank per GPU',
-                                'cfg2': 'cfg2: Listener 3 pyramidal + 1 BLSTM x512, DNNDecoder, CTC, Adam+clip; '
-                                        '32 utt x 1000 frames x 40 fbank per GPU',
-                                'cfg3': 'cfg3: cfg2 encoder + Speller (1x512 LSTMCell, Bahdanau attention), '
-                                        'average cross-entropy; 32 utt x 1000 frames x 40 fbank per GPU',
-                                'cfg5': 'cfg5: Listener-512 (bf16 input GEMMs) + Speller (location-aware attention); '
-                                        '64 utt x 1600 frames x 80 fbank per GPU'}[args.workload],
-                   'global_batch': world * B, 'frames': T, 'parallelism': 'dp%d' % world,
-                   'recurrent_path': 'persistent' if persistent else 'stepwise',
-                   'gemm_arith': {'f32': 'f32 (v_mfma_f32_32x32x2_f32, exact fp32)',
-                                  'bf16x6': 'f32 operands split into 3 bf16 pieces, 6 bf16 MFMA products, f32 accumulate',
-                                  'bf16x3': 'f32 operands split into 2 bf16 pieces, 3 bf16 MFMA products, f32 accumulate',
-                                  'bf16': 'operands rounded to bf16, f32 accumulate'}[args.gemm_precision]},
-        'roofline': roofline,
-        'roofline_gemm': (gemm_roofline(B, T, D, H, args.gemm_precision)
-                          if args.workload == 'cfg2' and args.gemm_precision == 'f32' and not args.no_gemm_roofline
-                          else None),
-        'hbm_roofline_frac_whole_step': round(step_bytes_total / (dt / args.steps) / (HBM_PEAK_GBS * 1e9), 4),
-        'final_loss': round(final_loss, 4),
-    }
+        return None
+    out = {'metric': None, 'value': round(world * wl.units_per_step * args.steps / dt, 2), 'unit': 'utterances/sec',
+           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+           'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+           'vs_baseline': None, 'dtype': None, 'data': 'synthetic'}
+    out.update(wl.describe(dt))
+    out['config'].update({'global_batch': world * wl.units_per_step, 'parallelism': 'dp%d' % world})
+    out['ranks'] = {'world_size_seen': world, 'backend': server.backend,
+                    'ms_per_step_per_rank': [round(t / args.steps * 1e3, 3) for t in per_rank],
+                    'allreduce': getattr(args, 'allreduce', 'flat') if world > 1 else None,
+                    'allreduce_ms_per_step': [round(v, 3) for v in ar_ranks] if world > 1 else None}
     if alt:
         n = min(args.steps, 5)
         out['alt_gemm_bf16x6'] = {
             'note': 'informational, not the headline: identical step with every dense product computed as 6 bf16 '
                     'MFMA products of 3-way split fp32 operands (fp32 accumulate; error vs float64 equal to the '
                     'exact-fp32 MFMA kernel, tests/test_hip_ops.py::test_gemm_bf16_split_precisions)',
-            'value': round(world * B * n / alt[0], 2), 'ms_per_step': round(alt[0] / n * 1e3, 3), 'steps': n,
-            'final_loss': round(alt[1], 4)}
-    if world == 1 and not args.no_cpu_baseline and args.workload == 'cfg2':
+            'value': round(world * wl.units_per_step * n / red[1], 2), 'ms_per_step': round(red[1] / n * 1e3, 3),
+            'steps': n, 'final_loss': round(alt[1], 4)}
+    if world == 1 and not args.no_cpu_baseline and wl.wants_cpu_baseline():
         out['cpu_baseline'] = cpu_baseline()
-    print(json.dumps(out))
+    return out
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    env_world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and env_world == 1:
+        # no ranks in the environment: start them ourselves
+        sys.exit(self_launch(argv, args.gpus))
+    server = make_server()
+    if server.world_size != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, server.world_size))
+    wl = make_workload(args, server)
+    out = run(args, server, wl)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    server.barrier()
+    server.shutdown()
 
 
 def alt_gemm_arith(tr, batches, server, steps):
-    '''informational: the same step with the dense products on the bf16 matrix pipe as 6 split
-    products (fp32-level accuracy, tests/test_hip_ops.py); NOT the headline value'''
+    """informational: the same step with the dense products on the bf16 matrix pipe as 6 split
+    products (fp32-level accuracy, tests/test_hip_ops.py); NOT the headline value"""
     import torch
     from nabu_amd import ops
     ops.set_gemm_precision('bf16x6')

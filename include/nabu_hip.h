@@ -14,7 +14,13 @@
  *  - every call is asynchronous on `stream` (a hipStream_t passed as void*);
  *  - return value: 0 = ok, < 0 = NABU_E* argument error, > 0 = hipError_t;
  *    nabu_last_error() returns a thread-local message;
- *  - no C++ exceptions cross the boundary, no global mutable state.
+ *  - no C++ exceptions cross the boundary;
+ *  - state the library keeps between calls — all of it listed here: (process-wide, set
+ *    before use, not synchronised) the default GEMM arithmetic (nabu_gemm_set_default_precision /
+ *    NABU_GEMM_PRECISION) and the persistent kernels' wait bound (nabu_persist_set_timeout_us);
+ *    (thread-local) the last error text, the profiling events of
+ *    nabu_blstm_set_profile_events and the hook of nabu_blstm_set_phase_hook; plus a lazily built per-kernel attribute cache.  Everything
+ *    else — parameters, activations, workspaces, status words — lives in caller-owned memory.
  */
 #ifndef NABU_HIP_H
 #define NABU_HIP_H
@@ -132,6 +138,22 @@ int nabu_blstm_uses_persistent(const nabu_blstm_desc *d);
  * recurrent kernel(s) on the call's stream, so that bench.py can time the
  * dominant kernel live inside the timed region.  Pass NULLs to switch it off. */
 int nabu_blstm_set_profile_events(void *ev_begin, void *ev_end);
+/* Hook (thread-local) that nabu_blstm_bwd calls on the host right after it has enqueued the
+ * recurrent kernel(s) and before it enqueues the dense products dWx, dWh, dx.  The persistent
+ * recurrent kernels need every one of their workgroups resident at the same time, so nothing else
+ * may run beside them; the products have no such constraint.  A data-parallel caller uses the hook
+ * to start the all-reduce of an already finished gradient bucket on its communication stream at
+ * exactly this point (ordered after the recurrence by an event) and joins that stream again before
+ * the next recurrent launch — the exchange then overlaps the products only.  NULL switches it off.
+ * Replaces: the asynchronous parameter-server pushes of the reference (trainers/trainer.py:479-510). */
+typedef void (*nabu_phase_hook_t)(void *user);
+int nabu_blstm_set_phase_hook(nabu_phase_hook_t fn, void *user);
+/* Bound of every in-kernel wait of the persistent recurrent kernels (process-wide setting;
+ * default 200 000 us, us <= 0 restores it).  A wait that runs out sets the status word (first
+ * int32 of ws: 4*block + {1 forward, 2 backward, 3 start-up handshake}), every workgroup leaves at
+ * its next barrier, later launches on that ws return at once until the caller has read and
+ * cleared the word: the results of the step are invalid and the host must raise. */
+int nabu_persist_set_timeout_us(long long us);
 
 /* ops.pyramid_stack (nabu/neuralnetworks/components/ops.py:6-60) when T is not
  * a multiple of numsteps: y [B,Tp,F] = x [B,T,F] zero-padded in time (for T a
@@ -433,6 +455,14 @@ int nabu_beam_prune(int B, int W, int C, const float *logits, float temperature,
 /* dst[b,w,:] = (stay[b,w] ? old : fresh)[b, parent[b,w], :]  for [B,W,F] float rows */
 int nabu_beam_gather(int B, int W, int F, const float *fresh, const float *old, const int32_t *parent,
                      const int32_t *stay, float *dst, nabu_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Host-side helper of the on-disk data path (the only entry point that takes HOST memory):
+ * CRC-32C (Castagnoli) of `n` bytes, continuing from `crc` (0 to start) — the checksum of the
+ * TFRecord framing of the reference's per-utterance files.
+ * Replaces: tf.python_io.TFRecordWriter / tf.TFRecordReader record checks
+ * (nabu/processing/tfwriters/tfwriter.py:30-45, nabu/processing/tfreaders/tfreader.py:71-92). */
+uint32_t nabu_crc32c_host(const void *data_host, size_t n, uint32_t crc);
 
 #ifdef __cplusplus
 }

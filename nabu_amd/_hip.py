@@ -41,6 +41,8 @@ SIGNATURES = {
                             _vp, _vp, _vp, _sz, _vp]),
     'nabu_blstm_uses_persistent': (_i, [_c.POINTER(BlstmDesc)]),
     'nabu_blstm_set_profile_events': (_i, [_vp, _vp]),
+    'nabu_persist_set_timeout_us': (_i, [_ll]),
+    'nabu_blstm_set_phase_hook': (_i, [_vp, _vp]),
     'nabu_pad_time_f32': (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     'nabu_unpad_time_f32': (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     'nabu_ctc_ws_bytes': (_sz, [_i, _i, _i]),
@@ -79,10 +81,12 @@ SIGNATURES = {
     'nabu_relu_f32': (_i, [_sz, _vp, _vp, _vp]),
     'nabu_relu_bwd_f32': (_i, [_sz, _vp, _vp, _vp, _vp]),
     'nabu_layer_norm_fwd': (_i, [_i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    'nabu_crc32c_host': (_c.c_uint32, [_c.c_char_p, _sz, _c.c_uint32]),
     'nabu_layer_norm_bwd': (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None
+PHASE_HOOK_T = _c.CFUNCTYPE(None, _c.c_void_p)
 
 
 class NabuHipError(RuntimeError):

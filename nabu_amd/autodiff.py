@@ -10,11 +10,14 @@ import torch
 from . import ops as hip_ops
 
 
-class _Op(object):
-    __slots__ = ('inputs', 'outputs', 'backward')
+UNIT = object()      # a backward closure's way of saying "this input's gradient is the unit upstream one"
 
-    def __init__(self, inputs, outputs, backward):
-        self.inputs, self.outputs, self.backward = inputs, outputs, backward
+
+class _Op(object):
+    __slots__ = ('inputs', 'outputs', 'backward', 'params')
+
+    def __init__(self, inputs, outputs, backward, params=()):
+        self.inputs, self.outputs, self.backward, self.params = inputs, outputs, backward, params
 
 
 class Tape(object):
@@ -24,6 +27,9 @@ class Tape(object):
         self.ops = []
         self.produced = set()
         self._prev = None
+        # called with a Variable once the last recorded op that declared it (record(..., params=))
+        # has run its backward closure: its gradient is final (bucketed gradient exchange)
+        self.on_param_ready = None
 
     def __enter__(self):
         self._prev = Tape.current
@@ -43,17 +49,35 @@ class Tape(object):
         """Run the recorded backward closures from ``root`` (the scalar loss)."""
         grads = {id(root): None}
         seen = {id(root)}
+        pending = {}
+        if self.on_param_ready is not None:
+            for op in self.ops:
+                for v in op.params:
+                    pending[id(v)] = pending.get(id(v), 0) + 1
+
+        def done(op):
+            for v in op.params:
+                if id(v) in pending:
+                    pending[id(v)] -= 1
+                    if pending[id(v)] == 0:
+                        self.on_param_ready(v)
         for op in reversed(self.ops):
             if not any(id(o) in seen for o in op.outputs):
+                done(op)
                 continue
             gouts = [grads.get(id(o)) for o in op.outputs]
             gins = op.backward(*gouts)
+            done(op)
             if gins is None:
                 continue
             for inp, g in zip(op.inputs, gins):
                 if g is None:
                     continue
                 key = id(inp)
+                if g is UNIT:                  # e.g. a term of a sum of losses: behaves like a root
+                    seen.add(key)
+                    grads.setdefault(key, None)
+                    continue
                 if key in seen and grads.get(key) is not None:
                     hip_ops.axpy_(grads[key], g)
                 else:
@@ -63,13 +87,14 @@ class Tape(object):
         self.produced = set()
 
 
-def record(inputs, outputs, backward):
+def record(inputs, outputs, backward, params=()):
     """Register ``backward(*grad_outputs) -> grad_inputs`` on the active tape (no-op
-    outside a tape, e.g. in validation)."""
+    outside a tape, e.g. in validation).  ``params``: the Variables whose gradient this
+    closure writes (optional; lets the tape report when a gradient is final)."""
     tape = Tape.current
     if tape is None:
         return
-    tape.ops.append(_Op(list(inputs), list(outputs), backward))
+    tape.ops.append(_Op(list(inputs), list(outputs), backward, tuple(params)))
     for o in outputs:
         tape.produced.add(id(o))
 

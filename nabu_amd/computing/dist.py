@@ -22,6 +22,13 @@ class ProcessGroup(object):
             dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
         return tensor
 
+    def all_reduce_sum_async(self, tensor):
+        """start the all-reduce and return a handle whose wait() joins the caller's stream with
+        the collective's (RCCL: stream-ordered, the host does not block; gloo: blocks)"""
+        if self.world_size > 1:
+            return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, async_op=True)
+        return None
+
     def broadcast_(self, tensor, src=0):
         if self.world_size > 1:
             dist.broadcast(tensor, src)
@@ -30,6 +37,10 @@ class ProcessGroup(object):
     def barrier(self):
         if self.world_size > 1:
             dist.barrier()
+
+    def shutdown(self):
+        if self.world_size > 1 and dist.is_initialized():
+            dist.destroy_process_group()
 
 
 def create_server(backend=None):

@@ -4,6 +4,12 @@
 
 namespace nabu {
 
+// tf.clip_by_value propagates NaN (min/max of the TF kernels are plain comparisons), fminf/fmaxf
+// return the non-NaN operand: a diverged gradient must stay visible, not become -clip.
+__device__ __forceinline__ float clip_value(float x, float clip) {
+  return x != x ? x : fminf(fmaxf(x, -clip), clip);
+}
+
 // ---------------------------------------------------------------------------
 // fused clip + TF-style Adam: 4 streams read (param, grad, m, v), 3 written.
 // 16-byte accesses, grid-stride, 7*4 = 28 algorithmic bytes per parameter.
@@ -23,7 +29,7 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(size_t n, float *__restr
     float4 vv = reinterpret_cast<float4 *>(v)[i];
 #define NABU_ADAM1(c)                                           \
   {                                                             \
-    float x = fminf(fmaxf(gg.c * gscale, -clip), clip);         \
+    float x = clip_value(gg.c * gscale, clip);                  \
     mm.c = b1 * mm.c + (1.f - b1) * x;                          \
     vv.c = b2 * vv.c + (1.f - b2) * x * x;                      \
     pp.c -= lr_t * mm.c / (sqrtf(vv.c) + eps);                  \
@@ -34,7 +40,7 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(size_t n, float *__restr
     reinterpret_cast<float4 *>(v)[i] = vv;
   }
   for (size_t i = n4 * 4 + tid; i < n; i += stride) {
-    float x = fminf(fmaxf(g[i] * gscale, -clip), clip);
+    float x = clip_value(g[i] * gscale, clip);
     float mm = b1 * m[i] + (1.f - b1) * x;
     float vv = b2 * v[i] + (1.f - b2) * x * x;
     m[i] = mm;
@@ -49,13 +55,13 @@ __global__ __launch_bounds__(256) void clip_kernel(size_t n, float *__restrict__
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (size_t i = tid; i < n4; i += stride) {
     float4 x = reinterpret_cast<float4 *>(g)[i];
-    x.x = fminf(fmaxf(x.x, -clip), clip);
-    x.y = fminf(fmaxf(x.y, -clip), clip);
-    x.z = fminf(fmaxf(x.z, -clip), clip);
-    x.w = fminf(fmaxf(x.w, -clip), clip);
+    x.x = clip_value(x.x, clip);
+    x.y = clip_value(x.y, clip);
+    x.z = clip_value(x.z, clip);
+    x.w = clip_value(x.w, clip);
     reinterpret_cast<float4 *>(g)[i] = x;
   }
-  for (size_t i = n4 * 4 + tid; i < n; i += stride) g[i] = fminf(fmaxf(g[i], -clip), clip);
+  for (size_t i = n4 * 4 + tid; i < n; i += stride) g[i] = clip_value(g[i], clip);
 }
 
 // ---------------------------------------------------------------------------

@@ -221,6 +221,9 @@ static int check_desc(const nabu_blstm_desc *d) {
 // optional profiling hook: caller-owned events recorded around the recurrent kernels
 static thread_local hipEvent_t g_ev_begin = nullptr, g_ev_end = nullptr;
 #define NABU_PROFILE_MARK(ev, s) do { if (ev) NABU_HIP(hipEventRecord(ev, s)); } while (0)
+// optional hook between the recurrent kernel(s) and the dense products of nabu_blstm_bwd
+static thread_local nabu_phase_hook_t g_phase_hook = nullptr;
+static thread_local void *g_phase_user = nullptr;
 
 static bool use_persistent(const nabu_blstm_desc *d) {
   if (d->mode == NABU_LSTM_STEPWISE) return false;
@@ -236,6 +239,16 @@ extern "C" int nabu_blstm_set_profile_events(void *ev_begin, void *ev_end) {
   g_ev_end = static_cast<hipEvent_t>(ev_end);
   return 0;
 }
+extern "C" int nabu_blstm_set_phase_hook(nabu_phase_hook_t fn, void *user) {
+  g_phase_hook = fn;
+  g_phase_user = user;
+  return 0;
+}
+extern "C" int nabu_persist_set_timeout_us(long long us) {
+  nabu::lstm_persist_set_timeout_us(us);
+  return 0;
+}
+
 extern "C" int nabu_blstm_uses_persistent(const nabu_blstm_desc *d) {
   if (check_desc(d)) return 0;
   return use_persistent(d) ? 1 : 0;
@@ -362,6 +375,7 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
     NABU_LAUNCH_CHECK();
   }
   NABU_PROFILE_MARK(g_ev_end, s);
+  if (g_phase_hook) g_phase_hook(g_phase_user);
 
   // weight / input gradients from dz (now stored in gates[])
   const int M = B * T;

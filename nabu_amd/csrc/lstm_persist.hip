@@ -744,6 +744,12 @@ __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8
 }
 
 // ===========================================================================
+// bound of every in-kernel spin, wall_clock64 ticks (100 MHz); process-wide setting
+static unsigned long long g_timeout_ticks = 20000000ull;   // 0.2 s: a step takes microseconds
+void lstm_persist_set_timeout_us(long long us) {
+  g_timeout_ticks = us > 0 ? (unsigned long long)us * 100ull : 20000000ull;
+}
+
 static int cu_count() {
   static int n = -1;
   if (n < 0) {
@@ -871,7 +877,7 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
   a.status = status;
   a.table = static_cast<unsigned *>(ws);
   a.xbuf = static_cast<char *>(ws) + TABLE_BYTES;
-  a.timeout_ticks = 20000000ull;   // 0.2 s at 100 MHz: a step takes microseconds
+  a.timeout_ticks = g_timeout_ticks;
   const int NU = 2 * a.nshard, P = H / UC;
   const int grid = NU * P;
   const int per_cu = (BS == 4 || grid > NCU) ? 2 : 1;

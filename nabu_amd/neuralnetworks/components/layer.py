@@ -50,7 +50,7 @@ def blstm(inputs, sequence_length, num_units, layer_norm=False, scope=None):
         hip.blstm_bwd(plan, x, lens.dev, kf.data, kb.data, out, dout.contiguous(), reserve, dx,
                       kf.grad, bf.grad, kb.grad, bb.grad)
         return [dx]
-    record([inputs], [out], backward)
+    record([inputs], [out], backward, params=(kf, bf, kb, bb))
     return out
 
 

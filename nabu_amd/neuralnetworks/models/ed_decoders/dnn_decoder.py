@@ -36,7 +36,7 @@ def linear(inputs, num_outputs, scope):
             dx = torch.empty_like(x)
             hip.gemm(d2, W.data, dx.view(B * T, F), trans_b=True)   # dx = dout W^T
         return [dx]
-    record([inputs], [out], backward)
+    record([inputs], [out], backward, params=(W, b))
     return out
 
 

@@ -6,7 +6,7 @@ gradient is handed to the tape."""
 import torch
 
 from nabu_amd import ops as hip
-from nabu_amd.autodiff import record, SeqLen
+from nabu_amd.autodiff import record, SeqLen, UNIT
 from nabu_amd.neuralnetworks.components import ops
 
 # device status words of the CTC kernels launched since the last check
@@ -35,9 +35,15 @@ def _labels(t):
 
 
 def _total(losses):
-    total = losses[0]
+    '''sum over the outputs (reference loss_functions.py:212: tf.reduce_sum over the per-output
+    losses).  With several outputs the sum is a node of its own and is recorded on the tape, so that
+    the backward pass reaches every term (each gets the unit gradient).'''
+    if len(losses) == 1:
+        return losses[0]
+    total = losses[0].clone()
     for l in losses[1:]:
-        total = hip.axpy_(total.clone(), l)
+        hip.axpy_(total, l)
+    record(losses, [total], lambda g: [UNIT] * len(losses))
     return total
 
 
@@ -99,3 +105,7 @@ def check_status():
         if code:
             raise Exception('CTC: Not enough time for target transition sequence '
                             '(utterance %d of the batch)' % (code - 1))
+    # a persistent recurrent kernel that gave up (bounded-spin timeout) leaves the results of the
+    # step invalid and its status word set: raise here, where the training / validation loops
+    # already synchronise
+    hip.check_persist_status()

@@ -12,7 +12,11 @@ underneath:
     RCCL all-reduce of the flat gradient buffer per step: every replica clips its
     own gradient, the clipped gradients are averaged, one Adam update is applied —
     the synchronous semantics the reference's SyncReplicasOptimizer branch
-    intends with numbatches_to_aggregate = number of workers."""
+    intends with numbatches_to_aggregate = number of workers.  Optional
+    (``allreduce_buckets = True``, an extension key; default False): the same sum
+    exchanged as one bucket per encoder layer (+ one for the decoder), each started
+    as soon as its gradients are final and overlapped with the dense products of the
+    next layer's backward pass — never with a persistent recurrent kernel."""
 import math
 import os
 import pickle
@@ -110,6 +114,7 @@ class Trainer(object, metaclass=ABCMeta):
         self.loss_fn = loss_functions.factory(self.conf['loss'])
         self.world = self.server.world_size if self.server is not None else 1
         self.flat = self.flat_grad = self.adam_m = self.adam_v = None
+        self.buckets = None
         # validation part (reference trainer.py:189-265): bookkeeping 'variables' of the
         # validate/ scope with the reference's initial values
         self.evaluator = None
@@ -204,9 +209,18 @@ class Trainer(object, metaclass=ABCMeta):
                 loss = hip.axpy_(loss, extra)
         if self.flat is None:
             self._init_optimizer()
-        tape.backward(loss)
-        self._update()
+        self._backward_and_update(tape, loss)
         return loss
+
+    def _backward_and_update(self, tape, loss):
+        if self.buckets is not None:
+            self._begin_bucketed(tape)
+        try:
+            tape.backward(loss)
+        finally:
+            if self.buckets is not None:
+                self._end_backward()
+        self._update()
 
     def _init_optimizer(self):
         store = self.model.store
@@ -215,6 +229,66 @@ class Trainer(object, metaclass=ABCMeta):
         self.adam_v = torch.zeros_like(self.flat)
         if self.world > 1:
             self.server.broadcast_(self.flat, 0)       # identical replicas
+        self.buckets = None
+        if self.world > 1 and self.conf.get('allreduce_buckets', 'False') == 'True':
+            self.buckets = self._make_buckets()
+
+    # ----------------------------------------------------- bucketed gradient exchange
+    @staticmethod
+    def bucket_key(name):
+        '''variables of one encoder layer share a bucket (<encoder>/<input>/layer<l>), everything
+        else (the decoder) forms one more'''
+        parts = name.split('/')
+        return '/'.join(parts[:3]) if len(parts) > 3 and parts[2].startswith('layer') else 'decoder'
+
+    def _make_buckets(self):
+        '''contiguous ranges of the flat gradient buffer, in variable-creation order'''
+        buckets = []
+        for v in self.model.store.trainable_variables():
+            key = self.bucket_key(v.name)
+            end = v.offset + (v.numel() + 3) // 4 * 4
+            if buckets and buckets[-1]['key'] == key and buckets[-1]['end'] == v.offset:
+                buckets[-1]['end'] = end
+                buckets[-1]['vars'].append(v)
+            else:
+                buckets.append(dict(key=key, start=v.offset, end=end, vars=[v]))
+        assert buckets[0]['start'] == 0 and buckets[-1]['end'] == self.flat_grad.numel()
+        return buckets
+
+    def _begin_bucketed(self, tape):
+        self._ready = set()            # ids of variables whose gradient is final
+        self._sent = set()             # bucket indices already on the wire
+        self._works = []
+        self._declared = {id(v) for op in tape.ops for v in op.params}
+        tape.on_param_ready = lambda v: self._ready.add(id(v))
+        hip.set_phase_hook(self._launch_ready_buckets)
+        hip.BEFORE_RECURRENT[0] = self._join_comm
+
+    def _end_backward(self):
+        hip.set_phase_hook(None)
+        hip.BEFORE_RECURRENT[0] = None
+
+    def _launch_ready_buckets(self, everything=False):
+        '''clip (per replica, before the aggregation: reference trainer.py:556-569) and start the
+        all-reduce of every bucket whose gradients are final.  Called between a recurrent kernel and
+        the dense products that follow it (nabu_blstm_set_phase_hook) and once after the backward pass.'''
+        for i, b in enumerate(self.buckets):
+            if i in self._sent:
+                continue
+            if not everything and not all(id(v) in self._ready and id(v) in self._declared for v in b['vars']):
+                continue
+            view = self.flat_grad[b['start']:b['end']]
+            hip.clip_(view, CLIP)
+            self._works.append(self.server.all_reduce_sum_async(view))
+            self._sent.add(i)
+
+    def _join_comm(self):
+        '''the launch stream waits for every exchange in flight (before a recurrent launch and
+        before the optimiser)'''
+        works, self._works = self._works, []
+        for w in works:
+            if w is not None:
+                w.wait()
 
     def _update(self):
         '''clip + Adam (reference trainer.py:512-580), with the gradient exchange of
@@ -223,15 +297,38 @@ class Trainer(object, metaclass=ABCMeta):
         self.adam_step += 1
         t = self.adam_step
         lr_t = lr * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
-        if self.world > 1:
+        if self.world > 1 and self.buckets is not None:
+            ev = self._allreduce_events()                        # exposed part of the exchange only
+            self._launch_ready_buckets(everything=True)
+            self._join_comm()
+            if ev is not None:
+                ev[1].record()
+            hip.adam_clip_step(self.flat, self.flat_grad, self.adam_m, self.adam_v, lr_t,
+                               ADAM_B1, ADAM_B2, ADAM_EPS, CLIP, 1.0 / self.world)
+        elif self.world > 1:
             hip.clip_(self.flat_grad, CLIP)                      # clip per replica ...
+            ev = self._allreduce_events()
             self.server.all_reduce_sum_(self.flat_grad)          # ... sum over xGMI ...
+            if ev is not None:
+                ev[1].record()
             hip.adam_clip_step(self.flat, self.flat_grad, self.adam_m, self.adam_v, lr_t,
                                ADAM_B1, ADAM_B2, ADAM_EPS, CLIP, 1.0 / self.world)   # ... mean, Adam
         else:
             hip.adam_clip_step(self.flat, self.flat_grad, self.adam_m, self.adam_v, lr_t,
                                ADAM_B1, ADAM_B2, ADAM_EPS, CLIP, 1.0)
         self.last_lr = lr
+
+    def _allreduce_events(self):
+        '''bench.py sets ``time_allreduce``: a pair of events on the launch stream around the
+        exchange (the collective's own stream is joined to it by torch.distributed)'''
+        if not getattr(self, 'time_allreduce', False) or not torch.cuda.is_available():
+            return None
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        if not hasattr(self, 'allreduce_ms'):
+            self.allreduce_ms = []
+        self.allreduce_ms.append(ev)
+        return ev
 
     # ------------------------------------------------------- state (checkpoints)
     def state(self):

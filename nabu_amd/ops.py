@@ -75,6 +75,8 @@ class BlstmPlan(object):
 def blstm_fwd(plan, x, lens_dev, k_fw, b_fw, k_bw, b_bw, out, reserve):
     L = _hip.lib()
     ws = Workspace.get(plan.ws_bytes, x.device, 'blstm')
+    if BEFORE_RECURRENT[0] is not None:
+        BEFORE_RECURRENT[0]()
     if PROFILER is not None:
         PROFILER.arm('fwd', plan)
     check(L.nabu_blstm_fwd(ctypes.byref(plan.desc), ptr(_f32(x, 'x')), ptr(lens_dev), ptr(k_fw), ptr(b_fw),
@@ -88,6 +90,8 @@ def blstm_fwd(plan, x, lens_dev, k_fw, b_fw, k_bw, b_bw, out, reserve):
 def blstm_bwd(plan, x, lens_dev, k_fw, k_bw, out, d_out, reserve, d_x, dk_fw, db_fw, dk_bw, db_bw):
     L = _hip.lib()
     ws = Workspace.get(plan.ws_bytes, x.device, 'blstm')
+    if BEFORE_RECURRENT[0] is not None:
+        BEFORE_RECURRENT[0]()
     if PROFILER is not None:
         PROFILER.arm('bwd', plan)
     check(L.nabu_blstm_bwd(ctypes.byref(plan.desc), ptr(x), ptr(lens_dev), ptr(k_fw), ptr(k_bw), ptr(out),
@@ -237,6 +241,31 @@ def enable_profiler():
         PROFILER = RecurrentProfiler()
     PROFILER.enabled = True
     return PROFILER
+
+
+_phase_hook = [None]       # keeps the ctypes trampoline alive
+
+
+def set_phase_hook(fn):
+    """fn() is called by nabu_blstm_bwd between its recurrent kernel(s) and its dense products
+    (include/nabu_hip.h nabu_blstm_set_phase_hook); None switches the hook off"""
+    if fn is None:
+        _phase_hook[0] = None
+        check(_hip.lib().nabu_blstm_set_phase_hook(None, None), 'nabu_blstm_set_phase_hook')
+        return
+    _phase_hook[0] = _hip.PHASE_HOOK_T(lambda user: fn())
+    check(_hip.lib().nabu_blstm_set_phase_hook(ctypes.cast(_phase_hook[0], ctypes.c_void_p), None),
+          'nabu_blstm_set_phase_hook')
+
+
+# called right before a recurrent launch is enqueued (forward and backward): the data-parallel
+# trainer joins its communication stream here (the persistent kernels must run alone)
+BEFORE_RECURRENT = [None]
+
+
+def set_persist_timeout_ms(ms):
+    """bound of the in-kernel waits of the persistent recurrent kernels (0 = the 200 ms default)"""
+    check(_hip.lib().nabu_persist_set_timeout_us(int(ms * 1000)), 'nabu_persist_set_timeout_us')
 
 
 def check_persist_status(device=None):

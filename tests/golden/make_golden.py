@@ -261,6 +261,53 @@ def make_cfg1_exact(steps=3):
     return losses
 
 
+# ---------------------------------------------------------------- BASELINE configs at their FULL size
+# (name -> setup): inputs and weights are regenerated from seeds on both sides, the fixture holds
+# the expected losses of `steps` clip+Adam steps, and for step 0 every variable's gradient norm
+# plus 32 sampled gradient entries.  SURVEY.md 8(d): parity lengths are ragged (at least one
+# full-length utterance), seeds 2234 / 3234 / 5234.
+def exact_setup(name):
+    """-> (names, data, step_fn, loss_name, recipe, steps)"""
+    if name == 'cfg2_exact':      # BASELINE.json configs[1]: the headline config, 32 x 1000 x 40
+        B, T, D, H, C = 32, 1000, 40, 512, 40
+        names, E = encoder_names('Listener', 3, D, H)
+        names += ctc_decoder_names(E, C)
+        data = SyntheticData(B, T, D, min_frames=600, min_labels=20, max_labels=60, time_reduction=8, seed=2234)
+        return names, data, (lambda ww, b: step_ctc(ww, b, 'Listener', 3)), 'CTC', 'cfg2_listener_ctc', 2
+    if name == 'cfg3_exact':      # configs[2]: cfg2 encoder + Speller 1x512, Bahdanau attention
+        B, T, D, H, C, U = 32, 1000, 40, 512, 40, 512
+        names, E = encoder_names('Listener', 3, D, H)
+        names += speller_names(E, U, C, 1, 'vanilla')
+        data = SyntheticData(B, T, D, min_frames=600, min_labels=20, max_labels=79, eos=True, time_reduction=8,
+                             seed=3234)
+        return (names, data, (lambda ww, b: step_las(ww, b, 3, 1, 'vanilla')), 'average_cross_entropy',
+                'cfg3_las_vanilla', 2)
+    if name == 'cfg5_exact':      # configs[4], one GPU's share: 64 x 1600 x 80, location-aware attention
+        B, T, D, H, C, U = 64, 1600, 80, 512, 40, 512
+        names, E = encoder_names('Listener', 3, D, H)
+        names += speller_names(E, U, C, 1, 'location_aware', K=101, F=10)
+        data = SyntheticData(B, T, D, min_frames=960, min_labels=40, max_labels=159, eos=True, time_reduction=8,
+                             seed=5234)
+        return (names, data, (lambda ww, b: step_las(ww, b, 3, 1, 'location_aware')), 'average_cross_entropy',
+                'cfg5_las_location', 1)
+    raise KeyError(name)
+
+
+def make_exact(name):
+    import time
+    names, data, step_fn, _, _, steps = exact_setup(name)
+    w = draw_weights(names)
+    t0 = time.time()
+    losses, g0, _ = trajectory(w, data, step_fn, steps)
+    out = dict(losses=losses, oracle_seconds=np.array(time.time() - t0))
+    for k, g in g0.items():
+        flat = np.asarray(g, np.float64).ravel()
+        out['gnorm:' + k.replace('/', '|')] = np.array(np.sqrt((flat ** 2).sum()))
+        out['gsample:' + k.replace('/', '|')] = flat[sample_index(k, flat.size)]
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    return losses
+
+
 def make_components():
     """small known-answer vectors for the individual kernels"""
     rng = np.random.default_rng(5)
@@ -344,6 +391,10 @@ def make_decode():
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1:             # full-size fixtures, one at a time (minutes of float64 each):
+        for n in sys.argv[1:]:        #   python tests/golden/make_golden.py cfg2_exact cfg3_exact cfg5_exact
+            print('%-14s' % n, make_exact(n), flush=True)
+        sys.exit(0)
     make_components()
     print('decode        ', make_decode())
     print('cfg1_exact    ', make_cfg1_exact())

@@ -97,6 +97,69 @@ def test_two_rank_gloo_update_matches_oracle():
     assert res[0][2] == res[1][2]                                # replicas stay identical
 
 
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from nabu_amd import recipes
+    from nabu_amd.computing import dist
+    from nabu_amd.neuralnetworks.trainers import trainer_factory
+    from nabu_amd.processing.synthetic import SyntheticData
+    from tests.bench_standin import FakeModelStep
+    server = dist.create_server(backend='gloo')
+    finals, logs = {}, {}
+    for mode in ('False', 'True'):
+        mc, tc, ec = recipes.load_recipe('cfg2_listener_ctc', **{'trainer.allreduce_buckets': mode})
+        tr = trainer_factory.factory('standard')(conf=tc, dataconf=SyntheticData(2, 16, 40), modelconf=mc,
+                                                 evaluatorconf=ec, expdir=None, server=server, task_index=rank)
+        events = []
+        fake = FakeModelStep(tr, server, events)
+        # record what the trainer puts on the wire, and when
+        orig = server.all_reduce_sum_async
+
+        def spy(t, orig=orig, events=events, tr=tr):
+            off = (t.data_ptr() - tr.flat_grad.data_ptr()) // 4
+            events.append(('allreduce', int(off), int(t.numel())))
+            return orig(t)
+        server.all_reduce_sum_async = spy
+        for _ in range(3):
+            fake.step()
+        server.all_reduce_sum_async = orig
+        finals[mode] = tr.flat.clone()
+        logs[mode] = events
+        if mode == 'True':
+            assert [b['key'] for b in tr.buckets] == ['Listener/features/layer0', 'Listener/features/layer1',
+                                                      'Listener/features/layer2', 'decoder']
+            assert tr.buckets[0]['start'] == 0 and tr.buckets[-1]['end'] == tr.flat_grad.numel()
+            assert all(a['end'] == b['start'] for a, b in zip(tr.buckets, tr.buckets[1:]))
+    # bucketed == flat to the bit (sum of two replicas: the order cannot matter)
+    assert torch.equal(finals['False'], finals['True'])
+    # schedule of one bucketed step: a bucket goes on the wire between a recurrent kernel and the
+    # products that follow it, and only after the products that wrote it; the decoder's bucket first
+    ev = logs['True'][:len(logs['True']) // 3]
+    kinds = [e[0] + (str(e[1]) if e[0] != 'allreduce' else '') for e in ev]
+    assert kinds == ['products3', 'recurrent2', 'allreduce', 'products2', 'recurrent1', 'allreduce', 'products1',
+                     'recurrent0', 'allreduce', 'products0', 'allreduce'], kinds
+    assert not any(e[0] == 'allreduce' for e in logs['False'])      # flat mode: one blocking all-reduce
+    q.put((rank, float(finals['True'].double().sum())))
+    server.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_bucketed_exchange_equals_flat_exchange_bitwise():
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert res[0][1] == res[1][1]
+
+
 def test_single_process_group_is_trivial(monkeypatch):
     from nabu_amd.computing import dist
     monkeypatch.delenv('WORLD_SIZE', raising=False)

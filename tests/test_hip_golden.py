@@ -124,6 +124,47 @@ def test_cfg1_exact_matches_golden():
     assert rel.max() < 1e-3 and rel.max() < 5e-5, (losses, fx['losses'])
 
 
+@pytest.mark.parametrize('name', ['cfg2_exact', 'cfg3_exact', 'cfg5_exact'])
+def test_full_size_configs_match_the_oracle_goldens(name):
+    """BASELINE.json configs[1], [2] and (one GPU's share of) [4] at their FULL size — the headline
+    config 32 x 1000 x 40, 4 x 512 included — against numbers the float64 oracle produced in the
+    build container (tests/golden/make_golden.py <name>; cross-checked by an independent torch
+    float64 implementation, tests/golden/exact_xcheck.json): loss of every step of the clip+Adam
+    trajectory <= 1e-3 relative (north_star; fp32 kernels achieve ~1e-5), and for step 0 every
+    variable's gradient norm and 32 sampled gradient entries <= 3e-4.  Ragged lengths (parity
+    batches of SURVEY.md 8(d)).  cfg5 runs its products in exact fp32 here (the bf16 variant of the
+    recipe is bounded against the fp32 goldens by the small-size test below and, at full size, by
+    the 1e-3 loss bar in test_cfg5_exact_bf16_loss)."""
+    from tests.golden import make_golden as G       # generators only (seeded numpy); no oracle math runs
+    fx = load(name)
+    names, data, _, loss_name, recipe, steps = G.exact_setup(name)
+    w = G.draw_weights(names)
+    over = {'encoder.gemm_precision': 'f32'} if name == 'cfg5_exact' else {}
+    tr = trainer_with_weights(recipe, over, data, w, data.batch(0))
+    loss0 = step0_grads(tr, data.batch(0), loss_name)
+    assert abs(loss0 - fx['losses'][0]) / fx['losses'][0] < 5e-5, (loss0, fx['losses'][0])
+    for v in tr.model.variables:
+        g = v.grad.cpu().numpy().astype(np.float64).ravel()
+        key = v.name.replace('/', '|')
+        assert abs(np.sqrt((g ** 2).sum()) - fx['gnorm:' + key]) / fx['gnorm:' + key] < 3e-4, v.name
+        ref = fx['gsample:' + key]
+        assert np.abs(g[G.sample_index(v.name, g.size)] - ref).max() < 3e-4 * np.abs(ref).max() + 1e-7, v.name
+    losses = [float(tr.step(tr.to_device(data.batch(s))).item()) for s in range(steps)]
+    rel = np.abs(np.array(losses) - fx['losses'][:steps]) / fx['losses'][:steps]
+    assert rel.max() < 1e-3 and rel.max() < 1e-4, (losses, fx['losses'])
+
+
+def test_cfg5_exact_bf16_loss():
+    """configs[4] as shipped (bf16 input-to-hidden GEMMs) at full size 64 x 1600 x 80: the loss stays
+    within the north_star tolerance of the fp32 oracle number"""
+    from tests.golden import make_golden as G
+    fx = load('cfg5_exact')
+    names, data, _, loss_name, recipe, _ = G.exact_setup('cfg5_exact')
+    tr = trainer_with_weights(recipe, {}, data, G.draw_weights(names), data.batch(0))
+    loss0 = step0_grads(tr, data.batch(0), loss_name)
+    assert abs(loss0 - fx['losses'][0]) / fx['losses'][0] < 1e-3, (loss0, fx['losses'][0])
+
+
 def test_cfg5_recipe_with_its_bf16_input_gemms_stays_within_the_north_star_tolerance():
     """BASELINE.json configs[4]: the cfg5 recipe as shipped (encoder.gemm_precision = bf16: operands of
     the input-to-hidden products rounded to bf16, fp32 accumulation and state) against the fp32

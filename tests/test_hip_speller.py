@@ -63,6 +63,24 @@ def grad_names(nl, attention):
     ('windowed:normalized_sigmoid', 1, 32, 1, 3)])
 def test_speller_step_matches_oracle(attention, nl, U, K, F, Te):
     """decoder alone on a given 'encoded' tensor: logits, loss and every gradient"""
+    enc_len = np.array([13, 9, 13, 4, 7], np.int32) if Te == 13 else np.array([70, 33, 70, 15, 52], np.int32)
+    check_speller(attention, nl, U, K, F, enc_len, np.array([6, 3, 5, 6, 1], np.int32))
+
+
+def test_speller_step_at_the_cfg5_attention_geometry():
+    """BASELINE.json configs[4] geometry of the frame-sliced location-aware attention — 64 utterances,
+    200 encoder frames (ragged), filtersize 101, numfilt 10 — with the feature widths shrunk (U = 64,
+    E = 24) so that the float64 oracle finishes in seconds: forward, loss and every gradient"""
+    rng = np.random.default_rng(55)
+    enc_len = rng.integers(120, 201, 64).astype(np.int32)
+    enc_len[0] = 200
+    tlen = rng.integers(1, 6, 64).astype(np.int32)
+    tlen[0] = 5
+    check_speller('location_aware', 1, 64, 101, 10, enc_len, tlen)
+    check_speller('vanilla', 1, 64, 0, 0, enc_len, tlen)
+
+
+def check_speller(attention, nl, U, K, F, enc_len, tlen):
     from nabu_amd import variables as vs
     from nabu_amd.autodiff import Tape, SeqLen
     from nabu_amd.neuralnetworks.models.ed_decoders import ed_decoder_factory
@@ -70,7 +88,8 @@ def test_speller_step_matches_oracle(attention, nl, U, K, F, Te):
     attention, _, prob_fn = attention.partition(':')
     prob_fn = prob_fn or 'softmax'
     rng = np.random.default_rng(U + K)
-    B, E, C = 5, 24, 8
+    B, E, C = len(enc_len), 24, 8
+    Te, Lmax = int(enc_len.max()), int(tlen.max()) + 1
     over = {'decoder.num_layers': nl, 'decoder.num_units': U, 'decoder.attention': attention,
             'decoder.probability_fn': prob_fn}
     if attention == 'location_aware':
@@ -79,11 +98,9 @@ def test_speller_step_matches_oracle(attention, nl, U, K, F, Te):
         over.update({'decoder.left_window_width': K, 'decoder.right_window_width': F})
     mc, _, _ = recipes.load_recipe('cfg3_las_vanilla', **over)
     dec = ed_decoder_factory.factory('speller')(mc, {'text': C}, None)
-    enc_len = np.array([13, 9, 13, 4, 7], np.int32) if Te == 13 else np.array([70, 33, 70, 15, 52], np.int32)
     enc = rng.normal(size=(B, Te, E)).astype(np.float32)
     enc *= (np.arange(Te)[None, :, None] < enc_len[:, None, None])
-    tlen = np.array([6, 3, 5, 6, 1], np.int32)
-    tg = rng.integers(0, C - 1, (B, 7)).astype(np.int32)
+    tg = rng.integers(0, C - 1, (B, Lmax)).astype(np.int32)
     for b in range(B):
         tg[b, tlen[b] - 1] = C - 1
         tg[b, tlen[b]:] = 0

@@ -52,7 +52,7 @@ def test_baseline_recipes_construct(recipe):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason='reference not mounted')
-@pytest.mark.parametrize('recipe', ['DBLSTM/TIMIT', 'LAS/TIMIT'])
+@pytest.mark.parametrize('recipe', ['DBLSTM/TIMIT', 'LAS/TIMIT', 'LAS/GP'])
 def test_reference_recipe_cfgs_load_unmodified(recipe):
     """The reference's own model.cfg / trainer.cfg drive the new classes unchanged."""
     from nabu_amd.neuralnetworks.trainers import trainer_factory
@@ -65,7 +65,12 @@ def test_reference_recipe_cfgs_load_unmodified(recipe):
         server=None, task_index=0)
     enc = tr.model.encoder.conf
     assert enc['num_units'] == '128' and float(enc['dropout']) == 0.5
-    if recipe == 'LAS/TIMIT':
+    if recipe == 'LAS/GP':        # the windowed-attention recipe (reference attention.py:294-396)
+        dec = tr.model.decoder.conf
+        assert (dec['attention'], dec['left_window_width'], dec['right_window_width']) == ('windowed', '10', '15')
+        assert dec['num_layers'] == '2' and tr.model.output_dims == {'phones': 48}
+        assert tr.conf['loss'] == 'average_cross_entropy'
+    elif recipe == 'LAS/TIMIT':
         assert tr.model.decoder.conf['attention'] == 'vanilla'       # from defaults/speller.cfg
         assert tr.model.decoder.conf['sample_prob'] == '0.1'
         assert tr.conf['loss'] == 'average_cross_entropy'
