@@ -83,6 +83,19 @@ int nabu_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
                   long long a_seg_stride, long long b_seg_stride, void *ws,
                   size_t ws_bytes, nabu_stream_t stream);
 
+/* Decoder-step product: C[M,N] = [A | A2]·[B ; B2] + beta*C + bias for M <= 64 batch rows — the
+ * reduction index runs over two operand pairs (the Speller cell's concat([context, h])·kernel,
+ * nabu/neuralnetworks/models/ed_decoders/speller.py:33-45 -> tf LSTMCell's single matmul on the
+ * concatenated input) without a concatenated copy, in ONE launch: workgroups own (column slice,
+ * k-chunk) pairs, write their partial tiles through to memory, and the last arriver of a column
+ * slice (a ticket per slice) sums the partials in chunk order — deterministic, no float atomics,
+ * no separate reduce launch.  Requirements: N % 32 == 0, K1 and K2 multiples of 64 (K2 may be 0),
+ * lda/lda2 % 4 == 0, 16-byte aligned operands; NABU_EUNSUP otherwise.  Exact fp32. */
+size_t nabu_gemm2_ws_bytes(int M, int N, int K1, int K2);
+int nabu_gemm2_f32(int M, int N, int K1, const float *A, int lda, const float *B, int ldb, int K2,
+                   const float *A2, int lda2, const float *B2, int ldb2, float beta, float *C, int ldc,
+                   const float *bias, void *ws, size_t ws_bytes, nabu_stream_t stream);
+
 /* out[n] = beta*out[n] + sum_m A[m*lda + n]  (bias gradients; deterministic
  * two-stage tree).  ws >= nabu_colsum_ws_bytes(M,N). */
 size_t nabu_colsum_ws_bytes(int M, int N);

@@ -30,6 +30,8 @@ SIGNATURES = {
                            _vp, _sz, _vp]),
     'nabu_gemm_ex': (_i, [_i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i, _vp, _i, _ll, _ll,
                           _vp, _sz, _vp]),
+    'nabu_gemm2_ws_bytes': (_sz, [_i, _i, _i, _i]),
+    'nabu_gemm2_f32': (_i, [_i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _i, _vp, _vp, _sz, _vp]),
     'nabu_gemm_set_default_precision': (_i, [_i]),
     'nabu_gemm_get_default_precision': (_i, []),
     'nabu_colsum_ws_bytes': (_sz, [_i, _i]),

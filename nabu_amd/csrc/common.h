@@ -36,6 +36,12 @@ int fail(int code, const char *fmt, ...);
 // speller.hip: x[r*ld] = 1 for r < rows (initial alignments of the windowed attention)
 int first_col_one(int rows, int ld, float *x, hipStream_t s);
 
+// elementwise.hip: dropout / scheduled sampling on a sub-batch of rows with the whole batch's random stream
+int dropout_rows(size_t n, const float *x, float *y, float keep_prob, unsigned long long seed, unsigned long long offset,
+                 size_t first_elem, hipStream_t stream);
+int sample_ids_rows(int B, int C, const float *logits, float prob, unsigned long long seed, unsigned long long offset,
+                    const int32_t *teacher_ids, int32_t *out_ids, int b0, hipStream_t stream);
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }

@@ -137,19 +137,22 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
 }
 __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
+// i0: index of the first 4-element group of x inside the array the random stream is defined on (a
+// sub-batch of rows draws exactly the numbers the whole batch would draw for those rows)
 __global__ __launch_bounds__(256) void dropout_kernel(size_t n, const float *__restrict__ x,
                                                       float *__restrict__ y, float keep,
-                                                      unsigned long long seed, unsigned long long offset) {
+                                                      unsigned long long seed, unsigned long long offset, size_t i0) {
   const size_t n4 = (n + 3) / 4;
   const float inv = 1.0f / keep;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+  for (size_t il = (size_t)blockIdx.x * 256 + threadIdx.x; il < n4; il += (size_t)gridDim.x * 256) {
+    const size_t i = il + i0;
     const uint4 r = philox4x32_10(make_uint4((unsigned)i, (unsigned)(i >> 32), (unsigned)offset,
                                              (unsigned)(offset >> 32)),
                                   make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
     const unsigned rr[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const size_t e = 4 * i + j;
+      const size_t e = 4 * il + j;
       if (e < n) y[e] = u01(rr[j]) < keep ? x[e] * inv : 0.f;
     }
   }
@@ -160,10 +163,10 @@ __global__ __launch_bounds__(256) void sample_ids_kernel(int B, int C, const flo
                                                          float prob, unsigned long long seed,
                                                          unsigned long long offset,
                                                          const int32_t *__restrict__ teacher,
-                                                         int32_t *__restrict__ out) {
+                                                         int32_t *__restrict__ out, int b0) {
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
-  const uint4 r = philox4x32_10(make_uint4((unsigned)b, 0u, (unsigned)offset, (unsigned)(offset >> 32)),
+  const uint4 r = philox4x32_10(make_uint4((unsigned)(b + b0), 0u, (unsigned)offset, (unsigned)(offset >> 32)),
                                 make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
   int id = teacher[b];
   if (u01(r.x) < prob) {
@@ -398,10 +401,31 @@ extern "C" int nabu_dropout_f32(size_t n, const float *x, float *y, float keep_p
   if (n == 0) return 0;
   NABU_CHECK_ARG(x && y && keep_prob > 0.f && keep_prob <= 1.f, "dropout: bad argument");
   hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), n, x, y, keep_prob, seed, offset);
+                     static_cast<hipStream_t>(stream), n, x, y, keep_prob, seed, offset, (size_t)0);
   NABU_LAUNCH_CHECK();
   return 0;
 }
+
+namespace nabu {
+// rows [first_elem, first_elem + n) of a larger array (first_elem % 4 == 0): the same random numbers the
+// call on the whole array would use for them
+int dropout_rows(size_t n, const float *x, float *y, float keep_prob, unsigned long long seed, unsigned long long offset,
+                 size_t first_elem, hipStream_t stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, stream, n, x, y, keep_prob, seed, offset,
+                     first_elem / 4);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+int sample_ids_rows(int B, int C, const float *logits, float prob, unsigned long long seed, unsigned long long offset,
+                    const int32_t *teacher_ids, int32_t *out_ids, int b0, hipStream_t stream) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(sample_ids_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, B, C, logits, prob, seed, offset,
+                     teacher_ids, out_ids, b0);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace nabu
 
 extern "C" int nabu_sample_ids(int B, int C, const float *logits, float prob, unsigned long long seed,
                                unsigned long long offset, const int32_t *teacher_ids, int32_t *out_ids,
@@ -410,7 +434,7 @@ extern "C" int nabu_sample_ids(int B, int C, const float *logits, float prob, un
   NABU_CHECK_ARG(B > 0 && C > 0 && logits && teacher_ids && out_ids && prob >= 0.f && prob <= 1.f,
                  "sample_ids: bad argument");
   hipLaunchKernelGGL(sample_ids_kernel, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     B, C, logits, prob, seed, offset, teacher_ids, out_ids);
+                     B, C, logits, prob, seed, offset, teacher_ids, out_ids, 0);
   NABU_LAUNCH_CHECK();
   return 0;
 }

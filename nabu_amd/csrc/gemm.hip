@@ -98,7 +98,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * a.ksplit;
+  if (a.nbatch > 1) {   // batched: blockIdx.z selects the product, the whole K is one slice
+    a.A += (size_t)blockIdx.z * a.a_bs;
+    a.B += (size_t)blockIdx.z * a.b_bs;
+    a.C += (size_t)blockIdx.z * a.c_bs;
+  }
+  const int kbeg = a.nbatch > 1 ? 0 : blockIdx.z * a.ksplit;
   const int kend = min(a.K, kbeg + a.ksplit);
 
   f32x16 acc[2][2];
@@ -391,6 +396,30 @@ static int choose_split(int M, int N, int K, int *ksplit) {
   return ns;
 }
 
+int gemm_batched_f32(bool transA, bool transB, int M, int N, int K, const float *A, int lda, long long a_bs,
+                     const float *B, int ldb, long long b_bs, float beta, float *C, int ldc, long long c_bs, int nbatch,
+                     hipStream_t s) {
+  if (M <= 0 || N <= 0 || nbatch <= 0) return 0;
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.bias = nullptr; a.partial = nullptr;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.alpha = 1.f; a.beta = beta; a.kseg = 0; a.a_seg = a.b_seg = 0;
+  a.ksplit = (K + BK - 1) / BK * BK; if (a.ksplit < BK) a.ksplit = BK;
+  a.nsplit = 1; a.swz = 0;
+  auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  a.vecA = al16(A) && lda % 4 == 0 && a_bs % 4 == 0;
+  a.vecB = al16(B) && ldb % 4 == 0 && b_bs % 4 == 0;
+  a.nbatch = nbatch > 1 ? nbatch : 2;   // > 1 selects the batched addressing (a single product: z = 0 only)
+  a.a_bs = a_bs; a.b_bs = b_bs; a.c_bs = c_bs;
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nbatch), block(256);
+  if (transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, a);
+  else if (transA) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, a);
+  else if (transB) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, a);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace nabu
 
 using namespace nabu;
@@ -406,6 +435,24 @@ extern "C" size_t nabu_gemm_ws_bytes(int M, int N, int K) {
   const int kc = gemm_skinny_chunk(M, N, K);
   if (kc && K / kc > ns) ns = K / kc;
   return ns > 1 ? (size_t)ns * M * N * sizeof(float) : 0;
+}
+
+// [A | A2]·[B ; B2] with the split-K reduction inside the launch (gemm_skinny.hip)
+extern "C" size_t nabu_gemm2_ws_bytes(int M, int N, int K1, int K2) {
+  if (M <= 0 || N <= 0 || K1 <= 0 || K2 < 0) return 0;
+  return 4096 + ((size_t)(K1 + K2) / 64 + 1) * M * N * sizeof(float);
+}
+extern "C" int nabu_gemm2_f32(int M, int N, int K1, const float *A, int lda, const float *B, int ldb, int K2,
+                              const float *A2, int lda2, const float *B2, int ldb2, float beta, float *C, int ldc,
+                              const float *bias, void *ws, size_t ws_bytes, nabu_stream_t stream) {
+  NABU_CHECK_ARG(M > 0 && N > 0 && K1 > 0 && K2 >= 0, "gemm2: bad dimensions");
+  NABU_CHECK_ARG(A && B && C && ws && (K2 == 0 || (A2 && B2)), "gemm2: null pointer");
+  NABU_CHECK_ARG(N / 32 * sizeof(unsigned) <= 4096, "gemm2: N too large");
+  if (ws_bytes < nabu_gemm2_ws_bytes(M, N, K1, K2)) return fail(NABU_EWS, "gemm2: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  NABU_HIP(hipMemsetAsync(ws, 0, 4096, s));
+  return gemm_skinny_fused(M, N, K1, A, lda, B, ldb, K2, A2, lda2, B2, ldb2, beta, C, ldc, bias,
+                           reinterpret_cast<float *>(static_cast<char *>(ws) + 4096), static_cast<unsigned *>(ws), s);
 }
 
 static int g_default_precision = 0;   // 0 = not initialised yet
@@ -497,6 +544,7 @@ static int gemm_run(int precision, int transA, int transB, int M, int N, int K, 
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.alpha = alpha; a.beta = beta;
   a.kseg = kseg; a.a_seg = a_seg_stride; a.b_seg = b_seg_stride;
+  a.nbatch = 1; a.a_bs = a.b_bs = a.c_bs = 0;
   a.nsplit = K > 0 ? choose_split(M, N, K, &a.ksplit) : 1;
   if (K == 0) a.ksplit = BK;
   auto al16p = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };

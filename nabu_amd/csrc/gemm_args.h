@@ -21,6 +21,9 @@ struct GemmArgs {
   int nsplit;
   int vecA, vecB;  // 16-byte vector loads allowed
   int swz;         // tile order: 0 = blockIdx as is, g > 0 = XCD-aware with groups of g row tiles
+  // batched products (generic kernel only): blockIdx.z = batch index, operands advance by these strides
+  int nbatch;
+  long long a_bs, b_bs, c_bs;
 };
 
 // Workgroup -> output tile.  The dispatcher deals workgroups round-robin over the 8 XCDs (linear id
@@ -44,6 +47,16 @@ __device__ __forceinline__ void tile_of_block(int swz, int *tm, int *tn) {
 // skinny products (gemm_skinny.hip): M <= 64, no transposes
 int gemm_skinny_chunk(int M, int N, int K);
 int gemm_skinny_launch(const GemmArgs &a, hipStream_t stream);
+// decoder-step variant: two operand pairs along the reduction, split-K reduce finished in the launch
+int gemm_skinny_fused(int M, int N, int K1, const float *A, int lda, const float *B, int ldb, int K2, const float *A2,
+                      int lda2, const float *B2, int ldb2, float beta, float *C, int ldc, const float *bias,
+                      float *partial, unsigned *tickets, hipStream_t s);
+
+// batch of nbatch independent products C_i (+)= op(A_i)·op(B_i) in ONE launch of the generic fp32 kernel
+// (operand i starts i*stride elements after operand 0); no split-K
+int gemm_batched_f32(bool transA, bool transB, int M, int N, int K, const float *A, int lda, long long a_bs,
+                     const float *B, int ldb, long long b_bs, float beta, float *C, int ldc, long long c_bs, int nbatch,
+                     hipStream_t s);
 
 // bf16-split kernels (gemm_bf16.hip); planes = 1 (bf16), 2 (bf16x3) or 3 (bf16x6)
 int gemm_bf16_launch(const GemmArgs &a, bool transA, bool transB, int planes, dim3 grid, hipStream_t stream);

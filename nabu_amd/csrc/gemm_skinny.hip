@@ -9,48 +9,59 @@
 // Exact fp32 (v_mfma_f32_32x32x2_f32).
 #include "gemm_args.h"
 
+#include <stdlib.h>
+
 namespace nabu {
 
-template <int MT>   // row tiles of 32
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+// The tile product shared by both kernels: acc (per wave, over its quarter of the k-chunk) of
+// A[M, k0:k0+KC] · B[k0:k0+KC, n0:n0+32].  Every global load of the workgroup — the wave's rows of B (one
+// float per lane and row, 128-byte row segments) and the A chunk — is issued BEFORE anything waits, so
+// the memory latency is paid once per workgroup instead of once per batch of 8 rows (which made a
+// 32 KB stream take ~8 us).
+template <int MT>
+__device__ __forceinline__ void skinny_tile(const float *__restrict__ Ap, int lda, const float *__restrict__ Bp, int ldb,
+                                            int k0, int KC, int M, int n0, float *sm, f32x16 (&acc)[MT]) {
   constexpr int MR = 32 * MT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int n0 = blockIdx.x * 32;
-  const int KC = a.ksplit;
-  const int k0 = blockIdx.y * KC;
+  const int kw = KC / 4;                              // k values of this wave: 16, 32 or 64
+  const int li = lane & 31, lk = lane >> 5;
+  const float *bp = Bp + (size_t)(k0 + w * kw + lk) * ldb + n0 + li;
+  const size_t bstep = 2 * (size_t)ldb;
+  float b[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) b[j] = (2 * j < kw) ? bp[(size_t)j * bstep] : 0.f;
   // A^T chunk -> LDS xT[k][m]
   for (int idx = tid; idx < (KC / 4) * MR; idx += 256) {
     const int m = idx % MR, kq = idx / MR;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (m < a.M) v = *reinterpret_cast<const float4 *>(a.A + (size_t)m * a.lda + k0 + 4 * kq);
+    if (m < M) v = *reinterpret_cast<const float4 *>(Ap + (size_t)m * lda + k0 + 4 * kq);
     float *d = sm + (size_t)(4 * kq) * MR + m;
     d[0] = v.x; d[MR] = v.y; d[2 * MR] = v.z; d[3 * MR] = v.w;
   }
   __syncthreads();
-  f32x16 acc[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  const int kw = KC / 4;                              // k values of this wave
-  const int li = lane & 31, lk = lane >> 5;
-  const float *bp = a.B + (size_t)(k0 + w * kw + lk) * a.ldb + n0 + li;
   const float *xp = sm + (size_t)(w * kw + lk) * MR + li;
-  const size_t bstep = 2 * (size_t)a.ldb;
-  for (int kk = 0; kk < kw; kk += 16) {               // 8 MFMA k-steps per batch of loads
-    float b[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) b[j] = bp[(size_t)j * bstep];
-    bp += 8 * bstep;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < 32; ++j) {
+    if (2 * j < kw) {
 #pragma unroll
       for (int t = 0; t < MT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xp[(size_t)(kk + 2 * j) * MR + 32 * t], b[j], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xp[(size_t)(2 * j) * MR + 32 * t], b[j], acc[t], 0, 0, 0);
     }
   }
-  __syncthreads();                                    // xT is dead: reuse LDS for the wave partials
+  __syncthreads();                                    // xT is dead: the callers reuse LDS for the wave partials
+}
+
+template <int MT>   // row tiles of 32
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n0 = blockIdx.x * 32;
+  f32x16 acc[MT];
+  skinny_tile<MT>(a.A, a.lda, a.B, a.ldb, blockIdx.y * a.ksplit, a.ksplit, a.M, n0, sm, acc);
   float *red = sm;                                    // [4 waves][MT][16][64]
 #pragma unroll
   for (int t = 0; t < MT; ++t)
@@ -71,6 +82,121 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
       a.partial[((size_t)blockIdx.y * a.M + m) * a.N + n] = s;
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// Decoder-step variant: the same product with (1) the reduction index running over TWO operand
+// pairs, C = [A | A2] · [B ; B2] (the Speller cell's [context, h]·kernel without a concatenated copy),
+// and (2) the split-K reduction finished INSIDE the launch: every workgroup writes its partial tile
+// through to memory, takes a ticket of its column slice, and the workgroup that draws the last
+// ticket sums the slice's partials in chunk order — the result does not depend on which workgroup
+// that is (deterministic, no float atomics), and the separate reduce launch (a third of a decoder
+// step's kernel time) is gone.  tickets: one counter per column slice, zero before the launch.
+struct SkinnyFuse {
+  const float *A2, *B2;
+  int lda2, ldb2, K1;        // reduction indices [0, K1) come from (A, B), the rest from (A2, B2)
+  unsigned *tickets;
+  int heavy;                 // 1: the partners of a column slice may sit on different XCDs (agent-scope fences)
+};
+
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_skinny_fused_kernel(GemmArgs a, SkinnyFuse f) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ int last_flag;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n0 = blockIdx.x * 32;
+  const int KC = a.ksplit;
+  int k0 = blockIdx.y * KC;
+  const float *Ap = a.A, *Bp = a.B;
+  int lda = a.lda, ldb = a.ldb;
+  if (k0 >= f.K1) { k0 -= f.K1; Ap = f.A2; Bp = f.B2; lda = f.lda2; ldb = f.ldb2; }
+  f32x16 acc[MT];
+  skinny_tile<MT>(Ap, lda, Bp, ldb, k0, KC, a.M, n0, sm, acc);
+  float *red = sm;
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((w * MT + t) * 16 + r) * 64 + lane] = acc[t][r];
+  __syncthreads();
+  const int ns = a.nsplit;
+  for (int e = tid; e < MT * 16 * 64; e += 256) {
+    const float s = red[e] + red[MT * 1024 + e] + red[2 * MT * 1024 + e] + red[3 * MT * 1024 + e];
+    const int l = e & 63, r = (e >> 6) & 15, t = e >> 10;
+    const int m = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), n = n0 + (l & 31);
+    if (m >= a.M) continue;
+    if (ns == 1) {
+      float *c = a.C + (size_t)m * a.ldc + n;
+      float v = a.alpha * s + (a.bias ? a.bias[n] : 0.f);
+      if (a.beta != 0.f) v += a.beta * *c;
+      *c = v;
+    } else {
+      a.partial[((size_t)blockIdx.y * a.M + m) * a.N + n] = s;
+    }
+  }
+  if (ns == 1) return;
+  if (f.heavy) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // partners on other XCDs: write back this L2
+  else         __builtin_amdgcn_s_waitcnt(0);                        // same L2: the stores have been performed there
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(f.tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = (old == (unsigned)(ns - 1));
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  if (f.heavy) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  for (int e = tid; e < a.M * 32; e += 256) {
+    const int m = e >> 5, n = n0 + (e & 31);
+    float s = 0.f;
+    for (int z = 0; z < ns; ++z)      // chunk order: independent of the arrival order
+      s += __hip_atomic_load(a.partial + ((size_t)z * a.M + m) * a.N + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float *c = a.C + (size_t)m * a.ldc + n;
+    float v = a.alpha * s + (a.bias ? a.bias[n] : 0.f);
+    if (a.beta != 0.f) v += a.beta * *c;
+    *c = v;
+  }
+  if (tid == 0) __hip_atomic_store(f.tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for reuse
+}
+
+// C[M,N] = [A | A2]·[B ; B2] (+ bias, beta*C); M <= 64, N % 32 == 0, K1 and K2 multiples of the
+// chunk (K2 may be 0).  partial: nchunks*M*N floats; tickets: N/32 zeroed counters (left zero).
+int gemm_skinny_fused(int M, int N, int K1, const float *A, int lda, const float *B, int ldb, int K2, const float *A2,
+                      int lda2, const float *B2, int ldb2, float beta, float *C, int ldc, const float *bias,
+                      float *partial, unsigned *tickets, hipStream_t s) {
+  int kc = 0;
+  for (int c = 256; c >= 64; c >>= 1)
+    if (K1 % c == 0 && K2 % c == 0) { kc = c; break; }
+  if (M > 64 || N % 32 != 0 || kc == 0 || K1 <= 0 || lda % 4 || (K2 && lda2 % 4))
+    return fail(NABU_EUNSUP, "skinny product: unsupported shape M=%d N=%d K=%d+%d", M, N, K1, K2);
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.bias = bias; a.partial = partial;
+  a.M = M; a.N = N; a.K = K1 + K2; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.alpha = 1.f; a.beta = beta; a.kseg = 0; a.a_seg = a.b_seg = 0;
+  a.ksplit = kc; a.nsplit = (K1 + K2) / kc; a.vecA = a.vecB = 1; a.swz = 0;
+  a.nbatch = 1; a.a_bs = a.b_bs = a.c_bs = 0;
+  // Workgroup (x, y) has linear id x + y*gridDim.x and the dispatcher deals linear ids round-robin over the
+  // 8 XCDs: with gridDim.x % 8 == 0 all k-chunk partners of a column slice share one XCD and therefore one
+  // L2 — the partial tiles never need to leave it (L1 is bypassed by the reader's sc1 loads).  Any other
+  // width, or NABU_SKINNY_HEAVY=1, takes agent-scope release/acquire fences.
+  static int heavy_env = -1;
+  if (heavy_env < 0) { const char *e = getenv("NABU_SKINNY_HEAVY"); heavy_env = e ? atoi(e) : 0; }
+  SkinnyFuse f = {A2, B2, lda2, ldb2, K1, tickets, ((N / 32) % 8 != 0 || heavy_env) ? 1 : 0};
+  const int MT = M > 32 ? 2 : 1;
+  const size_t xt = (size_t)kc * 32 * MT * sizeof(float), red = (size_t)4 * MT * 1024 * sizeof(float);
+  const size_t lds = xt > red ? xt : red;
+  dim3 grid(N / 32, a.nsplit);
+  if (MT == 1) {
+    hipLaunchKernelGGL(gemm_skinny_fused_kernel<1>, grid, dim3(256), lds, s, a, f);
+  } else {
+    static bool configured = false;
+    if (!configured) {
+      NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_fused_kernel<2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      configured = true;
+    }
+    hipLaunchKernelGGL(gemm_skinny_fused_kernel<2>, grid, dim3(256), lds, s, a, f);
+  }
+  NABU_LAUNCH_CHECK();
+  return 0;
 }
 
 // k-chunk of the skinny kernel: the largest of 256/128/64 that divides K (0 = not eligible)

@@ -12,6 +12,9 @@
 //   attn_bwd          : the matching gradient (tanh recomputed, not stored).
 // Layouts: keys [B,Te,U], values [B,Te,E] batch-major; per-step state time-major.
 #include "common.h"
+#include "gemm_args.h"
+
+#include <stdlib.h>
 
 namespace nabu {
 
@@ -1063,24 +1066,85 @@ struct SpWs {
   size_t z, dl, dH, dCtx, dkeys, dv, dwf, dck, attn, dq, dz[NABU_SPELLER_MAX_LAYERS], dh[2][NABU_SPELLER_MAX_LAYERS],
       dc[2][NABU_SPELLER_MAX_LAYERS], dctx[2], dal[2], dx, tmp, gemm, gemm_bytes, total;
   size_t wqT, kxT[NABU_SPELLER_MAX_LAYERS], khT[NABU_SPELLER_MAX_LAYERS];   // transposed weights (backward)
+  size_t tickets, fpart;   // fused skinny products: per-column-slice tickets (zeroed per call), partial tiles
+  // the decoder steps run as NS independent sub-batches on NS streams: per sub-batch slices of
+  // the scratch that a step's kernels share
+  int NS, S;               // sub-batches; attention-backward slices per utterance (of a sub-batch)
+  size_t attn_each, gemm_each, fpart_each, z_each;
 };
+
+// The L decoder steps are a chain of small dependent kernels (each ~5 us of launch + memory latency,
+// whatever its size).  Utterances are independent of each other until the weight gradients are summed, so
+// the batch is cut into NS sub-batches whose chains run concurrently on NS streams (forked from / joined
+// to the caller's stream by events); what one chain leaves idle the others use.  NABU_SPELLER_STREAMS=n
+// overrides (1 = off).
+static int sp_nsub(const nabu_speller_desc *d) {
+  static int env = -1;
+  if (env < 0) { const char *e = getenv("NABU_SPELLER_STREAMS"); env = e ? atoi(e) : 0; }
+  int want = env > 0 ? env : 4;
+  while (want > 1 && (d->B % want != 0 || d->B / want < (env > 0 ? 1 : 16))) want /= 2;
+  return want < 1 ? 1 : want;
+}
+
+struct SubStreams {
+  int n;
+  hipStream_t st[8];
+  hipEvent_t fork, done[8];
+};
+static int sub_streams(int n, hipStream_t main, SubStreams *out) {
+  static thread_local hipStream_t side[8] = {nullptr};
+  static thread_local hipEvent_t ev[9] = {nullptr};
+  out->n = n;
+  out->st[0] = main;
+  for (int i = 1; i < n; ++i) {
+    if (!side[i]) NABU_HIP(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
+    out->st[i] = side[i];
+  }
+  for (int i = 0; i <= n && i < 9; ++i)
+    if (!ev[i]) NABU_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+  out->fork = ev[0];
+  for (int i = 1; i < n; ++i) out->done[i] = ev[i];
+  return 0;
+}
+static int sub_fork(const SubStreams &ss) {
+  if (ss.n == 1) return 0;
+  NABU_HIP(hipEventRecord(ss.fork, ss.st[0]));
+  for (int i = 1; i < ss.n; ++i) NABU_HIP(hipStreamWaitEvent(ss.st[i], ss.fork, 0));
+  return 0;
+}
+static int sub_join(const SubStreams &ss) {
+  for (int i = 1; i < ss.n; ++i) {
+    NABU_HIP(hipEventRecord(ss.done[i], ss.st[i]));
+    NABU_HIP(hipStreamWaitEvent(ss.st[0], ss.done[i], 0));
+  }
+  return 0;
+}
+static nabu_attn_desc sub_attn_desc(const nabu_speller_desc *d, int Bn) {
+  nabu_attn_desc a = {sizeof(nabu_attn_desc), Bn, d->Te, d->E, d->U, d->kind, d->K, d->F, d->prob_fn};
+  return a;
+}
 
 static SpWs sp_ws(const nabu_speller_desc *d) {
   SpWs s;
   const size_t B = d->B, L = d->L, U = d->U, E = d->E, Te = d->Te, C = d->C, F = d->F, K = d->K;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 3) / 4 * 4; return r; };
+  s.NS = sp_nsub(d);
+  const size_t NS = s.NS, Bn = B / NS;
+  s.z_each = Bn * 4 * U;
   s.z = take(B * 4 * U);
   s.dl = take(L * B * C);
   s.dH = take(L * B * U);
   s.dCtx = take(L * B * E);
   s.dkeys = take(B * Te * U);
-  const nabu_attn_desc adesc = {sizeof(nabu_attn_desc), d->B, d->Te, d->E, d->U, d->kind, d->K, d->F, d->prob_fn};
+  const nabu_attn_desc adesc = sub_attn_desc(d, (int)Bn);
   const size_t S = attn_bwd_nslices(&adesc);
+  s.S = (int)S;
   s.dv = take(B * S * U);
   s.dwf = take(B * S * F * U + 4);
-  s.attn = take((nabu_attn_bwd_ws_bytes(&adesc) > nabu_attn_fwd_ws_bytes(&adesc) ? nabu_attn_bwd_ws_bytes(&adesc)
-                                                                                   : nabu_attn_fwd_ws_bytes(&adesc)) / 4 + 4);
+  s.attn_each = ((nabu_attn_bwd_ws_bytes(&adesc) > nabu_attn_fwd_ws_bytes(&adesc) ? nabu_attn_bwd_ws_bytes(&adesc)
+                                                                                    : nabu_attn_fwd_ws_bytes(&adesc)) / 4 + 4 + 3) / 4 * 4;
+  s.attn = take(NS * s.attn_each);
   s.dck = take(B * K * F + 4);
   s.dq = take(L * B * U);
   for (int n = 0; n < d->num_layers; ++n) {
@@ -1094,6 +1158,12 @@ static SpWs sp_ws(const nabu_speller_desc *d) {
   for (int n = 0; n < d->num_layers; ++n) {
     s.kxT[n] = take(4 * U * (n == 0 ? E : U));
     s.khT[n] = take(4 * U * U);
+  }
+  s.tickets = take(NS * 1024);
+  {
+    size_t kmax = E + U > 4 * U ? E + U : 4 * U, nmax = 4 * U > E ? 4 * U : E;
+    s.fpart_each = ((kmax / 64 + 1) * Bn * nmax + 3) / 4 * 4;
+    s.fpart = take(NS * s.fpart_each);
   }
   size_t g = 0;
   auto mx = [&](size_t v) { if (v > g) g = v; };
@@ -1111,7 +1181,8 @@ static SpWs sp_ws(const nabu_speller_desc *d) {
   mx(nabu_gemm_ws_bytes((int)U, (int)(4 * U), BL)); mx(nabu_gemm_ws_bytes((int)Te, (int)E, (int)L));
   mx(nabu_colsum_ws_bytes(BL, (int)(4 * U))); mx(nabu_colsum_ws_bytes((int)(B * 8), (int)(F * U + K * F + U)));
   s.gemm_bytes = (g + 255) / 256 * 256;
-  s.gemm = take(s.gemm_bytes / 4 + 4);
+  s.gemm_each = s.gemm_bytes / 4 + 4;
+  s.gemm = take(NS * s.gemm_each);
   s.total = o;
   return s;
 }
@@ -1134,6 +1205,25 @@ static int mm(bool ta, bool tb, int M, int N, int K, const float *A, int lda, co
   return nabu_gemm_f32(ta, tb, M, N, K, 1.f, A, lda, Bm, ldb, beta, C, ldc, bias, 0, 0, 0, ws, wsb, st);
 }
 #define SP_TRY(call) do { int e_ = (call); if (e_) return e_; } while (0)
+
+// C[M,N] = A·B + A2·B2 (+ beta*C): ONE launch with the split-K reduction inside it when the shape
+// allows (gemm_skinny.hip), else two plain products
+static bool fused_ok(int M, int N, int K1, int lda, int K2, int lda2) {
+  static int env = -1;
+  if (env < 0) { const char *e = getenv("NABU_SPELLER_FUSED"); env = e ? atoi(e) : 1; }
+  return env && M <= 64 && N % 32 == 0 && K1 > 0 && K1 % 64 == 0 && K2 % 64 == 0 && lda % 4 == 0 && (K2 == 0 || lda2 % 4 == 0);
+}
+static int mm2(int M, int N, int K1, const float *A, int lda, const float *Bm, int ldb, int K2, const float *A2, int lda2,
+               const float *B2, int ldb2, float beta, float *C, int ldc, float *w, const SpWs &W, int sub, float *gw,
+               size_t gwb, nabu_stream_t st) {
+  if (fused_ok(M, N, K1, lda, K2, lda2))
+    return gemm_skinny_fused(M, N, K1, A, lda, Bm, ldb, K2, A2, lda2, B2, ldb2, beta, C, ldc, nullptr,
+                             w + W.fpart + (size_t)sub * W.fpart_each,
+                             reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)sub * 1024, static_cast<hipStream_t>(st));
+  if (int e = mm(false, false, M, N, K1, A, lda, Bm, ldb, beta, C, ldc, nullptr, gw, gwb, st)) return e;
+  if (K2 > 0) return mm(false, false, M, N, K2, A2, lda2, B2, ldb2, 1.f, C, ldc, nullptr, gw, gwb, st);
+  return 0;
+}
 
 }  // namespace nabu
 
@@ -1170,8 +1260,8 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
   float *gw = w + W.gemm;
   const size_t gwb = W.gemm_bytes;
   const nabu_attn_desc ad = {sizeof(nabu_attn_desc), B, Te, E, U, d->kind, d->K, d->F, d->prob_fn};
-  const size_t attn_fwd_wsb = nabu_attn_fwd_ws_bytes(&ad);
   const bool drop = d->keep_prob < 1.f;
+  NABU_HIP(hipMemsetAsync(w + W.tickets, 0, (size_t)W.NS * 1024 * 4, s));
   // zero initial state (index 0 of every time-major array)
   for (int n = 0; n < nl; ++n) {
     NABU_HIP(hipMemsetAsync(r + R.H[n], 0, (size_t)B * U * 4, s));
@@ -1187,44 +1277,60 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
   const bool sampling = d->sample_prob > 0.f;
   // keys = memory_layer(values)
   SP_TRY(mm(false, false, B * Te, U, E, values, E, p->memory_kernel, U, 0.f, r + R.keys, U, nullptr, gw, gwb, stream));
-  float *z = w + W.z;
+  const int NS = W.NS, Bn = B / NS;
+  const nabu_attn_desc adn = sub_attn_desc(d, Bn);
+  const size_t attn_fwd_wsb_n = nabu_attn_fwd_ws_bytes(&adn);
+  SubStreams ss;
+  SP_TRY(sub_streams(NS, s, &ss));
+  SP_TRY(sub_fork(ss));
   for (int t = 0; t < L; ++t) {
-    for (int n = 0; n < nl; ++n) {
-      const float *Kn = p->lstm_kernel[n];
-      float *Hn = r + R.H[n], *Cn = r + R.Cs[n];
-      const size_t cur = (size_t)t * B * U, nxt = (size_t)(t + 1) * B * U;
-      if (n == 0) {
-        SP_TRY(mm(false, false, B, 4 * U, E, r + R.ctx + (size_t)t * B * E, E, Kn + (size_t)C * 4 * U, 4 * U, 0.f, z, 4 * U, nullptr, gw, gwb, stream));
-        SP_TRY(mm(false, false, B, 4 * U, U, Hn + cur, U, Kn + (size_t)(C + E) * 4 * U, 4 * U, 1.f, z, 4 * U, nullptr, gw, gwb, stream));
-        SP_TRY(nabu_lstm_cell_fwd(B, U, t, dec_len, z, p->lstm_bias[0], Kn, ids_used + (size_t)t * B, Cn + cur, Hn + cur,
-                                  r + R.acts[0] + (size_t)t * B * 4 * U, Cn + nxt, Hn + nxt, stream));
-      } else {
-        SP_TRY(mm(false, false, B, 4 * U, U, r + R.Ho[n - 1] + nxt, U, Kn, 4 * U, 0.f, z, 4 * U, nullptr, gw, gwb, stream));
-        SP_TRY(mm(false, false, B, 4 * U, U, Hn + cur, U, Kn + (size_t)U * 4 * U, 4 * U, 1.f, z, 4 * U, nullptr, gw, gwb, stream));
-        SP_TRY(nabu_lstm_cell_fwd(B, U, t, dec_len, z, p->lstm_bias[n], nullptr, nullptr, Cn + cur, Hn + cur,
-                                  r + R.acts[n] + (size_t)t * B * 4 * U, Cn + nxt, Hn + nxt, stream));
+    for (int sub = 0; sub < NS; ++sub) {
+      const int b0 = sub * Bn;
+      nabu_stream_t st = static_cast<nabu_stream_t>(ss.st[sub]);
+      float *gws = gw + (size_t)sub * W.gemm_each;
+      float *z = w + W.z + (size_t)b0 * 4 * U;
+      const int32_t *dlen = dec_len + b0;
+      for (int n = 0; n < nl; ++n) {
+        const float *Kn = p->lstm_kernel[n];
+        float *Hn = r + R.H[n] + (size_t)b0 * U, *Cn = r + R.Cs[n] + (size_t)b0 * U;
+        const size_t cur = (size_t)t * B * U, nxt = (size_t)(t + 1) * B * U;
+        if (n == 0) {
+          SP_TRY(mm2(Bn, 4 * U, E, r + R.ctx + (size_t)t * B * E + (size_t)b0 * E, E, Kn + (size_t)C * 4 * U, 4 * U, U,
+                     Hn + cur, U, Kn + (size_t)(C + E) * 4 * U, 4 * U, 0.f, z, 4 * U, w, W, sub, gws, gwb, st));
+          SP_TRY(nabu_lstm_cell_fwd(Bn, U, t, dlen, z, p->lstm_bias[0], Kn, ids_used + (size_t)t * B + b0, Cn + cur,
+                                    Hn + cur, r + R.acts[0] + (size_t)t * B * 4 * U + (size_t)b0 * 4 * U, Cn + nxt,
+                                    Hn + nxt, st));
+        } else {
+          SP_TRY(mm2(Bn, 4 * U, U, r + R.Ho[n - 1] + nxt + (size_t)b0 * U, U, Kn, 4 * U, U, Hn + cur, U,
+                     Kn + (size_t)U * 4 * U, 4 * U, 0.f, z, 4 * U, w, W, sub, gws, gwb, st));
+          SP_TRY(nabu_lstm_cell_fwd(Bn, U, t, dlen, z, p->lstm_bias[n], nullptr, nullptr, Cn + cur, Hn + cur,
+                                    r + R.acts[n] + (size_t)t * B * 4 * U + (size_t)b0 * 4 * U, Cn + nxt, Hn + nxt, st));
+        }
+        if (drop)
+          SP_TRY(dropout_rows((size_t)Bn * U, Hn + nxt, r + R.Ho[n] + nxt + (size_t)b0 * U, d->keep_prob, d->seed,
+                              d->seed_offset + (unsigned long long)t * nl + n, (size_t)b0 * U, ss.st[sub]));
       }
-      if (drop)
-        SP_TRY(nabu_dropout_f32((size_t)B * U, Hn + nxt, r + R.Ho[n] + nxt, d->keep_prob, d->seed,
-                                d->seed_offset + (unsigned long long)t * nl + n, stream));
-    }
-    const float *htop = r + R.Ho[nl - 1] + (size_t)(t + 1) * B * U;
-    float *qt = r + R.q + (size_t)t * B * U;
-    SP_TRY(mm(false, false, B, U, U, htop, U, p->query_kernel, U, 0.f, qt, U, nullptr, gw, gwb, stream));
-    SP_TRY(nabu_attn_fwd(&ad, t, dec_len, enc_len, r + R.keys, values, qt, p->attention_v, p->conv_kernel,
-                         p->conv_proj, r + R.align + (size_t)t * B * Te, r + R.ctx + (size_t)t * B * E,
-                         r + R.align + (size_t)(t + 1) * B * Te, r + R.ctx + (size_t)(t + 1) * B * E,
-                         r + R.znorm + (size_t)t * B, w + W.attn, attn_fwd_wsb, stream));
-    if (sampling && t + 1 < L) {
-      // ScheduledEmbeddingTrainingHelper: the step's logits decide the next input of selected rows
-      float *lt = r + R.logits_tm + (size_t)t * B * C;
-      SP_TRY(mm(false, false, B, C, U, htop, U, p->out_kernel, C, 0.f, lt, C, p->out_bias, gw, gwb, stream));
-      SP_TRY(mm(false, false, B, C, E, r + R.ctx + (size_t)(t + 1) * B * E, E, p->out_kernel + (size_t)U * C, C, 1.f, lt, C,
-                nullptr, gw, gwb, stream));
-      SP_TRY(nabu_sample_ids(B, C, lt, d->sample_prob, d->sample_seed, d->sample_offset + (unsigned long long)t,
-                             ids + (size_t)(t + 1) * B, ids_used + (size_t)(t + 1) * B, stream));
+      const float *htop = r + R.Ho[nl - 1] + (size_t)(t + 1) * B * U + (size_t)b0 * U;
+      float *qt = r + R.q + (size_t)t * B * U + (size_t)b0 * U;
+      SP_TRY(mm2(Bn, U, U, htop, U, p->query_kernel, U, 0, nullptr, 0, nullptr, 0, 0.f, qt, U, w, W, sub, gws, gwb, st));
+      SP_TRY(nabu_attn_fwd(&adn, t, dlen, enc_len + b0, r + R.keys + (size_t)b0 * Te * U, values + (size_t)b0 * Te * E, qt,
+                           p->attention_v, p->conv_kernel, p->conv_proj,
+                           r + R.align + (size_t)t * B * Te + (size_t)b0 * Te, r + R.ctx + (size_t)t * B * E + (size_t)b0 * E,
+                           r + R.align + (size_t)(t + 1) * B * Te + (size_t)b0 * Te,
+                           r + R.ctx + (size_t)(t + 1) * B * E + (size_t)b0 * E, r + R.znorm + (size_t)t * B + b0,
+                           w + W.attn + (size_t)sub * W.attn_each, attn_fwd_wsb_n, st));
+      if (sampling && t + 1 < L) {
+        // ScheduledEmbeddingTrainingHelper: the step's logits decide the next input of selected rows
+        float *lt = r + R.logits_tm + (size_t)t * B * C + (size_t)b0 * C;
+        SP_TRY(mm(false, false, Bn, C, U, htop, U, p->out_kernel, C, 0.f, lt, C, p->out_bias, gws, gwb, st));
+        SP_TRY(mm(false, false, Bn, C, E, r + R.ctx + (size_t)(t + 1) * B * E + (size_t)b0 * E, E,
+                  p->out_kernel + (size_t)U * C, C, 1.f, lt, C, nullptr, gws, gwb, st));
+        SP_TRY(sample_ids_rows(Bn, C, lt, d->sample_prob, d->sample_seed, d->sample_offset + (unsigned long long)t,
+                               ids + (size_t)(t + 1) * B + b0, ids_used + (size_t)(t + 1) * B + b0, b0, ss.st[sub]));
+      }
     }
   }
+  SP_TRY(sub_join(ss));
   // output projection of all steps: [h_t, ctx_t]·W + b, then batch-major + impute_finished
   float *ltm = r + R.logits_tm;
   SP_TRY(mm(false, false, L * B, C, U, r + R.Ho[nl - 1] + (size_t)B * U, U, p->out_kernel, C, 0.f, ltm, C, p->out_bias, gw, gwb, stream));
@@ -1264,8 +1370,8 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   SP_TRY(mm(false, true, BL, U, C, dl, C, p->out_kernel, C, 0.f, dH, U, nullptr, gw, gwb, stream));
   SP_TRY(mm(false, true, BL, E, C, dl, C, p->out_kernel + (size_t)U * C, C, 0.f, dCtx, E, nullptr, gw, gwb, stream));
   NABU_HIP(hipMemsetAsync(dkeys, 0, (size_t)B * Te * U * 4, s));
-  const int S = nabu_attn_bwd_slices(&ad);          // per-slice partial rows of the attention backward
-  const size_t attn_wsb = nabu_attn_bwd_ws_bytes(&ad);
+  NABU_HIP(hipMemsetAsync(w + W.tickets, 0, (size_t)W.NS * 1024 * 4, s));
+  const int S = W.S;          // per-slice partial rows of the attention backward (slices of a sub-batch's utterances)
   NABU_HIP(hipMemsetAsync(w + W.dv, 0, (size_t)B * S * U * 4, s));
   if (d->kind == 1) {
     NABU_HIP(hipMemsetAsync(w + W.dwf, 0, (size_t)B * S * F * U * 4, s));
@@ -1288,48 +1394,68 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
       SP_TRY(transpose(U, 4 * U, Kn + (size_t)U * 4 * U, 4 * U, w + W.khT[n], s));
     }
   }
+  const int NS = W.NS, Bn = B / NS;
+  const nabu_attn_desc adn = sub_attn_desc(d, Bn);
+  const size_t attn_wsb_n = nabu_attn_bwd_ws_bytes(&adn);
+  SubStreams ss;
+  SP_TRY(sub_streams(NS, s, &ss));
+  SP_TRY(sub_fork(ss));
   int cur = 0;   // index of the carries coming from step t+1
-  const float *dctx_carry = nullptr, *dal_carry = nullptr;
+  bool have_carry = false;
   for (int t = L - 1; t >= 0; --t) {
-    float *dCt = dCtx + (size_t)t * B * E;
-    if (dctx_carry) SP_TRY(nabu_axpy_f32((size_t)B * E, 1.f, dctx_carry, dCt, stream));
-    float *dal_out = d->kind == 1 ? w + W.dal[t & 1] : nullptr;
-    float *dqt = dq + (size_t)t * B * U;
-    SP_TRY(nabu_attn_bwd(&ad, t, dec_len, enc_len, r + R.keys, values, r + R.q + (size_t)t * B * U, p->attention_v,
-                         p->conv_kernel, p->conv_proj, r + R.align + (size_t)t * B * Te,
-                         r + R.align + (size_t)(t + 1) * B * Te, r + R.ctx + (size_t)(t + 1) * B * E, dCt, dal_carry,
-                         dqt, dkeys, w + W.dv, d->kind == 1 ? w + W.dwf : nullptr,
-                         d->kind == 1 ? w + W.dck : nullptr, dal_out, r + R.znorm + (size_t)t * B, w + W.attn,
-                         attn_wsb, stream));
-    dal_carry = dal_out;
-    float *dHt = dH + (size_t)t * B * U;
-    SP_TRY(mm(false, false, B, U, U, dqt, U, w + W.wqT, U, 1.f, dHt, U, nullptr, gw, gwb, stream));
-    const float *dtop = dHt;
-    for (int n = nl - 1; n >= 0; --n) {
-      const float *dh_in = dtop;
-      if (drop) {
-        SP_TRY(nabu_dropout_f32((size_t)B * U, dtop, w + W.tmp, d->keep_prob, d->seed,
-                                d->seed_offset + (unsigned long long)t * nl + n, stream));
-        dh_in = w + W.tmp;
-      }
-      float *dzt = w + W.dz[n] + (size_t)t * B * 4 * U;
-      const float *Cn = r + R.Cs[n];
-      SP_TRY(nabu_lstm_cell_bwd(B, U, t, dec_len, r + R.acts[n] + (size_t)t * B * 4 * U, Cn + (size_t)(t + 1) * B * U,
-                                Cn + (size_t)t * B * U, dh_in, w + W.dh[cur][n], w + W.dc[cur][n], dzt,
-                                w + W.dc[cur ^ 1][n], stream));
-      if (n == 0) {
-        float *nx = w + W.dctx[t & 1];
-        SP_TRY(mm(false, false, B, E, 4 * U, dzt, 4 * U, w + W.kxT[0], E, 0.f, nx, E, nullptr, gw, gwb, stream));
-        dctx_carry = nx;
-        SP_TRY(mm(false, false, B, U, 4 * U, dzt, 4 * U, w + W.khT[0], U, 0.f, w + W.dh[cur ^ 1][0], U, nullptr, gw, gwb, stream));
-      } else {
-        SP_TRY(mm(false, false, B, U, 4 * U, dzt, 4 * U, w + W.kxT[n], U, 0.f, w + W.dx, U, nullptr, gw, gwb, stream));
-        SP_TRY(mm(false, false, B, U, 4 * U, dzt, 4 * U, w + W.khT[n], U, 0.f, w + W.dh[cur ^ 1][n], U, nullptr, gw, gwb, stream));
-        dtop = w + W.dx;
+    for (int sub = 0; sub < NS; ++sub) {
+      const int b0 = sub * Bn;
+      nabu_stream_t st = static_cast<nabu_stream_t>(ss.st[sub]);
+      float *gws = gw + (size_t)sub * W.gemm_each;
+      const int32_t *dlen = dec_len + b0;
+      float *dCt = dCtx + (size_t)t * B * E + (size_t)b0 * E;
+      if (have_carry) SP_TRY(nabu_axpy_f32((size_t)Bn * E, 1.f, w + W.dctx[(t + 1) & 1] + (size_t)b0 * E, dCt, st));
+      float *dal_out = d->kind == 1 ? w + W.dal[t & 1] + (size_t)b0 * Te : nullptr;
+      const float *dal_carry = (d->kind == 1 && have_carry) ? w + W.dal[(t + 1) & 1] + (size_t)b0 * Te : nullptr;
+      float *dqt = dq + (size_t)t * B * U + (size_t)b0 * U;
+      SP_TRY(nabu_attn_bwd(&adn, t, dlen, enc_len + b0, r + R.keys + (size_t)b0 * Te * U, values + (size_t)b0 * Te * E,
+                           r + R.q + (size_t)t * B * U + (size_t)b0 * U, p->attention_v, p->conv_kernel, p->conv_proj,
+                           r + R.align + (size_t)t * B * Te + (size_t)b0 * Te,
+                           r + R.align + (size_t)(t + 1) * B * Te + (size_t)b0 * Te,
+                           r + R.ctx + (size_t)(t + 1) * B * E + (size_t)b0 * E, dCt, dal_carry, dqt,
+                           dkeys + (size_t)b0 * Te * U, w + W.dv + (size_t)b0 * S * U,
+                           d->kind == 1 ? w + W.dwf + (size_t)b0 * S * F * U : nullptr,
+                           d->kind == 1 ? w + W.dck + (size_t)b0 * K * F : nullptr, dal_out,
+                           r + R.znorm + (size_t)t * B + b0, w + W.attn + (size_t)sub * W.attn_each, attn_wsb_n, st));
+      float *dHt = dH + (size_t)t * B * U + (size_t)b0 * U;
+      SP_TRY(mm2(Bn, U, U, dqt, U, w + W.wqT, U, 0, nullptr, 0, nullptr, 0, 1.f, dHt, U, w, W, sub, gws, gwb, st));
+      const float *dtop = dHt;
+      for (int n = nl - 1; n >= 0; --n) {
+        const float *dh_in = dtop;
+        if (drop) {
+          SP_TRY(dropout_rows((size_t)Bn * U, dtop, w + W.tmp + (size_t)b0 * U, d->keep_prob, d->seed,
+                              d->seed_offset + (unsigned long long)t * nl + n, (size_t)b0 * U, ss.st[sub]));
+          dh_in = w + W.tmp + (size_t)b0 * U;
+        }
+        float *dzt = w + W.dz[n] + (size_t)t * B * 4 * U + (size_t)b0 * 4 * U;
+        const float *Cn = r + R.Cs[n] + (size_t)b0 * U;
+        SP_TRY(nabu_lstm_cell_bwd(Bn, U, t, dlen, r + R.acts[n] + (size_t)t * B * 4 * U + (size_t)b0 * 4 * U,
+                                  Cn + (size_t)(t + 1) * B * U, Cn + (size_t)t * B * U, dh_in,
+                                  w + W.dh[cur][n] + (size_t)b0 * U, w + W.dc[cur][n] + (size_t)b0 * U, dzt,
+                                  w + W.dc[cur ^ 1][n] + (size_t)b0 * U, st));
+        if (n == 0) {
+          float *nx = w + W.dctx[t & 1] + (size_t)b0 * E;
+          SP_TRY(mm2(Bn, E, 4 * U, dzt, 4 * U, w + W.kxT[0], E, 0, nullptr, 0, nullptr, 0, 0.f, nx, E, w, W, sub, gws, gwb, st));
+          SP_TRY(mm2(Bn, U, 4 * U, dzt, 4 * U, w + W.khT[0], U, 0, nullptr, 0, nullptr, 0, 0.f,
+                     w + W.dh[cur ^ 1][0] + (size_t)b0 * U, U, w, W, sub, gws, gwb, st));
+        } else {
+          SP_TRY(mm2(Bn, U, 4 * U, dzt, 4 * U, w + W.kxT[n], U, 0, nullptr, 0, nullptr, 0, 0.f, w + W.dx + (size_t)b0 * U, U,
+                     w, W, sub, gws, gwb, st));
+          SP_TRY(mm2(Bn, U, 4 * U, dzt, 4 * U, w + W.khT[n], U, 0, nullptr, 0, nullptr, 0, 0.f,
+                     w + W.dh[cur ^ 1][n] + (size_t)b0 * U, U, w, W, sub, gws, gwb, st));
+          dtop = w + W.dx + (size_t)b0 * U;
+        }
       }
     }
+    have_carry = true;
     cur ^= 1;
   }
+  SP_TRY(sub_join(ss));
   // sums over steps as single GEMMs
   SP_TRY(mm(true, false, U, U, BL, htop_all, U, dq, U, 0.f, g->query_kernel, U, nullptr, gw, gwb, stream));
   for (int n = 0; n < nl; ++n) {
@@ -1354,8 +1480,7 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   SP_TRY(mm(true, false, E, U, B * Te, values, E, dkeys, U, 0.f, g->memory_kernel, U, nullptr, gw, gwb, stream));
   SP_TRY(mm(false, true, B * Te, E, U, dkeys, U, p->memory_kernel, U, 0.f, dvalues, E, nullptr, gw, gwb, stream));
   const float *al1 = r + R.align + (size_t)B * Te;
-  for (int b = 0; b < B; ++b)
-    SP_TRY(mm(true, false, Te, E, L, al1 + (size_t)b * Te, B * Te, dCtx + (size_t)b * E, B * E, 1.f,
-              dvalues + (size_t)b * Te * E, E, nullptr, gw, gwb, stream));
+  // dvalues[b] += align[:, b, :]^T · dCtx[:, b, :] for every utterance: one batched launch
+  SP_TRY(gemm_batched_f32(true, false, Te, E, L, al1, B * Te, Te, dCtx, B * E, E, 1.f, dvalues, E, (long long)Te * E, B, s));
   return 0;
 }

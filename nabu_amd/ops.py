@@ -37,6 +37,20 @@ def gemm(a, b, c, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None,
     return c
 
 
+def gemm2(a, b, a2, b2, c, beta=0.0, bias=None):
+    """c = [a | a2] @ [b ; b2] + beta*c + bias for M <= 64 rows in one launch (nabu_gemm2_f32); a2/b2 may be None"""
+    L = _hip.lib()
+    M, K1 = a.shape
+    N = b.shape[1]
+    K2 = a2.shape[1] if a2 is not None else 0
+    ws_bytes = L.nabu_gemm2_ws_bytes(M, N, K1, K2)
+    ws = Workspace.get(ws_bytes, c.device, 'gemm2')
+    check(L.nabu_gemm2_f32(M, N, K1, ptr(a), a.stride(0), ptr(b), b.stride(0), K2, ptr(a2),
+                           a2.stride(0) if a2 is not None else 0, ptr(b2), b2.stride(0) if b2 is not None else 0,
+                           beta, ptr(c), c.stride(0), ptr(bias), ptr(ws), ws_bytes, stream()), 'nabu_gemm2_f32')
+    return c
+
+
 def set_gemm_precision(precision):
     """process default of every GEMM that does not name a precision ('f32' | 'bf16' | 'bf16x3' | 'bf16x6')"""
     check(_hip.lib().nabu_gemm_set_default_precision(_hip.GEMM_PRECISIONS[precision]), 'nabu_gemm_set_default_precision')

@@ -363,6 +363,35 @@ def test_gemm_skinny_rows(M, N, K):
     assert torch.equal(c, c2)
 
 
+@pytest.mark.parametrize('M,N,K1,K2', [(32, 2048, 1024, 512), (64, 2048, 1024, 512), (32, 512, 512, 0), (32, 1024, 2048, 0),
+                                        (5, 64, 64, 128), (33, 96, 192, 64)])
+def test_gemm2_two_segment_product_with_the_reduce_inside_the_launch(M, N, K1, K2):
+    """nabu_gemm2_f32: [A | A2]·[B ; B2] + beta*C + bias (the Speller cell's concat([context, h])·kernel) in one
+    launch with last-arriver split-K reduction: against float64, bitwise repeatable (the order of summation does
+    not depend on which workgroup arrives last), and usable again at once (tickets handed back)"""
+    from nabu_amd import ops
+    rng = np.random.default_rng(M + N + K1 + K2)
+    a = rng.normal(size=(M, K1)).astype(np.float32)
+    b = rng.normal(size=(K1, N)).astype(np.float32)
+    a2 = rng.normal(size=(M, K2)).astype(np.float32) if K2 else None
+    b2 = rng.normal(size=(K2, N)).astype(np.float32) if K2 else None
+    bias = rng.normal(size=N).astype(np.float32)
+    c0 = rng.normal(size=(M, N)).astype(np.float32)
+    ref = a.astype(np.float64) @ b.astype(np.float64) + bias + 2.0 * c0
+    if K2:
+        ref = ref + a2.astype(np.float64) @ b2.astype(np.float64)
+    dev = lambda x: None if x is None else torch.tensor(x, device='cuda')
+    outs = []
+    for _ in range(3):
+        c = dev(c0)
+        ops.gemm2(dev(a), dev(b), dev(a2), dev(b2), c, beta=2.0, bias=dev(bias))
+        outs.append(c)
+    assert np.abs(outs[0].cpu().numpy() - ref).max() / np.abs(ref).max() < 3e-6
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    with pytest.raises(Exception):          # K1 not a multiple of 64
+        ops.gemm2(dev(a[:, :40]), dev(b[:40]), None, None, dev(c0))
+
+
 def test_cross_entropy_losses_match_oracle():
     """average_cross_entropy (loss_functions.py:155-165) and sum_cross_entropy (:142-153) on ragged
     lengths: loss and the gradient the tape receives"""
