@@ -366,6 +366,96 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Short reduction, tall output (the first layer's input projection: [B*T, D] · [D, 4H], D = 40 or 80): the
+// product is bound by WRITING C (262 MB at cfg2), not by the matrix pipe.  One load phase for the whole
+// K (A tile [128 x K] row-major with an odd row stride, B tile [K x 128] k-major), one barrier, K/2 MFMA
+// steps, stores.  No k-loop pipeline to fill and drain: the generic kernel spent two barriers and a
+// load round trip per 16 reduction indices on it (150 us against ~60 us for the write alone).
+constexpr int SMALLK_MAX = 96;
+__global__ __launch_bounds__(256) void gemm_smallk_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float ssm[];
+  const int K = a.K, LDA_S = K + 1;                 // odd stride: the 32 rows of an MFMA operand hit 32 banks
+  float *As = ssm, *Bs = ssm + 128 * LDA_S + 3;     // Bs 16-byte aligned below
+  Bs = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(Bs) + 15) & ~(uintptr_t)15);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int KQ = K / 4;
+  for (int idx = tid; idx < 128 * KQ; idx += 256) {          // A: rows clamped, dropped at the store
+    const int r = idx / KQ, kq = idx % KQ;
+    const float4 v = *reinterpret_cast<const float4 *>(a.A + (size_t)min(m0 + r, a.M - 1) * a.lda + 4 * kq);
+    float *d = As + r * LDA_S + 4 * kq;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  for (int idx = tid; idx < K * 32; idx += 256) {            // B: 16-byte pieces along n
+    const int k = idx >> 5, c = 4 * (idx & 31);
+    const float4 v = *reinterpret_cast<const float4 *>(a.B + (size_t)k * a.ldb + min(n0 + c, a.N - 4));
+    *reinterpret_cast<float4 *>(Bs + k * LDT + c) = v;
+  }
+  __syncthreads();
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int li = lane & 31, lk = lane >> 5;
+  const float *ap0 = As + (wm * 64 + li) * LDA_S + lk, *ap1 = ap0 + 32 * LDA_S;
+  const float *bp0 = Bs + lk * LDT + wn * 64 + li;
+  for (int kk = 0; kk < K; kk += 2) {
+    const float a0 = ap0[kk], a1 = ap1[kk], b0 = bp0[kk * LDT], b1 = bp0[kk * LDT + 32];
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+  }
+  // epilogue through LDS: the accumulators hold one column per lane; written back as they are that is a
+  // 4-byte store per lane and element (2.2 TB/s on this write-bound product).  Transposed through LDS a
+  // lane stores 16 bytes of a row and a wave a full 512-byte row segment at a time.
+  __syncthreads();                                   // operand tiles are dead
+  float *Cs = ssm;                                   // [128][LDT]
+  const int col = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Cs[(wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + rbase) * LDT + wn * 64 + ni * 32 + col] = acc[mi][ni][r];
+  __syncthreads();
+  const int c4 = 4 * (tid & 31);
+  const int n = n0 + c4;
+  if (n < a.N) {                                     // N % 4 == 0: a 16-byte piece is inside or outside
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) bv = *reinterpret_cast<const float4 *>(a.bias + n);
+    for (int r = tid >> 5; r < 128; r += 8) {
+      const int m = m0 + r;
+      if (m >= a.M) break;
+      const float4 v = *reinterpret_cast<const float4 *>(Cs + r * LDT + c4);
+      float4 o = make_float4(a.alpha * v.x + bv.x, a.alpha * v.y + bv.y, a.alpha * v.z + bv.z, a.alpha * v.w + bv.w);
+      float4 *c = reinterpret_cast<float4 *>(a.C + (size_t)m * a.ldc + n);
+      if (a.beta != 0.f) {
+        const float4 p = *c;
+        o.x += a.beta * p.x; o.y += a.beta * p.y; o.z += a.beta * p.z; o.w += a.beta * p.w;
+      }
+      *c = o;
+    }
+  }
+}
+static bool smallk_ok(bool ta, bool tb, int M, int N, int K, const void *A, int lda, const void *B, int ldb, int kseg,
+                      const void *C, int ldc, const void *bias) {
+  auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return !ta && !tb && kseg == 0 && K >= 8 && K <= SMALLK_MAX && K % 4 == 0 && M >= 2048 && N >= 4 && N % 4 == 0 &&
+         al16(A) && lda % 4 == 0 && al16(B) && ldb % 4 == 0 && al16(C) && ldc % 4 == 0 && al16(bias);
+}
+static size_t smallk_lds(int K) {
+  const size_t ops = ((size_t)128 * (K + 1) + 8 + (size_t)K * LDT) * sizeof(float), out = (size_t)128 * LDT * sizeof(float);
+  return ops > out ? ops : out;
+}
+
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs a) {
   const size_t total = (size_t)a.M * a.N;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -571,6 +661,20 @@ static int gemm_run(int precision, int transA, int transB, int M, int N, int K, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool fast = M % 4 == 0 && N % 4 == 0 && K > 0 && K % FBK == 0 && a.vecA && a.vecB;      // bf16 kernels
   const bool fast32 = fast_f32_ok(transA != 0, transB != 0, M, N, K, A, lda, B, ldb, a_seg_stride, b_seg_stride);
+  if ((precision == NABU_GEMM_F32 || K % FBK != 0) && smallk_ok(transA != 0, transB != 0, M, N, K, A, lda, B, ldb, kseg, C, ldc, bias)) {
+    a.nsplit = 1; a.partial = nullptr;
+    const size_t lds = smallk_lds(K);
+    static bool configured = false;
+    if (!configured) {
+      NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_smallk_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)smallk_lds(SMALLK_MAX)));
+      configured = true;
+    }
+    hipLaunchKernelGGL(gemm_smallk_kernel, dim3((N + BN - 1) / BN, (M + BM - 1) / BM), block, lds, s, a);
+    NABU_LAUNCH_CHECK();
+    return 0;
+  }
   if (skinny_kc) {
     if (int e = gemm_skinny_launch(a, s)) return e;
   } else

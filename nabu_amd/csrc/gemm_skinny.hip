@@ -96,7 +96,7 @@ struct SkinnyFuse {
   const float *A2, *B2;
   int lda2, ldb2, K1;        // reduction indices [0, K1) come from (A, B), the rest from (A2, B2)
   unsigned *tickets;
-  int heavy;                 // 1: the partners of a column slice may sit on different XCDs (agent-scope fences)
+  int heavy;                 // 1: full agent-scope fences around the ticket (debugging)
 };
 
 template <int MT>
@@ -129,13 +129,19 @@ __global__ __launch_bounds__(256) void gemm_skinny_fused_kernel(GemmArgs a, Skin
       float v = a.alpha * s + (a.bias ? a.bias[n] : 0.f);
       if (a.beta != 0.f) v += a.beta * *c;
       *c = v;
-    } else {
-      a.partial[((size_t)blockIdx.y * a.M + m) * a.N + n] = s;
+    } else {   // sc1 (write-through) store: performed at the device coherence point, whatever XCD reads it
+      __hip_atomic_store(a.partial + ((size_t)blockIdx.y * a.M + m) * a.N + n, s, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (ns == 1) return;
-  if (f.heavy) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // partners on other XCDs: write back this L2
-  else         __builtin_amdgcn_s_waitcnt(0);                        // same L2: the stores have been performed there
+  // Hand-off recipe of MI355X_MICROARCH.md ("sc1 stores AND sc1 loads"): the partial tiles are written
+  // through and read back with L1/L2-bypassing loads, the ticket is an agent-scope atomic, and the stores
+  // have been acknowledged (vmcnt 0) before the ticket is taken — no assumption about which XCD the
+  // partners of a column slice run on.  NABU_SKINNY_HEAVY=1 adds full agent-scope release/acquire fences
+  // (L2 write-back + invalidate), for debugging; it doubles the kernel's duration.
+  if (f.heavy) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  else         __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (tid == 0) {
     const unsigned old = __hip_atomic_fetch_add(f.tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -173,13 +179,9 @@ int gemm_skinny_fused(int M, int N, int K1, const float *A, int lda, const float
   a.alpha = 1.f; a.beta = beta; a.kseg = 0; a.a_seg = a.b_seg = 0;
   a.ksplit = kc; a.nsplit = (K1 + K2) / kc; a.vecA = a.vecB = 1; a.swz = 0;
   a.nbatch = 1; a.a_bs = a.b_bs = a.c_bs = 0;
-  // Workgroup (x, y) has linear id x + y*gridDim.x and the dispatcher deals linear ids round-robin over the
-  // 8 XCDs: with gridDim.x % 8 == 0 all k-chunk partners of a column slice share one XCD and therefore one
-  // L2 — the partial tiles never need to leave it (L1 is bypassed by the reader's sc1 loads).  Any other
-  // width, or NABU_SKINNY_HEAVY=1, takes agent-scope release/acquire fences.
   static int heavy_env = -1;
   if (heavy_env < 0) { const char *e = getenv("NABU_SKINNY_HEAVY"); heavy_env = e ? atoi(e) : 0; }
-  SkinnyFuse f = {A2, B2, lda2, ldb2, K1, tickets, ((N / 32) % 8 != 0 || heavy_env) ? 1 : 0};
+  SkinnyFuse f = {A2, B2, lda2, ldb2, K1, tickets, heavy_env ? 1 : 0};
   const int MT = M > 32 ? 2 : 1;
   const size_t xt = (size_t)kc * 32 * MT * sizeof(float), red = (size_t)4 * MT * 1024 * sizeof(float);
   const size_t lds = xt > red ? xt : red;
