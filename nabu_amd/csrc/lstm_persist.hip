@@ -750,28 +750,34 @@ void lstm_persist_set_timeout_us(long long us) {
   g_timeout_ticks = us > 0 ? (unsigned long long)us * 100ull : 20000000ull;
 }
 
+// compute units of the CURRENT device (partitioned / CPX modes expose fewer than the 256 of a whole
+// MI355X); every geometry decision below uses it, so that a shape whose grid cannot be co-resident
+// is reported as unsupported — LSTM_AUTO then takes the step-wise kernels instead of failing at launch
 static int cu_count() {
-  static int n = -1;
-  if (n < 0) {
+  static thread_local int cached_dev = -1, cached = NCU;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return NCU; }
+  if (dev != cached_dev) {
     int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess || v <= 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) {
       (void)hipGetLastError();
       v = NCU;
     }
-    n = v;
+    cached = v > NCU ? NCU : v;     // block -> CU bookkeeping (block_identity) is written for <= 256 CUs
+    cached_dev = dev;
   }
-  return n;
+  return cached;
 }
 
 // geometry: BS = 4 (two 256-thread workgroups per CU) when the batch fits, else BS = 8
 static int pick_bs(int B, int H, bool fwd) {
-  const int P = H / UC;
-  if (2 * ((B + 3) / 4) * P <= 2 * NCU) return 4;
-  if (2 * ((B + 7) / 8) * P <= NCU) return 8;          // one 512-thread workgroup per CU
+  const int P = H / UC, ncu = cu_count();
+  if (2 * ((B + 3) / 4) * P <= 2 * ncu) return 4;
+  if (2 * ((B + 7) / 8) * P <= ncu) return 8;          // one 512-thread workgroup per CU
   // two 512-thread workgroups per CU (<= 128 VGPRs): cfg5's B = 64 at H = 512 in ONE launch.  Forward
   // only: measured 4.04 us per step against 2 x 2.41 for two launches of 32 rows; the backward kernel,
   // whose reduce-scatter volume doubles with the rows, takes 5.69 against 2 x 2.47 and stays chunked.
-  if (fwd && 2 * ((B + 7) / 8) * P <= 2 * NCU) return 8;
+  if (fwd && 2 * ((B + 7) / 8) * P <= 2 * ncu) return 8;
   return 0;
 }
 
@@ -780,7 +786,7 @@ static int pick_bs(int B, int H, bool fwd) {
 // launch takes up to 64 rows (BS = 8, two workgroups per CU), B = 96 is a launch of 64 and one of 32.
 static int chunk_rows(int B, int H, bool fwd) {
   if (pick_bs(B, H, fwd)) return B;
-  int c = (fwd ? 8 : 4) * (2 * NCU / (2 * (H / UC)));   // largest batch of one launch
+  int c = (fwd ? 8 : 4) * (2 * cu_count() / (2 * (H / UC)));   // largest batch of one launch
   return c < 4 ? 4 : c;
 }
 
@@ -867,7 +873,7 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
   PersistArgs a;
   { const char *e = getenv("NABU_PERSIST_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   int BS = pick_bs(B, H, fwd);
-  if ((a.dbg & 16) && 2 * ((B + 7) / 8) * (H / UC) <= NCU) BS = 8;
+  if ((a.dbg & 16) && 2 * ((B + 7) / 8) * (H / UC) <= cu_count()) BS = 8;
   a.B = B; a.T = T; a.D = D; a.H = H; a.max_len = max_len; a.nshard = (B + BS - 1) / BS;
   a.len = len;
   for (int i = 0; i < 2; ++i) { a.kernel[i] = kernel[i]; a.gates[i] = gates[i]; a.cs[i] = cs[i]; }
@@ -880,12 +886,12 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
   a.timeout_ticks = g_timeout_ticks;
   const int NU = 2 * a.nshard, P = H / UC;
   const int grid = NU * P;
-  const int per_cu = (BS == 4 || grid > NCU) ? 2 : 1;
+  const int per_cu = (BS == 4 || grid > cu_count()) ? 2 : 1;
   if (grid > per_cu * cu_count())
     return fail(NABU_EUNSUP, "persistent LSTM: %d workgroups > %d x %d CUs", grid, per_cu, cu_count());
   NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + ring_bytes(fwd, BS, a.nshard, H), stream));
   // dynamic LDS chosen so that exactly `per_cu` workgroups fit on a CU (160 KiB)
-  const size_t lds = BS == 4 ? 64 * 1024 : (grid > NCU ? 72 * 1024 : 96 * 1024);
+  const size_t lds = BS == 4 ? 64 * 1024 : (grid > cu_count() ? 72 * 1024 : 96 * 1024);
 #define NABU_PERSIST_CASE(h)                                                                         \
   case h:                                                                                            \
     if (BS == 4)                                                                                     \

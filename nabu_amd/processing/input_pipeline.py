@@ -14,8 +14,13 @@ the A0 batch contract of SURVEY.md 8(a):
   (boundaries from the greedy `bucket_boundaries` on the length histogram); a bucket emits a batch
   as soon as it holds its batch size (variable_batch_size: max(int(batch_size*b0/b), 1)); leftovers
   stay queued into the next epoch like in the reference's never-ending queues;
-* batches are zero padded to the longest member (dynamic_pad)."""
+* batches are zero padded to the longest member (dynamic_pad);
+* the next batch is assembled by a background thread while the current one trains (the reference's
+  queue runners), and bucketing takes the utterance lengths from the records' length prefixes instead
+  of decoding every file before the first step."""
 import os
+import threading
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -101,6 +106,10 @@ class RecordData(object):
             self.batch_sizes = [self.batch_size]
             self.num_steps = int(histogram.sum() / self.batch_size)
         self._lengths = None
+        self._pool = ThreadPoolExecutor(max_workers=1)
+        self._lock = threading.Lock()
+        self._ahead = {}           # step -> Future of its batch
+        self._last_step = None
         self._epochs = []          # per epoch: list of batches (lists of utterance indices)
         self._carry = [[] for _ in self.batch_sizes]
         self._cache = {}
@@ -111,7 +120,7 @@ class RecordData(object):
 
     def _first_lengths(self):
         if self._lengths is None:
-            self._lengths = np.array([self.readers[0](e[0])[1] for e in self.elements], np.int64)
+            self._lengths = np.array([self.readers[0].sequence_length(e[0]) for e in self.elements], np.int64)
         return self._lengths
 
     def _schedule_epoch(self):
@@ -151,7 +160,24 @@ class RecordData(object):
         return self._cache[u]
 
     def batch(self, step):
-        '''batch number `step` of the never-ending stream (A0 contract, numpy)'''
+        '''batch number `step` of the never-ending stream (A0 contract, numpy).  The batch the caller
+        will most likely ask for next (same stride as the last two requests) is read and padded by a
+        background thread meanwhile.'''
+        fut = self._ahead.pop(step, None)
+        out = fut.result() if fut is not None else self._assemble(step)
+        stride = step - self._last_step if self._last_step is not None and step > self._last_step else 1
+        self._last_step = step
+        nxt = step + stride
+        self._ahead = {nxt: self._ahead[nxt]} if nxt in self._ahead else {}      # drop guesses that were wrong
+        if nxt not in self._ahead:
+            self._ahead[nxt] = self._pool.submit(self._assemble, nxt)
+        return out
+
+    def _assemble(self, step):
+        with self._lock:                                   # schedule, carries and cache are shared state
+            return self._assemble_locked(step)
+
+    def _assemble_locked(self, step):
         utts = [self._read(u) for u in self._indices(step)]
         names = self.input_names + self.target_names
         out = dict(inputs={}, input_seq_length={}, targets={}, target_seq_length={})

@@ -20,6 +20,14 @@ class AudioFeatureReader(tfreader.TfReader):
                     raise Exception('all audio feature reader dimensions must be the same')
         return metadata
 
+    def sequence_length(self, filename):
+        '''frames = bytes of the 'data' feature / (4 * dim), read from the record's length prefixes'''
+        from nabu_amd.processing import tfrecord
+        n = tfrecord.peek_single_bytes_feature(filename, 'data')
+        if n is None or n % (4 * self.metadata['dim']):
+            return super(AudioFeatureReader, self).sequence_length(filename)
+        return n // (4 * self.metadata['dim'])
+
     def _process_features(self, features):
         data = np.frombuffer(features['data'][0], np.float32).reshape([-1, self.metadata['dim']])
         return data, data.shape[0]

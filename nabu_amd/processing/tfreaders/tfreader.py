@@ -22,6 +22,12 @@ class TfReader(object, metaclass=ABCMeta):
             raise Exception('%s: expected one example per file, found %d' % (filename, len(records)))
         return self._process_features(tfrecord.decode_example(records[0]))
 
+    def sequence_length(self, filename):
+        '''the sequence length of one utterance; readers that can tell it without decoding the
+        record override this (the bucketing input pipeline asks for the length of EVERY utterance
+        before the first step)'''
+        return self(filename)[1]
+
     @staticmethod
     def _lengths(datadirs, metadata):
         '''max_length and the summed sequence_length_histogram of the directories

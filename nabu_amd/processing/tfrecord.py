@@ -82,6 +82,35 @@ def read_records(path, check_crc=True):
     return out
 
 
+def peek_single_bytes_feature(path, name, head=96):
+    """Byte length of the only value of BytesList feature `name` in the first record of `path`, read from
+    the first `head` bytes of the file (framing + the nested length prefixes in front of the payload) —
+    the sequence length of an audio-feature utterance without reading its frames.  None when the record
+    does not start with that feature (several features in another order, a short file, another type)."""
+    with open(path, 'rb') as fid:
+        buf = fid.read(12 + head)
+    if len(buf) < 16:
+        return None
+    try:
+        pos = 12                                  # uint64 length + masked crc of the length
+        for field in (1, 1, 1):                   # Example.features, Features.feature (map entry), then the key
+            key, pos = _read_varint(buf, pos)
+            if key != ((field << 3) | 2):
+                return None
+            n, pos = _read_varint(buf, pos)
+        if buf[pos:pos + n] != name.encode():     # entry.key
+            return None
+        pos += n
+        for field in (2, 1, 1):                   # entry.value = Feature, Feature.bytes_list, BytesList.value[0]
+            key, pos = _read_varint(buf, pos)
+            if key != ((field << 3) | 2):
+                return None
+            n, pos = _read_varint(buf, pos)
+        return n
+    except IndexError:
+        return None
+
+
 # ----------------------------------------------------------------------------- protobuf wire format
 def _varint(n):
     n &= (1 << 64) - 1                      # int64 two's complement

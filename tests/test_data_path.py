@@ -196,3 +196,43 @@ def test_trainer_and_evaluator_read_the_database_conf(tmp_path):
     assert set(b['inputs']) == {'features'} and set(b['targets']) == {'text'}
     assert tr.evaluator is not None and tr.evaluator.data.num_batches() == 4          # 9 // 2
     assert tr.evaluator.data.batch(0)['inputs']['features'].shape[0] == 2
+
+
+def test_lengths_without_decoding_and_background_prefetch(tmp_path):
+    """bucketing takes every utterance's length from the record's length prefixes (no frame is read before
+    the first step), and the prefetching batch source hands out exactly the batches of a source that reads
+    on demand — in order, with a stride (data-parallel ranks), and after a jump"""
+    conf, feats, texts, alphabet = make_dataset(str(tmp_path), n=40, dim=7)
+    fr = tfreader_factory.factory('audio_feature')([conf.get('trainfbank', 'dir')])
+    elements, names = input_pipeline.get_filenames([[dict(conf.items('trainfbank'))], [dict(conf.items('traintext'))]])
+    calls = {'n': 0}
+    orig = type(fr).__call__
+
+    def counting(self, filename):
+        calls['n'] += 1
+        return orig(self, filename)
+    type(fr).__call__ = counting
+    try:
+        for (ff, _), name in zip(elements, names):
+            assert fr.sequence_length(ff) == feats[name.rsplit('-', 1)[0]].shape[0]
+        assert calls['n'] == 0                       # nothing was decoded
+    finally:
+        type(fr).__call__ = orig
+    # a record that does not start with the 'data' feature falls back to decoding
+    from nabu_amd.processing import tfrecord
+    odd = str(tmp_path / 'odd.tfrecord')
+    tfrecord.write_records(odd, [tfrecord.encode_example({'aaa': [1, 2], 'data': np.zeros((3, 7), np.float32).tobytes()})])
+    assert tfrecord.peek_single_bytes_feature(odd, 'data') is None and fr.sequence_length(odd) == 3
+
+    def source():
+        return input_pipeline.from_sections(conf, ['features'], [['trainfbank']], ['text'], [['traintext']],
+                                            batch_size=4, numbuckets=3, variable_batch_size=True, shuffle=True, seed=3)
+    a, b = source(), source()
+    b._pool = None
+    b.batch = b._assemble                            # reads on demand, no prefetch
+    for step in [0, 1, 2, 3, 5, 7, 9, 30, 31, 2]:
+        x, y = a.batch(step), b.batch(step)
+        for key in ('inputs', 'input_seq_length', 'targets', 'target_seq_length'):
+            for n in x[key]:
+                np.testing.assert_array_equal(x[key][n], y[key][n])
+    assert len(a._ahead) == 1
