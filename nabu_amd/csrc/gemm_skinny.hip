@@ -153,8 +153,16 @@ __global__ __launch_bounds__(256) void gemm_skinny_fused_kernel(GemmArgs a, Skin
   for (int e = tid; e < a.M * 32; e += 256) {
     const int m = e >> 5, n = n0 + (e & 31);
     float s = 0.f;
-    for (int z = 0; z < ns; ++z)      // chunk order: independent of the arrival order
-      s += __hip_atomic_load(a.partial + ((size_t)z * a.M + m) * a.N + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int z0 = 0; z0 < ns; z0 += 8) {   // chunk order: independent of the arrival order
+      float pv[8];                         // all loads of a batch in flight before the first add
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        pv[j] = (z0 + j < ns) ? __hip_atomic_load(a.partial + ((size_t)(z0 + j) * a.M + m) * a.N + n, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT)
+                              : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += pv[j];
+    }
     float *c = a.C + (size_t)m * a.ldc + n;
     float v = a.alpha * s + (a.bias ? a.bias[n] : 0.f);
     if (a.beta != 0.f) v += a.beta * *c;
