@@ -1,5 +1,7 @@
-"""GPU: the hot path at BASELINE.json's FULL sizes, where the float64 oracle would take hours.
-Checked through size-independent properties instead:
+"""GPU: the hot path at BASELINE.json's FULL sizes through size-independent properties.  (The oracle
+numbers at these sizes — minutes of float64 per config in the build container, not hours as round 1
+claimed — are committed as tests/golden/cfg{2,3,5}_exact.npz and compared in tests/test_hip_golden.py;
+the properties below need no reference numbers at all.)
 
   * the persistent recurrence (one launch per layer and pass) against the step-wise kernels (one
     launch per frame) — two independent implementations of the same layer, each pinned against the

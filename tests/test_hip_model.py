@@ -109,7 +109,10 @@ def test_training_trajectory_matches_oracle(recipe, enc, over, T, minT, red):
     for a, b_ in zip(got, layers):
         for k in a:
             # Adam moves a weight by ~lr per step whatever the gradient's size, so an
-            # element whose gradient is rounding noise may differ by up to steps*lr
+            # element whose gradient is rounding noise may differ by up to steps*lr: the MAX bound
+            # (4.5e-3 = the full distance 4 steps can travel) only catches gross errors — it is the
+            # MEAN bound (2e-5, i.e. almost every element agrees to float32 rounding) and the per-step
+            # loss bound above that carry this check
             d = np.abs(a[k] - b_[k])
             assert d.max() < 4.5e-3 and d.mean() < 2e-5, (k, d.max(), d.mean())
 
