@@ -47,10 +47,32 @@ __device__ __forceinline__ void tile_of_block(int swz, int *tm, int *tn) {
 // skinny products (gemm_skinny.hip): M <= 64, no transposes
 int gemm_skinny_chunk(int M, int N, int K);
 int gemm_skinny_launch(const GemmArgs &a, hipStream_t stream);
-// decoder-step variant: two operand pairs along the reduction, split-K reduce finished in the launch
+// decoder-step variant: two operand pairs along the reduction, split-K reduce finished in the launch,
+// optionally followed by an LSTM-cell epilogue on the finished tile (see gemm_skinny.hip)
+// Epilogues of the decoder-step product (kind): 0 = write C; 1 = LSTM cell forward on a tile of z whose
+// columns are GATE-INTERLEAVED (column 4u+g = gate g of unit u: the product runs against a column-permuted
+// copy of the TF kernel, so that a 32-column slice holds all four gates of 8 units); 2 = LSTM cell backward
+// on a tile of dh (the product dq·Wq^T + beta*dH, natural unit order).  Folding the cell into the product's
+// last workgroup removes one dependent kernel (launch + memory round trip) from every decoder step.
+// Same arithmetic as lstm_cell_fwd/_bwd_kernel (speller.hip).
+struct SkinnyEpilogue {
+  int kind, U, step;
+  const int32_t *seq_len;
+  // forward
+  const float *bias, *emb;
+  const int32_t *ids;
+  const float *c_prev, *h_prev;
+  float *acts, *c_new, *h_new;
+  // backward (acts, c_new = c of this step, c_prev as above are inputs)
+  const float *dh2;
+  int ld_dh2;
+  const float *dc_in;
+  float *dz, *dc_out;
+};
+
 int gemm_skinny_fused(int M, int N, int K1, const float *A, int lda, const float *B, int ldb, int K2, const float *A2,
                       int lda2, const float *B2, int ldb2, float beta, float *C, int ldc, const float *bias,
-                      float *partial, unsigned *tickets, hipStream_t s);
+                      float *partial, unsigned *tickets, hipStream_t s, const SkinnyEpilogue *ep = nullptr);
 
 // batch of nbatch independent products C_i (+)= op(A_i)·op(B_i) in ONE launch of the generic fp32 kernel
 // (operand i starts i*stride elements after operand 0); no split-K

@@ -97,6 +97,7 @@ struct SkinnyFuse {
   int lda2, ldb2, K1;        // reduction indices [0, K1) come from (A, B), the rest from (A2, B2)
   unsigned *tickets;
   int heavy;                 // 1: full agent-scope fences around the ticket (debugging)
+  SkinnyEpilogue ep;         // what the workgroup that holds the finished tile does with it
 };
 
 template <int MT>
@@ -119,63 +120,115 @@ __global__ __launch_bounds__(256) void gemm_skinny_fused_kernel(GemmArgs a, Skin
     for (int r = 0; r < 16; ++r) red[((w * MT + t) * 16 + r) * 64 + lane] = acc[t][r];
   __syncthreads();
   const int ns = a.nsplit;
+  __shared__ float zt[64 * 32];          // the finished tile [row][column of the slice] (cell epilogues)
+  const int epi = f.ep.kind;
   for (int e = tid; e < MT * 16 * 64; e += 256) {
     const float s = red[e] + red[MT * 1024 + e] + red[2 * MT * 1024 + e] + red[3 * MT * 1024 + e];
     const int l = e & 63, r = (e >> 6) & 15, t = e >> 10;
     const int m = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), n = n0 + (l & 31);
     if (m >= a.M) continue;
     if (ns == 1) {
-      float *c = a.C + (size_t)m * a.ldc + n;
       float v = a.alpha * s + (a.bias ? a.bias[n] : 0.f);
-      if (a.beta != 0.f) v += a.beta * *c;
-      *c = v;
+      if (a.beta != 0.f) v += a.beta * a.C[(size_t)m * a.ldc + n];
+      if (epi == 0) a.C[(size_t)m * a.ldc + n] = v;
+      else          zt[m * 32 + (l & 31)] = v;
     } else {   // sc1 (write-through) store: performed at the device coherence point, whatever XCD reads it
       __hip_atomic_store(a.partial + ((size_t)blockIdx.y * a.M + m) * a.N + n, s, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  if (ns == 1) return;
-  // Hand-off recipe of MI355X_MICROARCH.md ("sc1 stores AND sc1 loads"): the partial tiles are written
-  // through and read back with L1/L2-bypassing loads, the ticket is an agent-scope atomic, and the stores
-  // have been acknowledged (vmcnt 0) before the ticket is taken — no assumption about which XCD the
-  // partners of a column slice run on.  NABU_SKINNY_HEAVY=1 adds full agent-scope release/acquire fences
-  // (L2 write-back + invalidate), for debugging; it doubles the kernel's duration.
-  if (f.heavy) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  else         __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned old = __hip_atomic_fetch_add(f.tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    last_flag = (old == (unsigned)(ns - 1));
-  }
-  __syncthreads();
-  if (!last_flag) return;
-  if (f.heavy) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  for (int e = tid; e < a.M * 32; e += 256) {
-    const int m = e >> 5, n = n0 + (e & 31);
-    float s = 0.f;
-    for (int z0 = 0; z0 < ns; z0 += 8) {   // chunk order: independent of the arrival order
-      float pv[8];                         // all loads of a batch in flight before the first add
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        pv[j] = (z0 + j < ns) ? __hip_atomic_load(a.partial + ((size_t)(z0 + j) * a.M + m) * a.N + n, __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT)
-                              : 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += pv[j];
+  if (ns > 1) {
+    // Hand-off recipe of MI355X_MICROARCH.md ("sc1 stores AND sc1 loads"): the partial tiles are written
+    // through and read back with L1/L2-bypassing loads, the ticket is an agent-scope atomic, and the stores
+    // have been acknowledged (vmcnt 0) before the ticket is taken — no assumption about which XCD the
+    // partners of a column slice run on.  NABU_SKINNY_HEAVY=1 adds full agent-scope release/acquire fences
+    // (L2 write-back + invalidate), for debugging; it doubles the kernel's duration.
+    if (f.heavy) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    else         __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(f.tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_flag = (old == (unsigned)(ns - 1));
     }
-    float *c = a.C + (size_t)m * a.ldc + n;
-    float v = a.alpha * s + (a.bias ? a.bias[n] : 0.f);
-    if (a.beta != 0.f) v += a.beta * *c;
-    *c = v;
+    __syncthreads();
+    if (!last_flag) return;
+    if (f.heavy) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int e = tid; e < a.M * 32; e += 256) {
+      const int m = e >> 5, n = n0 + (e & 31);
+      float s = 0.f;
+      for (int z0 = 0; z0 < ns; z0 += 8) {   // chunk order: independent of the arrival order
+        float pv[8];                         // all loads of a batch in flight before the first add
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          pv[j] = (z0 + j < ns) ? __hip_atomic_load(a.partial + ((size_t)(z0 + j) * a.M + m) * a.N + n, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT)
+                                : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += pv[j];
+      }
+      float v = a.alpha * s + (a.bias ? a.bias[n] : 0.f);
+      if (a.beta != 0.f) v += a.beta * a.C[(size_t)m * a.ldc + n];
+      if (epi == 0) a.C[(size_t)m * a.ldc + n] = v;
+      else          zt[e] = v;
+    }
+    if (tid == 0) __hip_atomic_store(f.tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for reuse
   }
-  if (tid == 0) __hip_atomic_store(f.tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for reuse
+  if (epi == 0) return;
+  __syncthreads();
+  const SkinnyEpilogue &ep = f.ep;
+  const int U = ep.U;
+  if (epi == 1) {
+    // tile columns 4j+g: unit u = n0/4 + j, gates i,j,f,o (TF LSTMCell, forget bias 1)
+    for (int e = tid; e < a.M * 8; e += 256) {
+      const int b = e >> 3, u = (n0 >> 2) + (e & 7);
+      const size_t idx = (size_t)b * U + u, zo = (size_t)b * 4 * U + u;
+      if (ep.step >= ep.seq_len[b]) {   // finished row: dynamic_decode(impute_finished) freezes the state
+        ep.c_new[idx] = ep.c_prev[idx];
+        ep.h_new[idx] = ep.h_prev[idx];
+        ep.acts[zo] = ep.acts[zo + U] = ep.acts[zo + 2 * U] = ep.acts[zo + 3 * U] = 0.f;
+        continue;
+      }
+      const float *zr = zt + b * 32 + 4 * (e & 7);
+      float zi = zr[0] + ep.bias[u], zj = zr[1] + ep.bias[U + u];
+      float zf = zr[2] + ep.bias[2 * U + u], zq = zr[3] + ep.bias[3 * U + u];
+      if (ep.emb) {   // one-hot input times kernel == one row of the (unpermuted) kernel
+        const float *em = ep.emb + (size_t)ep.ids[b] * 4 * U + u;
+        zi += em[0]; zj += em[U]; zf += em[2 * U]; zq += em[3 * U];
+      }
+      const float i = sigmoidf_(zi), g = tanhf_(zj), fg = sigmoidf_(zf + 1.0f), o = sigmoidf_(zq);
+      const float c = ep.c_prev[idx] * fg + i * g;
+      ep.acts[zo] = i; ep.acts[zo + U] = g; ep.acts[zo + 2 * U] = fg; ep.acts[zo + 3 * U] = o;
+      ep.c_new[idx] = c;
+      ep.h_new[idx] = tanhf_(c) * o;
+    }
+  } else {
+    // tile = dh of units n0 .. n0+31 (the query projection's gradient added to the direct one)
+    for (int e = tid; e < a.M * 32; e += 256) {
+      const int b = e >> 5, u = n0 + (e & 31);
+      const size_t idx = (size_t)b * U + u, zo = (size_t)b * 4 * U + u;
+      if (ep.step >= ep.seq_len[b]) {
+        ep.dz[zo] = ep.dz[zo + U] = ep.dz[zo + 2 * U] = ep.dz[zo + 3 * U] = 0.f;
+        ep.dc_out[idx] = ep.dc_in[idx];
+        continue;
+      }
+      const float i = ep.acts[zo], g = ep.acts[zo + U], fg = ep.acts[zo + 2 * U], o = ep.acts[zo + 3 * U];
+      const float tc = tanhf_(ep.c_new[idx]);
+      const float dht = zt[e] + (ep.dh2 ? ep.dh2[(size_t)b * ep.ld_dh2 + u] : 0.f);
+      const float dct = ep.dc_in[idx] + dht * o * (1.f - tc * tc);
+      ep.dz[zo] = dct * g * i * (1.f - i);
+      ep.dz[zo + U] = dct * i * (1.f - g * g);
+      ep.dz[zo + 2 * U] = dct * ep.c_prev[idx] * fg * (1.f - fg);
+      ep.dz[zo + 3 * U] = dht * tc * o * (1.f - o);
+      ep.dc_out[idx] = dct * fg;
+    }
+  }
 }
 
 // C[M,N] = [A | A2]·[B ; B2] (+ bias, beta*C); M <= 64, N % 32 == 0, K1 and K2 multiples of the
 // chunk (K2 may be 0).  partial: nchunks*M*N floats; tickets: N/32 zeroed counters (left zero).
 int gemm_skinny_fused(int M, int N, int K1, const float *A, int lda, const float *B, int ldb, int K2, const float *A2,
                       int lda2, const float *B2, int ldb2, float beta, float *C, int ldc, const float *bias,
-                      float *partial, unsigned *tickets, hipStream_t s) {
+                      float *partial, unsigned *tickets, hipStream_t s, const SkinnyEpilogue *ep) {
   int kc = 0;
   for (int c = 256; c >= 64; c >>= 1)
     if (K1 % c == 0 && K2 % c == 0) { kc = c; break; }
@@ -189,7 +242,8 @@ int gemm_skinny_fused(int M, int N, int K1, const float *A, int lda, const float
   a.nbatch = 1; a.a_bs = a.b_bs = a.c_bs = 0;
   static int heavy_env = -1;
   if (heavy_env < 0) { const char *e = getenv("NABU_SKINNY_HEAVY"); heavy_env = e ? atoi(e) : 0; }
-  SkinnyFuse f = {A2, B2, lda2, ldb2, K1, tickets, heavy_env ? 1 : 0};
+  SkinnyFuse f = {A2, B2, lda2, ldb2, K1, tickets, heavy_env ? 1 : 0, {}};
+  if (ep) f.ep = *ep; else f.ep.kind = 0;
   const int MT = M > 32 ? 2 : 1;
   const size_t xt = (size_t)kc * 32 * MT * sizeof(float), red = (size_t)4 * MT * 1024 * sizeof(float);
   const size_t lds = xt > red ? xt : red;

@@ -16,6 +16,9 @@
 
 #include <stdlib.h>
 
+#include <string>
+#include <thread>
+
 namespace nabu {
 
 constexpr int AT = 512;   // threads per attention workgroup (8 wave64)
@@ -840,6 +843,26 @@ int first_col_one(int rows, int ld, float *x, hipStream_t s) {
   return 0;
 }
 
+// out[r][4u+g] = in[r][gU+u]: the gate-interleaved copy of a cell kernel's dense rows, so that a
+// 32-column slice of the step product holds all four gates of 8 units (LSTM-cell epilogue, gemm_skinny.hip)
+__global__ __launch_bounds__(256) void permute_gates_kernel(int R, int U, const float *__restrict__ in,
+                                                           float *__restrict__ out) {
+  const size_t n = (size_t)R * 4 * U;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / (4 * U);
+    const int c = (int)(i % (4 * U)), u = c >> 2, g = c & 3;
+    out[i] = in[r * 4 * U + (size_t)g * U + u];
+  }
+}
+// dst[r][c] += src[r][c] for row-strided operands
+__global__ __launch_bounds__(256) void add_rows_kernel(int R, int Cn, const float *__restrict__ src, int lds_,
+                                                      float *__restrict__ dst, int ldd) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * Cn) return;
+  const int r = i / Cn, c = i % Cn;
+  dst[(size_t)r * ldd + c] += src[(size_t)r * lds_ + c];
+}
+
 static int grid1(size_t n) {
   size_t b = (n + 255) / 256;
   return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
@@ -1034,6 +1057,12 @@ extern "C" int nabu_scatter_rows_f32(int C, int N, int W, const int32_t *ids, co
 // launches only (a Python/ctypes loop spent ~15 us of host time per launch).
 namespace nabu {
 
+// experiment / test switches, read at every call (a decoder call is milliseconds)
+static int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 struct SpLayout {
   size_t H[NABU_SPELLER_MAX_LAYERS], Cs[NABU_SPELLER_MAX_LAYERS], Ho[NABU_SPELLER_MAX_LAYERS],
       acts[NABU_SPELLER_MAX_LAYERS];
@@ -1066,6 +1095,8 @@ struct SpWs {
   size_t z, dl, dH, dCtx, dkeys, dv, dwf, dck, attn, dq, dz[NABU_SPELLER_MAX_LAYERS], dh[2][NABU_SPELLER_MAX_LAYERS],
       dc[2][NABU_SPELLER_MAX_LAYERS], dctx[2], dal[2], dx, tmp, gemm, gemm_bytes, total;
   size_t wqT, kxT[NABU_SPELLER_MAX_LAYERS], khT[NABU_SPELLER_MAX_LAYERS];   // transposed weights (backward)
+  size_t kperm[NABU_SPELLER_MAX_LAYERS];   // gate-interleaved copies of the cell kernels' dense rows (forward)
+  size_t kxhT, dxh[2];     // [4U, E+U] transposed rows of layer 0's kernel; [B, E+U] carries d(context | h) of a step
   size_t tickets, fpart;   // fused skinny products: per-column-slice tickets (zeroed per call), partial tiles
   // the decoder steps run as NS independent sub-batches on NS streams: per sub-batch slices of
   // the scratch that a step's kernels share
@@ -1079,8 +1110,7 @@ struct SpWs {
 // to the caller's stream by events); what one chain leaves idle the others use.  NABU_SPELLER_STREAMS=n
 // overrides (1 = off).
 static int sp_nsub(const nabu_speller_desc *d) {
-  static int env = -1;
-  if (env < 0) { const char *e = getenv("NABU_SPELLER_STREAMS"); env = e ? atoi(e) : 0; }
+  const int env = env_int("NABU_SPELLER_STREAMS", 0);
   int want = env > 0 ? env : 4;
   while (want > 1 && (d->B % want != 0 || d->B / want < (env > 0 ? 1 : 16))) want /= 2;
   return want < 1 ? 1 : want;
@@ -1119,6 +1149,37 @@ static int sub_join(const SubStreams &ss) {
   }
   return 0;
 }
+// Enqueue the sub-batch chains from one host thread each: a chain is thousands of launches, and ONE thread
+// feeding four streams is about as fast as the GPU drains them (2.5 us per launch against ~10 us kernels, four at a
+// time) — measured: with a single enqueuing thread every queue sat idle ~45% of the time waiting for its next
+// step.  body(sub) enqueues ALL steps of one sub-batch on its stream and returns a NABU_E* / hipError_t code.
+template <typename F>
+static int run_subs(int NS, F body) {
+  if (NS == 1) return body(0);
+  const int threads_env = env_int("NABU_SPELLER_THREADS", 0);
+  int codes[8] = {0};
+  std::string texts[8];
+  if (!threads_env) {
+    for (int i = 0; i < NS; ++i) if (int e = body(i)) return e;
+    return 0;
+  }
+  int dev = 0;
+  NABU_HIP(hipGetDevice(&dev));
+  std::thread th[8];
+  for (int i = 1; i < NS; ++i)
+    th[i] = std::thread([&, i]() {
+      if (hipSetDevice(dev) != hipSuccess) { codes[i] = (int)hipErrorInvalidDevice; texts[i] = "hipSetDevice failed in a decoder enqueue thread"; return; }
+      codes[i] = body(i);
+      if (codes[i]) texts[i] = err_buf();        // the error text is thread-local: hand it to the caller's thread
+    });
+  codes[0] = body(0);
+  for (int i = 1; i < NS; ++i) th[i].join();
+  if (codes[0]) return codes[0];
+  for (int i = 1; i < NS; ++i)
+    if (codes[i]) return fail(codes[i], "%s", texts[i].c_str());
+  return 0;
+}
+
 static nabu_attn_desc sub_attn_desc(const nabu_speller_desc *d, int Bn) {
   nabu_attn_desc a = {sizeof(nabu_attn_desc), Bn, d->Te, d->E, d->U, d->kind, d->K, d->F, d->prob_fn};
   return a;
@@ -1159,6 +1220,9 @@ static SpWs sp_ws(const nabu_speller_desc *d) {
     s.kxT[n] = take(4 * U * (n == 0 ? E : U));
     s.khT[n] = take(4 * U * U);
   }
+  for (int n = 0; n < d->num_layers; ++n) s.kperm[n] = take((n == 0 ? E + U : 2 * U) * 4 * U);
+  s.kxhT = take(4 * U * (E + U));
+  for (int i = 0; i < 2; ++i) s.dxh[i] = take(B * (E + U));
   s.tickets = take(NS * 1024);
   {
     size_t kmax = E + U > 4 * U ? E + U : 4 * U, nmax = 4 * U > E ? 4 * U : E;
@@ -1209,9 +1273,7 @@ static int mm(bool ta, bool tb, int M, int N, int K, const float *A, int lda, co
 // C[M,N] = A·B + A2·B2 (+ beta*C): ONE launch with the split-K reduction inside it when the shape
 // allows (gemm_skinny.hip), else two plain products
 static bool fused_ok(int M, int N, int K1, int lda, int K2, int lda2) {
-  static int env = -1;
-  if (env < 0) { const char *e = getenv("NABU_SPELLER_FUSED"); env = e ? atoi(e) : 1; }
-  return env && M <= 64 && N % 32 == 0 && K1 > 0 && K1 % 64 == 0 && K2 % 64 == 0 && lda % 4 == 0 && (K2 == 0 || lda2 % 4 == 0);
+  return env_int("NABU_SPELLER_FUSED", 1) && M <= 64 && N % 32 == 0 && K1 > 0 && K1 % 64 == 0 && K2 % 64 == 0 && lda % 4 == 0 && (K2 == 0 || lda2 % 4 == 0);
 }
 static int mm2(int M, int N, int K1, const float *A, int lda, const float *Bm, int ldb, int K2, const float *A2, int lda2,
                const float *B2, int ldb2, float beta, float *C, int ldc, float *w, const SpWs &W, int sub, float *gw,
@@ -1280,11 +1342,26 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
   const int NS = W.NS, Bn = B / NS;
   const nabu_attn_desc adn = sub_attn_desc(d, Bn);
   const size_t attn_fwd_wsb_n = nabu_attn_fwd_ws_bytes(&adn);
+  // LSTM cell folded into the step product's last workgroup (gemm_skinny.hip) when the shapes allow:
+  // the product then runs against gate-interleaved copies of the kernels' dense rows
+  const int epi_env = env_int("NABU_SPELLER_EPILOGUE", 1);
+  bool cell_epi[NABU_SPELLER_MAX_LAYERS];
+  for (int n = 0; n < nl; ++n) {
+    const int K1 = n == 0 ? E : U;
+    cell_epi[n] = epi_env && fused_ok(Bn, 4 * U, K1, K1, U, U);
+    if (cell_epi[n]) {
+      const int rows = K1 + U;
+      const float *src = p->lstm_kernel[n] + (n == 0 ? (size_t)C * 4 * U : 0);
+      hipLaunchKernelGGL(permute_gates_kernel, dim3(grid1((size_t)rows * 4 * U)), dim3(256), 0, s, rows, U, src,
+                         w + W.kperm[n]);
+      NABU_LAUNCH_CHECK();
+    }
+  }
   SubStreams ss;
   SP_TRY(sub_streams(NS, s, &ss));
   SP_TRY(sub_fork(ss));
-  for (int t = 0; t < L; ++t) {
-    for (int sub = 0; sub < NS; ++sub) {
+  auto fwd_chain = [&](int sub) -> int {
+    for (int t = 0; t < L; ++t) {
       const int b0 = sub * Bn;
       nabu_stream_t st = static_cast<nabu_stream_t>(ss.st[sub]);
       float *gws = gw + (size_t)sub * W.gemm_each;
@@ -1294,7 +1371,22 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
         const float *Kn = p->lstm_kernel[n];
         float *Hn = r + R.H[n] + (size_t)b0 * U, *Cn = r + R.Cs[n] + (size_t)b0 * U;
         const size_t cur = (size_t)t * B * U, nxt = (size_t)(t + 1) * B * U;
-        if (n == 0) {
+        if (cell_epi[n]) {   // product + cell in one launch
+          SkinnyEpilogue ep = {};
+          ep.kind = 1; ep.U = U; ep.step = t; ep.seq_len = dlen;
+          ep.bias = p->lstm_bias[n];
+          ep.emb = n == 0 ? Kn : nullptr;
+          ep.ids = n == 0 ? ids_used + (size_t)t * B + b0 : nullptr;
+          ep.c_prev = Cn + cur; ep.h_prev = Hn + cur;
+          ep.acts = r + R.acts[n] + (size_t)t * B * 4 * U + (size_t)b0 * 4 * U;
+          ep.c_new = Cn + nxt; ep.h_new = Hn + nxt;
+          const int K1 = n == 0 ? E : U;
+          const float *x1 = n == 0 ? r + R.ctx + (size_t)t * B * E + (size_t)b0 * E : r + R.Ho[n - 1] + nxt + (size_t)b0 * U;
+          const float *Kp = w + W.kperm[n];
+          SP_TRY(gemm_skinny_fused(Bn, 4 * U, K1, x1, K1, Kp, 4 * U, U, Hn + cur, U, Kp + (size_t)K1 * 4 * U, 4 * U, 0.f, z,
+                                   4 * U, nullptr, w + W.fpart + (size_t)sub * W.fpart_each,
+                                   reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)sub * 1024, ss.st[sub], &ep));
+        } else if (n == 0) {
           SP_TRY(mm2(Bn, 4 * U, E, r + R.ctx + (size_t)t * B * E + (size_t)b0 * E, E, Kn + (size_t)C * 4 * U, 4 * U, U,
                      Hn + cur, U, Kn + (size_t)(C + E) * 4 * U, 4 * U, 0.f, z, 4 * U, w, W, sub, gws, gwb, st));
           SP_TRY(nabu_lstm_cell_fwd(Bn, U, t, dlen, z, p->lstm_bias[0], Kn, ids_used + (size_t)t * B + b0, Cn + cur,
@@ -1329,7 +1421,9 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
                                ids + (size_t)(t + 1) * B + b0, ids_used + (size_t)(t + 1) * B + b0, b0, ss.st[sub]));
       }
     }
-  }
+    return 0;
+  };
+  SP_TRY(run_subs(NS, fwd_chain));
   SP_TRY(sub_join(ss));
   // output projection of all steps: [h_t, ctx_t]·W + b, then batch-major + impute_finished
   float *ltm = r + R.logits_tm;
@@ -1400,16 +1494,30 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   SubStreams ss;
   SP_TRY(sub_streams(NS, s, &ss));
   SP_TRY(sub_fork(ss));
+  // single-layer decoder without dropout (the BASELINE recipes): the cell's backward pass is folded into the
+  // last workgroup of dq·Wq^T, and dz·[Kx^T | Kh^T] is ONE product whose [B, E+U] result carries d context and
+  // d h to the next step — 4 dependent launches per step instead of 7
+  const int epi_env_b = env_int("NABU_SPELLER_EPILOGUE", 1);
+  const bool fuse_b = epi_env_b && nl == 1 && !drop && fused_ok(Bn, U, U, U, 0, 0) && fused_ok(Bn, E + U, 4 * U, 4 * U, 0, 0) &&
+                      (E + U) / 32 <= 1024;
+  if (fuse_b) SP_TRY(transpose(E + U, 4 * U, p->lstm_kernel[0] + (size_t)C * 4 * U, 4 * U, w + W.kxhT, s));
+  auto bwd_chain = [&](int sub) -> int {
   int cur = 0;   // index of the carries coming from step t+1
   bool have_carry = false;
   for (int t = L - 1; t >= 0; --t) {
-    for (int sub = 0; sub < NS; ++sub) {
+    {
       const int b0 = sub * Bn;
       nabu_stream_t st = static_cast<nabu_stream_t>(ss.st[sub]);
       float *gws = gw + (size_t)sub * W.gemm_each;
       const int32_t *dlen = dec_len + b0;
       float *dCt = dCtx + (size_t)t * B * E + (size_t)b0 * E;
-      if (have_carry) SP_TRY(nabu_axpy_f32((size_t)Bn * E, 1.f, w + W.dctx[(t + 1) & 1] + (size_t)b0 * E, dCt, st));
+      if (have_carry && fuse_b) {
+        hipLaunchKernelGGL(add_rows_kernel, dim3(grid1((size_t)Bn * E)), dim3(256), 0, ss.st[sub], Bn, E,
+                           w + W.dxh[(t + 1) & 1] + (size_t)b0 * (E + U), E + U, dCt, E);
+        NABU_LAUNCH_CHECK();
+      } else if (have_carry) {
+        SP_TRY(nabu_axpy_f32((size_t)Bn * E, 1.f, w + W.dctx[(t + 1) & 1] + (size_t)b0 * E, dCt, st));
+      }
       float *dal_out = d->kind == 1 ? w + W.dal[t & 1] + (size_t)b0 * Te : nullptr;
       const float *dal_carry = (d->kind == 1 && have_carry) ? w + W.dal[(t + 1) & 1] + (size_t)b0 * Te : nullptr;
       float *dqt = dq + (size_t)t * B * U + (size_t)b0 * U;
@@ -1423,6 +1531,29 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
                            d->kind == 1 ? w + W.dck + (size_t)b0 * K * F : nullptr, dal_out,
                            r + R.znorm + (size_t)t * B + b0, w + W.attn + (size_t)sub * W.attn_each, attn_wsb_n, st));
       float *dHt = dH + (size_t)t * B * U + (size_t)b0 * U;
+      if (fuse_b) {
+        float *dzt = w + W.dz[0] + (size_t)t * B * 4 * U + (size_t)b0 * 4 * U;
+        const float *Cn = r + R.Cs[0] + (size_t)b0 * U;
+        SkinnyEpilogue ep = {};
+        ep.kind = 2; ep.U = U; ep.step = t; ep.seq_len = dlen;
+        ep.acts = r + R.acts[0] + (size_t)t * B * 4 * U + (size_t)b0 * 4 * U;
+        ep.c_new = const_cast<float *>(Cn + (size_t)(t + 1) * B * U);
+        ep.c_prev = Cn + (size_t)t * B * U;
+        ep.dh2 = have_carry ? w + W.dxh[(t + 1) & 1] + (size_t)b0 * (E + U) + E : nullptr;
+        ep.ld_dh2 = E + U;
+        ep.dc_in = w + W.dc[cur][0] + (size_t)b0 * U;
+        ep.dz = dzt;
+        ep.dc_out = w + W.dc[cur ^ 1][0] + (size_t)b0 * U;
+        float *fp = w + W.fpart + (size_t)sub * W.fpart_each;
+        unsigned *tk = reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)sub * 1024;
+        SP_TRY(gemm_skinny_fused(Bn, U, U, dqt, U, w + W.wqT, U, 0, nullptr, 0, nullptr, 0, 1.f, dHt, U, nullptr, fp, tk,
+                                 ss.st[sub], &ep));
+        SP_TRY(gemm_skinny_fused(Bn, E + U, 4 * U, dzt, 4 * U, w + W.kxhT, E + U, 0, nullptr, 0, nullptr, 0, 0.f,
+                                 w + W.dxh[t & 1] + (size_t)b0 * (E + U), E + U, nullptr, fp, tk, ss.st[sub], nullptr));
+        have_carry = true;
+        cur ^= 1;
+        continue;
+      }
       SP_TRY(mm2(Bn, U, U, dqt, U, w + W.wqT, U, 0, nullptr, 0, nullptr, 0, 1.f, dHt, U, w, W, sub, gws, gwb, st));
       const float *dtop = dHt;
       for (int n = nl - 1; n >= 0; --n) {
@@ -1455,6 +1586,9 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
     have_carry = true;
     cur ^= 1;
   }
+  return 0;
+  };
+  SP_TRY(run_subs(NS, bwd_chain));
   SP_TRY(sub_join(ss));
   // sums over steps as single GEMMs
   SP_TRY(mm(true, false, U, U, BL, htop_all, U, dq, U, 0.f, g->query_kernel, U, nullptr, gw, gwb, stream));

@@ -392,6 +392,27 @@ def test_gemm2_two_segment_product_with_the_reduce_inside_the_launch(M, N, K1, K
         ops.gemm2(dev(a[:, :40]), dev(b[:40]), None, None, dev(c0))
 
 
+@pytest.mark.parametrize('M,N,K', [(4000, 260, 40), (2500, 2048, 80), (32000, 128, 8), (2049, 132, 96)])
+def test_gemm_small_k_tall_output(M, N, K):
+    """the first layer's input projection shape class (K <= 96, M >= 2048): gemm_smallk_kernel — whole K in one load
+    phase, 16-byte row stores through LDS — with bias, beta and edge tiles in both dimensions, against float64"""
+    from nabu_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    a = rng.normal(size=(M, K)).astype(np.float32)
+    b = rng.normal(size=(K, N)).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    c0 = rng.normal(size=(M, N)).astype(np.float32)
+    ref = a.astype(np.float64) @ b.astype(np.float64)
+    c = torch.empty((M, N), device='cuda').fill_(float('nan'))         # beta = 0 must not read C
+    ops.gemm(torch.tensor(a, device='cuda'), torch.tensor(b, device='cuda'), c)
+    assert np.abs(c.cpu().numpy() - ref).max() / np.abs(ref).max() < 2e-6
+    c = torch.tensor(c0, device='cuda')
+    ops.gemm(torch.tensor(a, device='cuda'), torch.tensor(b, device='cuda'), c, alpha=0.5, beta=2.0,
+             bias=torch.tensor(bias, device='cuda'))
+    ref2 = 0.5 * ref + bias + 2.0 * c0
+    assert np.abs(c.cpu().numpy() - ref2).max() / np.abs(ref2).max() < 2e-6
+
+
 def test_cross_entropy_losses_match_oracle():
     """average_cross_entropy (loss_functions.py:155-165) and sum_cross_entropy (:142-153) on ragged
     lengths: loss and the gradient the tape receives"""

@@ -80,7 +80,36 @@ def test_speller_step_at_the_cfg5_attention_geometry():
     check_speller('vanilla', 1, 64, 0, 0, enc_len, tlen)
 
 
-def check_speller(attention, nl, U, K, F, enc_len, tlen):
+@pytest.mark.parametrize('attention,nl,K,F', [('vanilla', 1, 0, 0), ('location_aware', 1, 5, 3), ('vanilla', 2, 0, 0),
+                                              ('windowed', 1, 2, 3)])
+def test_speller_step_on_the_fused_and_multi_stream_paths(attention, nl, K, F):
+    """shapes that take every round-2 path of the decoder driver — 32 utterances (two sub-batches on two
+    streams), E = U = 64 (the [context | h]·kernel product with the LSTM-cell epilogue, the cell's backward pass
+    in the epilogue of dq·Wq^T, dz·[Kx^T | Kh^T] as one product; two layers: the unfused fallbacks) — against
+    the oracle, and bit-identical with the sub-batching switched off"""
+    import os
+    rng = np.random.default_rng(77)
+    enc_len = rng.integers(20, 41, 32).astype(np.int32)
+    enc_len[0] = 40
+    tlen = rng.integers(1, 7, 32).astype(np.int32)
+    tlen[3] = 6
+    got = check_speller(attention, nl, 64, K, F, enc_len, tlen, E=64)
+    os.environ['NABU_SPELLER_EPILOGUE'] = '0'
+    try:
+        ref = check_speller(attention, nl, 64, K, F, enc_len, tlen, E=64)
+    finally:
+        del os.environ['NABU_SPELLER_EPILOGUE']
+    # the epilogue variants reorder float additions (one product over [context | h] instead of two): close, not equal
+    assert np.abs(got - ref).max() < 1e-5
+    os.environ['NABU_SPELLER_STREAMS'] = '1'       # no sub-batching: the same arithmetic per utterance
+    try:
+        one = check_speller(attention, nl, 64, K, F, enc_len, tlen, E=64)
+    finally:
+        del os.environ['NABU_SPELLER_STREAMS']
+    np.testing.assert_array_equal(got, one)
+
+
+def check_speller(attention, nl, U, K, F, enc_len, tlen, E=24):
     from nabu_amd import variables as vs
     from nabu_amd.autodiff import Tape, SeqLen
     from nabu_amd.neuralnetworks.models.ed_decoders import ed_decoder_factory
@@ -88,7 +117,7 @@ def check_speller(attention, nl, U, K, F, enc_len, tlen):
     attention, _, prob_fn = attention.partition(':')
     prob_fn = prob_fn or 'softmax'
     rng = np.random.default_rng(U + K)
-    B, E, C = len(enc_len), 24, 8
+    B, C = len(enc_len), 8
     Te, Lmax = int(enc_len.max()), int(tlen.max()) + 1
     over = {'decoder.num_layers': nl, 'decoder.num_units': U, 'decoder.attention': attention,
             'decoder.probability_fn': prob_fn}
@@ -143,6 +172,7 @@ def check_speller(attention, nl, U, K, F, enc_len, tlen):
         q = PRE + 'attention_wrapper/multi_rnn_cell/cell_%d/lstm_cell/' % n
         assert rel(store.vars[q + 'kernel'].grad.cpu().numpy(), rg['lstm'][n]['kernel']) < 2e-4, n
         assert rel(store.vars[q + 'bias'].grad.cpu().numpy(), rg['lstm'][n]['bias']) < 2e-4, n
+    return lg
 
 
 @pytest.mark.parametrize('recipe,over', [
