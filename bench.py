@@ -58,8 +58,10 @@ def cpu_baseline(budget_s=150.0):
     threads for these small per-frame products (measured: cfg1 6.5 s/step at 128 threads, 0.6 s at
     8), so a short sweep on cfg1 picks the fastest count and `cores` reports the threads actually
     used — the baseline should be the CPU at its best, not at its worst.  cfg1: 2 warm-ups + median
-    of 5 steps.  cfg2 (the headline workload): 1 warm-up + >= 2 FULL steps inside the time budget —
-    no extrapolation from shorter sequences.  torch.nn.LSTM's fused kernel is the upper baseline."""
+    of 5 steps.  cfg2 (the headline workload): 2 complete steps at FULL T, no extrapolation from
+    shorter sequences and no warm-up (a step is ~40 s; on this path the first step is not slower
+    than the second: 40.4 s / 42.1 s measured) so that the default run stays near three minutes.
+    torch.nn.LSTM's fused kernel is the upper baseline."""
     from oracle import cpu_baseline as cb
     t_start = time.perf_counter()
     phys = cb.physical_cores()
@@ -72,13 +74,13 @@ def cpu_baseline(budget_s=150.0):
     c1 = cb.time_config('cfg1', 2, 5, threads=cores)
     c1f = cb.time_config('cfg1', 2, 5, fused=True, threads=cores)
     left = budget_s - (time.perf_counter() - t_start)
-    c2 = cb.time_config('cfg2', 1, 5, threads=cores, budget_s=0.55 * left)
+    c2 = cb.time_config('cfg2', 0, 2, threads=cores, budget_s=0.55 * left)
     left = budget_s - (time.perf_counter() - t_start)
     # the upper baseline gets no warm-up at cfg2 (a step is tens of seconds and the first one was not
     # measurably slower: 40.4 s against 42.1 s) so that the default run stays within a few minutes
     c2f = cb.time_config('cfg2', 0, 2, fused=True, threads=cores, budget_s=max(left, 1.0))
     return {'value': c2['utt_per_s'], 'unit': 'utterances/sec', 'cores': cores, 'kind': 'port',
-            'sample': 'cfg2 (32 x 1000 x 40, 4x512 Listener + CTC), full T: %d warm-up + median of %d complete '
+            'sample': 'cfg2 (32 x 1000 x 40, 4x512 Listener + CTC), full T: %d warm-ups + median of %d complete '
                       'training steps (%s s each) of the reference graph restated at TF op granularity in '
                       'PyTorch-CPU float32 (per-frame [B,in+H]x[in+H,4H] matmul per direction, autograd, '
                       'per-variable clip+Adam); torch.set_num_threads(%d) = the fastest of a sweep on cfg1 '
