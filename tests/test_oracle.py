@@ -348,3 +348,39 @@ def test_relu_layer_norm_vs_torch_autograd():
     np.testing.assert_allclose(tb.grad.numpy(), db, atol=1e-11)
     r = O.relu_fwd(x)
     assert np.array_equal(O.relu_bwd(dy, r), np.where(x > 0, dy, 0))
+
+
+def test_cpu_baseline_restatement_is_the_same_graph():
+    """oracle/cpu_baseline.py (what bench.py times on the host: the reference graph at TF op granularity in
+    PyTorch-CPU) computes what the oracle computes — a ragged BLSTM layer in both its per-frame form and its
+    torch.nn.LSTM form, values and input gradient, in float64"""
+    from oracle import cpu_baseline as CB
+    rng = np.random.default_rng(11)
+    B, T, D, H = 3, 9, 5, 4
+    lens = np.array([9, 6, 2], np.int32)
+    x = rng.normal(size=(B, T, D))
+    x *= (np.arange(T)[None, :, None] < lens[:, None, None])
+    p = {'%s_%s' % (d, k): rng.normal(size=s) * 0.5 for d in ('fw', 'bw')
+         for k, s in (('kernel', (D + H, 4 * H)), ('bias', (4 * H,)))}
+    y, cache = O.blstm_fwd(x, lens, p)
+    dy = rng.normal(size=y.shape)
+    dx, _ = O.blstm_bwd(dy, cache)
+    tl = torch.tensor(lens).long()
+    for fn in (CB.dynamic_rnn, CB.fused_lstm_dir):
+        xt = torch.tensor(x, requires_grad=True)
+        yt = torch.cat([fn(xt, tl, torch.tensor(p['fw_kernel']), torch.tensor(p['fw_bias']), False),
+                        fn(xt, tl, torch.tensor(p['bw_kernel']), torch.tensor(p['bw_bias']), True)], 2)
+        np.testing.assert_allclose(yt.detach().numpy(), y, atol=1e-12)
+        (yt * torch.tensor(dy)).sum().backward()
+        np.testing.assert_allclose(xt.grad.numpy(), dx, atol=1e-12)
+    # and one whole training step of the timed configuration runs and decreases nothing silently: same loss
+    # from the per-frame and the fused form on identical weights
+    layers, out = CB.make_params('cfg1')
+    batch = CB.make_batch('cfg1')
+    small = (batch[0][:2, :30], torch.tensor([30, 22]), batch[2][:2, :5], torch.tensor([5, 4]))
+    l1 = CB.train_step('cfg1', [{k: v.detach().clone().requires_grad_() for k, v in l.items()} for l in layers],
+                       {k: v.detach().clone().requires_grad_() for k, v in out.items()}, small, {'t': 0, 'm': {}, 'v': {}})
+    l2 = CB.train_step('cfg1', [{k: v.detach().clone().requires_grad_() for k, v in l.items()} for l in layers],
+                       {k: v.detach().clone().requires_grad_() for k, v in out.items()}, small, {'t': 0, 'm': {}, 'v': {}},
+                       fused=True)
+    assert abs(l1 - l2) < 1e-4 * abs(l1)
