@@ -302,18 +302,31 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
     const bool have_next = k0 + KT < kend && !(a.vecA & 2);       // registers hold tile k0+KT
     const bool load_next2 = k0 + 2 * KT < kend && !(a.vecA & 2);
     const float *As = NABU_ATILE(cur), *Bs = NABU_BTILE(cur);
-    // operands of k-step kk+2 are read from LDS before the MFMAs of k-step kk are issued (left to
-    // itself hipcc reads them after, and the wave then waits out the LDS latency with an empty pipe)
-    float a0n = NABU_AEL(As, wm * 64 + li, lk), a1n = NABU_AEL(As, wm * 64 + 32 + li, lk);
-    float b0n = NABU_BEL(Bs, wn * 64 + li, lk), b1n = NABU_BEL(Bs, wn * 64 + 32 + li, lk);
+    // Operand reads as explicit ds_read_b32 with IMMEDIATE offsets off one base register per operand and
+    // tile: hipcc pairs the reads into ds_read2(st64)_b32, whose 8-bit offsets cannot hold the k-step
+    // offset, and re-computes a base with a VALU add for every pair — ~1 VALU instruction per MFMA, paid
+    // out of the matrix pipe's own cycles (fp32 MFMA and VALU share it on gfx950).  The loads are
+    // invisible to the compiler's wait-count bookkeeping, so every k-step claims the previous step's four
+    // values with a counted wait (LDS operations complete in order: "at most the four newest outstanding"
+    // means everything older, compiler-issued stores included, is done) whose in/out operands tie the
+    // MFMAs below to it.  Operands of k-step kk+2 are read before the MFMAs of k-step kk are issued.
+    const unsigned a_base = (unsigned)(reinterpret_cast<uintptr_t>(TA ? As + lk * LDT + wm * 64 + li : As + (wm * 64 + li) * LDK + lk));
+    const unsigned b_base = (unsigned)(reinterpret_cast<uintptr_t>(TB ? Bs + (wn * 64 + li) * LDK + lk : Bs + lk * LDT + wn * 64 + li));
+    constexpr int A_KSTEP = TA ? 2 * LDT * 4 : 2 * 4, A_ROW32 = TA ? 32 * 4 : 32 * LDK * 4;   // bytes per k-step / per 32 rows
+    constexpr int B_KSTEP = TB ? 2 * 4 : 2 * LDT * 4, B_ROW32 = TB ? 32 * LDK * 4 : 32 * 4;
+#define NABU_LDSR(dst, base, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off))
+    float a0n, a1n, b0n, b1n;
+    NABU_LDSR(a0n, a_base, 0); NABU_LDSR(a1n, a_base, A_ROW32);
+    NABU_LDSR(b0n, b_base, 0); NABU_LDSR(b1n, b_base, B_ROW32);
 #pragma unroll
     for (int kk = 0; kk < KT; kk += 2) {
-      const float a0 = a0n, a1 = a1n, b0 = b0n, b1 = b1n;
+      float a0 = a0n, a1 = a1n, b0 = b0n, b1 = b1n;
       if (kk + 2 < KT) {
-        a0n = NABU_AEL(As, wm * 64 + li, kk + 2 + lk);
-        a1n = NABU_AEL(As, wm * 64 + 32 + li, kk + 2 + lk);
-        b0n = NABU_BEL(Bs, wn * 64 + li, kk + 2 + lk);
-        b1n = NABU_BEL(Bs, wn * 64 + 32 + li, kk + 2 + lk);
+        NABU_LDSR(a0n, a_base, (kk / 2 + 1) * A_KSTEP); NABU_LDSR(a1n, a_base, (kk / 2 + 1) * A_KSTEP + A_ROW32);
+        NABU_LDSR(b0n, b_base, (kk / 2 + 1) * B_KSTEP); NABU_LDSR(b1n, b_base, (kk / 2 + 1) * B_KSTEP + B_ROW32);
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
       }
       __builtin_amdgcn_sched_barrier(0);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
@@ -331,6 +344,7 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
     __syncthreads();
     cur ^= 1;
   }
+#undef NABU_LDSR
 #undef NABU_ATILE
 #undef NABU_BTILE
 #undef NABU_AEL
