@@ -96,6 +96,25 @@ int nabu_gemm2_f32(int M, int N, int K1, const float *A, int lda, const float *B
                    const float *A2, int lda2, const float *B2, int ldb2, float beta, float *C, int ldc,
                    const float *bias, void *ws, size_t ws_bytes, nabu_stream_t stream);
 
+/* bf16-RESIDENT operands — the "bf16 MFMA input-to-hidden GEMMs" of BASELINE.json configs[4] with the
+ * operands converted once instead of inside every product (each is used several times: the layer input
+ * in the forward product and the weight gradient, dz in the input gradient and the weight gradient):
+ *   nabu_cvt_bf16      dst (bf16, [R,ldd], or [C,ldd] when transpose != 0) = RNE(src fp32 [R,ld]);
+ *                      plain copy: C % 8 == 0, ld % 4 == 0, ldd % 8 == 0; transposed: ld % 4, ldd % 2;
+ *   nabu_gemm_bf16_nt  C[M,N] (fp32) = alpha * sum_k A[m,k]·B[n,k] + beta*C + bias[N], A [M,lda] and B [N,ldb]
+ *                      bf16 with the reduction index contiguous; K % 64 == 0, lda % 8 == ldb % 8 == 0
+ *                      (NABU_EUNSUP otherwise); fp32 accumulation (v_mfma_f32_32x32x16_bf16), deterministic
+ *                      split-K through ws (nabu_gemm_bf16_nt_ws_bytes).
+ * nabu_blstm_fwd/_bwd use them for the products X·Wx, dZ·Wx^T, X^T·dZ when desc.gemm_precision is
+ * NABU_GEMM_BF16 and the shapes allow; same rounding as NABU_GEMM_BF16 of nabu_gemm_ex.
+ * Replaces: the same tf MatMul ops as nabu_gemm_ex (components/layer.py:35-47 and their autodiff). */
+int nabu_cvt_bf16(size_t R, int C, const float *src, int ld, void *dst_bf16, int ldd, int transpose,
+                  nabu_stream_t stream);
+size_t nabu_gemm_bf16_nt_ws_bytes(int M, int N, int K);
+int nabu_gemm_bf16_nt(int M, int N, int K, float alpha, const void *A_bf16, int lda, const void *B_bf16, int ldb,
+                      float beta, float *C, int ldc, const float *bias, void *ws, size_t ws_bytes,
+                      nabu_stream_t stream);
+
 /* out[n] = beta*out[n] + sum_m A[m*lda + n]  (bias gradients; deterministic
  * two-stage tree).  ws >= nabu_colsum_ws_bytes(M,N). */
 size_t nabu_colsum_ws_bytes(int M, int N);

@@ -32,6 +32,9 @@ SIGNATURES = {
                           _vp, _sz, _vp]),
     'nabu_gemm2_ws_bytes': (_sz, [_i, _i, _i, _i]),
     'nabu_gemm2_f32': (_i, [_i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _i, _vp, _vp, _sz, _vp]),
+    'nabu_cvt_bf16': (_i, [_sz, _i, _vp, _i, _vp, _i, _i, _vp]),
+    'nabu_gemm_bf16_nt_ws_bytes': (_sz, [_i, _i, _i]),
+    'nabu_gemm_bf16_nt': (_i, [_i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i, _vp, _vp, _sz, _vp]),
     'nabu_gemm_set_default_precision': (_i, [_i]),
     'nabu_gemm_get_default_precision': (_i, []),
     'nabu_colsum_ws_bytes': (_sz, [_i, _i]),

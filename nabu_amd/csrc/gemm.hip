@@ -500,6 +500,31 @@ static int choose_split(int M, int N, int K, int *ksplit) {
   return ns;
 }
 
+int gemm_split_for(int M, int N, int K, int kmult, int target, int *ksplit) {
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  int ns = 1;
+  if (tiles < target && K >= 1024) {
+    ns = (target + tiles - 1) / tiles;
+    const int maxs = K / (K >= 4096 ? 512 : 256);
+    if (ns > maxs) ns = maxs;
+    if (ns < 1) ns = 1;
+  }
+  int ks = (K + ns - 1) / ns;
+  ks = (ks + kmult - 1) / kmult * kmult;
+  ns = (K + ks - 1) / ks;
+  *ksplit = ks;
+  return ns;
+}
+
+int gemm_splitk_reduce(const GemmArgs &a, hipStream_t s) {
+  const size_t total = (size_t)a.M * a.N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
 int gemm_batched_f32(bool transA, bool transB, int M, int N, int K, const float *A, int lda, long long a_bs,
                      const float *B, int ldb, long long b_bs, float beta, float *C, int ldc, long long c_bs, int nbatch,
                      hipStream_t s) {
@@ -557,6 +582,29 @@ extern "C" int nabu_gemm2_f32(int M, int N, int K1, const float *A, int lda, con
   NABU_HIP(hipMemsetAsync(ws, 0, 4096, s));
   return gemm_skinny_fused(M, N, K1, A, lda, B, ldb, K2, A2, lda2, B2, ldb2, beta, C, ldc, bias,
                            reinterpret_cast<float *>(static_cast<char *>(ws) + 4096), static_cast<unsigned *>(ws), s);
+}
+
+// bf16-resident operands (gemm_bf16_pre.hip)
+extern "C" int nabu_cvt_bf16(size_t R, int C, const float *src, int ld, void *dst_bf16, int ldd, int transpose,
+                             nabu_stream_t stream) {
+  NABU_CHECK_ARG(src && dst_bf16 && C > 0, "cvt_bf16: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (transpose) return cvt_bf16_t((int)R, C, src, ld, static_cast<unsigned short *>(dst_bf16), ldd, s);
+  return cvt_bf16(R, C, src, ld, static_cast<unsigned short *>(dst_bf16), ldd, s);
+}
+extern "C" size_t nabu_gemm_bf16_nt_ws_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return gemm_bf16_pre_ws_bytes(M, N, K);
+}
+extern "C" int nabu_gemm_bf16_nt(int M, int N, int K, float alpha, const void *A_bf16, int lda, const void *B_bf16,
+                                 int ldb, float beta, float *C, int ldc, const float *bias, void *ws, size_t ws_bytes,
+                                 nabu_stream_t stream) {
+  NABU_CHECK_ARG(M >= 0 && N >= 0 && K > 0, "gemm_bf16_nt: bad dimensions");
+  if (M == 0 || N == 0) return 0;
+  NABU_CHECK_ARG(A_bf16 && B_bf16 && C, "gemm_bf16_nt: null pointer");
+  return gemm_bf16_pre(M, N, K, alpha, static_cast<const unsigned short *>(A_bf16), lda,
+                       static_cast<const unsigned short *>(B_bf16), ldb, beta, C, ldc, bias, ws, ws_bytes,
+                       static_cast<hipStream_t>(stream));
 }
 
 static int g_default_precision = 0;   // 0 = not initialised yet

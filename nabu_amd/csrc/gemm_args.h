@@ -80,6 +80,19 @@ int gemm_batched_f32(bool transA, bool transB, int M, int N, int K, const float 
                      const float *B, int ldb, long long b_bs, float beta, float *C, int ldc, long long c_bs, int nbatch,
                      hipStream_t s);
 
+// split-K policy shared by the tile kernels: >= target workgroups, k-range a multiple of kmult
+int gemm_split_for(int M, int N, int K, int kmult, int target, int *ksplit);
+int gemm_splitk_reduce(const GemmArgs &a, hipStream_t s);
+
+// bf16 operands resident in memory (gemm_bf16_pre.hip): C = alpha * A·B^T + beta*C + bias, A [M,lda] and
+// B [N,ldb] bf16 with k contiguous; conversions fp32 -> bf16 (plain / transposed copies)
+bool gemm_bf16_pre_ok(int M, int N, int K, int lda, int ldb);
+size_t gemm_bf16_pre_ws_bytes(int M, int N, int K);
+int gemm_bf16_pre(int M, int N, int K, float alpha, const unsigned short *A, int lda, const unsigned short *B, int ldb,
+                  float beta, float *C, int ldc, const float *bias, void *ws, size_t ws_bytes, hipStream_t s);
+int cvt_bf16(size_t R, int C, const float *src, int ld, unsigned short *dst, int ldd, hipStream_t s);
+int cvt_bf16_t(int R, int C, const float *src, int ld, unsigned short *dst, int ldd, hipStream_t s);
+
 // bf16-split kernels (gemm_bf16.hip); planes = 1 (bf16), 2 (bf16x3) or 3 (bf16x6)
 int gemm_bf16_launch(const GemmArgs &a, bool transA, bool transB, int planes, dim3 grid, hipStream_t stream);
 

@@ -13,6 +13,9 @@
 #include "common.h"
 #include "lstm_persist.h"
 
+#include <stdlib.h>
+#include "gemm_args.h"
+
 namespace nabu {
 
 struct StepArgs {
@@ -182,7 +185,20 @@ struct Layout {
   size_t reserve_bytes;
   // workspace carve
   size_t hstate_off, cstate_off, gemm_off, gemm_bytes, persist_off, persist_bytes, total;
+  // bf16-resident input products (gemm_precision = bf16): converted copies of the operands
+  bool bf16_pre;
+  size_t bf16_off, bf16_bytes;
 };
+
+// the input-to-hidden products X·Wx, dZ·Wx^T, X^T·dZ run on bf16 copies of their operands (converted once per
+// call, gemm_bf16_pre.hip) when bf16 arithmetic is requested and every reduction length is a multiple of 64
+static bool bf16_resident(const nabu_blstm_desc *d) {
+  const int prec = d->gemm_precision == NABU_GEMM_DEFAULT ? nabu_gemm_get_default_precision() : d->gemm_precision;
+  static int env = -1;
+  if (env < 0) { const char *e = getenv("NABU_BF16_RESIDENT"); env = e ? atoi(e) : 1; }
+  const long long BT = (long long)d->B * d->T;
+  return env && prec == NABU_GEMM_BF16 && d->D % 64 == 0 && (4 * d->H) % 64 == 0 && BT % 64 == 0 && BT < (1ll << 31);
+}
 
 static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 
@@ -203,9 +219,23 @@ static Layout make_layout(const nabu_blstm_desc *d) {
   g = max_sz(g, nabu_gemm_ws_bytes((int)D, (int)(4 * H), M));            // x^T·dz
   if (T > 1) g = max_sz(g, nabu_gemm_ws_bytes((int)H, (int)(4 * H), (int)(B * (T - 1))));
   g = max_sz(g, nabu_colsum_ws_bytes(M, (int)(4 * H)));
+  if (bf16_resident(d)) {
+    g = max_sz(g, gemm_bf16_pre_ws_bytes(M, (int)(4 * H), (int)D));
+    g = max_sz(g, gemm_bf16_pre_ws_bytes(M, (int)D, (int)(4 * H)));
+    g = max_sz(g, gemm_bf16_pre_ws_bytes((int)D, (int)(4 * H), M));
+  }
   L.gemm_off = off; L.gemm_bytes = align_up(g, 256); off += L.gemm_bytes;
   L.persist_bytes = align_up(lstm_persist_ws_bytes(d->B, d->T, d->H), 256);
   L.persist_off = off; off += L.persist_bytes;
+  L.bf16_pre = bf16_resident(d);
+  L.bf16_off = off;
+  L.bf16_bytes = 0;
+  if (L.bf16_pre) {
+    const size_t BT = B * T, G = 4 * H;
+    const size_t fwd = 2 * (BT * D + G * D), bwd = 2 * (BT * G + G * BT + D * BT + D * G);
+    L.bf16_bytes = align_up(max_sz(fwd, bwd), 256);
+    off += L.bf16_bytes;
+  }
   L.total = off;
   return L;
 }
@@ -285,6 +315,18 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const in
   const float *bias[2] = {bias_fw, bias_bw};
 
   // time-batched input projections (MFMA): gates_d = x·Wx_d + b_d
+  if (L.bf16_pre) {
+    // bf16 copies: x once, Wx_d transposed ([4H, D]: the reduction index contiguous), then 2-byte operands
+    unsigned short *xb = reinterpret_cast<unsigned short *>(w + L.bf16_off);
+    unsigned short *wt = xb + (size_t)B * T * D;
+    if (int e = cvt_bf16((size_t)B * T, D, x, D, xb, D, s)) return e;
+    for (int dir = 0; dir < 2; ++dir) {
+      if (int e = cvt_bf16_t(D, 4 * H, kern[dir], 4 * H, wt, D, s)) return e;
+      if (int e = gemm_bf16_pre(B * T, 4 * H, D, 1.f, xb, D, wt, D, 0.f, gates[dir], 4 * H, bias[dir], w + L.gemm_off,
+                                L.gemm_bytes, s))
+        return e;
+    }
+  } else
   for (int dir = 0; dir < 2; ++dir) {
     int e = nabu_gemm_ex(d->gemm_precision, 0, 0, B * T, 4 * H, D, 1.f, x, D, kern[dir], 4 * H, 0.f, gates[dir],
                           4 * H, bias[dir], 0, 0, 0, w + L.gemm_off, L.gemm_bytes, stream);
@@ -379,12 +421,28 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
 
   // weight / input gradients from dz (now stored in gates[])
   const int M = B * T;
+  unsigned short *dzb = nullptr, *dzT = nullptr, *xT = nullptr, *wb = nullptr;
+  if (L.bf16_pre) {   // bf16 copies of this call's operands: x^T once; dz and dz^T, Wx per direction
+    dzb = reinterpret_cast<unsigned short *>(w + L.bf16_off);
+    dzT = dzb + (size_t)M * 4 * H;
+    xT = dzT + (size_t)4 * H * M;
+    wb = xT + (size_t)D * M;
+    if (int e = cvt_bf16_t(M, D, x, D, xT, M, s)) return e;
+  }
   for (int dir = 0; dir < 2; ++dir) {
     int e;
+    if (L.bf16_pre) {
+      if ((e = cvt_bf16_t(M, 4 * H, gates[dir], 4 * H, dzT, M, s))) return e;
+      // dWx = x^T · dz = sum over frames of xT[d, k] * dzT[n, k]
+      if ((e = gemm_bf16_pre(D, 4 * H, M, 1.f, xT, M, dzT, M, 0.f, dkern[dir], 4 * H, nullptr, w + L.gemm_off,
+                             L.gemm_bytes, s)))
+        return e;
+    } else {
     // dWx = x^T · dz
     e = nabu_gemm_ex(d->gemm_precision, 1, 0, D, 4 * H, M, 1.f, x, D, gates[dir], 4 * H, 0.f, dkern[dir], 4 * H,
                       nullptr, 0, 0, 0, w + L.gemm_off, L.gemm_bytes, stream);
     if (e) return e;
+    }
     // dWh = h_{prev}^T · dz : fw pairs (out[b,t-1,:H], dz[b,t]); bw pairs (out[b,t+1,H:], dz[b,t])
     const float *A = dir == 0 ? out : out + H + (size_t)2 * H;
     const float *Bm = dir == 0 ? gates[0] + (size_t)4 * H : gates[1];
@@ -400,7 +458,13 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
       e = nabu_colsum_f32(M, 4 * H, gates[dir], 4 * H, 0.f, dbias[dir], w + L.gemm_off, L.gemm_bytes, stream);
     if (e) return e;
     // dx (+)= dz · Wx^T
-    if (d_x) {
+    if (d_x && L.bf16_pre) {
+      if ((e = cvt_bf16((size_t)M, 4 * H, gates[dir], 4 * H, dzb, 4 * H, s))) return e;
+      if ((e = cvt_bf16((size_t)D, 4 * H, kern[dir], 4 * H, wb, 4 * H, s))) return e;
+      if ((e = gemm_bf16_pre(M, D, 4 * H, 1.f, dzb, 4 * H, wb, 4 * H, dir == 0 ? 0.f : 1.f, d_x, D, nullptr,
+                             w + L.gemm_off, L.gemm_bytes, s)))
+        return e;
+    } else if (d_x) {
       e = nabu_gemm_ex(d->gemm_precision, 0, 1, M, D, 4 * H, 1.f, gates[dir], 4 * H, kern[dir], 4 * H,
                         dir == 0 ? 0.f : 1.f, d_x, D, nullptr, 0, 0, 0, w + L.gemm_off, L.gemm_bytes, stream);
       if (e) return e;

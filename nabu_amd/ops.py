@@ -51,6 +51,27 @@ def gemm2(a, b, a2, b2, c, beta=0.0, bias=None):
     return c
 
 
+def cvt_bf16(src, transpose=False):
+    """bf16 copy (RNE) of a 2-D fp32 tensor, optionally transposed; returned as a torch.bfloat16 tensor"""
+    R, C = src.shape
+    out = torch.empty((C, R) if transpose else (R, C), dtype=torch.bfloat16, device=src.device)
+    check(_hip.lib().nabu_cvt_bf16(R, C, ptr(src), src.stride(0), ptr(out), out.stride(0), int(transpose), stream()),
+          'nabu_cvt_bf16')
+    return out
+
+
+def gemm_bf16_nt(a_bf16, b_bf16, c, alpha=1.0, beta=0.0, bias=None):
+    """c (fp32) = alpha * a_bf16 @ b_bf16.T + beta*c + bias for bf16 operands with k contiguous"""
+    L = _hip.lib()
+    M, K = a_bf16.shape
+    N = b_bf16.shape[0]
+    ws_bytes = L.nabu_gemm_bf16_nt_ws_bytes(M, N, K)
+    ws = Workspace.get(ws_bytes, c.device, 'gemm') if ws_bytes else None
+    check(L.nabu_gemm_bf16_nt(M, N, K, alpha, ptr(a_bf16), a_bf16.stride(0), ptr(b_bf16), b_bf16.stride(0), beta,
+                              ptr(c), c.stride(0), ptr(bias), ptr(ws), ws_bytes, stream()), 'nabu_gemm_bf16_nt')
+    return c
+
+
 def set_gemm_precision(precision):
     """process default of every GEMM that does not name a precision ('f32' | 'bf16' | 'bf16x3' | 'bf16x6')"""
     check(_hip.lib().nabu_gemm_set_default_precision(_hip.GEMM_PRECISIONS[precision]), 'nabu_gemm_set_default_precision')

@@ -413,6 +413,33 @@ def test_gemm_small_k_tall_output(M, N, K):
     assert np.abs(c.cpu().numpy() - ref2).max() / np.abs(ref2).max() < 2e-6
 
 
+@pytest.mark.parametrize('M,N,K', [(256, 256, 128), (16000, 2048, 2048), (2048, 2048, 12800), (130, 200, 64), (1000, 136, 4096)])
+def test_gemm_bf16_resident_operands(M, N, K):
+    """nabu_cvt_bf16 + nabu_gemm_bf16_nt (configs[4]'s bf16 input GEMMs with the operands converted once): the
+    conversion is round-to-nearest-even (bit-identical with torch's), plain and transposed; the product equals
+    the float64 product of the ROUNDED operands to fp32 accumulation accuracy, with bias / beta / split-K / edges"""
+    from nabu_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    a = torch.tensor(rng.normal(size=(M, K)).astype(np.float32), device='cuda')
+    b = torch.tensor(rng.normal(size=(N, K)).astype(np.float32), device='cuda')
+    ab, bb = ops.cvt_bf16(a), ops.cvt_bf16(b)
+    assert torch.equal(ab, a.to(torch.bfloat16)) and torch.equal(bb, b.to(torch.bfloat16))
+    if M % 2 == 0:
+        assert torch.equal(ops.cvt_bf16(a, transpose=True), a.to(torch.bfloat16).t().contiguous())
+    ref = ab.double().cpu().numpy() @ bb.double().cpu().numpy().T
+    c = torch.empty((M, N), device='cuda').fill_(float('nan'))
+    ops.gemm_bf16_nt(ab, bb, c)
+    assert np.abs(c.cpu().numpy() - ref).max() / np.abs(ref).max() < 3e-6
+    bias = torch.tensor(rng.normal(size=N).astype(np.float32), device='cuda')
+    c0 = rng.normal(size=(M, N)).astype(np.float32)
+    c = torch.tensor(c0, device='cuda')
+    ops.gemm_bf16_nt(ab, bb, c, alpha=0.5, beta=2.0, bias=bias)
+    ref2 = 0.5 * ref + bias.cpu().numpy() + 2.0 * c0
+    assert np.abs(c.cpu().numpy() - ref2).max() / np.abs(ref2).max() < 3e-6
+    with pytest.raises(Exception):
+        ops.gemm_bf16_nt(ab[:, :40].contiguous(), bb[:, :40].contiguous(), c)        # K % 64
+
+
 def test_cross_entropy_losses_match_oracle():
     """average_cross_entropy (loss_functions.py:155-165) and sum_cross_entropy (:142-153) on ragged
     lengths: loss and the gradient the tape receives"""
