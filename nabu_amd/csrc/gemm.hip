@@ -390,25 +390,14 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs a) {
 constexpr int SMALLK_MAX = 96;
 __global__ __launch_bounds__(256) void gemm_smallk_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float ssm[];
-  const int K = a.K, LDA_S = K + 1;                 // odd stride: the 32 rows of an MFMA operand hit 32 banks
+  // K > 48 is taken in chunks of <= 48 (K = 80: 40 + 40) so that the operand tiles never need more LDS than
+  // the 128 x 128 output tile of the epilogue does: two workgroups per CU at every K
+  const int nchunk = (a.K + 47) / 48, K = ((a.K + nchunk - 1) / nchunk + 3) & ~3, LDA_S = K + 1;   // odd stride: 32 rows hit 32 banks
   float *As = ssm, *Bs = ssm + 128 * LDA_S + 3;     // Bs 16-byte aligned below
   Bs = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(Bs) + 15) & ~(uintptr_t)15);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int KQ = K / 4;
-  for (int idx = tid; idx < 128 * KQ; idx += 256) {          // A: rows clamped, dropped at the store
-    const int r = idx / KQ, kq = idx % KQ;
-    const float4 v = *reinterpret_cast<const float4 *>(a.A + (size_t)min(m0 + r, a.M - 1) * a.lda + 4 * kq);
-    float *d = As + r * LDA_S + 4 * kq;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-  }
-  for (int idx = tid; idx < K * 32; idx += 256) {            // B: 16-byte pieces along n
-    const int k = idx >> 5, c = 4 * (idx & 31);
-    const float4 v = *reinterpret_cast<const float4 *>(a.B + (size_t)k * a.ldb + min(n0 + c, a.N - 4));
-    *reinterpret_cast<float4 *>(Bs + k * LDT + c) = v;
-  }
-  __syncthreads();
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -419,12 +408,29 @@ __global__ __launch_bounds__(256) void gemm_smallk_kernel(GemmArgs a) {
   const int li = lane & 31, lk = lane >> 5;
   const float *ap0 = As + (wm * 64 + li) * LDA_S + lk, *ap1 = ap0 + 32 * LDA_S;
   const float *bp0 = Bs + lk * LDT + wn * 64 + li;
-  for (int kk = 0; kk < K; kk += 2) {
-    const float a0 = ap0[kk], a1 = ap1[kk], b0 = bp0[kk * LDT], b1 = bp0[kk * LDT + 32];
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+  for (int kc = 0; kc < a.K; kc += K) {
+    const int kn = min(K, a.K - kc);                  // a multiple of 4 (K % 4 == 0); odd halves are zero-filled below
+    const int KQ = kn / 4;
+    if (kc) __syncthreads();                          // the previous chunk's operands have been read
+    for (int idx = tid; idx < 128 * KQ; idx += 256) {          // A: rows clamped, dropped at the store
+      const int r = idx / KQ, kq = idx % KQ;
+      const float4 v = *reinterpret_cast<const float4 *>(a.A + (size_t)min(m0 + r, a.M - 1) * a.lda + kc + 4 * kq);
+      float *d = As + r * LDA_S + 4 * kq;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    for (int idx = tid; idx < kn * 32; idx += 256) {           // B: 16-byte pieces along n
+      const int k = idx >> 5, c = 4 * (idx & 31);
+      const float4 v = *reinterpret_cast<const float4 *>(a.B + (size_t)(kc + k) * a.ldb + min(n0 + c, a.N - 4));
+      *reinterpret_cast<float4 *>(Bs + k * LDT + c) = v;
+    }
+    __syncthreads();
+    for (int kk = 0; kk < kn; kk += 2) {
+      const float a0 = ap0[kk], a1 = ap1[kk], b0 = bp0[kk * LDT], b1 = bp0[kk * LDT + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
   }
   // epilogue through LDS: the accumulators hold one column per lane; written back as they are that is a
   // 4-byte store per lane and element (2.2 TB/s on this write-bound product).  Transposed through LDS a
@@ -465,7 +471,8 @@ static bool smallk_ok(bool ta, bool tb, int M, int N, int K, const void *A, int 
   return !ta && !tb && kseg == 0 && K >= 8 && K <= SMALLK_MAX && K % 4 == 0 && M >= 2048 && N >= 4 && N % 4 == 0 &&
          al16(A) && lda % 4 == 0 && al16(B) && ldb % 4 == 0 && al16(C) && ldc % 4 == 0 && al16(bias);
 }
-static size_t smallk_lds(int K) {
+static size_t smallk_lds(int Kfull) {
+  const int nchunk = (Kfull + 47) / 48, K = ((Kfull + nchunk - 1) / nchunk + 3) & ~3;
   const size_t ops = ((size_t)128 * (K + 1) + 8 + (size_t)K * LDT) * sizeof(float), out = (size_t)128 * LDT * sizeof(float);
   return ops > out ? ops : out;
 }
