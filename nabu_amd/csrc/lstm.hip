@@ -186,7 +186,7 @@ struct Layout {
   // workspace carve
   size_t hstate_off, cstate_off, gemm_off, gemm_bytes, persist_off, persist_bytes, total;
   // bf16-resident input products (gemm_precision = bf16): converted copies of the operands
-  bool bf16_pre;
+  bool bf16_pre, bf16_fwd;
   size_t bf16_off, bf16_bytes;
 };
 
@@ -199,6 +199,17 @@ static bool bf16_resident(const nabu_blstm_desc *d) {
   const long long BT = (long long)d->B * d->T;
   return env && prec == NABU_GEMM_BF16 && d->D % 64 == 0 && (4 * d->H) % 64 == 0 && BT % 64 == 0 && BT < (1ll << 31);
 }
+// the forward product alone also takes an input width that is not a multiple of 64 (the first layer: D = 80):
+// the bf16 copies of x and Wx^T are zero-padded to the next multiple of 64 along the reduction index
+static bool bf16_resident_fwd(const nabu_blstm_desc *d) {
+  if (bf16_resident(d)) return true;
+  const int prec = d->gemm_precision == NABU_GEMM_DEFAULT ? nabu_gemm_get_default_precision() : d->gemm_precision;
+  static int env = -1;
+  if (env < 0) { const char *e = getenv("NABU_BF16_RESIDENT"); env = e ? atoi(e) : 1; }
+  const long long BT = (long long)d->B * d->T;
+  return env && prec == NABU_GEMM_BF16 && d->D % 8 == 0 && (4 * d->H) % 64 == 0 && BT < (1ll << 31) && BT >= 2048;
+}
+static int pad64(int x) { return (x + 63) / 64 * 64; }
 
 static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 
@@ -219,6 +230,7 @@ static Layout make_layout(const nabu_blstm_desc *d) {
   g = max_sz(g, nabu_gemm_ws_bytes((int)D, (int)(4 * H), M));            // x^T·dz
   if (T > 1) g = max_sz(g, nabu_gemm_ws_bytes((int)H, (int)(4 * H), (int)(B * (T - 1))));
   g = max_sz(g, nabu_colsum_ws_bytes(M, (int)(4 * H)));
+  if (bf16_resident_fwd(d)) g = max_sz(g, gemm_bf16_pre_ws_bytes(M, (int)(4 * H), pad64((int)D)));
   if (bf16_resident(d)) {
     g = max_sz(g, gemm_bf16_pre_ws_bytes(M, (int)(4 * H), (int)D));
     g = max_sz(g, gemm_bf16_pre_ws_bytes(M, (int)D, (int)(4 * H)));
@@ -228,11 +240,12 @@ static Layout make_layout(const nabu_blstm_desc *d) {
   L.persist_bytes = align_up(lstm_persist_ws_bytes(d->B, d->T, d->H), 256);
   L.persist_off = off; off += L.persist_bytes;
   L.bf16_pre = bf16_resident(d);
+  L.bf16_fwd = bf16_resident_fwd(d);
   L.bf16_off = off;
   L.bf16_bytes = 0;
-  if (L.bf16_pre) {
-    const size_t BT = B * T, G = 4 * H;
-    const size_t fwd = 2 * (BT * D + G * D), bwd = 2 * (BT * G + G * BT + D * BT + D * G);
+  if (L.bf16_fwd) {
+    const size_t BT = B * T, G = 4 * H, Dp = pad64((int)D);
+    const size_t fwd = 2 * (BT * Dp + G * Dp), bwd = L.bf16_pre ? 2 * (BT * G + G * BT + D * BT + D * G) : 0;
     L.bf16_bytes = align_up(max_sz(fwd, bwd), 256);
     off += L.bf16_bytes;
   }
@@ -315,14 +328,17 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const in
   const float *bias[2] = {bias_fw, bias_bw};
 
   // time-batched input projections (MFMA): gates_d = x·Wx_d + b_d
-  if (L.bf16_pre) {
-    // bf16 copies: x once, Wx_d transposed ([4H, D]: the reduction index contiguous), then 2-byte operands
+  if (L.bf16_fwd) {
+    // bf16 copies: x once, Wx_d transposed ([4H, Dp]: the reduction index contiguous, zero-padded to a
+    // multiple of 64), then 2-byte operands
+    const int Dp = pad64(D);
     unsigned short *xb = reinterpret_cast<unsigned short *>(w + L.bf16_off);
-    unsigned short *wt = xb + (size_t)B * T * D;
-    if (int e = cvt_bf16((size_t)B * T, D, x, D, xb, D, s)) return e;
+    unsigned short *wt = xb + (size_t)B * T * Dp;
+    if (Dp != D) NABU_HIP(hipMemsetAsync(xb, 0, ((size_t)B * T + 4 * H) * Dp * 2, s));
+    if (int e = cvt_bf16((size_t)B * T, D, x, D, xb, Dp, s)) return e;
     for (int dir = 0; dir < 2; ++dir) {
-      if (int e = cvt_bf16_t(D, 4 * H, kern[dir], 4 * H, wt, D, s)) return e;
-      if (int e = gemm_bf16_pre(B * T, 4 * H, D, 1.f, xb, D, wt, D, 0.f, gates[dir], 4 * H, bias[dir], w + L.gemm_off,
+      if (int e = cvt_bf16_t(D, 4 * H, kern[dir], 4 * H, wt, Dp, s)) return e;
+      if (int e = gemm_bf16_pre(B * T, 4 * H, Dp, 1.f, xb, Dp, wt, Dp, 0.f, gates[dir], 4 * H, bias[dir], w + L.gemm_off,
                                 L.gemm_bytes, s))
         return e;
     }
