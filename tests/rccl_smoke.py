@@ -30,6 +30,10 @@ class Forced(ProcessGroup):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t
 
+    def all_reduce_sum_async(self, t):
+        self.async_calls = getattr(self, 'async_calls', 0) + 1
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
     def broadcast_(self, t, src=0):
         dist.broadcast(t, src)
         return t
@@ -38,8 +42,8 @@ class Forced(ProcessGroup):
         dist.barrier()
 
 
-def losses(server, force_dp):
-    over = {'encoder.num_units': 64, 'trainer.batch_size': 8}
+def losses(server, force_dp, buckets=False):
+    over = {'encoder.num_units': 64, 'trainer.batch_size': 8, 'trainer.allreduce_buckets': str(buckets)}
     mc, tc, ec = recipes.load_recipe('cfg2_listener_ctc', **over)
     data = SyntheticData(8, 128, 40, min_frames=100, min_labels=2, max_labels=6, time_reduction=8, seed=9)
     tr = trainer_factory.factory('standard')(conf=tc, dataconf=data, modelconf=mc, evaluatorconf=ec, expdir=None,
@@ -56,8 +60,15 @@ def main():
     dist.init_process_group('nccl', rank=0, world_size=1)
     a = losses(Forced(0, 1, 'nccl'), True)
     b = losses(None, False)
+    # the bucketed exchange: per-layer buckets started from the hook nabu_blstm_bwd calls between its
+    # recurrent kernel and its dense products (a C -> Python callback on the real GPU path), asynchronous
+    # collectives on RCCL's stream, joined before the next persistent launch
+    srv = Forced(0, 1, 'nccl')
+    c = losses(srv, True, buckets=True)
     dist.destroy_process_group()
     assert np.allclose(a, b, rtol=1e-5), (a, b)
+    assert np.allclose(c, b, rtol=1e-5), (c, b)
+    assert srv.async_calls == 4 * 5, srv.async_calls          # 4 steps x (4 encoder layers + the decoder)
     print('RCCL_SMOKE_OK', a)
 
 
