@@ -27,10 +27,14 @@
 //   0xFFFFFFFF (a NaN no h or dh value can take); a consumer re-loads a slot
 //   until no word holds the sentinel.  No flags, no fences, no atomics; every
 //   32-bit word is individually valid or sentinel, so torn 16-byte stores are
-//   harmless.  Slots form a ring of R=4; a slot is reset to the sentinel by its
-//   owner after it was consumed, and every workgroup drains its stores
-//   (s_waitcnt vmcnt(0)) before publishing, which orders the reset before any
-//   later write to the same slot.
+//   harmless.  Slots form a ring (forward 4 deep, backward 2); a slot is reset to
+//   the sentinel after it was consumed (forward: by its producer, backward: by
+//   its single reader).  No timing assumption orders a reset against the
+//   slot's next use: a workgroup publishes only after loads it issued behind
+//   its reset stores have returned (vector-memory operations complete in
+//   issue order); the backward kernel, whose ring is only 2 deep, drains the
+//   resets and meets at a second, execution-only barrier before it publishes
+//   (DESIGN.md section 5).
 //   PLACEMENT-INDEPENDENT CORRECTNESS: consumers always use sc1 loads (bypass
 //   the per-CU L1).  At kernel start the workgroups of a unit exchange their
 //   XCC ids (through sc1 stores); only if ALL of them sit on one XCD do they
@@ -58,7 +62,11 @@ namespace nabu {
 constexpr unsigned SENT = 0xFFFFFFFFu;
 constexpr unsigned OOB = 0xFFFFFFF0u;   // buffer offset beyond every exchange ring / tensor: access dropped
 constexpr int UC = 16;    // hidden units per workgroup
-constexpr int RING = 4;   // exchange ring depth
+#ifndef NABU_RING_BWD
+#define NABU_RING_BWD 2
+#endif
+constexpr int RING = 4;               // exchange ring depth, forward (all-gather of h)
+constexpr int RINGB = NABU_RING_BWD;  // ... backward (reduce-scatter of dh)
 constexpr int NCU = 256;  // MI355X
 constexpr size_t TABLE_BYTES = 4096;   // XCC-id table in front of the ring
 
@@ -107,6 +115,9 @@ __device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __builtin_am
 
 __device__ __forceinline__ bool has_sentinel(const u32x4 v) {
   return v.x == SENT || v.y == SENT || v.z == SENT || v.w == SENT;
+}
+__device__ __forceinline__ bool all_sentinel(const u32x4 v) {
+  return v.x == SENT && v.y == SENT && v.z == SENT && v.w == SENT;
 }
 __device__ __forceinline__ float sel4(int q, float a, float b, float c, float d) {
   return q == 0 ? a : q == 1 ? b : q == 2 ? c : d;
@@ -432,9 +443,10 @@ __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8
     if (act_g) { c_state = c_new; h_state = h_new; }
 
     // (d) publish h_s (frozen rows republish their state): 4 rows -> one 16-byte store.
-    // Ordering of my slot reset (issued two steps ago) before this store: vector memory
-    // operations complete in issue order and the exchange loads issued after that reset have
-    // been consumed, so the reset is performed.
+    // Ordering of my slot reset (issued two steps ago) before this store: same lane, same address.
+    // Ordering of my slot reset of the PREVIOUS step (h_{s-3}) before this publish — consumers poll that
+    // slot for h_{s+1} once they have seen h_s and must not find h_{s-3} there: vector-memory operations
+    // complete in issue order and this step's exchange loads, issued after that reset, have been consumed.
     {
       const float h1 = row_shl_f(h_state, 4), h2 = row_shl_f(h_state, 8), h3 = row_shl_f(h_state, 12);
       u32x4 pv;
@@ -547,7 +559,7 @@ __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8
   const size_t block_bytes = (size_t)P * piece_bytes;      // what one destination reads
   const size_t slot_bytes = (size_t)P * block_bytes;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-      p.xbuf + (size_t)unit * RING * slot_bytes, 0, (int)(RING * slot_bytes), 0x00020000);
+      p.xbuf + (size_t)unit * RINGB * slot_bytes, 0, (int)(RINGB * slot_bytes), 0x00020000);
   const u32x4 sent4 = {SENT, SENT, SENT, SENT};
 
   // saved forward values of step s, fetched one step ahead: av = my gate's activation,
@@ -583,12 +595,21 @@ __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8
   fetched(p.max_len - 1, av_next, xv_next);
 
   if (hi_prio) __builtin_amdgcn_s_setprio(2);
+  // where my partial products of step s go: piece (dest, me) of slot s % RINGB; OOB = nothing to publish
+  auto out_off = [&](int s, int m) -> unsigned {
+    const int k = (w * GPW + m) * 64 + lane;
+    const int dest = k / UC, ul = k % UC;
+    return (s > 0 && mfma_wave && k < H)
+               ? (unsigned)((s % RINGB) * slot_bytes + (size_t)dest * block_bytes + (size_t)slot * piece_bytes +
+                            (size_t)ul * BS * 4)
+               : OOB;
+  };
   for (int s = p.max_len - 1; s >= 0; --s) {
     NABU_STAMP(1, 0);
     // (a) reduce-scatter input: the partial products of step s+1 addressed to me
     float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
     u32x4 v[NQ] = {};
-    const unsigned base = (unsigned)(((s + 1) % RING) * slot_bytes + (size_t)slot * block_bytes);
+    const unsigned base = (unsigned)(((s + 1) % RINGB) * slot_bytes + (size_t)slot * block_bytes);
     const bool have_in = s + 1 < p.max_len && !(p.dbg & 1);
     if (have_in) {
       SpinGuard guard;
@@ -701,19 +722,26 @@ __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8
         }
       }
       NABU_STAMP(1, 4);
-      // publish.  My slot resets of this slot's previous use were issued three steps ago and
-      // exchange loads issued after them have been consumed: they are performed (in-order
-      // completion of vector memory operations).
+      // publish.  The pieces I write into (slot s % RINGB) were handed back by their readers RINGB - 1
+      // steps ago; what makes that reset PERFORMED before this store arrives:
+      //   RINGB >= 3: I have polled the reader's publish of the step AFTER its reset, and every wave of the
+      //     reader completed a poll loop in between (loads issued after the reset stores returned:
+      //     vector-memory operations complete in issue order);
+      //   RINGB == 2 (the ring of an XCD then is 1 MB and stays in its L2): I have only
+      //     polled the publish of the reset's own step, issued by other waves than the resetting ones — so
+      //     every wave drains its reset stores (all but the 3 prefetch loads issued after them) and the
+      //     workgroup meets at an execution barrier before anybody publishes.
+      if (RINGB == 2) {
+        wait_vm<3>();
+        __builtin_amdgcn_s_barrier();
+      }
 #pragma unroll
       for (int m = 0; m < GPW; ++m) {
-        const int k = (w * GPW + m) * 64 + lane;
-        const int dest = k / UC, ul = k % UC;
-        const unsigned off = (unsigned)((s % RING) * slot_bytes + (size_t)dest * block_bytes +
-                                        (size_t)slot * piece_bytes + (size_t)ul * BS * 4);
+        const unsigned off = out_off(s, m);
 #pragma unroll
         for (int g = 0; g < RG; ++g) {
           const mf32x4 t = acc[m][g][0] + acc[m][g][1];
-          xstore(__builtin_bit_cast(u32x4, t), rs, (mfma_wave && k < H) ? off + 16 * g : OOB, coloc);
+          xstore(__builtin_bit_cast(u32x4, t), rs, off == OOB ? OOB : off + 16 * g, coloc);
         }
       }
     }
@@ -803,7 +831,7 @@ static size_t db_part_bytes(int B, int H) { return (size_t)((B + 3) / 4) * 2 * 4
 
 static size_t ring_bytes(bool fwd, int BS, int nshard, int H) {
   const size_t NU = 2 * (size_t)nshard, P = H / UC;
-  return fwd ? NU * RING * (size_t)H * BS * 4 : NU * RING * P * P * UC * BS * 4;
+  return fwd ? NU * RING * (size_t)H * BS * 4 : NU * RINGB * P * P * UC * BS * 4;
 }
 
 size_t lstm_persist_ws_bytes(int B, int T, int H) {

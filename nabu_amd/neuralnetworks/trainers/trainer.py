@@ -94,8 +94,11 @@ class Trainer(object, metaclass=ABCMeta):
             raise Exception('norm_constraint (MaxNorm) is off by default in the reference '
                             '(standardtrainer.cfg:18) and not on the MI355X hot path')
         if int(self.conf['cut_sequence_length']):
-            raise Exception('cut_sequence_length is part of the input pipeline (SURVEY.md 8(f) '
-                            'row 3) and not supported yet')
+            # reference trainer.py:364-384, 917-973: needs frame-synchronous targets (assert_equal over all
+            # sequence lengths) and cannot build its graph on the pinned stack (tf.ceil over an int32
+            # floor division, trainer.py:929) -- a non-zero key raises there too
+            raise Exception('cut_sequence_length is not supported (it requires inputs and targets of equal '
+                            'lengths and fails at graph construction in the reference, DESIGN.md section 8)')
         self.model = Model(conf=modelconf, trainlabels=int(self.conf['trainlabels']), constraint=None)
         self._graph = None
 

@@ -51,6 +51,17 @@ def test_baseline_recipes_construct(recipe):
     assert abs(tr.learning_rate() - 1e-3) < 1e-12
 
 
+def test_unsupported_trainer_keys_raise():
+    """cut_sequence_length (reference trainer.py:364-384): frame-synchronous targets only, and the reference's
+    own graph construction fails on it (tf.ceil over an int32 division, trainer.py:929) -- loud, not silent"""
+    from nabu_amd.neuralnetworks.trainers import trainer_factory
+    from nabu_amd.processing.synthetic import SyntheticData
+    mc, tc, ec = recipes.load_recipe('cfg1_dblstm_ctc', **{'trainer.cut_sequence_length': '100'})
+    with pytest.raises(Exception, match='cut_sequence_length'):
+        trainer_factory.factory('standard')(conf=tc, dataconf=SyntheticData(8, 64, 40), modelconf=mc,
+                                            evaluatorconf=ec, expdir=None, server=None, task_index=0)
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason='reference not mounted')
 @pytest.mark.parametrize('recipe', ['DBLSTM/TIMIT', 'LAS/TIMIT', 'LAS/GP'])
 def test_reference_recipe_cfgs_load_unmodified(recipe):
