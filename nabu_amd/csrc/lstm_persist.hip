@@ -804,7 +804,8 @@ static int pick_bs(int B, int H, bool fwd) {
   if (2 * ((B + 7) / 8) * P <= ncu) return 8;          // one 512-thread workgroup per CU
   // two 512-thread workgroups per CU (<= 128 VGPRs): cfg5's B = 64 at H = 512 in ONE launch.  Forward
   // only: measured 4.04 us per step against 2 x 2.41 for two launches of 32 rows; the backward kernel,
-  // whose reduce-scatter volume doubles with the rows, takes 5.69 against 2 x 2.47 and stays chunked.
+  // whose reduce-scatter volume doubles with the rows, takes 5.69 against 2 x 2.47 (5.02 against 2 x 2.41
+  // with the 2-deep ring) and stays chunked.
   if (fwd && 2 * ((B + 7) / 8) * P <= 2 * ncu) return 8;
   return 0;
 }
