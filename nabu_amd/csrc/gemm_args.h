@@ -70,9 +70,18 @@ struct SkinnyEpilogue {
   float *dz, *dc_out;
 };
 
+// optional second destination of the fused skinny product: columns >= split (a multiple of 32) are written to
+// C2[m * ldc2 + n - split] with their own beta (no epilogue kinds with it)
+struct SkinnySplit {
+  float *C2;
+  int ldc2, split;
+  float beta2;
+};
+
 int gemm_skinny_fused(int M, int N, int K1, const float *A, int lda, const float *B, int ldb, int K2, const float *A2,
                       int lda2, const float *B2, int ldb2, float beta, float *C, int ldc, const float *bias,
-                      float *partial, unsigned *tickets, hipStream_t s, const SkinnyEpilogue *ep = nullptr);
+                      float *partial, unsigned *tickets, hipStream_t s, const SkinnyEpilogue *ep = nullptr,
+                      const SkinnySplit *split = nullptr);
 
 // batch of nbatch independent products C_i (+)= op(A_i)·op(B_i) in ONE launch of the generic fp32 kernel
 // (operand i starts i*stride elements after operand 0); no split-K

@@ -98,6 +98,9 @@ struct SkinnyFuse {
   unsigned *tickets;
   int heavy;                 // 1: full agent-scope fences around the ticket (debugging)
   SkinnyEpilogue ep;         // what the workgroup that holds the finished tile does with it
+  float *C2;                 // columns >= split (a multiple of 32) go to C2[m * ldc2 + n - split] with beta2
+  int ldc2, split;
+  float beta2;
 };
 
 template <int MT>
@@ -129,8 +132,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_fused_kernel(GemmArgs a, Skin
     if (m >= a.M) continue;
     if (ns == 1) {
       float v = a.alpha * s + (a.bias ? a.bias[n] : 0.f);
-      if (a.beta != 0.f) v += a.beta * a.C[(size_t)m * a.ldc + n];
-      if (epi == 0) a.C[(size_t)m * a.ldc + n] = v;
+      float *c = n0 >= f.split ? f.C2 + (size_t)m * f.ldc2 + (n - f.split) : a.C + (size_t)m * a.ldc + n;
+      const float beta = n0 >= f.split ? f.beta2 : a.beta;
+      if (beta != 0.f) v += beta * *c;
+      if (epi == 0) *c = v;
       else          zt[m * 32 + (l & 31)] = v;
     } else {   // sc1 (write-through) store: performed at the device coherence point, whatever XCD reads it
       __hip_atomic_store(a.partial + ((size_t)blockIdx.y * a.M + m) * a.N + n, s, __ATOMIC_RELAXED,
@@ -167,8 +172,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_fused_kernel(GemmArgs a, Skin
         for (int j = 0; j < 8; ++j) s += pv[j];
       }
       float v = a.alpha * s + (a.bias ? a.bias[n] : 0.f);
-      if (a.beta != 0.f) v += a.beta * a.C[(size_t)m * a.ldc + n];
-      if (epi == 0) a.C[(size_t)m * a.ldc + n] = v;
+      float *c = n0 >= f.split ? f.C2 + (size_t)m * f.ldc2 + (n - f.split) : a.C + (size_t)m * a.ldc + n;
+      const float beta = n0 >= f.split ? f.beta2 : a.beta;
+      if (beta != 0.f) v += beta * *c;
+      if (epi == 0) *c = v;
       else          zt[e] = v;
     }
     if (tid == 0) __hip_atomic_store(f.tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for reuse
@@ -228,7 +235,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_fused_kernel(GemmArgs a, Skin
 // chunk (K2 may be 0).  partial: nchunks*M*N floats; tickets: N/32 zeroed counters (left zero).
 int gemm_skinny_fused(int M, int N, int K1, const float *A, int lda, const float *B, int ldb, int K2, const float *A2,
                       int lda2, const float *B2, int ldb2, float beta, float *C, int ldc, const float *bias,
-                      float *partial, unsigned *tickets, hipStream_t s, const SkinnyEpilogue *ep) {
+                      float *partial, unsigned *tickets, hipStream_t s, const SkinnyEpilogue *ep,
+                      const SkinnySplit *split) {
   int kc = 0;
   for (int c = 256; c >= 64; c >>= 1)
     if (K1 % c == 0 && K2 % c == 0) { kc = c; break; }
@@ -242,8 +250,13 @@ int gemm_skinny_fused(int M, int N, int K1, const float *A, int lda, const float
   a.nbatch = 1; a.a_bs = a.b_bs = a.c_bs = 0;
   static int heavy_env = -1;
   if (heavy_env < 0) { const char *e = getenv("NABU_SKINNY_HEAVY"); heavy_env = e ? atoi(e) : 0; }
-  SkinnyFuse f = {A2, B2, lda2, ldb2, K1, tickets, heavy_env ? 1 : 0, {}};
+  SkinnyFuse f = {A2, B2, lda2, ldb2, K1, tickets, heavy_env ? 1 : 0, {}, nullptr, 0, N, 0.f};
   if (ep) f.ep = *ep; else f.ep.kind = 0;
+  if (split) {
+    if (split->split % 32 || split->split <= 0 || split->split >= N || (ep && ep->kind))
+      return fail(NABU_EUNSUP, "skinny product: bad output split %d of %d columns", split->split, N);
+    f.C2 = split->C2; f.ldc2 = split->ldc2; f.split = split->split; f.beta2 = split->beta2;
+  }
   const int MT = M > 32 ? 2 : 1;
   const size_t xt = (size_t)kc * 32 * MT * sizeof(float), red = (size_t)4 * MT * 1024 * sizeof(float);
   const size_t lds = xt > red ? xt : red;

@@ -98,7 +98,31 @@ struct AttnArgs {
   float *dq, *dkeys, *dv_part, *dwf_part, *dck_part, *dalign_out;
   float *dq_part, *dcf_g;   // [B,S,U] per-slice dq, [B,Te,F] d location features (backward scratch)
   float *fwd_part;          // [B,S,E+4] per-slice context + (local max, local sum) (forward scratch)
+  unsigned *tickets;        // [B] zeroed counters: the slice that arrives last finishes its utterance inside
+                            // the launch (no finish kernel); nullptr = separate finish kernel
 };
+
+// store / load of data handed from one workgroup to another inside a launch: write-through store, L1-bypassing
+// load (MI355X_MICROARCH.md "sc1 stores AND sc1 loads"); plain when the hand-off is a kernel boundary
+__device__ __forceinline__ void xst(float *p, float v, bool x) {
+  if (x) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else   *p = v;
+}
+__device__ __forceinline__ float xld(const float *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every wave has drained its stores; returns true in the workgroup that arrives last of n
+__device__ __forceinline__ bool last_arriver(unsigned *ticket, unsigned n, int *flag) {
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = old == n - 1;
+    if (old == n - 1) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for reuse
+  }
+  __syncthreads();
+  return *flag != 0;
+}
 
 // LDS carve for the attention kernels (floats): al[Te] prev alignment (padded conv input),
 // sc[Te] scores / alignments, cf[Te*F] location features, red[...] reductions
@@ -143,10 +167,13 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
   float *alp = base, *sc = alp + Te, *cf = sc + Te, *red = cf + (KIND ? Te * p.F : 0);
   float *align = p.align + (size_t)b * Te;
   float *ctx = S > 1 ? p.fwd_part + ((size_t)b * S + sl) * (E + 4) : p.ctx + (size_t)b * E;
+  const bool fused = S > 1 && p.tickets != nullptr;   // the last slice to arrive finishes the utterance
+  __shared__ int last_flag;
   if (p.step >= p.dec_len[b]) {   // finished row: state frozen
-    if (S > 1) return;            // ... by the finish kernel
+    if (S > 1 && !(fused && sl == 0)) return;         // ... by the finish kernel / by slice 0
+    float *cx = p.ctx + (size_t)b * E;
     for (int t = tid; t < Te; t += AT) align[t] = p.align_prev[(size_t)b * Te + t];
-    for (int e = tid; e < E; e += AT) ctx[e] = p.ctx_prev[(size_t)b * E + e];
+    for (int e = tid; e < E; e += AT) cx[e] = p.ctx_prev[(size_t)b * E + e];
     return;
   }
   const int nfull = min(max(p.enc_len[b], 0), Te);
@@ -279,7 +306,7 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
     for (int t = lo + tid; t < n; t += AT) {
       const float e = p.prob_fn == 0 ? expf(sc[t] - m) : 1.0f / (1.0f + expf(-sc[t]));
       sc[t] = e;
-      align[t] = e;
+      xst(align + t, e, fused);
       z += e;
     }
     z = wave_sum(z);
@@ -287,7 +314,7 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
     __syncthreads();
     z = 0.f;
     for (int i = 0; i < AT / 64; ++i) z += red[i];
-    if (tid == 0) { ctx[E] = m; ctx[E + 1] = z; }
+    if (tid == 0) { xst(ctx + E, m, fused); xst(ctx + E + 1, z, fused); }
     __syncthreads();
   } else
   if (p.prob_fn != 0) {
@@ -377,9 +404,41 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
           const float4 o = part[i * (AT / nsp) + tid];
           c.x += o.x; c.y += o.y; c.z += o.z; c.w += o.w;
         }
-        reinterpret_cast<float4 *>(ctx)[c0 + tid] = c;
+        if (fused) {
+          float *o = ctx + 4 * (c0 + tid);
+          xst(o, c.x, true); xst(o + 1, c.y, true); xst(o + 2, c.z, true); xst(o + 3, c.w, true);
+        } else {
+          reinterpret_cast<float4 *>(ctx)[c0 + tid] = c;
+        }
       }
       __syncthreads();
+    }
+  }
+  if (!fused) return;
+  // ---- the slice that arrives last combines the utterance's slices (what attn_fwd_finish_kernel does)
+  if (!last_arriver(p.tickets + b, (unsigned)S, &last_flag)) return;
+  {
+    float *fac = red;
+    const float *part = p.fwd_part + (size_t)b * S * (E + 4);
+    if (tid == 0) {
+      float M = -3.0e38f, Z = 0.f;
+      for (int i = 0; i < S; ++i) M = fmaxf(M, xld(part + (size_t)i * (E + 4) + E));
+      for (int i = 0; i < S; ++i) {
+        const float f = p.prob_fn == 0 ? expf(xld(part + (size_t)i * (E + 4) + E) - M) : 1.0f;
+        fac[i] = f;
+        Z += f * xld(part + (size_t)i * (E + 4) + E + 1);
+      }
+      const float inv = p.prob_fn == 1 ? 1.0f : 1.0f / Z;
+      for (int i = 0; i < S; ++i) fac[i] *= inv;
+      if (p.prob_fn == 2 && p.znorm) p.znorm[b] = Z;
+    }
+    __syncthreads();
+    for (int t = tid; t < Te; t += AT) align[t] = t < nfull ? xld(align + t) * fac[t / per] : 0.f;
+    float *cx = p.ctx + (size_t)b * E;
+    for (int e = tid; e < E; e += AT) {
+      float c = 0.f;
+      for (int i = 0; i < S; ++i) c = fmaf(fac[i], xld(part + (size_t)i * (E + 4) + e), c);
+      cx[e] = c;
     }
   }
 }
@@ -439,7 +498,18 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
   // [NW * U] cross-wave partials (dq / dv), also scalars; 16-byte aligned
   float *red = base + ((2 * Te + (KIND ? Te * F : 0) + 3) & ~3);
   float *dq = p.dq_part + ((size_t)b * S + sl) * U;
-  if (p.step >= p.dec_len[b]) return;      // finished row: the finish kernel writes its zeros
+  // vanilla / windowed attention: the slice that arrives last sums the utterance's dq partials inside the launch
+  const bool fused = !KIND && p.tickets != nullptr;
+  __shared__ int last_flag;
+  if (p.step >= p.dec_len[b]) {            // finished row: the finish kernel (fused: slice 0) writes its zeros
+    if (fused && sl == 0) {
+      for (int u = tid; u < U; u += AT) p.dq[(size_t)b * U + u] = 0.f;
+      if (p.dalign_out)
+        for (int t = tid; t < Te; t += AT)
+          p.dalign_out[(size_t)b * Te + t] = p.dalign_in ? p.dalign_in[(size_t)b * Te + t] : 0.f;
+    }
+    return;
+  }
   const int n = min(max(p.enc_len[b], 0), Te);
   const int per = (Te + S - 1) / S, lo = min(sl * per, n), hi = min(lo + per, n);
   float *dcf = p.dcf_g + (size_t)b * Te * F;   // [Te*F] in HBM
@@ -611,7 +681,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
   for (int u = tid; u < U; u += AT) {
     float s = 0.f;
     for (int i = 0; i < NW; ++i) s += red[i * U + u];
-    dq[u] = s;
+    xst(dq + u, s, fused);
   }
   __syncthreads();
 #pragma unroll
@@ -624,6 +694,17 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
     float s = 0.f;
     for (int i = 0; i < NW; ++i) s += red[i * U + u];
     p.dv_part[((size_t)b * S + sl) * U + u] += s;
+  }
+  if (fused) {
+    if (!last_arriver(p.tickets + b, (unsigned)S, &last_flag)) return;
+    for (int u = tid; u < U; u += AT) {
+      float s = 0.f;
+      for (int i = 0; i < S; ++i) s += xld(p.dq_part + ((size_t)b * S + i) * U + u);
+      p.dq[(size_t)b * U + u] = s;
+    }
+    if (p.dalign_out)
+      for (int t = tid; t < Te; t += AT) p.dalign_out[(size_t)b * Te + t] = 0.f;
+    return;
   }
   if (KIND) {
     __syncthreads();
@@ -929,12 +1010,13 @@ extern "C" int nabu_lstm_cell_bwd(int B, int U, int step, const int32_t *seq_len
   return 0;
 }
 
-extern "C" int nabu_attn_fwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
-                             const int32_t *enc_len, const float *keys, const float *values,
-                             const float *q, const float *v, const float *conv_kernel,
-                             const float *conv_proj, const float *align_prev, const float *ctx_prev,
-                             float *align, float *ctx, float *znorm, void *ws, size_t ws_bytes,
-                             nabu_stream_t stream) {
+// tickets: B zeroed counters (left zero) -> the finish steps run inside the attention launches
+static int attn_fwd_impl(const nabu_attn_desc *d, int step, const int32_t *dec_len,
+                         const int32_t *enc_len, const float *keys, const float *values,
+                         const float *q, const float *v, const float *conv_kernel,
+                         const float *conv_proj, const float *align_prev, const float *ctx_prev,
+                         float *align, float *ctx, float *znorm, void *ws, size_t ws_bytes,
+                         nabu_stream_t stream, unsigned *tickets) {
   if (int e = check_attn(d)) return e;
   NABU_CHECK_ARG(dec_len && enc_len && keys && values && q && v && align_prev && ctx_prev && align && ctx,
                  "attn_fwd: null pointer");
@@ -947,6 +1029,7 @@ extern "C" int nabu_attn_fwd(const nabu_attn_desc *d, int step, const int32_t *d
   p.ck = conv_kernel; p.wf = conv_proj; p.align_prev = align_prev; p.ctx_prev = ctx_prev;
   p.align = align; p.ctx = ctx; p.prob_fn = d->prob_fn; p.znorm = znorm;
   p.fwd_part = static_cast<float *>(ws);
+  p.tickets = tickets;
   const size_t shm = attn_lds(d, false);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool reg = d->kind == 1 && d->U <= 256 * RJ && d->F <= RF;
@@ -956,11 +1039,20 @@ extern "C" int nabu_attn_fwd(const nabu_attn_desc *d, int step, const int32_t *d
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   hipLaunchKernelGGL(kern, dim3(d->B, S), dim3(AT), shm, s, p);
   NABU_LAUNCH_CHECK();
-  if (S > 1) {
+  if (S > 1 && !tickets) {
     hipLaunchKernelGGL(attn_fwd_finish_kernel, dim3(d->B), dim3(256), 0, s, p, S);
     NABU_LAUNCH_CHECK();
   }
   return 0;
+}
+extern "C" int nabu_attn_fwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
+                             const int32_t *enc_len, const float *keys, const float *values,
+                             const float *q, const float *v, const float *conv_kernel,
+                             const float *conv_proj, const float *align_prev, const float *ctx_prev,
+                             float *align, float *ctx, float *znorm, void *ws, size_t ws_bytes,
+                             nabu_stream_t stream) {
+  return attn_fwd_impl(d, step, dec_len, enc_len, keys, values, q, v, conv_kernel, conv_proj, align_prev, ctx_prev,
+                       align, ctx, znorm, ws, ws_bytes, stream, nullptr);
 }
 
 extern "C" size_t nabu_attn_fwd_ws_bytes(const nabu_attn_desc *d) {
@@ -980,14 +1072,14 @@ extern "C" size_t nabu_attn_bwd_ws_bytes(const nabu_attn_desc *d) {
   return ((size_t)d->B * S * d->U + (d->kind == 1 ? (size_t)d->B * d->Te * d->F : 0) + 4) * sizeof(float);
 }
 
-extern "C" int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
-                             const int32_t *enc_len, const float *keys, const float *values,
-                             const float *q, const float *v, const float *conv_kernel,
-                             const float *conv_proj, const float *align_prev, const float *align,
-                             const float *ctx, const float *dctx, const float *dalign_in, float *dq,
-                             float *dkeys, float *dv_part, float *dconv_proj_part,
-                             float *dconv_kernel_part, float *dalign_out, const float *znorm, void *ws,
-                             size_t ws_bytes, nabu_stream_t stream) {
+static int attn_bwd_impl(const nabu_attn_desc *d, int step, const int32_t *dec_len,
+                         const int32_t *enc_len, const float *keys, const float *values,
+                         const float *q, const float *v, const float *conv_kernel,
+                         const float *conv_proj, const float *align_prev, const float *align,
+                         const float *ctx, const float *dctx, const float *dalign_in, float *dq,
+                         float *dkeys, float *dv_part, float *dconv_proj_part,
+                         float *dconv_kernel_part, float *dalign_out, const float *znorm, void *ws,
+                         size_t ws_bytes, nabu_stream_t stream, unsigned *tickets) {
   if (int e = check_attn(d)) return e;
   NABU_CHECK_ARG(dec_len && enc_len && keys && values && q && v && align && ctx && dctx && dq && dkeys && dv_part && ws,
                  "attn_bwd: null pointer");
@@ -1007,6 +1099,7 @@ extern "C" int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *d
   p.prob_fn = d->prob_fn; p.znorm = const_cast<float *>(znorm);
   p.dq_part = static_cast<float *>(ws);
   p.dcf_g = p.dq_part + (size_t)d->B * S * d->U;
+  p.tickets = d->kind != 1 ? tickets : nullptr;   // location-aware: the finish is a wide kernel of its own
   NABU_CHECK_ARG(d->prob_fn != 2 || znorm, "attn_bwd: normalized_sigmoid needs the normalisers of the forward pass");
   const size_t shm = attn_lds(d, true);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1017,6 +1110,7 @@ extern "C" int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *d
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   hipLaunchKernelGGL(kern, dim3(d->B, S), dim3(AT), shm, s, p);
   NABU_LAUNCH_CHECK();
+  if (p.tickets) return 0;
   const size_t shm2 = ((size_t)d->Te + (d->kind == 1 ? (size_t)d->Te * d->F + (size_t)d->K * d->F : 0) + 4) * sizeof(float);
   if (shm2 > 64 * 1024)
     NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_finish_kernel),
@@ -1024,6 +1118,18 @@ extern "C" int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *d
   hipLaunchKernelGGL(attn_bwd_finish_kernel, dim3(d->B, d->kind == 1 ? 2 : 1), dim3(d->kind == 1 ? FT : 256), shm2, s, p, S);
   NABU_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
+                             const int32_t *enc_len, const float *keys, const float *values,
+                             const float *q, const float *v, const float *conv_kernel,
+                             const float *conv_proj, const float *align_prev, const float *align,
+                             const float *ctx, const float *dctx, const float *dalign_in, float *dq,
+                             float *dkeys, float *dv_part, float *dconv_proj_part,
+                             float *dconv_kernel_part, float *dalign_out, const float *znorm, void *ws,
+                             size_t ws_bytes, nabu_stream_t stream) {
+  return attn_bwd_impl(d, step, dec_len, enc_len, keys, values, q, v, conv_kernel, conv_proj, align_prev, align, ctx,
+                       dctx, dalign_in, dq, dkeys, dv_part, dconv_proj_part, dconv_kernel_part, dalign_out, znorm, ws,
+                       ws_bytes, stream, nullptr);
 }
 
 extern "C" int nabu_mask_time_f32(int B, int L, int F, float *x, const int32_t *len, nabu_stream_t stream) {
@@ -1223,7 +1329,7 @@ static SpWs sp_ws(const nabu_speller_desc *d) {
   for (int n = 0; n < d->num_layers; ++n) s.kperm[n] = take((n == 0 ? E + U : 2 * U) * 4 * U);
   s.kxhT = take(4 * U * (E + U));
   for (int i = 0; i < 2; ++i) s.dxh[i] = take(B * (E + U));
-  s.tickets = take(NS * 1024);
+  s.tickets = take(NS * 1024 + B + 4);   // + one counter per utterance for the attention launches
   {
     size_t kmax = E + U > 4 * U ? E + U : 4 * U, nmax = 4 * U > E ? 4 * U : E;
     s.fpart_each = ((kmax / 64 + 1) * Bn * nmax + 3) / 4 * 4;
@@ -1323,7 +1429,7 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
   const size_t gwb = W.gemm_bytes;
   const nabu_attn_desc ad = {sizeof(nabu_attn_desc), B, Te, E, U, d->kind, d->K, d->F, d->prob_fn};
   const bool drop = d->keep_prob < 1.f;
-  NABU_HIP(hipMemsetAsync(w + W.tickets, 0, (size_t)W.NS * 1024 * 4, s));
+  NABU_HIP(hipMemsetAsync(w + W.tickets, 0, ((size_t)W.NS * 1024 + B + 4) * 4, s));
   // zero initial state (index 0 of every time-major array)
   for (int n = 0; n < nl; ++n) {
     NABU_HIP(hipMemsetAsync(r + R.H[n], 0, (size_t)B * U * 4, s));
@@ -1357,6 +1463,7 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
       NABU_LAUNCH_CHECK();
     }
   }
+  unsigned *atk = env_int("NABU_SPELLER_ATTN_FUSED", 1) ? reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)NS * 1024 : nullptr;
   SubStreams ss;
   SP_TRY(sub_streams(NS, s, &ss));
   SP_TRY(sub_fork(ss));
@@ -1405,12 +1512,12 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
       const float *htop = r + R.Ho[nl - 1] + (size_t)(t + 1) * B * U + (size_t)b0 * U;
       float *qt = r + R.q + (size_t)t * B * U + (size_t)b0 * U;
       SP_TRY(mm2(Bn, U, U, htop, U, p->query_kernel, U, 0, nullptr, 0, nullptr, 0, 0.f, qt, U, w, W, sub, gws, gwb, st));
-      SP_TRY(nabu_attn_fwd(&adn, t, dlen, enc_len + b0, r + R.keys + (size_t)b0 * Te * U, values + (size_t)b0 * Te * E, qt,
+      SP_TRY(attn_fwd_impl(&adn, t, dlen, enc_len + b0, r + R.keys + (size_t)b0 * Te * U, values + (size_t)b0 * Te * E, qt,
                            p->attention_v, p->conv_kernel, p->conv_proj,
                            r + R.align + (size_t)t * B * Te + (size_t)b0 * Te, r + R.ctx + (size_t)t * B * E + (size_t)b0 * E,
                            r + R.align + (size_t)(t + 1) * B * Te + (size_t)b0 * Te,
                            r + R.ctx + (size_t)(t + 1) * B * E + (size_t)b0 * E, r + R.znorm + (size_t)t * B + b0,
-                           w + W.attn + (size_t)sub * W.attn_each, attn_fwd_wsb_n, st));
+                           w + W.attn + (size_t)sub * W.attn_each, attn_fwd_wsb_n, st, atk ? atk + b0 : nullptr));
       if (sampling && t + 1 < L) {
         // ScheduledEmbeddingTrainingHelper: the step's logits decide the next input of selected rows
         float *lt = r + R.logits_tm + (size_t)t * B * C + (size_t)b0 * C;
@@ -1464,7 +1571,7 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   SP_TRY(mm(false, true, BL, U, C, dl, C, p->out_kernel, C, 0.f, dH, U, nullptr, gw, gwb, stream));
   SP_TRY(mm(false, true, BL, E, C, dl, C, p->out_kernel + (size_t)U * C, C, 0.f, dCtx, E, nullptr, gw, gwb, stream));
   NABU_HIP(hipMemsetAsync(dkeys, 0, (size_t)B * Te * U * 4, s));
-  NABU_HIP(hipMemsetAsync(w + W.tickets, 0, (size_t)W.NS * 1024 * 4, s));
+  NABU_HIP(hipMemsetAsync(w + W.tickets, 0, ((size_t)W.NS * 1024 + B + 4) * 4, s));
   const int S = W.S;          // per-slice partial rows of the attention backward (slices of a sub-batch's utterances)
   NABU_HIP(hipMemsetAsync(w + W.dv, 0, (size_t)B * S * U * 4, s));
   if (d->kind == 1) {
@@ -1501,6 +1608,8 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   const bool fuse_b = epi_env_b && nl == 1 && !drop && fused_ok(Bn, U, U, U, 0, 0) && fused_ok(Bn, E + U, 4 * U, 4 * U, 0, 0) &&
                       (E + U) / 32 <= 1024;
   if (fuse_b) SP_TRY(transpose(E + U, 4 * U, p->lstm_kernel[0] + (size_t)C * 4 * U, 4 * U, w + W.kxhT, s));
+  const bool split_b = fuse_b && E % 32 == 0 && env_int("NABU_SPELLER_SPLIT", 1);
+  unsigned *atk = env_int("NABU_SPELLER_ATTN_FUSED", 1) ? reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)NS * 1024 : nullptr;
   auto bwd_chain = [&](int sub) -> int {
   int cur = 0;   // index of the carries coming from step t+1
   bool have_carry = false;
@@ -1511,17 +1620,17 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
       float *gws = gw + (size_t)sub * W.gemm_each;
       const int32_t *dlen = dec_len + b0;
       float *dCt = dCtx + (size_t)t * B * E + (size_t)b0 * E;
-      if (have_carry && fuse_b) {
+      if (have_carry && fuse_b && !split_b) {
         hipLaunchKernelGGL(add_rows_kernel, dim3(grid1((size_t)Bn * E)), dim3(256), 0, ss.st[sub], Bn, E,
                            w + W.dxh[(t + 1) & 1] + (size_t)b0 * (E + U), E + U, dCt, E);
         NABU_LAUNCH_CHECK();
-      } else if (have_carry) {
+      } else if (have_carry && !fuse_b) {
         SP_TRY(nabu_axpy_f32((size_t)Bn * E, 1.f, w + W.dctx[(t + 1) & 1] + (size_t)b0 * E, dCt, st));
       }
       float *dal_out = d->kind == 1 ? w + W.dal[t & 1] + (size_t)b0 * Te : nullptr;
       const float *dal_carry = (d->kind == 1 && have_carry) ? w + W.dal[(t + 1) & 1] + (size_t)b0 * Te : nullptr;
       float *dqt = dq + (size_t)t * B * U + (size_t)b0 * U;
-      SP_TRY(nabu_attn_bwd(&adn, t, dlen, enc_len + b0, r + R.keys + (size_t)b0 * Te * U, values + (size_t)b0 * Te * E,
+      SP_TRY(attn_bwd_impl(&adn, t, dlen, enc_len + b0, r + R.keys + (size_t)b0 * Te * U, values + (size_t)b0 * Te * E,
                            r + R.q + (size_t)t * B * U + (size_t)b0 * U, p->attention_v, p->conv_kernel, p->conv_proj,
                            r + R.align + (size_t)t * B * Te + (size_t)b0 * Te,
                            r + R.align + (size_t)(t + 1) * B * Te + (size_t)b0 * Te,
@@ -1529,7 +1638,8 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
                            dkeys + (size_t)b0 * Te * U, w + W.dv + (size_t)b0 * S * U,
                            d->kind == 1 ? w + W.dwf + (size_t)b0 * S * F * U : nullptr,
                            d->kind == 1 ? w + W.dck + (size_t)b0 * K * F : nullptr, dal_out,
-                           r + R.znorm + (size_t)t * B + b0, w + W.attn + (size_t)sub * W.attn_each, attn_wsb_n, st));
+                           r + R.znorm + (size_t)t * B + b0, w + W.attn + (size_t)sub * W.attn_each, attn_wsb_n, st,
+                           atk ? atk + b0 : nullptr));
       float *dHt = dH + (size_t)t * B * U + (size_t)b0 * U;
       if (fuse_b) {
         float *dzt = w + W.dz[0] + (size_t)t * B * 4 * U + (size_t)b0 * 4 * U;
@@ -1548,8 +1658,17 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
         unsigned *tk = reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)sub * 1024;
         SP_TRY(gemm_skinny_fused(Bn, U, U, dqt, U, w + W.wqT, U, 0, nullptr, 0, nullptr, 0, 1.f, dHt, U, nullptr, fp, tk,
                                  ss.st[sub], &ep));
-        SP_TRY(gemm_skinny_fused(Bn, E + U, 4 * U, dzt, 4 * U, w + W.kxhT, E + U, 0, nullptr, 0, nullptr, 0, 0.f,
-                                 w + W.dxh[t & 1] + (size_t)b0 * (E + U), E + U, nullptr, fp, tk, ss.st[sub], nullptr));
+        if (split_b && t > 0) {
+          // d context of step t-1 goes straight into that step's dCtx row block (on top of the output
+          // projection's share), d h into the carry: no separate add launch in front of the next attention
+          SkinnySplit sp = {w + W.dxh[t & 1] + (size_t)b0 * (E + U) + E, E + U, E, 0.f};
+          SP_TRY(gemm_skinny_fused(Bn, E + U, 4 * U, dzt, 4 * U, w + W.kxhT, E + U, 0, nullptr, 0, nullptr, 0, 1.f,
+                                   dCtx + (size_t)(t - 1) * B * E + (size_t)b0 * E, E, nullptr, fp, tk, ss.st[sub], nullptr,
+                                   &sp));
+        } else {
+          SP_TRY(gemm_skinny_fused(Bn, E + U, 4 * U, dzt, 4 * U, w + W.kxhT, E + U, 0, nullptr, 0, nullptr, 0, 0.f,
+                                   w + W.dxh[t & 1] + (size_t)b0 * (E + U), E + U, nullptr, fp, tk, ss.st[sub], nullptr));
+        }
         have_carry = true;
         cur ^= 1;
         continue;
