@@ -5,6 +5,7 @@
 namespace nabu {
 bool lstm_persist_supported(int B, int T, int H);
 void lstm_persist_set_timeout_us(long long us);
+unsigned long long lstm_persist_timeout_ticks();   // bound of every in-kernel wait (wall_clock64 ticks)
 size_t lstm_persist_ws_bytes(int B, int T, int H);
 int lstm_persist_fwd(int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2],

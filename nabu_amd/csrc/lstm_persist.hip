@@ -774,6 +774,7 @@ __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8
 // ===========================================================================
 // bound of every in-kernel spin, wall_clock64 ticks (100 MHz); process-wide setting
 static unsigned long long g_timeout_ticks = 20000000ull;   // 0.2 s: a step takes microseconds
+unsigned long long lstm_persist_timeout_ticks() { return g_timeout_ticks; }
 void lstm_persist_set_timeout_us(long long us) {
   g_timeout_ticks = us > 0 ? (unsigned long long)us * 100ull : 20000000ull;
 }

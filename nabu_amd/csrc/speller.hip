@@ -13,6 +13,7 @@
 // Layouts: keys [B,Te,U], values [B,Te,E] batch-major; per-step state time-major.
 #include "common.h"
 #include "gemm_args.h"
+#include "speller_persist.h"
 
 #include <stdlib.h>
 
@@ -1204,6 +1205,7 @@ struct SpWs {
   size_t kperm[NABU_SPELLER_MAX_LAYERS];   // gate-interleaved copies of the cell kernels' dense rows (forward)
   size_t kxhT, dxh[2];     // [4U, E+U] transposed rows of layer 0's kernel; [B, E+U] carries d(context | h) of a step
   size_t tickets, fpart;   // fused skinny products: per-column-slice tickets (zeroed per call), partial tiles
+  size_t status, persist, persist_bytes;   // persistent decoder kernel: status word (ws[0]), XCC table + exchange rings
   // the decoder steps run as NS independent sub-batches on NS streams: per sub-batch slices of
   // the scratch that a step's kernels share
   int NS, S;               // sub-batches; attention-backward slices per utterance (of a sub-batch)
@@ -1298,6 +1300,14 @@ static SpWs sp_ws(const nabu_speller_desc *d) {
   auto take = [&](size_t n) { size_t r = o; o += (n + 3) / 4 * 4; return r; };
   s.NS = sp_nsub(d);
   const size_t NS = s.NS, Bn = B / NS;
+  // ws[0]: status word of the persistent decoder kernel (0 = ok; sticky, the caller provides the workspace
+  // zero-initialised once, like the recurrent layers' workspace), then its XCC table and exchange rings
+  s.status = take(64);
+  {
+    const SpPersistDesc pd = {(int)B, (int)L, (int)U, (int)E, (int)Te, (int)C};
+    s.persist_bytes = speller_persist_ws_bytes(pd);
+    s.persist = take(s.persist_bytes / 4 + 4);
+  }
   s.z_each = Bn * 4 * U;
   s.z = take(B * 4 * U);
   s.dl = take(L * B * C);
@@ -1463,10 +1473,22 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
       NABU_LAUNCH_CHECK();
     }
   }
+  // the whole step loop as ONE persistent launch (speller_persist.hip) where the geometry allows:
+  // one LSTM layer, vanilla softmax attention, teacher forcing, no dropout, B = 32 (cfg3)
+  const SpPersistDesc pd = {B, L, U, E, Te, C};
+  const bool persist = nl == 1 && !drop && !sampling && d->kind == 0 && d->prob_fn == 0 && cell_epi[0] &&
+                       W.persist_bytes > 0 && speller_persist_ok(pd);
+  if (persist)
+    SP_TRY(speller_persist_fwd(pd, dec_len, enc_len, ids_used, w + W.kperm[0], p->lstm_bias[0], p->lstm_kernel[0],
+                               p->query_kernel, p->attention_v, r + R.keys, values, r + R.H[0], r + R.Cs[0],
+                               r + R.acts[0], r + R.q, r + R.ctx, r + R.align, reinterpret_cast<int *>(w + W.status),
+                               w + W.persist, W.persist_bytes, s));
   unsigned *atk = env_int("NABU_SPELLER_ATTN_FUSED", 1) ? reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)NS * 1024 : nullptr;
   SubStreams ss;
+  if (!persist) {
   SP_TRY(sub_streams(NS, s, &ss));
   SP_TRY(sub_fork(ss));
+  }
   auto fwd_chain = [&](int sub) -> int {
     for (int t = 0; t < L; ++t) {
       const int b0 = sub * Bn;
@@ -1530,8 +1552,10 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
     }
     return 0;
   };
+  if (!persist) {
   SP_TRY(run_subs(NS, fwd_chain));
   SP_TRY(sub_join(ss));
+  }
   // output projection of all steps: [h_t, ctx_t]·W + b, then batch-major + impute_finished
   float *ltm = r + R.logits_tm;
   SP_TRY(mm(false, false, L * B, C, U, r + R.Ho[nl - 1] + (size_t)B * U, U, p->out_kernel, C, 0.f, ltm, C, p->out_bias, gw, gwb, stream));

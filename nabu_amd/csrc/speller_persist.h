@@ -1,0 +1,26 @@
+// speller_persist.h — the Speller's decoder steps as ONE persistent launch (internal API, forward pass).
+#pragma once
+#include "common.h"
+
+namespace nabu {
+
+struct SpPersistDesc {
+  int B, L, U, E, Te, C;
+};
+
+// shapes the persistent forward kernel takes (single LSTM layer, vanilla softmax attention, no dropout, no
+// scheduled sampling are checked by the caller): B = 32, U and E multiples of 32, the slices of keys and
+// values of an utterance fit the LDS
+bool speller_persist_ok(const SpPersistDesc &d);
+size_t speller_persist_ws_bytes(const SpPersistDesc &d);
+
+// kperm: [(E+U), 4U] gate-interleaved dense rows of the cell kernel (column 4u+g); emb: the kernel's first C rows
+// (gate-major columns g*U+u); bias [4U] gate-major; wq [U,U]; v [U]; keys [B,Te,U]; values [B,Te,E]; ids [L,B].
+// Writes the time-major reserve arrays of nabu_speller_fwd: H, Cs [(L+1),B,U] (index 0 = zero state, set by the
+// caller), acts [L,B,4U], q [L,B,U], ctx [(L+1),B,E], align [(L+1),B,Te].
+int speller_persist_fwd(const SpPersistDesc &d, const int32_t *dec_len, const int32_t *enc_len, const int32_t *ids,
+                        const float *kperm, const float *bias, const float *emb, const float *wq, const float *v,
+                        const float *keys, const float *values, float *H, float *Cs, float *acts, float *q, float *ctx,
+                        float *align, int *status, void *ws, size_t ws_bytes, hipStream_t stream);
+
+}  // namespace nabu

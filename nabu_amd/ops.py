@@ -305,16 +305,16 @@ def set_persist_timeout_ms(ms):
 
 def check_persist_status(device=None):
     """Raise if a persistent recurrent kernel gave up (bounded-spin timeout); the
-    status word is the first int32 of the 'blstm' workspace.  Synchronises."""
+    status word is the first int32 of the 'blstm' / 'speller' workspace.  Synchronises."""
     for (dev, tag), buf in list(Workspace._bufs.items()):
-        if tag != 'blstm':
+        if tag not in ('blstm', 'speller'):     # 'speller': the persistent decoder kernel (speller_persist.hip)
             continue
         code = int(buf[:4].view(torch.int32).item())
         if code:
             buf[:4].zero_()
             raise _hip.NabuHipError(
-                'persistent LSTM kernel timed out waiting for a peer workgroup (code %d: block %d, %s); '
-                'results of this step are invalid' % (code, code // 4,
+                'persistent %s kernel timed out waiting for a peer workgroup (code %d: block %d, %s); '
+                'results of this step are invalid' % ('LSTM' if tag == 'blstm' else 'decoder', code, code // 4,
                                                       {1: 'forward pass', 2: 'backward pass',
                                                        3: 'start-up handshake'}.get(code % 4, '?')))
 
