@@ -62,18 +62,48 @@ struct Args {
 __device__ __forceinline__ bool has_sentinel(const u32x4 v) {
   return v.x == SENT || v.y == SENT || v.z == SENT || v.w == SENT;
 }
-__device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+// wave64 reductions on the DPP network (no LDS round trips); every lane gets the result
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dppf(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                               CTRL, ROW_MASK, 0xF, false));
 }
-__device__ __forceinline__ float quad_bcast(float v, int i) { return __shfl(v, (threadIdx.x & ~3) | i); }
+__device__ __forceinline__ float wsum(float v) {
+  v += dppf<0xB1, 0xF>(0.f, v);          // quad_perm [1,0,3,2]
+  v += dppf<0x4E, 0xF>(0.f, v);          // quad_perm [2,3,0,1]
+  v += dppf<0x141, 0xF>(0.f, v);         // row_half_mirror
+  v += dppf<0x140, 0xF>(0.f, v);         // row_mirror: every lane of a row holds the row's sum
+  v += dppf<0x142, 0xA>(0.f, v);         // row_bcast15 -> rows 1, 3
+  v += dppf<0x143, 0xC>(0.f, v);         // row_bcast31 -> rows 2, 3: lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wmax(float v) {
+  v = fmaxf(v, dppf<0xB1, 0xF>(v, v));
+  v = fmaxf(v, dppf<0x4E, 0xF>(v, v));
+  v = fmaxf(v, dppf<0x141, 0xF>(v, v));
+  v = fmaxf(v, dppf<0x140, 0xF>(v, v));
+  v = fmaxf(v, dppf<0x142, 0xA>(v, v));
+  v = fmaxf(v, dppf<0x143, 0xC>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float quad_bcast(float v, int i) {
+  switch (i) {
+    case 0: return dppf<0x00, 0xF>(v, v);
+    case 1: return dppf<0x55, 0xF>(v, v);
+    case 2: return dppf<0xAA, 0xF>(v, v);
+    default: return dppf<0xFF, 0xF>(v, v);
+  }
+}
+// one exp + one rcp (lstm_persist.hip uses the same forms; relative error ~1e-7)
+__device__ __forceinline__ float fsig(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 struct Spin {
   unsigned long long t0;
   unsigned n;
-  __device__ __forceinline__ void start() { t0 = wall_clock64(); n = 0; }
+  __device__ __forceinline__ void start() { n = 0; }
   __device__ __forceinline__ bool expired(const Args &p) {
+    if (n == 0) t0 = wall_clock64();      // the clock is only read once a poll has failed
     if ((++n & 31u) != 0) return false;
     __builtin_amdgcn_s_sleep(1);
     if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
@@ -154,7 +184,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   __syncthreads();
   if (flag[0]) return;
   const bool coloc = flag[1] != 0;
-  if ((p.dbg & 4) && tid == 0 && blockIdx.x < 32) p.status[160 + blockIdx.x] = (int)xcc * 2 + (coloc ? 1 : 0);
 
   // ---- exchange rings of my unit: h [R][U], q [R][U], ctx [R][E], partials [R*S][E+4]
   const unsigned hb = (unsigned)(R * U * 4), cb = (unsigned)(R * E * 4), pb = (unsigned)(R * S * (E + 4) * 4);
@@ -182,8 +211,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   float *red0 = red_in_x ? scr : scr + NW * R * KR;   // tile of wave ww at red0 + ww * red_stride: [64 columns][4 rows]
   // (KW < KR: the staged X has zero padding that must stay zero -> the other duties' scratch lies behind it)
   float *aux = KW == KR ? scr : scr + NW * R * KR + (red_in_x ? 0 : NW * 256);
-  float *hs = aux;
-  float *qs = aux + R * U;
+  float *hs = aux;                                    // [R][U + 4]
+  float *qred = aux + R * (U + 4);                    // [NW][16 columns][4 rows]: duty B's partial sums
+  float *qs = qred + NW * 64;
   float *sc_s = qs + U;
   float *parts = aux;
   float *mz = parts + S * CB;
@@ -199,7 +229,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int f = f0 + i / E;
     vals_s[i] = f < Te ? p.values[((size_t)cbg * Te + f) * E + i % E] : 0.f;
   }
-  for (int i = tid; i < U * UW; i += NT) wq_s[(i % UW) * U + i / UW] = p.wq[(size_t)(i / UW) * U + UW * slot + i % UW];   // [column][k]
+  for (int i = tid; i < U * UW; i += NT) wq_s[i] = p.wq[(size_t)(i / UW) * U + UW * slot + i % UW];   // [k][column]
   for (int i = tid; i < U; i += NT) v_s[i] = p.v[i];
   for (int i = tid; i < NW * R * KR; i += NT) scr[i] = 0.f;
 
@@ -234,11 +264,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         p.H[((size_t)(ts + 1) * B + gb) * U + gunit] = h_state;
       }
     }
-    {
-      const int NO = R * UW, KG = min(64, NT / NO);
-      const int o = tid / KG, kg = tid % KG;
-      if (o < NO && kg == 0) p.q[((size_t)ts * B + unit * R + o / UW) * U + UW * slot + o % UW] = q_last;
-    }
+    if (tid < R * UW) p.q[((size_t)ts * B + unit * R + tid / UW) * U + UW * slot + tid % UW] = q_last;
     if (tid < CB) p.ctx[((size_t)(ts + 1) * B + cbg) * E + cs * CB + tid] = ctx_prev;
     if (tid < FS && f0 + tid < Te) p.align[((size_t)(ts + 1) * B + cbg) * Te + f0 + tid] = al_prev;
   };
@@ -249,7 +275,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
   for (int t = 0; t < L; ++t) {
     const unsigned so = (unsigned)(t % RING), sp = (unsigned)((t + RING - 1) % RING), sr = (unsigned)((t + RING - 2) % RING);
-    if ((p.dbg & 4) && unit == 0 && tid == 0 && t == L / 2) p.status[128 + slot] = (int)wall_clock64();   // step start
     SP_STAMP(0);
     // =========================== A: cell ===========================
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -286,21 +311,37 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (qi < NPC) *reinterpret_cast<f32x4 *>(Xs + (qi / PR) * KR + 4 * (qi % PR)) = __builtin_bit_cast(f32x4, v[i]);
       }
       SP_STAMP(1);
-      if (!(p.dbg & 16)) save_step(t - 1);
+      save_step(t - 1);
       // product (in-order LDS: my wave reads what it wrote)
       const float *xr = Xs + (lane & 3) * KR;
-      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-      f32x4 xq[2];
-      xq[0] = *reinterpret_cast<const f32x4 *>(xr);
+      // four accumulator chains: with ONE wave per SIMD nobody else fills the result latency of a dependent product
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f}, a3 = {0.f, 0.f, 0.f, 0.f};
+      // One wave per SIMD: nobody else hides the LDS latency, and the compiler sinks operand reads to one group
+      // ahead — so the reads of the NEXT chunk of 16 k are pinned in front of this chunk's 16 products
+      constexpr int CH = 4, NCH = KR / 4 / CH;
+      f32x4 xq[2][CH];
 #pragma unroll
-      for (int k4 = 0; k4 < KR / 4; ++k4) {      // straight line: the operands of the next four k travel while these multiply
-        if (k4 + 1 < KR / 4) xq[(k4 + 1) & 1] = *reinterpret_cast<const f32x4 *>(xr + 4 * (k4 + 1));
-        const f32x4 x = xq[k4 & 1];
-        a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.x, Wr[4 * k4 + 0], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.y, Wr[4 * k4 + 1], a1, 0, 0, 0);
-        a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.z, Wr[4 * k4 + 2], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.w, Wr[4 * k4 + 3], a1, 0, 0, 0);
+      for (int i = 0; i < CH; ++i) xq[0][i] = *reinterpret_cast<const f32x4 *>(xr + 4 * i);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) {
+#pragma unroll
+          for (int i = 0; i < CH; ++i) xq[(c + 1) & 1][i] = *reinterpret_cast<const f32x4 *>(xr + 4 * ((c + 1) * CH + i));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const f32x4 x = xq[c & 1][i];
+          const int k4 = c * CH + i;
+          a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.x, Wr[4 * k4 + 0], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.y, Wr[4 * k4 + 1], a1, 0, 0, 0);
+          a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.z, Wr[4 * k4 + 2], a2, 0, 0, 0);
+          a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.w, Wr[4 * k4 + 3], a3, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
+      a0 += a2;
+      a1 += a3;
       acc = a0 + a1;
     }
     SP_STAMP(2);
@@ -314,23 +355,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       float a = 0.f;
       if (gate_thr) {
         z += gbias + p.emb[(size_t)p.ids[(size_t)t * B + gb] * 4 * U + gg * U + gunit];
-        a = gg == 1 ? tanhf_(z) : sigmoidf_(gg == 2 ? z + 1.0f : z);
+        a = gg == 1 ? ftanh(z) : fsig(gg == 2 ? z + 1.0f : z);
       }
       const float gi = quad_bcast(a, 0), gj = quad_bcast(a, 1), gf = quad_bcast(a, 2), go = quad_bcast(a, 3);
       const bool act = t < glen;
       if (gate_thr && act) {
         c_state = c_state * gf + gi * gj;
-        h_state = tanhf_(c_state) * go;
+        h_state = ftanh(c_state) * go;
       }
       a_last = act ? a : 0.f;        // saved tensors of this step go to HBM under the NEXT step's product
-      if ((p.dbg & 4) && unit == 0 && tid == 0 && t == L / 2) p.status[64 + slot] = (int)wall_clock64();   // publish time of h_t
       const bool pub = gate_thr && gg == 0;
       xst1(fbits(h_state), rh, pub ? so * hb + (unsigned)((grow * U + gunit) * 4) : OOB, coloc);
       xst1(SENT, rh, (pub && t >= 2) ? sr * hb + (unsigned)((grow * U + gunit) * 4) : OOB, coloc);
     }
     SP_STAMP(3);
     __syncthreads();     // the partial tiles have been read: the scratch is free for h_t
-    SP_STAMP(11);
     // =========================== B: query ==========================
     {
       const int NPC = R * U / 4;                       // <= 2 * NT (host check)
@@ -338,40 +377,49 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       u32x4 v0, v1;
       Spin g;
       g.start();
-      int iters = 0;
       for (;;) {
         v0 = xld4(rh, so * hb + (unsigned)(q0 * 16));
         v1 = xld4(rh, so * hb + (unsigned)(q1 * 16));
-        ++iters;
-        if ((p.dbg & 4) && blockIdx.x == 0 && tid == 0 && t == L / 2 && iters < 30) p.status[192 + iters] = (int)wall_clock64();
         if (__all(!has_sentinel(v0) && !has_sentinel(v1))) break;
         if (g.expired(p)) { SP_TIMEOUT(1); break; }
       }
-      if ((p.dbg & 4) && blockIdx.x == 0 && tid == 0 && t == L / 2) { p.status[224] = iters; p.status[225] = (int)wall_clock64(); }
-      if (tid < NPC) *reinterpret_cast<f32x4 *>(hs + 4 * q0) = __builtin_bit_cast(f32x4, v0);
-      if (NT + tid < NPC) *reinterpret_cast<f32x4 *>(hs + 4 * q1) = __builtin_bit_cast(f32x4, v1);
+      if (tid < NPC) *reinterpret_cast<f32x4 *>(hs + (4 * q0 / U) * (U + 4) + 4 * q0 % U) = __builtin_bit_cast(f32x4, v0);
+      if (NT + tid < NPC) *reinterpret_cast<f32x4 *>(hs + (4 * q1 / U) * (U + 4) + 4 * q1 % U) = __builtin_bit_cast(f32x4, v1);
     }
     SP_STAMP(4);
     __syncthreads();
     if (flag[0]) return;
     {
-      // outputs (row, c): R*UW; KG lanes split k
-      const int NO = R * UW, KG = min(64, NT / NO), kper = U / KG;
-      const int o = tid / KG, kg = tid % KG;
-      float s = 0.f;
-      if (o < NO) {
-        // lanes kg of an output take interleaved 16-byte pieces of k: conflict-free LDS reads, four independent chains
-        const f32x4 *h4 = reinterpret_cast<const f32x4 *>(hs + (o / UW) * U), *w4 = reinterpret_cast<const f32x4 *>(wq_s + (o % UW) * U);
-        f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int j = kg; j < U / 4; j += KG) a4 += h4[j] * w4[j];
-        s = (a4.x + a4.y) + (a4.z + a4.w);
+      // q[4 rows][my UW columns] on the matrix pipe: blocks = (column group cg, k phase ks); wave w takes the k range
+      // [w U/4, (w+1) U/4), lane (cg, ks, j): A = h[row j][k + ks], B = Wq[k + ks][4 cg + j].  hs rows are padded by
+      // 4 floats: the 16 (row, ks) operands of an instruction then sit in 16 different banks.
+      const int bcg = lane >> 4, bks = (lane >> 2) & 3, bj = lane & 3;
+      f32x4 qa = {0.f, 0.f, 0.f, 0.f}, qb = {0.f, 0.f, 0.f, 0.f};
+      {
+        const float *ha = hs + bj * (U + 4) + w * (U / 4) + bks;
+        const float *wb = wq_s + (size_t)(w * (U / 4) + bks) * UW + min(4 * bcg + bj, UW - 1);
+        const bool colok = 4 * bcg + bj < UW;
+#pragma unroll 8
+        for (int kk = 0; kk < U / 16; kk += 2) {
+          const float a0 = ha[4 * kk], a1 = ha[4 * kk + 4];
+          const float b0 = colok ? wb[(size_t)4 * kk * UW] : 0.f, b1 = colok ? wb[(size_t)(4 * kk + 4) * UW] : 0.f;
+          qa = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b0, qa, 0, 0, 0);
+          qb = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b1, qb, 0, 0, 0);
+        }
       }
-      (void)kper;
-      for (int m = 1; m < KG; m <<= 1) s += __shfl_xor(s, m);
-      if ((p.dbg & 4) && unit == 0 && tid == 0 && t == L / 2) p.status[96 + slot] = (int)wall_clock64();   // publish time of q_t
-      const bool pub = o < NO && kg == 0;
-      const int row = pub ? o / UW : 0, c = pub ? o % UW : 0;
+      f32x4 qs4 = qa + qb;       // [row i] of column 4 cg + j, k phase ks: add the four phases (lanes ^4, ^8)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        qs4[i] += __shfl_xor(qs4[i], 4);
+        qs4[i] += __shfl_xor(qs4[i], 8);
+      }
+      if (bks == 0) *reinterpret_cast<f32x4 *>(qred + ((size_t)w * 16 + 4 * bcg + bj) * 4) = qs4;   // [wave][column][row]
+      __syncthreads();
+      // thread (row, column) adds the four k ranges
+      const int row = tid / UW, c = tid % UW;
+      float s = 0.f;
+      if (tid < R * UW) s = (qred[(0 * 16 + c) * 4 + row] + qred[(1 * 16 + c) * 4 + row]) + (qred[(2 * 16 + c) * 4 + row] + qred[(3 * 16 + c) * 4 + row]);
+      const bool pub = tid < R * UW;
       q_last = s;
       xst1(fbits(s), rq, pub ? so * hb + (unsigned)((row * U + UW * slot + c) * 4) : OOB, coloc);
       xst1(SENT, rq, (pub && t >= 2) ? sr * hb + (unsigned)((row * U + UW * slot + c) * 4) : OOB, coloc);
@@ -405,10 +453,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int i = 0; i < 4; ++i) {
           const int f = min(fg + w + NW * i, FS - 1);
           const f32x4 kk = reinterpret_cast<const f32x4 *>(keys_s + (size_t)f * U)[u4];
-          sacc[i] = fmaf(vv.x, tanhf_(kk.x + qq.x), sacc[i]);
-          sacc[i] = fmaf(vv.y, tanhf_(kk.y + qq.y), sacc[i]);
-          sacc[i] = fmaf(vv.z, tanhf_(kk.z + qq.z), sacc[i]);
-          sacc[i] = fmaf(vv.w, tanhf_(kk.w + qq.w), sacc[i]);
+          sacc[i] = fmaf(vv.x, ftanh(kk.x + qq.x), sacc[i]);
+          sacc[i] = fmaf(vv.y, ftanh(kk.y + qq.y), sacc[i]);
+          sacc[i] = fmaf(vv.z, ftanh(kk.z + qq.z), sacc[i]);
+          sacc[i] = fmaf(vv.w, ftanh(kk.w + qq.w), sacc[i]);
         }
       }
 #pragma unroll
@@ -425,10 +473,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     float *es_w = es + w * 64;
     {
       const float sc = lane < FS ? sc_s[lane] : -INFINITY;
-      float m = fmaxf(sc, -3.0e38f);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-      const float e = lane < FS ? expf(sc - m) : 0.f;
+      const float m = wmax(fmaxf(sc, -3.0e38f));
+      const float e = lane < FS ? __expf(sc - m) : 0.f;
       es_w[lane] = e;
       m_loc = m;
       z_loc = wsum(e);
@@ -492,10 +538,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       for (int i = 0; i < S; ++i) M = fmaxf(M, mz[2 * i]);
 #pragma unroll
       for (int i = 0; i < S; ++i) {
-        fac[i] = expf(mz[2 * i] - M);
+        fac[i] = __expf(mz[2 * i] - M);
         Z += fac[i] * mz[2 * i + 1];
       }
-      const float inv = 1.0f / Z;
+      const float inv = __builtin_amdgcn_rcpf(Z);
       if (tid < CB) {
         float c = 0.f;
 #pragma unroll
@@ -506,7 +552,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       xst1(fbits(ctx_prev), rc, tid < CB ? so * cb + (unsigned)((ci * E + cs * CB + tid) * 4) : OOB, coloc);
       xst1(SENT, rc, (tid < CB && t >= 2) ? sr * cb + (unsigned)((ci * E + cs * CB + tid) * 4) : OOB, coloc);
       if (tid < FS) {
-        float a = frozen ? al_prev : es[tid] * expf(m_loc - M) * inv;     // (tid < FS <= 64: wave 0's copy)
+        float a = frozen ? al_prev : es[tid] * __expf(m_loc - M) * inv;     // (tid < FS <= 64: wave 0's copy)
         if (!frozen && f0 + tid >= cn) a = 0.f;
         al_prev = a;
       }
@@ -523,7 +569,7 @@ size_t lds_floats(const SpPersistDesc &d, int FS) {
   const size_t KR = kr_for((int)(K / NW));
   size_t scr = NW * R * KR;
   if (R * KR < 256) scr += NW * 256;
-  const size_t need_c = (size_t)R * d.U + d.U + FS + 64, need_d = (size_t)S * (d.E / S) + 2 * S + 64;
+  const size_t need_c = (size_t)R * (d.U + 4) + NW * 64 + d.U + FS + 64, need_d = (size_t)S * (d.E / S) + 2 * S + 64;
   const size_t aux = need_c > need_d ? need_c : need_d;
   if (K / NW == KR) scr = scr > aux ? scr : aux;   // aliased
   else scr += aux;
@@ -537,10 +583,7 @@ size_t ring_bytes(const SpPersistDesc &d) {
 
 }  // namespace
 
-bool speller_persist_ok(const SpPersistDesc &d) {
-  static int env = -1;
-  if (env < 0) { const char *e = getenv("NABU_SPELLER_PERSIST"); env = e ? atoi(e) : 1; }
-  if (!env) return false;
+static bool shape_ok(const SpPersistDesc &d) {
   if (d.B != NU * R || d.U % 32 || d.E % 32 || d.U < 32 || d.E < 32) return false;
   const int K = d.E + d.U;
   if (K % (NW * 4) || K / NW > 384) return false;      // k range of a wave: whole 16-byte pieces, <= 384 weight registers
@@ -549,13 +592,18 @@ bool speller_persist_ok(const SpPersistDesc &d) {
   if ((d.E / S) % 4 || d.E / S > NT) return false;
   const int FS = frames_per_slice(d);
   if (FS > 64 || FS < 1) return false;
-  if (NT / (R * (d.U / P)) < 1) return false;
-  if (d.U % (NT / (R * (d.U / P)) > 64 ? 64 : NT / (R * (d.U / P)))) return false;
+  if (d.U / P > 16 || d.U % 32) return false;          // duty B: 16 columns per workgroup at most
   return lds_floats(d, FS) * 4 <= 160 * 1024 - 512;
 }
 
-size_t speller_persist_ws_bytes(const SpPersistDesc &d) {
-  if (!speller_persist_ok(d)) return 0;
+bool speller_persist_ok(const SpPersistDesc &d) {
+  const char *env = getenv("NABU_SPELLER_PERSIST");     // 0 = the step chain of speller.hip
+  if (env && !atoi(env)) return false;
+  return shape_ok(d);
+}
+
+size_t speller_persist_ws_bytes(const SpPersistDesc &d) {   // (independent of the switch: the workspace layout is)
+  if (!shape_ok(d)) return 0;
   return TABLE_BYTES + ring_bytes(d);
 }
 

@@ -109,6 +109,30 @@ def test_speller_step_on_the_fused_and_multi_stream_paths(attention, nl, K, F):
     np.testing.assert_array_equal(got, one)
 
 
+@pytest.mark.parametrize('U,E,Te', [(64, 64, 40), (128, 256, 70), (64, 192, 33)])
+def test_persistent_decoder_forward(U, E, Te):
+    """speller_persist.hip: the step loop of nabu_speller_fwd as ONE persistent launch (B = 32, one layer, vanilla
+    softmax attention, teacher forcing) — ragged decoder lengths (frozen rows), ragged encoder lengths (masked
+    frames), Te not a multiple of the 8 frame slices, the 64- and 192-register instantiations — against the oracle,
+    and against the step chain (NABU_SPELLER_PERSIST=0) on the same inputs"""
+    import os
+    rng = np.random.default_rng(5 + U)
+    enc_len = rng.integers(Te // 2, Te + 1, 32).astype(np.int32)
+    enc_len[0] = Te
+    enc_len[5] = 3                       # fewer frames than slices
+    tlen = rng.integers(1, 9, 32).astype(np.int32)
+    tlen[3] = 8
+    got = check_speller('vanilla', 1, U, 0, 0, enc_len, tlen, E=E)
+    os.environ['NABU_SPELLER_PERSIST'] = '0'
+    try:
+        ref = check_speller('vanilla', 1, U, 0, 0, enc_len, tlen, E=E)
+    finally:
+        del os.environ['NABU_SPELLER_PERSIST']
+    assert np.abs(got - ref).max() < 2e-5
+    from nabu_amd import ops as hip
+    hip.check_persist_status()
+
+
 def check_speller(attention, nl, U, K, F, enc_len, tlen, E=24):
     from nabu_amd import variables as vs
     from nabu_amd.autodiff import Tape, SeqLen
