@@ -1206,6 +1206,7 @@ struct SpWs {
   size_t kxhT, dxh[2];     // [4U, E+U] transposed rows of layer 0's kernel; [B, E+U] carries d(context | h) of a step
   size_t tickets, fpart;   // fused skinny products: per-column-slice tickets (zeroed per call), partial tiles
   size_t status, persist, persist_bytes;   // persistent decoder kernel: status word (ws[0]), XCC table + exchange rings
+  size_t dv8;                              // its d attention_v partial rows [B*8, U]
   // the decoder steps run as NS independent sub-batches on NS streams: per sub-batch slices of
   // the scratch that a step's kernels share
   int NS, S;               // sub-batches; attention-backward slices per utterance (of a sub-batch)
@@ -1306,7 +1307,9 @@ static SpWs sp_ws(const nabu_speller_desc *d) {
   {
     const SpPersistDesc pd = {(int)B, (int)L, (int)U, (int)E, (int)Te, (int)C};
     s.persist_bytes = speller_persist_ws_bytes(pd);
+    if (speller_persist_bwd_ws_bytes(pd) > s.persist_bytes) s.persist_bytes = speller_persist_bwd_ws_bytes(pd);
     s.persist = take(s.persist_bytes / 4 + 4);
+    s.dv8 = take(speller_persist_bwd_ws_bytes(pd) ? B * 8 * U : 0);
   }
   s.z_each = Bn * 4 * U;
   s.z = take(B * 4 * U);
@@ -1633,6 +1636,14 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
                       (E + U) / 32 <= 1024;
   if (fuse_b) SP_TRY(transpose(E + U, 4 * U, p->lstm_kernel[0] + (size_t)C * 4 * U, 4 * U, w + W.kxhT, s));
   const bool split_b = fuse_b && E % 32 == 0 && env_int("NABU_SPELLER_SPLIT", 1);
+  // the whole step loop as ONE persistent launch (speller_persist.hip), as in the forward pass
+  const SpPersistDesc pd = {B, L, U, E, Te, C};
+  const bool persist = fuse_b && d->kind == 0 && d->prob_fn == 0 && W.persist_bytes > 0 &&
+                       speller_persist_bwd_ok(pd);
+  if (persist)
+    SP_TRY(speller_persist_bwd(pd, dec_len, enc_len, w + W.kxhT, p->query_kernel, p->attention_v, r + R.keys, values,
+                               r + R.acts[0], r + R.Cs[0], r + R.q, r + R.ctx, r + R.align, dH, dCtx, dq, w + W.dz[0],
+                               dkeys, w + W.dv8, reinterpret_cast<int *>(w + W.status), w + W.persist, W.persist_bytes, s));
   unsigned *atk = env_int("NABU_SPELLER_ATTN_FUSED", 1) ? reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)NS * 1024 : nullptr;
   auto bwd_chain = [&](int sub) -> int {
   int cur = 0;   // index of the carries coming from step t+1
@@ -1731,8 +1742,10 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   }
   return 0;
   };
+  if (!persist) {
   SP_TRY(run_subs(NS, bwd_chain));
   SP_TRY(sub_join(ss));
+  }
   // sums over steps as single GEMMs
   SP_TRY(mm(true, false, U, U, BL, htop_all, U, dq, U, 0.f, g->query_kernel, U, nullptr, gw, gwb, stream));
   for (int n = 0; n < nl; ++n) {
@@ -1748,7 +1761,8 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
     }
     SP_TRY(nabu_colsum_f32(BL, 4 * U, dzn, 4 * U, 0.f, g->lstm_bias[n], gw, gwb, stream));
   }
-  SP_TRY(nabu_colsum_f32(B * S, U, w + W.dv, U, 0.f, g->attention_v, gw, gwb, stream));
+  if (persist) SP_TRY(nabu_colsum_f32(B * 8, U, w + W.dv8, U, 0.f, g->attention_v, gw, gwb, stream));
+  else         SP_TRY(nabu_colsum_f32(B * S, U, w + W.dv, U, 0.f, g->attention_v, gw, gwb, stream));
   if (d->kind == 1) {
     SP_TRY(nabu_colsum_f32(B * S, F * U, w + W.dwf, F * U, 0.f, g->conv_proj, gw, gwb, stream));
     SP_TRY(nabu_colsum_f32(B, K * F, w + W.dck, K * F, 0.f, g->conv_kernel, gw, gwb, stream));

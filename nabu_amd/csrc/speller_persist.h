@@ -23,4 +23,16 @@ int speller_persist_fwd(const SpPersistDesc &d, const int32_t *dec_len, const in
                         const float *keys, const float *values, float *H, float *Cs, float *acts, float *q, float *ctx,
                         float *align, int *status, void *ws, size_t ws_bytes, hipStream_t stream);
 
+// Backward pass of the step loop (same shapes; the caller has run the output projection's gradient into dH / dCtx).
+// kxhT [4U, E+U]: transposed dense rows of the cell kernel (k = gate-major column).  Writes dq [L,B,U], dz [L,B,4U]
+// (gate-major), dkeys [B,Te,U] (overwritten), dv_part [B*8,U] (one row per utterance and frame slice), and adds the
+// carried d context into dCtx [L,B,E].
+bool speller_persist_bwd_ok(const SpPersistDesc &d);
+size_t speller_persist_bwd_ws_bytes(const SpPersistDesc &d);
+int speller_persist_bwd(const SpPersistDesc &d, const int32_t *dec_len, const int32_t *enc_len, const float *kxhT,
+                        const float *wq, const float *v, const float *keys, const float *values, const float *acts,
+                        const float *Cs, const float *q, const float *ctx, const float *align, const float *dH, float *dCtx,
+                        float *dq, float *dz, float *dkeys, float *dv_part, int *status, void *ws, size_t ws_bytes,
+                        hipStream_t stream);
+
 }  // namespace nabu

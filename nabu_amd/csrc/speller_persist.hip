@@ -563,6 +563,477 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   save_step(L - 1);
 }
 
+
+// ===========================================================================================================
+// Backward pass of the step loop, same decomposition (one XCD per 4 utterances, steps t = L-1 .. 0):
+//   D1  attention backward of (utterance i, frame slice s): d context = dCtx[t] (output projection) + the carry of
+//       step t+1 -> d alignment of its frames -> softmax backward (sum_f a da = dctx . context_t) -> through
+//       v.tanh(keys + q): its part of dq -> publishes dq_part[U]; d keys of ITS frames accumulate in registers for the
+//       whole launch, d v in registers
+//   D1b the 8 slices of an utterance each add a U/8 block of dq                       -> publishes dq block
+//   D2  workgroup j: dh of its 16 units = dH[t] + carry + dq . Wq^T (matrix pipe), LSTM cell backward
+//                                                                                       -> publishes dz (gate-major)
+//   D3  [d ctx_{t-1} | d h_{t-1}] = dz . [Kx^T | Kh^T]: its (E+U)/32 output columns, the transposed cell kernel in
+//       REGISTERS (the same 12.6 MB per XCD as the forward pass), k phases in the blocks of v_mfma_f32_4x4x1
+//                                                                                       -> publishes the carry
+// Rings and hand-back rule as in the forward kernel (every publisher has gathered, one duty earlier at the latest,
+// pieces that all 32 workgroups published after reading what it now resets).
+struct BArgs {
+  int L, U, E, Te, FS;
+  const int32_t *dec_len, *enc_len;
+  const float *kxhT;       // [4U][E+U] (k = gate-major column of the cell kernel)
+  const float *wq, *v, *keys, *values;
+  const float *acts, *Cs, *q, *ctx, *align;     // saved by the forward pass (time-major)
+  const float *dH;         // [L][B][U] d h_t of the output projection
+  float *dCtx;             // [L][B][E] in: the output projection's share; out: the whole d context_t
+  float *dq, *dz;          // [L][B][U], [L][B][4U] (gate-major): inputs of the weight-gradient products
+  float *dkeys;            // [B][Te][U]
+  float *dv_part;          // [B*S][U]
+  unsigned *table;
+  char *xbuf;
+  int *status;
+  unsigned long long timeout_ticks;
+  int dbg;
+};
+
+#define SPB_TIMEOUT()                                                                                       \
+  do {                                                                                                      \
+    if ((threadIdx.x & 63) == 0) {                                                                          \
+      flag[0] = 1;                                                                                          \
+      __hip_atomic_store(p.status, 2 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     \
+    }                                                                                                       \
+  } while (0)
+
+struct SpinB {
+  unsigned long long t0;
+  unsigned n;
+  __device__ __forceinline__ void start() { n = 0; }
+  __device__ __forceinline__ bool expired(const BArgs &p) {
+    if (n == 0) t0 = wall_clock64();
+    if ((++n & 31u) != 0) return false;
+    __builtin_amdgcn_s_sleep(1);
+    if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+    return wall_clock64() - t0 > p.timeout_ticks;
+  }
+};
+
+// NSETC sets of NKQC instructions per wave (weight registers per lane: NSETC * NKQC); KS = k phases in the 16 blocks
+// of an instruction (4: a set is 16 columns, 16: a set is 4 columns); DKR = frames per thread in D1
+template <int NSETC, int NKQC, int KS, int DKR>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void speller_persist_bwd_kernel(BArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int flag[2];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int unit = blockIdx.x % NU, slot = blockIdx.x / NU;
+  const int U = p.U, E = p.E, Te = p.Te, FS = p.FS, L = p.L;
+  const int KB = 4 * U, KBW = KB / NW;          // reduction index of D3 (gate columns), range of a wave
+  const int NC = (E + U) / P;                  // my output columns of D3
+  const int UW = U / P, UB = U / S;            // my units (D2); my dq block (D1b)
+  const int B = NU * R;
+  constexpr int CGS = 16 / KS;                 // column groups of 4 per instruction
+  constexpr int KR = NSETC * NKQC;
+  const int NSET = NC / (4 * CGS);             // <= NSETC
+
+  const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));
+  if (tid == 0) {
+    flag[0] = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flag[1] = 0;
+    __hip_atomic_store(p.table + unit + NU * slot, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (flag[0]) return;
+  if (tid < 64) {
+    SpinB g;
+    g.start();
+    unsigned vx = xcc;
+    bool failed = false;
+    for (;;) {
+      if (tid < P) vx = __hip_atomic_load(p.table + unit + NU * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__all(vx != SENT)) break;
+      if (g.expired(p)) { failed = true; break; }
+    }
+    const bool same = __all(vx == xcc) && !(p.dbg & 8);
+    if (tid == 0) {
+      if (failed) {
+        flag[0] = 1;
+        __hip_atomic_store(p.status, 3 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      flag[1] = same ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  if (flag[0]) return;
+  const bool coloc = flag[1] != 0;
+
+  // rings: carry [R][E+U], dq partials [R*S][U], dq [R][U], dz [R][4U]
+  const unsigned kb = (unsigned)(R * (E + U) * 4), ab = (unsigned)(R * S * U * 4), qb = (unsigned)(R * U * 4), zb = (unsigned)(R * 4 * U * 4);
+  const size_t unit_bytes = (size_t)RING * (kb + ab + qb + zb);
+  char *ub = p.xbuf + (size_t)unit * unit_bytes;
+  __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)(RING * kb), 0x00020000);
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(ub + (size_t)RING * kb, 0, (int)(RING * ab), 0x00020000);
+  __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(ub + (size_t)RING * (kb + ab), 0, (int)(RING * qb), 0x00020000);
+  __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(ub + (size_t)RING * (kb + ab + qb), 0, (int)(RING * zb), 0x00020000);
+  const u32x4 sent4 = {SENT, SENT, SENT, SENT};
+
+  // LDS
+  float *keys_s = smem;                               // [FS][U]
+  float *vals_s = keys_s + (size_t)FS * U;            // [FS][E]
+  float *wqr_s = vals_s + (size_t)FS * E;             // [UW][U + 4]: Wq rows of my units
+  float *v_s = wqr_s + (size_t)UW * (U + 4);          // [U]
+  float *scr = v_s + U;                               // scratch
+  // D3: my wave stages dz[4 rows][half of its k range] (two halves);  D1: dcx [E], red [NW] + da/ds [FS], dqh [2][U]
+  // D1b: blk [S][UB];  D2: dqs [R][U + 4], chs [R][UW], qred [NW][64][4]
+  const int HK = KBW / 2;
+  float *Zs = scr + (size_t)w * R * HK;
+  float *dcx = scr;
+  float *redw = scr + E;                              // [NW] + [FS] + [FS]
+  float *dqh = redw + 64 + 2 * 64;                    // [2][U]
+  float *blk = scr;
+  float *dqs = scr;
+  float *chs = dqs + R * (U + 4);
+  float *qred = chs + 64;
+  float *ored = scr + (size_t)NW * R * HK;            // D3 output tiles [NW][NC][4] (behind the staging)
+
+  const int ci = slot / S, cs = slot % S, cbg = unit * R + ci, f0 = cs * FS;
+  for (int i = tid; i < FS * U; i += NT) {
+    const int f = f0 + i / U;
+    keys_s[i] = f < Te ? p.keys[((size_t)cbg * Te + f) * U + i % U] : 0.f;
+  }
+  for (int i = tid; i < FS * E; i += NT) {
+    const int f = f0 + i / E;
+    vals_s[i] = f < Te ? p.values[((size_t)cbg * Te + f) * E + i % E] : 0.f;
+  }
+  for (int i = tid; i < UW * U; i += NT) wqr_s[(i / U) * (U + 4) + i % U] = p.wq[(size_t)(UW * slot + i / U) * U + i % U];
+  for (int i = tid; i < U; i += NT) v_s[i] = p.v[i];
+
+  // D3 weights: lane (cg, ks, j) of set st, instruction kq of my wave: kxhT[k = w*KBW + KS*kq + ks][NC*slot + 4*CGS*st + 4*cg + j]
+  const int mcg = lane / (4 * KS), mks = (lane >> 2) % KS, mj = lane & 3;
+  const int NKQ = KBW / KS;                       // instructions per set and wave (<= NKQC, even)
+  float Wr[KR];
+#pragma unroll
+  for (int r = 0; r < KR; ++r) {
+    const int st = r / NKQC, kq = r % NKQC;
+    const int k = w * KBW + KS * kq + mks, col = 4 * CGS * st + 4 * mcg + mj;
+    Wr[r] = (st < NSET && kq < NKQ && col < NC) ? p.kxhT[(size_t)k * (E + U) + NC * slot + col] : 0.f;
+  }
+
+  // D2 identities: gate thread (row, col = 4*unit + gate)
+  const int grow = tid >> 6, gcol = tid & 63, gu = gcol >> 2, gg = gcol & 3;
+  const bool gate_thr = gcol < 4 * UW;
+  const int gb = unit * R + grow, gunit = UW * slot + gu;
+  const int glen = p.dec_len[gb];
+  float dc_state = 0.f;
+  // D1 identities: thread = (4 units uq, frame half fh)
+  const int U4 = U / 4;
+  const int uq = tid % U4, fh = tid / U4;            // U4 <= NT; threads with fh >= NFH idle
+  const int NFH = NT / U4 > 0 ? (NT / U4 < FS ? NT / U4 : FS) : 1;
+  const int FPH = (FS + NFH - 1) / NFH;              // frames per thread
+  const int clen = p.dec_len[cbg], cn = min(max(p.enc_len[cbg], 0), Te);
+  f32x4 dk[DKR];                                      // d keys of my frames, my 4 units
+#pragma unroll
+  for (int i = 0; i < DKR; ++i) dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 dvacc = {0.f, 0.f, 0.f, 0.f};
+  float dq_last = 0.f, dz_last = 0.f;
+  f32x4 dcx_last = {0.f, 0.f, 0.f, 0.f};
+  auto save_step = [&](int ts) {
+    if (tid < UB) p.dq[((size_t)ts * B + cbg) * U + cs * UB + tid] = dq_last;
+    if (gate_thr) p.dz[((size_t)ts * B + gb) * 4 * U + gg * U + gunit] = dz_last;
+    if (cs == 0 && tid < E / 4) *reinterpret_cast<f32x4 *>(p.dCtx + ((size_t)ts * B + cbg) * E + 4 * tid) = dcx_last;
+  };
+  __syncthreads();
+
+  for (int n = 0; n < L; ++n) {
+    const int t = L - 1 - n;
+    const unsigned so = (unsigned)(n % RING), sp = (unsigned)((n + RING - 1) % RING), sr = (unsigned)((n + RING - 2) % RING);
+    const bool frozen = t >= clen;
+    // =========================== D1: attention backward ===========================
+    {
+      // d context of (step t, my utterance) and its product with the context (softmax backward's sum)
+      f32x4 dc4 = {0.f, 0.f, 0.f, 0.f}, cx4 = {0.f, 0.f, 0.f, 0.f};
+      if (tid < E / 4) {
+        dc4 = *reinterpret_cast<const f32x4 *>(p.dCtx + ((size_t)t * B + cbg) * E + 4 * tid);
+        cx4 = *reinterpret_cast<const f32x4 *>(p.ctx + ((size_t)(t + 1) * B + cbg) * E + 4 * tid);
+      }
+      if (n > 0) {
+        const unsigned off = tid < E / 4 ? sp * kb + (unsigned)((ci * (E + U) + 4 * tid) * 4) : OOB;
+        u32x4 v;
+        SpinB g;
+        g.start();
+        for (;;) {
+          v = xld4(rk, off);
+          if (__all(off == OOB || !has_sentinel(v))) break;
+          if (g.expired(p)) { SPB_TIMEOUT(); break; }
+        }
+        if (tid < E / 4) dc4 += __builtin_bit_cast(f32x4, v);
+      }
+      if (n > 0) save_step(t + 1);
+      dcx_last = dc4;
+      if (tid < E / 4) *reinterpret_cast<f32x4 *>(dcx + 4 * tid) = dc4;
+      float rp = dc4.x * cx4.x + dc4.y * cx4.y + dc4.z * cx4.z + dc4.w * cx4.w;
+      rp = wsum(rp);
+      if (lane == 0) redw[w] = rp;
+    }
+    __syncthreads();
+    if (flag[0]) return;
+    {
+      const float r = (redw[0] + redw[1]) + (redw[2] + redw[3]);
+      // d alignment of my frames: wave w takes frames w, w + NW, ...
+      for (int f = w; f < FS; f += NW) {
+        f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+        for (int e4 = lane; e4 < E / 4; e4 += 64)
+          a4 += *reinterpret_cast<const f32x4 *>(dcx + 4 * e4) * *reinterpret_cast<const f32x4 *>(vals_s + (size_t)f * E + 4 * e4);
+        const float da = wsum((a4.x + a4.y) + (a4.z + a4.w));
+        if (lane == 0) {
+          const float a = (f0 + f < cn && !frozen) ? p.align[((size_t)(t + 1) * B + cbg) * Te + f0 + f] : 0.f;
+          redw[64 + f] = a * (da - r);          // d score
+        }
+      }
+    }
+    __syncthreads();
+    {
+      // through v . tanh(keys + q): my 4 units, my half of the frames
+      f32x4 dq4 = {0.f, 0.f, 0.f, 0.f};
+      if (fh < NFH) {
+        const f32x4 qq = *reinterpret_cast<const f32x4 *>(p.q + ((size_t)t * B + cbg) * U + 4 * uq);
+        const f32x4 vv = *reinterpret_cast<const f32x4 *>(v_s + 4 * uq);
+#pragma unroll
+        for (int i = 0; i < DKR; ++i) {
+          const int f = fh * FPH + i;
+          if (i < FPH && f < FS) {
+            const float g = redw[64 + f];
+            const f32x4 kk = *reinterpret_cast<const f32x4 *>(keys_s + (size_t)f * U + 4 * uq);
+            f32x4 th, dd;
+            th.x = ftanh(kk.x + qq.x); th.y = ftanh(kk.y + qq.y); th.z = ftanh(kk.z + qq.z); th.w = ftanh(kk.w + qq.w);
+            dd.x = g * vv.x * (1.f - th.x * th.x); dd.y = g * vv.y * (1.f - th.y * th.y);
+            dd.z = g * vv.z * (1.f - th.z * th.z); dd.w = g * vv.w * (1.f - th.w * th.w);
+            dq4 += dd;
+            dk[i] += dd;
+            dvacc += g * th;
+          }
+        }
+        *reinterpret_cast<f32x4 *>(dqh + (size_t)fh * U + 4 * uq) = dq4;
+      }
+    }
+    __syncthreads();
+    if (tid < U4) {
+      f32x4 s4 = *reinterpret_cast<const f32x4 *>(dqh + 4 * tid);
+      for (int h = 1; h < NFH; ++h) s4 += *reinterpret_cast<const f32x4 *>(dqh + (size_t)h * U + 4 * tid);
+      xst4(__builtin_bit_cast(u32x4, s4), ra, so * ab + (unsigned)(((ci * S + cs) * U + 4 * tid) * 4), coloc);
+      xst4(sent4, ra, n >= 2 ? sr * ab + (unsigned)(((ci * S + cs) * U + 4 * tid) * 4) : OOB, coloc);
+    }
+    // =========================== D1b: my block of dq ===========================
+    {
+      const int PC = UB / 4, NPC = S * PC;            // <= NT (host check)
+      const int qi = min(tid, NPC - 1), ii = qi / PC, c4 = qi % PC;
+      const unsigned off = so * ab + (unsigned)(((ci * S + ii) * U + cs * UB + 4 * c4) * 4);
+      u32x4 v;
+      SpinB g;
+      g.start();
+      for (;;) {
+        v = xld4(ra, off);
+        if (__all(!has_sentinel(v))) break;
+        if (g.expired(p)) { SPB_TIMEOUT(); break; }
+      }
+      __syncthreads();        // dqh has been read by everybody: blk may overwrite the scratch
+      if (tid < NPC) *reinterpret_cast<f32x4 *>(blk + ii * UB + 4 * c4) = __builtin_bit_cast(f32x4, v);
+    }
+    __syncthreads();
+    if (flag[0]) return;
+    {
+      float s = 0.f;
+      if (tid < UB)
+        for (int i = 0; i < S; ++i) s += blk[i * UB + tid];
+      dq_last = s;
+      xst1(fbits(s), rq, tid < UB ? so * qb + (unsigned)((ci * U + cs * UB + tid) * 4) : OOB, coloc);
+      xst1(SENT, rq, (tid < UB && n >= 2) ? sr * qb + (unsigned)((ci * U + cs * UB + tid) * 4) : OOB, coloc);
+    }
+    __syncthreads();          // blk read: the scratch is free for dq / carry
+    // =========================== D2: dq . Wq^T, cell backward ===================
+    {
+      const int NPC = R * U / 4;                       // <= 2 * NT
+      const int q0 = min(tid, NPC - 1), q1 = min(NT + tid, NPC - 1);
+      // my units' carry of d h: [row][E + UW*slot .. + UW): UW/4 pieces per row (UW % 4 == 0) or single words
+      const int CP = (UW + 3) / 4;
+      const bool cthr = tid < R * CP && n > 0;
+      const int crow = tid / CP, cpc = tid % CP;
+      const unsigned coff = cthr ? sp * kb + (unsigned)((crow * (E + U) + E + UW * slot + 4 * cpc) * 4) : OOB;
+      u32x4 v0, v1, vc;
+      SpinB g;
+      g.start();
+      for (;;) {
+        v0 = xld4(rq, so * qb + (unsigned)(q0 * 16));
+        v1 = xld4(rq, so * qb + (unsigned)(q1 * 16));
+        vc = xld4(rk, coff);
+        bool ok = !has_sentinel(v0) && !has_sentinel(v1);
+        if (cthr) {      // only the words of my units count (UW may not fill the last piece)
+          const int nw = min(4, UW - 4 * cpc);
+          ok = ok && vc.x != SENT && (nw < 2 || vc.y != SENT) && (nw < 3 || vc.z != SENT) && (nw < 4 || vc.w != SENT);
+        }
+        if (__all(ok)) break;
+        if (g.expired(p)) { SPB_TIMEOUT(); break; }
+      }
+      if (tid < NPC) *reinterpret_cast<f32x4 *>(dqs + (4 * q0 / U) * (U + 4) + 4 * q0 % U) = __builtin_bit_cast(f32x4, v0);
+      if (NT + tid < NPC) *reinterpret_cast<f32x4 *>(dqs + (4 * q1 / U) * (U + 4) + 4 * q1 % U) = __builtin_bit_cast(f32x4, v1);
+      if (tid < R * CP) {
+        const f32x4 fc = cthr ? __builtin_bit_cast(f32x4, vc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        float *d = chs + crow * 16 + 4 * cpc;
+        d[0] = fc.x; d[1] = fc.y; d[2] = fc.z; d[3] = fc.w;
+      }
+    }
+    __syncthreads();
+    if (flag[0]) return;
+    {
+      // dhq[4 rows][my UW units] = dq . Wq^T on the matrix pipe: blocks (unit group cg, k phase ks) as in the forward duty B
+      const int bcg = lane >> 4, bks = (lane >> 2) & 3, bj = lane & 3;
+      f32x4 qa = {0.f, 0.f, 0.f, 0.f}, qbb = {0.f, 0.f, 0.f, 0.f};
+      {
+        const float *ha = dqs + bj * (U + 4) + w * (U / 4) + bks;
+        const bool colok = 4 * bcg + bj < UW;
+        const float *wb = wqr_s + (size_t)min(4 * bcg + bj, UW - 1) * (U + 4) + w * (U / 4) + bks;
+#pragma unroll 8
+        for (int kk = 0; kk < U / 16; kk += 2) {
+          const float a0 = ha[4 * kk], a1 = ha[4 * kk + 4];
+          const float b0 = colok ? wb[4 * kk] : 0.f, b1 = colok ? wb[4 * kk + 4] : 0.f;
+          qa = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b0, qa, 0, 0, 0);
+          qbb = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b1, qbb, 0, 0, 0);
+        }
+      }
+      f32x4 q4 = qa + qbb;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        q4[i] += __shfl_xor(q4[i], 4);
+        q4[i] += __shfl_xor(q4[i], 8);
+      }
+      if (bks == 0) *reinterpret_cast<f32x4 *>(qred + ((size_t)w * 16 + 4 * bcg + bj) * 4) = q4;   // [wave][unit][row]
+    }
+    __syncthreads();
+    {
+      float dzv = 0.f;
+      if (gate_thr) {
+        const float dhq = (qred[(0 * 16 + gu) * 4 + grow] + qred[(1 * 16 + gu) * 4 + grow]) +
+                          (qred[(2 * 16 + gu) * 4 + grow] + qred[(3 * 16 + gu) * 4 + grow]);
+        const size_t sidx = ((size_t)t * B + gb) * U + gunit;
+        const float a = p.acts[((size_t)t * B + gb) * 4 * U + gg * U + gunit];
+        const float gi = quad_bcast(a, 0), gj = quad_bcast(a, 1), gf = quad_bcast(a, 2), go = quad_bcast(a, 3);
+        if (t < glen) {
+          const float dh = p.dH[sidx] + dhq + chs[grow * 16 + gu];
+          const float cnew = p.Cs[sidx + (size_t)B * U], cprev = p.Cs[sidx];
+          const float tc = ftanh(cnew);
+          const float dct = dc_state + dh * go * (1.f - tc * tc);
+          dzv = gg == 0 ? dct * gj * gi * (1.f - gi)
+              : gg == 1 ? dct * gi * (1.f - gj * gj)
+              : gg == 2 ? dct * cprev * gf * (1.f - gf)
+                        : dh * tc * go * (1.f - go);
+          dc_state = dct * gf;
+        }
+      }
+      dz_last = dzv;
+      xst1(fbits(dzv), rz, gate_thr ? so * zb + (unsigned)((grow * 4 * U + gg * U + gunit) * 4) : OOB, coloc);
+      xst1(SENT, rz, (gate_thr && n >= 2) ? sr * zb + (unsigned)((grow * 4 * U + gg * U + gunit) * 4) : OOB, coloc);
+    }
+    __syncthreads();          // dqs / qred read: the scratch is free for the staged dz
+    // =========================== D3: dz . [Kx^T | Kh^T] ==========================
+    f32x4 acc[NSETC];
+#pragma unroll
+    for (int st = 0; st < NSETC; ++st) acc[st] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (t > 0) {      // (the carry of step 0 has no consumer)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        // gather dz[4 rows][my k range, this half]: R * HK / 4 pieces, NQ per lane
+        constexpr int NQ = (R * KS * NKQC / 2 / 4 + 63) / 64;      // pieces per lane: R * HK / 4 <= 64 * NQ
+        const int PR = HK / 4, NPC = R * PR;
+        u32x4 v[NQ];
+        unsigned off[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+          const int qi = min(64 * i + lane, NPC - 1);
+          off[i] = so * zb + (unsigned)(((qi / PR) * KB + w * KBW + half * HK + 4 * (qi % PR)) * 4);
+        }
+        SpinB g;
+        g.start();
+        for (;;) {
+          bool ok = true;
+#pragma unroll
+          for (int i = 0; i < NQ; ++i) {
+            v[i] = xld4(rz, off[i]);
+            ok = ok && !has_sentinel(v[i]);
+          }
+          if (__all(ok)) break;
+          if (g.expired(p)) { SPB_TIMEOUT(); break; }
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+          const int qi = 64 * i + lane;
+          if (qi < NPC) *reinterpret_cast<f32x4 *>(Zs + (qi / PR) * HK + 4 * (qi % PR)) = __builtin_bit_cast(f32x4, v[i]);
+        }
+        // products of this half: instruction kq covers k = KS*kq + ks; my A operand: dz[row j][k]
+        const float *za = Zs + mj * HK + mks;
+        const int kq0 = half * (NKQ / 2);
+        if (NKQ == NKQC) {          // full-size shape: straight line
+#pragma unroll
+          for (int kk = 0; kk < NKQC / 2; ++kk) {
+            const float a = za[KS * kk];
+#pragma unroll
+            for (int st = 0; st < NSETC; ++st)
+              acc[st] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, Wr[st * NKQC + half * (NKQC / 2) + kk], acc[st], 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int kq = 0; kq < NKQC; ++kq)
+            if (kq >= kq0 && kq < kq0 + NKQ / 2) {
+              const float a = za[KS * (kq - kq0)];
+#pragma unroll
+              for (int st = 0; st < NSETC; ++st) acc[st] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, Wr[st * NKQC + kq], acc[st], 0, 0, 0);
+            }
+        }
+      }
+      // add the k phases (lanes that differ in ks), then the waves
+#pragma unroll
+      for (int st = 0; st < NSETC; ++st)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int m = 4; m < 4 * KS; m <<= 1) acc[st][i] += __shfl_xor(acc[st][i], m);
+      if (mks == 0) {
+#pragma unroll
+        for (int st = 0; st < NSETC; ++st) {
+          const int col = 4 * CGS * st + 4 * mcg + mj;
+          if (st < NSET && col < NC) *reinterpret_cast<f32x4 *>(ored + ((size_t)w * NC + col) * 4) = acc[st];
+        }
+      }
+    }
+    __syncthreads();
+    if (flag[0]) return;
+    if (t > 0) {
+      // thread (row, column) adds the four waves and publishes the carry
+      const int col = tid % NC, row = tid / NC;
+      float s = 0.f;
+      const bool pub = tid < R * NC;
+      if (pub) s = (ored[((size_t)0 * NC + col) * 4 + row] + ored[((size_t)1 * NC + col) * 4 + row]) +
+                   (ored[((size_t)2 * NC + col) * 4 + row] + ored[((size_t)3 * NC + col) * 4 + row]);
+      xst1(fbits(s), rk, pub ? so * kb + (unsigned)((row * (E + U) + NC * slot + col) * 4) : OOB, coloc);
+      xst1(SENT, rk, (pub && n >= 2) ? sr * kb + (unsigned)((row * (E + U) + NC * slot + col) * 4) : OOB, coloc);
+    }
+    __syncthreads();
+  }
+  save_step(0);
+  // d keys of my frames, d v partial row of (utterance, slice)
+  if (fh < NFH) {
+#pragma unroll
+    for (int i = 0; i < DKR; ++i) {
+      const int f = f0 + fh * FPH + i;
+      if (i < FPH && fh * FPH + i < FS && f < Te) *reinterpret_cast<f32x4 *>(p.dkeys + ((size_t)cbg * Te + f) * U + 4 * uq) = dk[i];
+    }
+    *reinterpret_cast<f32x4 *>(dqh + (size_t)fh * U + 4 * uq) = dvacc;
+  }
+  __syncthreads();
+  if (tid < U4) {
+    f32x4 s4 = *reinterpret_cast<const f32x4 *>(dqh + 4 * tid);
+    for (int h = 1; h < NFH; ++h) s4 += *reinterpret_cast<const f32x4 *>(dqh + (size_t)h * U + 4 * tid);
+    *reinterpret_cast<f32x4 *>(p.dv_part + ((size_t)cbg * S + cs) * U + 4 * tid) = s4;
+  }
+}
+
 int kr_for(int KW) { return KW <= 64 ? 64 : KW <= 192 ? 192 : 384; }
 size_t lds_floats(const SpPersistDesc &d, int FS) {
   const size_t K = d.E + d.U, UW = d.U / P;
@@ -594,6 +1065,86 @@ static bool shape_ok(const SpPersistDesc &d) {
   if (FS > 64 || FS < 1) return false;
   if (d.U / P > 16 || d.U % 32) return false;          // duty B: 16 columns per workgroup at most
   return lds_floats(d, FS) * 4 <= 160 * 1024 - 512;
+}
+
+// ---- backward
+static bool bwd_ks4(const SpPersistDesc &d) { return ((d.E + d.U) / P) % 16 == 0; }
+static int bwd_frames_per_thread(const SpPersistDesc &d) {
+  const int FS = frames_per_slice(d), U4 = d.U / 4;
+  int nfh = NT / U4;
+  if (nfh > FS) nfh = FS;
+  if (nfh < 1) nfh = 1;
+  return (FS + nfh - 1) / nfh;
+}
+static size_t bwd_lds_floats(const SpPersistDesc &d) {
+  const int FS = frames_per_slice(d), UW = d.U / P, NC = (d.E + d.U) / P, KBW = 4 * d.U / NW;
+  int nfh = NT / (d.U / 4);
+  if (nfh > FS) nfh = FS;
+  if (nfh < 1) nfh = 1;
+  size_t scr = (size_t)NW * R * (KBW / 2) + (size_t)NW * NC * 4;
+  const size_t d1 = (size_t)d.E + 192 + (size_t)nfh * d.U, d1b = d.U, d2 = (size_t)R * (d.U + 4) + 64 + NW * 64;
+  if (scr < d1) scr = d1;
+  if (scr < d1b) scr = d1b;
+  if (scr < d2) scr = d2;
+  return (size_t)FS * d.U + (size_t)FS * d.E + (size_t)UW * (d.U + 4) + d.U + scr + 64;
+}
+static bool bwd_shape_ok(const SpPersistDesc &d) {
+  if (!shape_ok(d)) return false;
+  const int NC = (d.E + d.U) / P, KBW = 4 * d.U / NW;
+  if ((d.E + d.U) % P || NC % 4 || R * NC > NT) return false;
+  if (bwd_ks4(d)) {
+    if (NC / 16 > 3 || KBW / 4 > 128 || (KBW / 4) % 2) return false;
+  } else {
+    if (NC / 4 > 3 || KBW % 32 || KBW / 16 > 8) return false;
+  }
+  if (d.E / 4 > NT || d.U / 4 > NT || (d.U / S) % 4) return false;
+  if (bwd_frames_per_thread(d) > 8) return false;
+  return bwd_lds_floats(d) * 4 <= 160 * 1024 - 512;
+}
+static size_t bwd_ring_bytes(const SpPersistDesc &d) {
+  const size_t kb = (size_t)R * (d.E + d.U) * 4, ab = (size_t)R * S * d.U * 4, qb = (size_t)R * d.U * 4, zb = (size_t)R * 4 * d.U * 4;
+  return (size_t)NU * RING * (kb + ab + qb + zb);
+}
+bool speller_persist_bwd_ok(const SpPersistDesc &d) {
+  const char *env = getenv("NABU_SPELLER_PERSIST_BWD");
+  if (env && !atoi(env)) return false;
+  return bwd_shape_ok(d);
+}
+size_t speller_persist_bwd_ws_bytes(const SpPersistDesc &d) { return bwd_shape_ok(d) ? TABLE_BYTES + bwd_ring_bytes(d) : 0; }
+
+int speller_persist_bwd(const SpPersistDesc &d, const int32_t *dec_len, const int32_t *enc_len, const float *kxhT,
+                        const float *wq, const float *v, const float *keys, const float *values, const float *acts,
+                        const float *Cs, const float *q, const float *ctx, const float *align, const float *dH, float *dCtx,
+                        float *dq, float *dz, float *dkeys, float *dv_part, int *status, void *ws, size_t ws_bytes,
+                        hipStream_t stream) {
+  if (!speller_persist_bwd_ok(d)) return fail(NABU_EUNSUP, "persistent decoder (backward): unsupported shape");
+  if (ws_bytes < speller_persist_bwd_ws_bytes(d)) return fail(NABU_EWS, "persistent decoder (backward): workspace too small");
+  BArgs a;
+  a.L = d.L; a.U = d.U; a.E = d.E; a.Te = d.Te; a.FS = frames_per_slice(d);
+  a.dec_len = dec_len; a.enc_len = enc_len; a.kxhT = kxhT; a.wq = wq; a.v = v; a.keys = keys; a.values = values;
+  a.acts = acts; a.Cs = Cs; a.q = q; a.ctx = ctx; a.align = align; a.dH = dH; a.dCtx = dCtx; a.dq = dq; a.dz = dz;
+  a.dkeys = dkeys; a.dv_part = dv_part;
+  a.table = static_cast<unsigned *>(ws);
+  a.xbuf = static_cast<char *>(ws) + TABLE_BYTES;
+  a.status = status;
+  a.timeout_ticks = lstm_persist_timeout_ticks();
+  const char *e = getenv("NABU_PERSIST_DEBUG");
+  a.dbg = e ? atoi(e) : 0;
+  NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + bwd_ring_bytes(d), stream));
+  const size_t lds = bwd_lds_floats(d) * 4;
+  auto kern = bwd_ks4(d) ? speller_persist_bwd_kernel<3, 128, 4, 8> : speller_persist_bwd_kernel<3, 8, 16, 8>;
+  static thread_local const void *configured[2] = {nullptr, nullptr};
+  const void *fn = reinterpret_cast<const void *>(kern);
+  bool done = false;
+  for (auto c : configured) done = done || c == fn;
+  if (!done) {
+    NABU_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+    for (auto &c : configured)
+      if (!c) { c = fn; break; }
+  }
+  hipLaunchKernelGGL(kern, dim3(NU * P), dim3(NT), lds, stream, a);
+  NABU_LAUNCH_CHECK();
+  return 0;
 }
 
 bool speller_persist_ok(const SpPersistDesc &d) {
