@@ -133,6 +133,32 @@ def test_persistent_decoder_forward(U, E, Te):
     hip.check_persist_status()
 
 
+def test_persistent_decoder_status_word_is_sticky_and_reported():
+    """the persistent decoder kernels' hang safety (include/nabu_hip.h, nabu_speller_fwd): ws[0] of the Speller
+    workspace is their status word.  A non-zero word (what a timed-out launch leaves) makes the next launches return
+    at once and ops.check_persist_status() raise; the check clears it and the following step is right again."""
+    from nabu_amd import _hip, ops as hip
+    rng = np.random.default_rng(11)
+    enc_len = rng.integers(20, 41, 32).astype(np.int32)
+    enc_len[0] = 40
+    tlen = rng.integers(1, 6, 32).astype(np.int32)
+    tlen[1] = 5
+    ref = check_speller('vanilla', 1, 64, 0, 0, enc_len, tlen, E=64)
+    hip.check_persist_status()
+    buf = [v for (d, t), v in _hip.Workspace._bufs.items() if t == 'speller'][0]
+    buf[:4].view(torch.int32).fill_(4 * 7 + 1)          # "block 7 gave up in the forward pass"
+    try:
+        check_speller('vanilla', 1, 64, 0, 0, enc_len, tlen, E=64)
+        wrong = False
+    except AssertionError:
+        wrong = True                                     # the launches returned at once: no results
+    assert wrong
+    with pytest.raises(_hip.NabuHipError, match='decoder kernel timed out'):
+        hip.check_persist_status()
+    hip.check_persist_status()                           # cleared
+    np.testing.assert_array_equal(check_speller('vanilla', 1, 64, 0, 0, enc_len, tlen, E=64), ref)
+
+
 def check_speller(attention, nl, U, K, F, enc_len, tlen, E=24):
     from nabu_amd import variables as vs
     from nabu_amd.autodiff import Tape, SeqLen
