@@ -24,9 +24,10 @@
 // without timing: when a workgroup publishes into ring X at step t it has gathered (in this or the previous duty)
 // pieces that EVERY reader of its X_{t-2} piece published after reading it; and a reader polls slot t+2 of X only
 // after gathering something the producer published after its reset AND after a later poll loop of its own (loads
-// issued behind the reset store have returned: vector-memory operations complete in issue order).  Placement:
-// block b -> unit b % 8; the XCC ids are compared at start-up; a unit that is not on one XCD publishes
-// write-through (correct, slower).  Every spin is bounded (time-out -> status word -> everybody leaves).
+// issued behind the reset store have returned: vector-memory operations complete in issue order).  Placement: the
+// units are formed at run time — a workgroup reads its XCC id and takes the next free slot of that XCD's unit (one
+// fetch-add); one workgroup fills a CU, so every XCD ends up with exactly 32 whatever the dispatch order.
+// Every spin is bounded (time-out -> status word -> everybody leaves).
 #include "speller_persist.h"
 
 #include <stdlib.h>
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int flag[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int unit = blockIdx.x % NU, slot = blockIdx.x / NU;
+  int unit, slot;     // decided at start-up: unit = the XCD this workgroup runs on, slot = its arrival rank there
   const int U = p.U, E = p.E, Te = p.Te, FS = p.FS, L = p.L;
   const int K = E + U, KW = K / NW;          // k range of a wave
   const int CW = 4 * U / P, UW = U / P;      // my gate columns / my units (= my q columns)
@@ -154,36 +155,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   const int B = NU * R;
 
   // ---- start-up: XCC ids of the unit (lstm_persist.hip: unit_handshake)
+  // Which XCD a block lands on is the dispatcher's business (observed: b % 8 in one launch, pairs of consecutive
+  // blocks per XCD in another).  So the units are formed at run time: a workgroup joins the unit of the XCD it runs on
+  // and takes the next free slot there (one agent-scope fetch-add).  One workgroup fits a CU (one wave per SIMD, most
+  // of the register file), an XCD has 32 CUs and all 256 workgroups are resident: every XCD ends up with exactly 32.
   const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));
   if (tid == 0) {
     flag[0] = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    flag[1] = 0;
-    __hip_atomic_store(p.table + unit + NU * slot, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (flag[0]) return;          // an earlier launch on this workspace timed out
-  if (tid < 64) {
-    Spin g;
-    g.start();
-    unsigned vx = xcc;
-    bool failed = false;
-    for (;;) {
-      if (tid < P) vx = __hip_atomic_load(p.table + unit + NU * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__all(vx != SENT)) break;
-      if (g.expired(p)) { failed = true; break; }
-    }
-    const bool same = __all(vx == xcc) && !(p.dbg & 8);
-    if (tid == 0) {
-      if (failed) {
-        flag[0] = 1;
-        __hip_atomic_store(p.status, 3 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      flag[1] = same ? 1 : 0;
+    // counters start at 0xFFFFFFFF (the workspace prefill): the first arrival reads that and takes slot 0
+    const unsigned old = __hip_atomic_fetch_add(p.table + 512 + (xcc & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flag[1] = (int)(old + 1u);
+    if (old + 1u >= (unsigned)P || xcc >= (unsigned)NU) {       // cannot happen on a whole MI355X: give up loudly
+      flag[0] = 1;
+      __hip_atomic_store(p.status, 3 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   __syncthreads();
-  if (flag[0]) return;
-  const bool coloc = flag[1] != 0;
+  if (flag[0]) return;          // an earlier launch on this workspace timed out / no slot
+  unit = (int)xcc;
+  slot = flag[1];
+  __syncthreads();
+  const bool coloc = !(p.dbg & 8);      // the unit shares one L2 by construction (bit 3: force write-through)
 
   // ---- exchange rings of my unit: h [R][U], q [R][U], ctx [R][E], partials [R*S][E+4]
   const unsigned hb = (unsigned)(R * U * 4), cb = (unsigned)(R * E * 4), pb = (unsigned)(R * S * (E + 4) * 4);
@@ -624,7 +616,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int flag[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int unit = blockIdx.x % NU, slot = blockIdx.x / NU;
+  int unit, slot;     // decided at start-up: unit = the XCD this workgroup runs on, slot = its arrival rank there
   const int U = p.U, E = p.E, Te = p.Te, FS = p.FS, L = p.L;
   const int KB = 4 * U, KBW = KB / NW;          // reduction index of D3 (gate columns), range of a wave
   const int NC = (E + U) / P;                  // my output columns of D3
@@ -634,36 +626,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   constexpr int KR = NSETC * NKQC;
   const int NSET = NC / (4 * CGS);             // <= NSETC
 
+  // Which XCD a block lands on is the dispatcher's business (observed: b % 8 in one launch, pairs of consecutive
+  // blocks per XCD in another).  So the units are formed at run time: a workgroup joins the unit of the XCD it runs on
+  // and takes the next free slot there (one agent-scope fetch-add).  One workgroup fits a CU (one wave per SIMD, most
+  // of the register file), an XCD has 32 CUs and all 256 workgroups are resident: every XCD ends up with exactly 32.
   const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));
   if (tid == 0) {
     flag[0] = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    flag[1] = 0;
-    __hip_atomic_store(p.table + unit + NU * slot, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (flag[0]) return;
-  if (tid < 64) {
-    SpinB g;
-    g.start();
-    unsigned vx = xcc;
-    bool failed = false;
-    for (;;) {
-      if (tid < P) vx = __hip_atomic_load(p.table + unit + NU * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__all(vx != SENT)) break;
-      if (g.expired(p)) { failed = true; break; }
-    }
-    const bool same = __all(vx == xcc) && !(p.dbg & 8);
-    if (tid == 0) {
-      if (failed) {
-        flag[0] = 1;
-        __hip_atomic_store(p.status, 3 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      flag[1] = same ? 1 : 0;
+    // counters start at 0xFFFFFFFF (the workspace prefill): the first arrival reads that and takes slot 0
+    const unsigned old = __hip_atomic_fetch_add(p.table + 512 + (xcc & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flag[1] = (int)(old + 1u);
+    if (old + 1u >= (unsigned)P || xcc >= (unsigned)NU) {       // cannot happen on a whole MI355X: give up loudly
+      flag[0] = 1;
+      __hip_atomic_store(p.status, 3 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   __syncthreads();
-  if (flag[0]) return;
-  const bool coloc = flag[1] != 0;
+  if (flag[0]) return;          // an earlier launch on this workspace timed out / no slot
+  unit = (int)xcc;
+  slot = flag[1];
+  __syncthreads();
+  const bool coloc = !(p.dbg & 8);      // the unit shares one L2 by construction (bit 3: force write-through)
 
   // rings: carry [R][E+U], dq partials [R*S][U], dq [R][U], dz [R][4U]
   const unsigned kb = (unsigned)(R * (E + U) * 4), ab = (unsigned)(R * S * U * 4), qb = (unsigned)(R * U * 4), zb = (unsigned)(R * 4 * U * 4);
