@@ -261,8 +261,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if (tid < FS && f0 + tid < Te) p.align[((size_t)(ts + 1) * B + cbg) * Te + f0 + tid] = al_prev;
   };
   const int clen = p.dec_len[cbg], cn = min(max(p.enc_len[cbg], 0), Te);
-  const float vreg_dummy = 0.f;
-  (void)vreg_dummy;
   __syncthreads();
 
   for (int t = 0; t < L; ++t) {
@@ -391,7 +389,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const float *ha = hs + bj * (U + 4) + w * (U / 4) + bks;
         const float *wb = wq_s + (size_t)(w * (U / 4) + bks) * UW + min(4 * bcg + bj, UW - 1);
         const bool colok = 4 * bcg + bj < UW;
-#pragma unroll 8
         for (int kk = 0; kk < U / 16; kk += 2) {
           const float a0 = ha[4 * kk], a1 = ha[4 * kk + 4];
           const float b0 = colok ? wb[(size_t)4 * kk * UW] : 0.f, b1 = colok ? wb[(size_t)(4 * kk + 4) * UW] : 0.f;
@@ -476,7 +473,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       for (int c4 = tid; c4 < E / 4; c4 += NT) {
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
         if (!frozen) {
-#pragma unroll 4
           for (int f = 0; f < FS; ++f) a += es_w[f] * *reinterpret_cast<const f32x4 *>(vals_s + (size_t)f * E + 4 * c4);
         }
         xst4(__builtin_bit_cast(u32x4, a), rp, so * pb + (unsigned)(((ci * S + cs) * (E + 4) + 4 * c4) * 4), coloc);
@@ -873,7 +869,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const float *ha = dqs + bj * (U + 4) + w * (U / 4) + bks;
         const bool colok = 4 * bcg + bj < UW;
         const float *wb = wqr_s + (size_t)min(4 * bcg + bj, UW - 1) * (U + 4) + w * (U / 4) + bks;
-#pragma unroll 8
         for (int kk = 0; kk < U / 16; kk += 2) {
           const float a0 = ha[4 * kk], a1 = ha[4 * kk + 4];
           const float b0 = colok ? wb[4 * kk] : 0.f, b1 = colok ? wb[4 * kk + 4] : 0.f;
