@@ -1440,7 +1440,6 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
   const int B = d->B, L = d->L, U = d->U, E = d->E, Te = d->Te, C = d->C, nl = d->num_layers;
   float *gw = w + W.gemm;
   const size_t gwb = W.gemm_bytes;
-  const nabu_attn_desc ad = {sizeof(nabu_attn_desc), B, Te, E, U, d->kind, d->K, d->F, d->prob_fn};
   const bool drop = d->keep_prob < 1.f;
   NABU_HIP(hipMemsetAsync(w + W.tickets, 0, ((size_t)W.NS * 1024 + B + 4) * 4, s));
   // zero initial state (index 0 of every time-major array)
@@ -1584,7 +1583,6 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   const int B = d->B, L = d->L, U = d->U, E = d->E, Te = d->Te, C = d->C, nl = d->num_layers, F = d->F, K = d->K;
   float *gw = w + W.gemm;
   const size_t gwb = W.gemm_bytes;
-  const nabu_attn_desc ad = {sizeof(nabu_attn_desc), B, Te, E, U, d->kind, d->K, d->F, d->prob_fn};
   const bool drop = d->keep_prob < 1.f;
   const int BL = B * L;
   float *dl = w + W.dl, *dH = w + W.dH, *dCtx = w + W.dCtx, *dkeys = w + W.dkeys, *dq = w + W.dq;
