@@ -310,8 +310,8 @@ int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *dec_len,
  * gradients that are sums over steps are single GEMMs over all steps.
  *   values [B,Te,E] encoder output (rows >= enc_len zero), ids [L,B] decoder input
  *   labels (row 0 = C-1, then the targets shifted by one), logits [B,L,C].
- * With one layer, vanilla softmax attention, no dropout / sampling and B = 32 the L steps of the forward and of
- * the backward pass are ONE persistent launch each (speller_persist.hip; NABU_SPELLER_PERSIST=0 /
+ * With one layer, softmax attention (vanilla; forward also location-aware), no dropout / sampling and B = 32 (forward:
+ * or 64) the L steps of the forward and of the backward pass are ONE persistent launch each (speller_persist.hip; NABU_SPELLER_PERSIST=0 /
  * NABU_SPELLER_PERSIST_BWD=0 keep the per-step kernels).
  * Its in-kernel waits are bounded like those of the recurrent layers: ws[0] (int32) is its status word,
  * 0 = ok, sticky — provide the workspace zero-initialised once; a non-zero word means a launch gave up

@@ -1305,7 +1305,8 @@ static SpWs sp_ws(const nabu_speller_desc *d) {
   // zero-initialised once, like the recurrent layers' workspace), then its XCC table and exchange rings
   s.status = take(64);
   {
-    const SpPersistDesc pd = {(int)B, (int)L, (int)U, (int)E, (int)Te, (int)C};
+    SpPersistDesc pd = {(int)B, (int)L, (int)U, (int)E, (int)Te, (int)C};
+    pd.kind = d->kind; pd.K = d->K; pd.F = d->F;
     s.persist_bytes = speller_persist_ws_bytes(pd);
     if (speller_persist_bwd_ws_bytes(pd) > s.persist_bytes) s.persist_bytes = speller_persist_bwd_ws_bytes(pd);
     s.persist = take(s.persist_bytes / 4 + 4);
@@ -1477,12 +1478,13 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
   }
   // the whole step loop as ONE persistent launch (speller_persist.hip) where the geometry allows:
   // one LSTM layer, vanilla softmax attention, teacher forcing, no dropout, B = 32 (cfg3)
-  const SpPersistDesc pd = {B, L, U, E, Te, C};
-  const bool persist = nl == 1 && !drop && !sampling && d->kind == 0 && d->prob_fn == 0 && cell_epi[0] &&
+  SpPersistDesc pd = {B, L, U, E, Te, C};
+  pd.kind = d->kind; pd.K = d->K; pd.F = d->F;
+  const bool persist = nl == 1 && !drop && !sampling && (d->kind == 0 || d->kind == 1) && d->prob_fn == 0 && cell_epi[0] &&
                        W.persist_bytes > 0 && speller_persist_ok(pd);
   if (persist)
     SP_TRY(speller_persist_fwd(pd, dec_len, enc_len, ids_used, w + W.kperm[0], p->lstm_bias[0], p->lstm_kernel[0],
-                               p->query_kernel, p->attention_v, r + R.keys, values, r + R.H[0], r + R.Cs[0],
+                               p->query_kernel, p->attention_v, r + R.keys, values, p->conv_kernel, p->conv_proj, r + R.H[0], r + R.Cs[0],
                                r + R.acts[0], r + R.q, r + R.ctx, r + R.align, reinterpret_cast<int *>(w + W.status),
                                w + W.persist, W.persist_bytes, s));
   unsigned *atk = env_int("NABU_SPELLER_ATTN_FUSED", 1) ? reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)NS * 1024 : nullptr;
@@ -1635,7 +1637,8 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   if (fuse_b) SP_TRY(transpose(E + U, 4 * U, p->lstm_kernel[0] + (size_t)C * 4 * U, 4 * U, w + W.kxhT, s));
   const bool split_b = fuse_b && E % 32 == 0 && env_int("NABU_SPELLER_SPLIT", 1);
   // the whole step loop as ONE persistent launch (speller_persist.hip), as in the forward pass
-  const SpPersistDesc pd = {B, L, U, E, Te, C};
+  SpPersistDesc pd = {B, L, U, E, Te, C};
+  pd.kind = d->kind; pd.K = d->K; pd.F = d->F;
   const bool persist = fuse_b && d->kind == 0 && d->prob_fn == 0 && W.persist_bytes > 0 &&
                        speller_persist_bwd_ok(pd);
   if (persist)

@@ -6,11 +6,12 @@ namespace nabu {
 
 struct SpPersistDesc {
   int B, L, U, E, Te, C;
+  int kind = 0, K = 0, F = 0;      // attention: 0 vanilla, 1 location-aware (filter taps, filters); softmax
 };
 
 // shapes the persistent forward kernel takes (single LSTM layer, vanilla softmax attention, no dropout, no
-// scheduled sampling are checked by the caller): B = 32, U and E multiples of 32, the slices of keys and
-// values of an utterance fit the LDS
+// scheduled sampling are checked by the caller): B = 32 or 64 (two launches of 32 rows), U and E multiples of 32, the
+// keys slice of a workgroup (and the location-aware filters) fit the LDS; the values slice too, or it is streamed
 bool speller_persist_ok(const SpPersistDesc &d);
 size_t speller_persist_ws_bytes(const SpPersistDesc &d);
 
@@ -20,8 +21,9 @@ size_t speller_persist_ws_bytes(const SpPersistDesc &d);
 // caller), acts [L,B,4U], q [L,B,U], ctx [(L+1),B,E], align [(L+1),B,Te].
 int speller_persist_fwd(const SpPersistDesc &d, const int32_t *dec_len, const int32_t *enc_len, const int32_t *ids,
                         const float *kperm, const float *bias, const float *emb, const float *wq, const float *v,
-                        const float *keys, const float *values, float *H, float *Cs, float *acts, float *q, float *ctx,
-                        float *align, int *status, void *ws, size_t ws_bytes, hipStream_t stream);
+                        const float *keys, const float *values, const float *conv_kernel, const float *conv_proj, float *H,
+                        float *Cs, float *acts, float *q, float *ctx, float *align, int *status, void *ws, size_t ws_bytes,
+                        hipStream_t stream);
 
 // Backward pass of the step loop (same shapes; the caller has run the output projection's gradient into dH / dCtx).
 // kxhT [4U, E+U]: transposed dense rows of the cell kernel (k = gate-major column).  Writes dq [L,B,U], dz [L,B,4U]

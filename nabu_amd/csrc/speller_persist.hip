@@ -50,6 +50,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Args {
   int L, U, E, Te, FS;               // FS = frames per slice
+  int Bt, b0;                        // rows of the whole batch (strides of the time-major tensors); my first row
+  int K, F, stream_vals;             // location-aware attention: filter taps, filters; values slice read from L2 per step
+  const float *ck, *wf;              // conv kernel [K][F], feature projection [F][U]
   const int32_t *dec_len, *enc_len, *ids;
   const float *kperm, *bias, *emb, *wq, *v, *keys, *values;
   float *H, *Cs, *acts, *q, *ctx, *align;
@@ -142,7 +145,9 @@ __device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(u
   } while (0)
 
 // KR = weight registers per lane >= (E+U)/4
-template <int KR>
+// LOC: location-aware attention (attention.py:186-292): the score also takes conv1d(previous alignments)·conv_proj;
+// the normalised alignments travel in a fifth ring
+template <int KR, bool LOC>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void speller_persist_fwd_kernel(Args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int flag[2];
@@ -152,7 +157,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   const int K = E + U, KW = K / NW;          // k range of a wave
   const int CW = 4 * U / P, UW = U / P;      // my gate columns / my units (= my q columns)
   const int CB = E / S;                      // my context columns in duty D
-  const int B = NU * R;
+  const int B = p.Bt;
+  const int Kc = LOC ? p.K : 0, Fc = LOC ? p.F : 0, pbc = (Kc - 1) / 2, TeP = S * FS;
 
   // ---- start-up: XCC ids of the unit (lstm_persist.hip: unit_handshake)
   // Which XCD a block lands on is the dispatcher's business (observed: b % 8 in one launch, pairs of consecutive
@@ -179,21 +185,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
   // ---- exchange rings of my unit: h [R][U], q [R][U], ctx [R][E], partials [R*S][E+4]
   const unsigned hb = (unsigned)(R * U * 4), cb = (unsigned)(R * E * 4), pb = (unsigned)(R * S * (E + 4) * 4);
-  const size_t unit_bytes = (size_t)RING * (2 * hb + cb + pb);
+  const unsigned lb = (unsigned)(R * TeP * 4);          // (LOC) alignments [R][S*FS]
+  const size_t unit_bytes = (size_t)RING * (2 * hb + cb + pb + (LOC ? lb : 0));
   char *ub = p.xbuf + (size_t)unit * unit_bytes;
   __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)(RING * hb), 0x00020000);
   __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(ub + (size_t)RING * hb, 0, (int)(RING * hb), 0x00020000);
   __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(ub + (size_t)RING * 2 * hb, 0, (int)(RING * cb), 0x00020000);
   __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(ub + (size_t)RING * (2 * hb + cb), 0, (int)(RING * pb), 0x00020000);
+  __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(ub + (size_t)RING * (2 * hb + cb + pb), 0, (int)(RING * lb), 0x00020000);
   const u32x4 sent4 = {SENT, SENT, SENT, SENT};
 
   // ---- LDS: keys / values slices of my (utterance, frame slice), my columns of Wq, scratch
   float *keys_s = smem;                               // [FS][U]
-  float *vals_s = keys_s + (size_t)FS * U;            // [FS][E]
-  float *wq_s = vals_s + (size_t)FS * E;              // [U][UW]
+  float *vals_s = keys_s + (size_t)FS * U;            // [FS][E] (absent when the values are streamed)
+  float *wq_s = vals_s + (p.stream_vals ? 0 : (size_t)FS * E);              // [U][UW]
   float *v_s = wq_s + (size_t)U * UW;                 // [U] attention vector
   float *es = v_s + U;                                // [FS] exp(score - local max) of my frames
-  float *scr = es + NW * 64;                          // (one copy of es per wave)  scratch, sized by the host
+  // (LOC) feature projection [F][U], conv kernel [K][F], padded previous alignments [pb + S*FS + K], features [FS][F]
+  float *wf_s = es + NW * 64;
+  float *ck_s = wf_s + (size_t)Fc * U;
+  float *alp_s = ck_s + (((Kc + 3) & ~3) * Fc);
+  float *cf_s = alp_s + (LOC ? ((pbc + TeP + Kc + 8) & ~3) : 0);
+  float *scr = cf_s + ((FS * Fc + 3) & ~3);           // scratch, sized by the host
   // scratch, re-used by the duties of a step (barriers in between):
   //   A: Xs = my wave's X[4 rows][KW]; its partial tile (256 floats) goes where its own X was (or behind all X)
   //   B: hs = h_t [R][U];  C: qs = q_t of my utterance [U], sc_s [FS] behind hs;  D: parts [S][CB], mz [S][2] over hs
@@ -211,15 +224,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   float *mz = parts + S * CB;
 
   const int ci = slot / S, cs = slot % S;             // duties C, D: utterance of the unit, frame slice
-  const int cbg = unit * R + ci;                      // its batch row
+  const int cbg = p.b0 + unit * R + ci;               // its batch row
   const int f0 = cs * FS;
   for (int i = tid; i < FS * U; i += NT) {
     const int f = f0 + i / U;
     keys_s[i] = f < Te ? p.keys[((size_t)cbg * Te + f) * U + i % U] : 0.f;
   }
-  for (int i = tid; i < FS * E; i += NT) {
-    const int f = f0 + i / E;
-    vals_s[i] = f < Te ? p.values[((size_t)cbg * Te + f) * E + i % E] : 0.f;
+  if (!p.stream_vals)
+    for (int i = tid; i < FS * E; i += NT) {
+      const int f = f0 + i / E;
+      vals_s[i] = f < Te ? p.values[((size_t)cbg * Te + f) * E + i % E] : 0.f;
+    }
+  if (LOC) {
+    for (int i = tid; i < Fc * U; i += NT) wf_s[i] = p.wf[i];
+    for (int i = tid; i < ((Kc + 3) & ~3) * Fc; i += NT) {      // [filter][tap], taps padded to a multiple of 4 with zeros
+      const int j = i / ((Kc + 3) & ~3), d = i % ((Kc + 3) & ~3);
+      ck_s[i] = d < Kc ? p.ck[d * Fc + j] : 0.f;
+    }
+    for (int i = tid; i < ((pbc + TeP + Kc + 8) & ~3); i += NT) alp_s[i] = 0.f;       // the pads stay zero; alignments of step -1 are zero
   }
   for (int i = tid; i < U * UW; i += NT) wq_s[i] = p.wq[(size_t)(i / UW) * U + UW * slot + i % UW];   // [k][column]
   for (int i = tid; i < U; i += NT) v_s[i] = p.v[i];
@@ -237,7 +259,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   // gate phase: thread = (row, my column col_l = 4*unit + gate), tid < 4 * 64
   const int grow = tid >> 6, gcol = tid & 63, gu = gcol >> 2, gg = gcol & 3;
   const bool gate_thr = tid < R * 64 && gcol < CW;
-  const int gb = unit * R + grow;                       // batch row
+  const int gb = p.b0 + unit * R + grow;                // batch row
   const int gunit = UW * slot + gu;                     // hidden unit
   const float gbias = gate_thr ? p.bias[gg * U + gunit] : 0.f;
   const int glen = gate_thr ? p.dec_len[gb] : 0;
@@ -256,7 +278,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         p.H[((size_t)(ts + 1) * B + gb) * U + gunit] = h_state;
       }
     }
-    if (tid < R * UW) p.q[((size_t)ts * B + unit * R + tid / UW) * U + UW * slot + tid % UW] = q_last;
+    if (tid < R * UW) p.q[((size_t)ts * B + p.b0 + unit * R + tid / UW) * U + UW * slot + tid % UW] = q_last;
     if (tid < CB) p.ctx[((size_t)(ts + 1) * B + cbg) * E + cs * CB + tid] = ctx_prev;
     if (tid < FS && f0 + tid < Te) p.align[((size_t)(ts + 1) * B + cbg) * Te + f0 + tid] = al_prev;
   };
@@ -430,18 +452,64 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       if (tid < NPC) *reinterpret_cast<f32x4 *>(qs + 4 * qi) = __builtin_bit_cast(f32x4, v);
     }
     SP_STAMP(6);
+    if (LOC && t > 0) {
+      // previous alignments of my utterance (published in duty D of the step before: long there)
+      const int NPC = TeP / 4;                         // <= NT (host check)
+      const int qi = min(tid, NPC - 1);
+      const unsigned off = sp * lb + (unsigned)((ci * TeP + 4 * qi) * 4);
+      u32x4 v;
+      Spin g;
+      g.start();
+      for (;;) {
+        v = xld4(rl, off);
+        if (__all(!has_sentinel(v))) break;
+        if (g.expired(p)) { SP_TIMEOUT(1); break; }
+      }
+      if (tid < NPC) {
+        const f32x4 fv = __builtin_bit_cast(f32x4, v);
+        float *d = alp_s + pbc + 4 * qi;
+        d[0] = fv.x; d[1] = fv.y; d[2] = fv.z; d[3] = fv.w;
+      }
+    }
     __syncthreads();
     if (flag[0]) return;
+    if (LOC) {
+      // location features of my frames: cf[f][j] = sum_d a_prev[f0 + f + d - pb] * ck[d][j] ('same' padding)
+      for (int i = tid; i < FS * Fc; i += NT) {
+        const int f = i / Fc, j = i % Fc;
+        const int K4 = (Kc + 3) & ~3;
+        const float *a = alp_s + f0 + f;                 // (not 16-byte aligned in general: scalar reads of a, 16-byte of c)
+        const f32x4 *c4 = reinterpret_cast<const f32x4 *>(ck_s + (size_t)j * K4);
+        f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+        for (int d = 0; d < K4; d += 4) {
+          const f32x4 cc = c4[d / 4];
+          acc4.x = fmaf(a[d], cc.x, acc4.x);
+          acc4.y = fmaf(a[d + 1], cc.y, acc4.y);
+          acc4.z = fmaf(a[d + 2], cc.z, acc4.z);
+          acc4.w = fmaf(a[d + 3], cc.w, acc4.w);
+        }
+        cf_s[i] = (acc4.x + acc4.y) + (acc4.z + acc4.w);
+      }
+      __syncthreads();
+    }
     const bool frozen = t >= clen;
     for (int fg = 0; fg < FS; fg += 4 * NW) {      // four frames of a wave at a time: independent chains
       float sacc[4] = {0.f, 0.f, 0.f, 0.f};
       const f32x4 *q4 = reinterpret_cast<const f32x4 *>(qs), *v4 = reinterpret_cast<const f32x4 *>(v_s);
       for (int u4 = lane; u4 < U / 4; u4 += 64) {
         const f32x4 qq = q4[u4], vv = v4[u4];
+        f32x4 kx[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kx[i] = reinterpret_cast<const f32x4 *>(keys_s + (size_t)min(fg + w + NW * i, FS - 1) * U)[u4];
+        if (LOC)
+          for (int j = 0; j < Fc; ++j) {       // one read of the projection row per filter, four frames on it
+            const f32x4 wj = reinterpret_cast<const f32x4 *>(wf_s + (size_t)j * U)[u4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kx[i] += cf_s[min(fg + w + NW * i, FS - 1) * Fc + j] * wj;
+          }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int f = min(fg + w + NW * i, FS - 1);
-          const f32x4 kk = reinterpret_cast<const f32x4 *>(keys_s + (size_t)f * U)[u4];
+          const f32x4 kk = kx[i];
           sacc[i] = fmaf(vv.x, ftanh(kk.x + qq.x), sacc[i]);
           sacc[i] = fmaf(vv.y, ftanh(kk.y + qq.y), sacc[i]);
           sacc[i] = fmaf(vv.z, ftanh(kk.z + qq.z), sacc[i]);
@@ -472,8 +540,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       // partial context: thread = 4 columns
       for (int c4 = tid; c4 < E / 4; c4 += NT) {
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        if (!frozen) {
+        if (!frozen && !p.stream_vals) {
           for (int f = 0; f < FS; ++f) a += es_w[f] * *reinterpret_cast<const f32x4 *>(vals_s + (size_t)f * E + 4 * c4);
+        } else if (!frozen) {
+          // the values of my frames come from the XCD's L2 (they do not fit the LDS next to the keys): 5 loads in flight
+          const float *vp = p.values + ((size_t)cbg * Te + f0) * E + 4 * c4;
+          const int nf = min(FS, max(cn - f0, 0));        // masked frames carry weight 0: not read
+          for (int fb = 0; fb < nf; fb += 5) {
+            f32x4 vv[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) vv[i] = *reinterpret_cast<const f32x4 *>(vp + (size_t)min(fb + i, nf - 1) * E);
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+              if (fb + i < nf) a += es_w[fb + i] * vv[i];
+          }
         }
         xst4(__builtin_bit_cast(u32x4, a), rp, so * pb + (unsigned)(((ci * S + cs) * (E + 4) + 4 * c4) * 4), coloc);
         xst4(sent4, rp, t >= 2 ? sr * pb + (unsigned)(((ci * S + cs) * (E + 4) + 4 * c4) * 4) : OOB, coloc);
@@ -543,6 +623,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         float a = frozen ? al_prev : es[tid] * __expf(m_loc - M) * inv;     // (tid < FS <= 64: wave 0's copy)
         if (!frozen && f0 + tid >= cn) a = 0.f;
         al_prev = a;
+      }
+      if (LOC) {
+        xst1(fbits(al_prev), rl, tid < FS ? so * lb + (unsigned)((ci * TeP + f0 + tid) * 4) : OOB, coloc);
+        xst1(SENT, rl, (tid < FS && t >= 2) ? sr * lb + (unsigned)((ci * TeP + f0 + tid) * 4) : OOB, coloc);
       }
     }
     SP_STAMP(10);
@@ -1013,7 +1097,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 }
 
 int kr_for(int KW) { return KW <= 64 ? 64 : KW <= 192 ? 192 : 384; }
-size_t lds_floats(const SpPersistDesc &d, int FS) {
+size_t lds_floats(const SpPersistDesc &d, int FS, bool stream);
+// the values slice stays in LDS when it fits, else it is read from L2 every step
+bool stream_values(const SpPersistDesc &d, int FS) {
+  if (const char *e = getenv("NABU_SPELLER_STREAM_VALUES")) return atoi(e) != 0;     // (tests: force the streamed path)
+  return lds_floats(d, FS, false) * 4 > 160 * 1024 - 512;
+}
+size_t lds_floats(const SpPersistDesc &d, int FS, bool stream) {
   const size_t K = d.E + d.U, UW = d.U / P;
   const size_t KR = kr_for((int)(K / NW));
   size_t scr = NW * R * KR;
@@ -1022,18 +1112,26 @@ size_t lds_floats(const SpPersistDesc &d, int FS) {
   const size_t aux = need_c > need_d ? need_c : need_d;
   if (K / NW == KR) scr = scr > aux ? scr : aux;   // aliased
   else scr += aux;
-  return (size_t)FS * d.U + (size_t)FS * d.E + (size_t)d.U * UW + d.U + NW * 64 + scr + 64;
+  size_t loc = 0;
+  if (d.kind == 1) {
+    const size_t pb = (d.K - 1) / 2, TeP = (size_t)S * FS;
+    loc = (size_t)d.F * d.U + (size_t)((d.K + 3) & ~3) * d.F + ((pb + TeP + d.K + 8) & ~3) + ((FS * d.F + 3) & ~3);
+  }
+  return (size_t)FS * d.U + (stream ? 0 : (size_t)FS * d.E) + (size_t)d.U * UW + d.U + NW * 64 + loc + scr + 64;
 }
 int frames_per_slice(const SpPersistDesc &d) { return (d.Te + S - 1) / S; }
 size_t ring_bytes(const SpPersistDesc &d) {
   const size_t hb = (size_t)R * d.U * 4, cb = (size_t)R * d.E * 4, pb = (size_t)R * S * (d.E + 4) * 4;
-  return (size_t)NU * RING * (2 * hb + cb + pb);
+  const size_t lb = d.kind == 1 ? (size_t)R * S * frames_per_slice(d) * 4 : 0;
+  return (size_t)NU * RING * (2 * hb + cb + pb + lb);
 }
 
 }  // namespace
 
 static bool shape_ok(const SpPersistDesc &d) {
-  if (d.B != NU * R || d.U % 32 || d.E % 32 || d.U < 32 || d.E < 32) return false;
+  if ((d.B != NU * R && d.B != 2 * NU * R) || d.U % 32 || d.E % 32 || d.U < 32 || d.E < 32) return false;
+  if (d.kind != 0 && d.kind != 1) return false;
+  if (d.kind == 1 && (d.K < 1 || d.F < 1 || S * frames_per_slice(d) / 4 > NT)) return false;
   const int K = d.E + d.U;
   if (K % (NW * 4) || K / NW > 384) return false;      // k range of a wave: whole 16-byte pieces, <= 384 weight registers
   if (R * d.U / 4 > 2 * NT || d.U / 4 > NT || S * (d.E / S / 4) + S > 2 * NT) return false;   // gathers: <= 2 pieces per thread
@@ -1042,7 +1140,7 @@ static bool shape_ok(const SpPersistDesc &d) {
   const int FS = frames_per_slice(d);
   if (FS > 64 || FS < 1) return false;
   if (d.U / P > 16 || d.U % 32) return false;          // duty B: 16 columns per workgroup at most
-  return lds_floats(d, FS) * 4 <= 160 * 1024 - 512;
+  return lds_floats(d, FS, stream_values(d, FS)) * 4 <= 160 * 1024 - 512;
 }
 
 // ---- backward
@@ -1067,7 +1165,7 @@ static size_t bwd_lds_floats(const SpPersistDesc &d) {
   return (size_t)FS * d.U + (size_t)FS * d.E + (size_t)UW * (d.U + 4) + d.U + scr + 64;
 }
 static bool bwd_shape_ok(const SpPersistDesc &d) {
-  if (!shape_ok(d)) return false;
+  if (!shape_ok(d) || d.kind != 0 || d.B != NU * R) return false;
   const int NC = (d.E + d.U) / P, KBW = 4 * d.U / NW;
   if ((d.E + d.U) % P || NC % 4 || R * NC > NT) return false;
   if (bwd_ks4(d)) {
@@ -1138,12 +1236,16 @@ size_t speller_persist_ws_bytes(const SpPersistDesc &d) {   // (independent of t
 
 int speller_persist_fwd(const SpPersistDesc &d, const int32_t *dec_len, const int32_t *enc_len, const int32_t *ids,
                         const float *kperm, const float *bias, const float *emb, const float *wq, const float *v,
-                        const float *keys, const float *values, float *H, float *Cs, float *acts, float *q, float *ctx,
-                        float *align, int *status, void *ws, size_t ws_bytes, hipStream_t stream) {
+                        const float *keys, const float *values, const float *conv_kernel, const float *conv_proj, float *H,
+                        float *Cs, float *acts, float *q, float *ctx, float *align, int *status, void *ws, size_t ws_bytes,
+                        hipStream_t stream) {
   if (!speller_persist_ok(d)) return fail(NABU_EUNSUP, "persistent decoder: unsupported shape");
   if (ws_bytes < speller_persist_ws_bytes(d)) return fail(NABU_EWS, "persistent decoder: workspace too small");
+  if (d.kind == 1 && !(conv_kernel && conv_proj)) return fail(NABU_EINVAL, "persistent decoder: location-aware attention needs its kernels");
   Args a;
   a.L = d.L; a.U = d.U; a.E = d.E; a.Te = d.Te; a.FS = frames_per_slice(d);
+  a.Bt = d.B; a.K = d.K; a.F = d.F; a.stream_vals = stream_values(d, a.FS) ? 1 : 0;
+  a.ck = conv_kernel; a.wf = conv_proj;
   a.dec_len = dec_len; a.enc_len = enc_len; a.ids = ids;
   a.kperm = kperm; a.bias = bias; a.emb = emb; a.wq = wq; a.v = v; a.keys = keys; a.values = values;
   a.H = H; a.Cs = Cs; a.acts = acts; a.q = q; a.ctx = ctx; a.align = align;
@@ -1153,11 +1255,12 @@ int speller_persist_fwd(const SpPersistDesc &d, const int32_t *dec_len, const in
   a.timeout_ticks = lstm_persist_timeout_ticks();
   const char *e = getenv("NABU_PERSIST_DEBUG");
   a.dbg = e ? atoi(e) : 0;
-  NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + ring_bytes(d), stream));
-  const size_t lds = lds_floats(d, a.FS) * 4;
+  const size_t lds = lds_floats(d, a.FS, a.stream_vals != 0) * 4;
   const int KW = (d.E + d.U) / NW;
-  auto kern = KW <= 64 ? speller_persist_fwd_kernel<64> : KW <= 192 ? speller_persist_fwd_kernel<192> : speller_persist_fwd_kernel<384>;
-  static thread_local const void *configured[3] = {nullptr, nullptr, nullptr};
+  const bool loc = d.kind == 1;
+  auto kern = loc ? (KW <= 64 ? speller_persist_fwd_kernel<64, true> : KW <= 192 ? speller_persist_fwd_kernel<192, true> : speller_persist_fwd_kernel<384, true>)
+                  : (KW <= 64 ? speller_persist_fwd_kernel<64, false> : KW <= 192 ? speller_persist_fwd_kernel<192, false> : speller_persist_fwd_kernel<384, false>);
+  static thread_local const void *configured[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   const void *fn = reinterpret_cast<const void *>(kern);
   bool done = false;
   for (auto c : configured) done = done || c == fn;
@@ -1166,8 +1269,13 @@ int speller_persist_fwd(const SpPersistDesc &d, const int32_t *dec_len, const in
     for (auto &c : configured)
       if (!c) { c = fn; break; }
   }
-  hipLaunchKernelGGL(kern, dim3(NU * P), dim3(NT), lds, stream, a);
-  NABU_LAUNCH_CHECK();
+  // 32 utterances per launch (4 per XCD): a batch of 64 runs as two launches on the stream
+  for (int b0 = 0; b0 < d.B; b0 += NU * R) {
+    a.b0 = b0;
+    NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + ring_bytes(d), stream));
+    hipLaunchKernelGGL(kern, dim3(NU * P), dim3(NT), lds, stream, a);
+    NABU_LAUNCH_CHECK();
+  }
   return 0;
 }
 
