@@ -39,7 +39,10 @@ namespace {
 
 constexpr unsigned SENT = 0xFFFFFFFFu;
 constexpr unsigned OOB = 0xFFFFFFF0u;
-constexpr int NT = 256, NW = 4;      // threads, waves per workgroup: ONE wave per SIMD, up to 512 registers per lane
+#ifndef SP_NW
+#define SP_NW 4
+#endif
+constexpr int NW = SP_NW, NT = 64 * NW;      // waves, threads per workgroup (4: ONE wave per SIMD, up to 512 registers per lane)
 constexpr int NU = 8, P = 32;        // units (XCDs), workgroups per unit
 constexpr int R = 4, S = 8;          // utterances per unit, frame slices per utterance
 constexpr int RING = 4;
@@ -148,7 +151,7 @@ __device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(u
 // LOC: location-aware attention (attention.py:186-292): the score also takes conv1d(previous alignments)·conv_proj;
 // the normalised alignments travel in a fifth ring
 template <int KR, bool LOC>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void speller_persist_fwd_kernel(Args p) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void speller_persist_fwd_kernel(Args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int flag[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -408,10 +411,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       const int bcg = lane >> 4, bks = (lane >> 2) & 3, bj = lane & 3;
       f32x4 qa = {0.f, 0.f, 0.f, 0.f}, qb = {0.f, 0.f, 0.f, 0.f};
       {
-        const float *ha = hs + bj * (U + 4) + w * (U / 4) + bks;
-        const float *wb = wq_s + (size_t)(w * (U / 4) + bks) * UW + min(4 * bcg + bj, UW - 1);
+        const float *ha = hs + bj * (U + 4) + w * (U / NW) + bks;
+        const float *wb = wq_s + (size_t)(w * (U / NW) + bks) * UW + min(4 * bcg + bj, UW - 1);
         const bool colok = 4 * bcg + bj < UW;
-        for (int kk = 0; kk < U / 16; kk += 2) {
+        for (int kk = 0; kk < U / NW / 4; kk += 2) {
           const float a0 = ha[4 * kk], a1 = ha[4 * kk + 4];
           const float b0 = colok ? wb[(size_t)4 * kk * UW] : 0.f, b1 = colok ? wb[(size_t)(4 * kk + 4) * UW] : 0.f;
           qa = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b0, qa, 0, 0, 0);
@@ -429,7 +432,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       // thread (row, column) adds the four k ranges
       const int row = tid / UW, c = tid % UW;
       float s = 0.f;
-      if (tid < R * UW) s = (qred[(0 * 16 + c) * 4 + row] + qred[(1 * 16 + c) * 4 + row]) + (qred[(2 * 16 + c) * 4 + row] + qred[(3 * 16 + c) * 4 + row]);
+      if (tid < R * UW)
+        for (int ww = 0; ww < NW; ww += 2) s += qred[(ww * 16 + c) * 4 + row] + qred[((ww + 1) * 16 + c) * 4 + row];
       const bool pub = tid < R * UW;
       q_last = s;
       xst1(fbits(s), rq, pub ? so * hb + (unsigned)((row * U + UW * slot + c) * 4) : OOB, coloc);
@@ -692,7 +696,7 @@ struct SpinB {
 // NSETC sets of NKQC instructions per wave (weight registers per lane: NSETC * NKQC); KS = k phases in the 16 blocks
 // of an instruction (4: a set is 16 columns, 16: a set is 4 columns); DKR = frames per thread in D1
 template <int NSETC, int NKQC, int KS, int DKR>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void speller_persist_bwd_kernel(BArgs p) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void speller_persist_bwd_kernel(BArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int flag[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
