@@ -109,12 +109,38 @@ def test_speller_step_on_the_fused_and_multi_stream_paths(attention, nl, K, F):
     np.testing.assert_array_equal(got, one)
 
 
+@pytest.mark.parametrize('B', [32, 64])
+@pytest.mark.parametrize('stream', [0, 1])
+def test_persistent_decoder_location_aware_forward(B, stream):
+    """the location-aware variant of the persistent forward kernel (fifth ring with the alignments, conv features,
+    feature projection in the score duty), a batch of 64 as two launches of 32, and the values slice read from L2
+    instead of LDS (what cfg5's geometry needs; forced here) — against the oracle (inside check_speller) and the chain"""
+    import os
+    rng = np.random.default_rng(21 + B)
+    Te = 37
+    enc_len = rng.integers(Te // 2, Te + 1, B).astype(np.int32)
+    enc_len[0] = Te
+    tlen = rng.integers(1, 7, B).astype(np.int32)
+    tlen[2] = 6
+    os.environ['NABU_SPELLER_STREAM_VALUES'] = str(stream)
+    try:
+        got = check_speller('location_aware', 1, 64, 7, 3, enc_len, tlen, E=64)
+        os.environ['NABU_SPELLER_PERSIST'] = '0'
+        ref = check_speller('location_aware', 1, 64, 7, 3, enc_len, tlen, E=64)
+    finally:
+        os.environ.pop('NABU_SPELLER_PERSIST', None)
+        del os.environ['NABU_SPELLER_STREAM_VALUES']
+    assert np.abs(got - ref).max() < 2e-5
+    from nabu_amd import ops as hip
+    hip.check_persist_status()
+
+
 @pytest.mark.parametrize('U,E,Te', [(64, 64, 40), (128, 256, 70), (64, 192, 33)])
 def test_persistent_decoder_forward(U, E, Te):
-    """speller_persist.hip: the step loop of nabu_speller_fwd as ONE persistent launch (B = 32, one layer, vanilla
-    softmax attention, teacher forcing) — ragged decoder lengths (frozen rows), ragged encoder lengths (masked
-    frames), Te not a multiple of the 8 frame slices, the 64- and 192-register instantiations — against the oracle,
-    and against the step chain (NABU_SPELLER_PERSIST=0) on the same inputs"""
+    """speller_persist.hip: the step loops of nabu_speller_fwd / _bwd as ONE persistent launch each (B = 32, one layer,
+    vanilla softmax attention, teacher forcing) — ragged decoder lengths (frozen rows), ragged encoder lengths (masked
+    frames), Te not a multiple of the 8 frame slices, the 64- and 192-register instantiations — logits and every
+    gradient against the oracle, and the logits against the step chain (NABU_SPELLER_PERSIST=0) on the same inputs"""
     import os
     rng = np.random.default_rng(5 + U)
     enc_len = rng.integers(Te // 2, Te + 1, 32).astype(np.int32)
