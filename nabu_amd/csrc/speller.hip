@@ -1626,8 +1626,6 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   const nabu_attn_desc adn = sub_attn_desc(d, Bn);
   const size_t attn_wsb_n = nabu_attn_bwd_ws_bytes(&adn);
   SubStreams ss;
-  SP_TRY(sub_streams(NS, s, &ss));
-  SP_TRY(sub_fork(ss));
   // single-layer decoder without dropout (the BASELINE recipes): the cell's backward pass is folded into the
   // last workgroup of dq·Wq^T, and dz·[Kx^T | Kh^T] is ONE product whose [B, E+U] result carries d context and
   // d h to the next step — 4 dependent launches per step instead of 7
@@ -1645,6 +1643,10 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
     SP_TRY(speller_persist_bwd(pd, dec_len, enc_len, w + W.kxhT, p->query_kernel, p->attention_v, r + R.keys, values,
                                r + R.acts[0], r + R.Cs[0], r + R.q, r + R.ctx, r + R.align, dH, dCtx, dq, w + W.dz[0],
                                dkeys, w + W.dv8, reinterpret_cast<int *>(w + W.status), w + W.persist, W.persist_bytes, s));
+  if (!persist) {
+    SP_TRY(sub_streams(NS, s, &ss));
+    SP_TRY(sub_fork(ss));
+  }
   unsigned *atk = env_int("NABU_SPELLER_ATTN_FUSED", 1) ? reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)NS * 1024 : nullptr;
   auto bwd_chain = [&](int sub) -> int {
   int cur = 0;   // index of the carries coming from step t+1
