@@ -99,6 +99,7 @@ struct AttnArgs {
   float *dq, *dkeys, *dv_part, *dwf_part, *dck_part, *dalign_out;
   float *dq_part, *dcf_g;   // [B,S,U] per-slice dq, [B,Te,F] d location features (backward scratch)
   float *fwd_part;          // [B,S,E+4] per-slice context + (local max, local sum) (forward scratch)
+  float *ds_out, *cf_out;   // DEFER: d score [B,Te] and location features [B,Te,F] of this step, for attn_param_grads_kernel
   unsigned *tickets;        // [B] zeroed counters: the slice that arrives last finishes its utterance inside
                             // the launch (no finish kernel); nullptr = separate finish kernel
 };
@@ -481,7 +482,11 @@ __global__ __launch_bounds__(256) void attn_fwd_finish_kernel(AttnArgs p, int S)
   }
 }
 
-template <int MODE>
+// DEFER: the sums over decoder steps that nobody in the step chain waits for — d keys, d attention_v, d conv_proj —
+// are left to attn_param_grads_kernel (one launch after the chain, all steps in parallel); this kernel then only saves
+// d score (and the location features) of the step and is rid of the dkeys read-modify-write, of 96 accumulation
+// registers and of a dozen cross-wave reductions
+template <int MODE, bool DEFER>
 __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
   constexpr bool REG = MODE == 2, KIND = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -582,6 +587,11 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
     for (int t = lo + tid; t < hi; t += AT) ds[t] = (ds[t] - r) * al[t] * (1.f - al[t] * z);
   }
   __syncthreads();
+  if (DEFER) {
+    for (int t = lo + tid; t < hi; t += AT) p.ds_out[(size_t)b * Te + t] = ds[t];
+    if (KIND)
+      for (int i = lo * F + tid; i < hi * F; i += AT) p.cf_out[(size_t)b * Te * F + i] = cf[i];
+  }
   // through v·tanh(keys + q + f): lanes own 16-byte groups of units (u4 = lane + 64 j), waves split
   // the frames (2 frames of a wave in flight); keys are read and dkeys updated with 1 KiB wave accesses
   constexpr int MAXJ = REG ? RJ : 4;       // U <= 1024 (REG: U <= 512)
@@ -597,11 +607,24 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int j = 0; j < RJ; ++j) dwf_l[f][j] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  // DEFER: those 96 registers hold the projection rows instead (every frame needs them twice: for x and for d features)
+  constexpr bool WREG = REG && DEFER;
+  float4 wfr[WREG ? RF : 1][WREG ? RJ : 1];
+  if (WREG) {
+#pragma unroll
+    for (int f = 0; f < RF; ++f)
+#pragma unroll
+      for (int j = 0; j < RJ; ++j) {
+        const int u4 = lane + 64 * j;
+        wfr[f][j] = (f < F && u4 < U / 4) ? *reinterpret_cast<const float4 *>(p.wf + (size_t)f * U + 4 * u4)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+  }
   {
     const float4 *keys4 = reinterpret_cast<const float4 *>(keys);
     float4 *dkeys4 = reinterpret_cast<float4 *>(dkeys);
     const float4 *q4 = reinterpret_cast<const float4 *>(q), *v4 = reinterpret_cast<const float4 *>(p.v);
-    constexpr int FR = KIND ? 1 : 2;         // frames of a wave in flight (registers!)
+    constexpr int FR = (KIND && !DEFER) ? 1 : 2;         // frames of a wave in flight (registers!)
     for (int t0 = lo + w; t0 < hi; t0 += FR * NW) {
       float dcf_l[FR][NF];
 #pragma unroll
@@ -618,7 +641,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
           for (int i = 0; i < FR; ++i) {
             const size_t o = (size_t)min(t0 + i * NW, hi - 1) * U4 + u4;
             kx[i] = keys4[o];
-            dk[i] = dkeys4[o];
+            if (!DEFER) dk[i] = dkeys4[o];
           }
 #pragma unroll
           for (int i = 0; i < FR; ++i) {
@@ -626,7 +649,15 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
             if (t < hi) {
               const float g = ds[t];
               float x[4] = {kx[i].x + qq.x, kx[i].y + qq.y, kx[i].z + qq.z, kx[i].w + qq.w};
-              if (KIND)
+              if (WREG) {
+#pragma unroll
+                for (int f = 0; f < RF; ++f)
+                  if (f < F) {
+                    const float c = cf[t * F + f];
+                    const float4 wf = wfr[f][j];
+                    x[0] = fmaf(c, wf.x, x[0]); x[1] = fmaf(c, wf.y, x[1]); x[2] = fmaf(c, wf.z, x[2]); x[3] = fmaf(c, wf.w, x[3]);
+                  }
+              } else if (KIND)
                 for (int f = 0; f < F; ++f) {
                   const float c = cf[t * F + f];
                   const float4 wf = *reinterpret_cast<const float4 *>(p.wf + (size_t)f * U + 4 * u4);
@@ -639,17 +670,19 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
                 th[c] = tanhf_(x[c]);
                 d[c] = g * vvv[c] * (1.f - th[c] * th[c]);
               }
-              dv_l[j].x = fmaf(g, th[0], dv_l[j].x); dv_l[j].y = fmaf(g, th[1], dv_l[j].y);
-              dv_l[j].z = fmaf(g, th[2], dv_l[j].z); dv_l[j].w = fmaf(g, th[3], dv_l[j].w);
               dq_l[j].x += d[0]; dq_l[j].y += d[1]; dq_l[j].z += d[2]; dq_l[j].w += d[3];
-              dkeys4[(size_t)t * U4 + u4] = make_float4(dk[i].x + d[0], dk[i].y + d[1], dk[i].z + d[2], dk[i].w + d[3]);
+              if (!DEFER) {
+                dv_l[j].x = fmaf(g, th[0], dv_l[j].x); dv_l[j].y = fmaf(g, th[1], dv_l[j].y);
+                dv_l[j].z = fmaf(g, th[2], dv_l[j].z); dv_l[j].w = fmaf(g, th[3], dv_l[j].w);
+                dkeys4[(size_t)t * U4 + u4] = make_float4(dk[i].x + d[0], dk[i].y + d[1], dk[i].z + d[2], dk[i].w + d[3]);
+              }
               if (KIND) {
 #pragma unroll
                 for (int f = 0; f < (REG ? RF : 16); ++f)
                   if (f < F) {
-                    const float4 wf = *reinterpret_cast<const float4 *>(p.wf + (size_t)f * U + 4 * u4);
+                    const float4 wf = WREG ? wfr[WREG ? f : 0][WREG ? j : 0] : *reinterpret_cast<const float4 *>(p.wf + (size_t)f * U + 4 * u4);
                     dcf_l[i][f] = fmaf(d[0], wf.x, fmaf(d[1], wf.y, fmaf(d[2], wf.z, fmaf(d[3], wf.w, dcf_l[i][f]))));
-                    if (REG) {
+                    if (REG && !DEFER) {
                       const float c = cf[t * F + f];
                       dwf_l[f][j].x = fmaf(c, d[0], dwf_l[f][j].x); dwf_l[f][j].y = fmaf(c, d[1], dwf_l[f][j].y);
                       dwf_l[f][j].z = fmaf(c, d[2], dwf_l[f][j].z); dwf_l[f][j].w = fmaf(c, d[3], dwf_l[f][j].w);
@@ -684,7 +717,9 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
     for (int i = 0; i < NW; ++i) s += red[i * U + u];
     xst(dq + u, s, fused);
   }
+  if (DEFER && !fused) return;
   __syncthreads();
+  if (!DEFER) {
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j) {
     const int u4 = lane + 64 * j;
@@ -695,6 +730,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
     float s = 0.f;
     for (int i = 0; i < NW; ++i) s += red[i * U + u];
     p.dv_part[((size_t)b * S + sl) * U + u] += s;
+  }
   }
   if (fused) {
     if (!last_arriver(p.tickets + b, (unsigned)S, &last_flag)) return;
@@ -707,7 +743,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
       for (int t = tid; t < Te; t += AT) p.dalign_out[(size_t)b * Te + t] = 0.f;
     return;
   }
-  if (KIND) {
+  if (KIND && !DEFER) {
     __syncthreads();
     if (REG) {
       // d conv_proj[f,u] += sum_t cf[t,f] * d[t,u]: the per-wave register sums, reduced across waves
@@ -747,6 +783,120 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int f = 0; f < 16; ++f)
         if (f < F) p.dwf_part[(((size_t)b * S + sl) * F + f) * U + u] += acc[f];
+    }
+  }
+}
+
+// The sums over decoder steps that the step chain does not wait for (DEFER): for its frames [lo, hi) of utterance b a
+// workgroup walks the steps l < dec_len[b] and accumulates in registers
+//   d keys[t,u] = sum_l d_l[t,u],  d v[u] += sum_{l,t} ds_l[t] tanh(x_l[t,u]),  d conv_proj[f,u] += sum_{l,t} cf_l[t,f] d_l[t,u]
+// with x_l[t,u] = keys[t,u] + q_l[u] + cf_l[t,:].conv_proj[:,u],  d_l[t,u] = ds_l[t] v[u] (1 - tanh(x)^2)
+// from the d scores (and location features) the chain's attention kernels saved: no dependency between steps here, one
+// launch of B x S workgroups instead of a read-modify-write of dkeys in every step.  grid (B, S), PT threads:
+// thread = (16-byte unit group u4, frame group fg); frames of a thread: lo + fg, lo + fg + NG, ...
+constexpr int PT = 512, PFR = 8, PNF = 12;      // threads; frames per thread (max); location filters held in registers (max)
+template <bool KIND>
+__global__ __launch_bounds__(PT) void attn_param_grads_kernel(int B, int Te, int U, int F, int L, const int32_t *dec_len,
+                                                              const int32_t *enc_len, const float *keys, const float *q_all,
+                                                              const float *v, const float *wf, const float *ds_all,
+                                                              const float *cf_all, float *dkeys, float *dv_part,
+                                                              float *dwf_part) {
+  extern __shared__ __attribute__((aligned(16))) float psm[];
+  const int b = blockIdx.x, sl = blockIdx.y, S = gridDim.y, tid = threadIdx.x;
+  const int n = min(max(enc_len[b], 0), Te);
+  const int per = (Te + S - 1) / S, lo = min(sl * per, n), hi = min(lo + per, n);
+  const int U4 = U / 4, NG = PT / U4;            // frame groups
+  const int u4 = tid % U4, fg = tid / U4;
+  const bool act = fg < NG;
+  float *ds_s = psm;                              // [per] d scores of the step
+  float *cf_s = ds_s + ((per + 3) & ~3);          // [per][F]
+  float *red = cf_s + ((per * F + 3) & ~3);       // [NG][U] cross-group sums at the end
+  float4 kx[PFR], dk[PFR], wfr[KIND ? PNF : 1], dwf[KIND ? PNF : 1];
+  float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 vv = act ? reinterpret_cast<const float4 *>(v)[u4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < PFR; ++i) {
+    const int t = lo + fg + NG * i;
+    dk[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    kx[i] = (act && t < hi) ? reinterpret_cast<const float4 *>(keys + ((size_t)b * Te + t) * U)[u4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (KIND) {
+#pragma unroll
+    for (int f = 0; f < PNF; ++f) {
+      dwf[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+      wfr[f] = (act && f < F) ? reinterpret_cast<const float4 *>(wf + (size_t)f * U)[u4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const int steps = min(max(dec_len[b], 0), L);
+  for (int l = 0; l < steps; ++l) {
+    __syncthreads();
+    for (int t = lo + tid; t < hi; t += PT) ds_s[t - lo] = ds_all[((size_t)l * B + b) * Te + t];
+    if (KIND)
+      for (int i = lo * F + tid; i < hi * F; i += PT) cf_s[i - lo * F] = cf_all[((size_t)l * B + b) * Te * F + i];
+    __syncthreads();
+    if (!act) continue;
+    const float4 qq = reinterpret_cast<const float4 *>(q_all + ((size_t)l * B + b) * U)[u4];
+#pragma unroll
+    for (int i = 0; i < PFR; ++i) {
+      const int t = lo + fg + NG * i;
+      if (t < hi) {
+        const float g = ds_s[t - lo];
+        float x[4] = {kx[i].x + qq.x, kx[i].y + qq.y, kx[i].z + qq.z, kx[i].w + qq.w};
+        if (KIND) {
+#pragma unroll
+          for (int f = 0; f < PNF; ++f)
+            if (f < F) {
+              const float c = cf_s[(t - lo) * F + f];
+              x[0] = fmaf(c, wfr[f].x, x[0]); x[1] = fmaf(c, wfr[f].y, x[1]); x[2] = fmaf(c, wfr[f].z, x[2]); x[3] = fmaf(c, wfr[f].w, x[3]);
+            }
+        }
+        const float th0 = tanhf_(x[0]), th1 = tanhf_(x[1]), th2 = tanhf_(x[2]), th3 = tanhf_(x[3]);
+        const float d0 = g * vv.x * (1.f - th0 * th0), d1 = g * vv.y * (1.f - th1 * th1);
+        const float d2 = g * vv.z * (1.f - th2 * th2), d3 = g * vv.w * (1.f - th3 * th3);
+        dk[i].x += d0; dk[i].y += d1; dk[i].z += d2; dk[i].w += d3;
+        dv.x = fmaf(g, th0, dv.x); dv.y = fmaf(g, th1, dv.y); dv.z = fmaf(g, th2, dv.z); dv.w = fmaf(g, th3, dv.w);
+        if (KIND) {
+#pragma unroll
+          for (int f = 0; f < PNF; ++f)
+            if (f < F) {
+              const float c = cf_s[(t - lo) * F + f];
+              dwf[f].x = fmaf(c, d0, dwf[f].x); dwf[f].y = fmaf(c, d1, dwf[f].y);
+              dwf[f].z = fmaf(c, d2, dwf[f].z); dwf[f].w = fmaf(c, d3, dwf[f].w);
+            }
+        }
+      }
+    }
+  }
+  // d keys: my frames (frames >= enc_len keep the caller's zeros)
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < PFR; ++i) {
+      const int t = lo + fg + NG * i;
+      if (t < hi) reinterpret_cast<float4 *>(dkeys + ((size_t)b * Te + t) * U)[u4] = dk[i];
+    }
+  }
+  // d v and d conv_proj: add the frame groups (fixed order) -> one partial row per (utterance, slice)
+  __syncthreads();
+  if (act) *reinterpret_cast<float4 *>(red + (size_t)fg * U + 4 * u4) = dv;
+  __syncthreads();
+  for (int u = tid; u < U; u += PT) {
+    float sm = 0.f;
+    for (int g = 0; g < NG; ++g) sm += red[(size_t)g * U + u];
+    dv_part[((size_t)b * S + sl) * U + u] = sm;
+  }
+  if (KIND) {
+#pragma unroll
+    for (int f = 0; f < PNF; ++f) {
+      if (f < F) {
+        __syncthreads();
+        if (act) *reinterpret_cast<float4 *>(red + (size_t)fg * U + 4 * u4) = dwf[f];
+        __syncthreads();
+        for (int u = tid; u < U; u += PT) {
+          float sm = 0.f;
+          for (int g = 0; g < NG; ++g) sm += red[(size_t)g * U + u];
+          dwf_part[(((size_t)b * S + sl) * F + f) * U + u] = sm;
+        }
+      }
     }
   }
 }
@@ -1080,7 +1230,8 @@ static int attn_bwd_impl(const nabu_attn_desc *d, int step, const int32_t *dec_l
                          const float *ctx, const float *dctx, const float *dalign_in, float *dq,
                          float *dkeys, float *dv_part, float *dconv_proj_part,
                          float *dconv_kernel_part, float *dalign_out, const float *znorm, void *ws,
-                         size_t ws_bytes, nabu_stream_t stream, unsigned *tickets) {
+                         size_t ws_bytes, nabu_stream_t stream, unsigned *tickets, float *ds_out = nullptr,
+                         float *cf_out = nullptr) {
   if (int e = check_attn(d)) return e;
   NABU_CHECK_ARG(dec_len && enc_len && keys && values && q && v && align && ctx && dctx && dq && dkeys && dv_part && ws,
                  "attn_bwd: null pointer");
@@ -1101,11 +1252,14 @@ static int attn_bwd_impl(const nabu_attn_desc *d, int step, const int32_t *dec_l
   p.dq_part = static_cast<float *>(ws);
   p.dcf_g = p.dq_part + (size_t)d->B * S * d->U;
   p.tickets = d->kind != 1 ? tickets : nullptr;   // location-aware: the finish is a wide kernel of its own
+  p.ds_out = ds_out; p.cf_out = cf_out;
+  const bool defer = ds_out != nullptr;
   NABU_CHECK_ARG(d->prob_fn != 2 || znorm, "attn_bwd: normalized_sigmoid needs the normalisers of the forward pass");
   const size_t shm = attn_lds(d, true);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool reg = d->kind == 1 && d->U <= 256 * RJ && d->F <= RF;
-  auto kern = d->kind != 1 ? attn_bwd_kernel<0> : reg ? attn_bwd_kernel<2> : attn_bwd_kernel<1>;
+  auto kern = defer ? (d->kind != 1 ? attn_bwd_kernel<0, true> : reg ? attn_bwd_kernel<2, true> : attn_bwd_kernel<1, true>)
+                    : (d->kind != 1 ? attn_bwd_kernel<0, false> : reg ? attn_bwd_kernel<2, false> : attn_bwd_kernel<1, false>);
   if (shm > 64 * 1024)
     NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
@@ -1131,6 +1285,28 @@ extern "C" int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *d
   return attn_bwd_impl(d, step, dec_len, enc_len, keys, values, q, v, conv_kernel, conv_proj, align_prev, align, ctx,
                        dctx, dalign_in, dq, dkeys, dv_part, dconv_proj_part, dconv_kernel_part, dalign_out, znorm, ws,
                        ws_bytes, stream, nullptr);
+}
+
+// attn_param_grads_kernel: S = slices per utterance (the partition of nabu_attn_bwd for the same descriptor)
+static bool attn_defer_ok(const nabu_attn_desc *d, int S) {
+  if (d->U % 4 || d->U / 4 > PT || PT % (d->U / 4)) return false;
+  const int NG = PT / (d->U / 4), per = (d->Te + S - 1) / S;
+  if ((per + NG - 1) / NG > PFR) return false;
+  if (d->kind == 1 && d->F > PNF) return false;
+  return true;
+}
+static int attn_param_grads(const nabu_attn_desc *d, int S, int L, const int32_t *dec_len, const int32_t *enc_len,
+                            const float *keys, const float *q_all, const float *v, const float *wf, const float *ds_all,
+                            const float *cf_all, float *dkeys, float *dv_part, float *dwf_part, hipStream_t s) {
+  const int per = (d->Te + S - 1) / S, NG = PT / (d->U / 4);
+  const size_t shm = (((size_t)per + 3) / 4 * 4 + ((size_t)per * (d->kind == 1 ? d->F : 0) + 3) / 4 * 4 + (size_t)NG * d->U + 4) * sizeof(float);
+  auto kern = d->kind == 1 ? attn_param_grads_kernel<true> : attn_param_grads_kernel<false>;
+  if (shm > 64 * 1024)
+    NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipLaunchKernelGGL(kern, dim3(d->B, S), dim3(PT), shm, s, d->B, d->Te, d->U, d->kind == 1 ? d->F : 0, L, dec_len, enc_len,
+                     keys, q_all, v, wf, ds_all, cf_all, dkeys, dv_part, dwf_part);
+  NABU_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int nabu_mask_time_f32(int B, int L, int F, float *x, const int32_t *len, nabu_stream_t stream) {
@@ -1207,6 +1383,7 @@ struct SpWs {
   size_t tickets, fpart;   // fused skinny products: per-column-slice tickets (zeroed per call), partial tiles
   size_t status, persist, persist_bytes;   // persistent decoder kernel: status word (ws[0]), XCC table + exchange rings
   size_t dv8;                              // its d attention_v partial rows [B*8, U]
+  size_t ds_all, cf_all;                   // deferred attention gradients: d scores [L,B,Te], location features [L,B,Te,F]
   // the decoder steps run as NS independent sub-batches on NS streams: per sub-batch slices of
   // the scratch that a step's kernels share
   int NS, S;               // sub-batches; attention-backward slices per utterance (of a sub-batch)
@@ -1311,6 +1488,8 @@ static SpWs sp_ws(const nabu_speller_desc *d) {
     if (speller_persist_bwd_ws_bytes(pd) > s.persist_bytes) s.persist_bytes = speller_persist_bwd_ws_bytes(pd);
     s.persist = take(s.persist_bytes / 4 + 4);
     s.dv8 = take(speller_persist_bwd_ws_bytes(pd) ? B * 8 * U : 0);
+    s.ds_all = take(L * B * Te);
+    s.cf_all = take(d->kind == 1 ? L * B * Te * F : 0);
   }
   s.z_each = Bn * 4 * U;
   s.z = take(B * 4 * U);
@@ -1647,6 +1826,8 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
     SP_TRY(sub_streams(NS, s, &ss));
     SP_TRY(sub_fork(ss));
   }
+  // d keys / d attention_v / d conv_proj of all steps in ONE launch after the chain (attn_param_grads_kernel)
+  const bool defer = !persist && env_int("NABU_SPELLER_DEFER", 1) && attn_defer_ok(&adn, S);
   unsigned *atk = env_int("NABU_SPELLER_ATTN_FUSED", 1) ? reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)NS * 1024 : nullptr;
   auto bwd_chain = [&](int sub) -> int {
   int cur = 0;   // index of the carries coming from step t+1
@@ -1677,7 +1858,9 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
                            d->kind == 1 ? w + W.dwf + (size_t)b0 * S * F * U : nullptr,
                            d->kind == 1 ? w + W.dck + (size_t)b0 * K * F : nullptr, dal_out,
                            r + R.znorm + (size_t)t * B + b0, w + W.attn + (size_t)sub * W.attn_each, attn_wsb_n, st,
-                           atk ? atk + b0 : nullptr));
+                           atk ? atk + b0 : nullptr,
+                           defer ? w + W.ds_all + ((size_t)t * B + b0) * Te : nullptr,
+                           (defer && d->kind == 1) ? w + W.cf_all + ((size_t)t * B + b0) * Te * F : nullptr));
       float *dHt = dH + (size_t)t * B * U + (size_t)b0 * U;
       if (fuse_b) {
         float *dzt = w + W.dz[0] + (size_t)t * B * 4 * U + (size_t)b0 * 4 * U;
@@ -1748,6 +1931,13 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   if (!persist) {
   SP_TRY(run_subs(NS, bwd_chain));
   SP_TRY(sub_join(ss));
+  }
+  if (defer) {
+    // every sub-batch has the same slice partition (S slices of ceil(Te/S) frames): one launch over the whole batch
+    nabu_attn_desc adb = adn;
+    adb.B = B;
+    SP_TRY(attn_param_grads(&adb, S, L, dec_len, enc_len, r + R.keys, r + R.q, p->attention_v, p->conv_proj, w + W.ds_all,
+                            w + W.cf_all, dkeys, w + W.dv, w + W.dwf, s));
   }
   // sums over steps as single GEMMs
   SP_TRY(mm(true, false, U, U, BL, htop_all, U, dq, U, 0.f, g->query_kernel, U, nullptr, gw, gwb, stream));
