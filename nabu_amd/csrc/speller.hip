@@ -624,7 +624,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
     const float4 *keys4 = reinterpret_cast<const float4 *>(keys);
     float4 *dkeys4 = reinterpret_cast<float4 *>(dkeys);
     const float4 *q4 = reinterpret_cast<const float4 *>(q), *v4 = reinterpret_cast<const float4 *>(p.v);
-    constexpr int FR = (KIND && !DEFER) ? 1 : 2;         // frames of a wave in flight (registers!)
+    constexpr int FR = (MODE == 1 || (KIND && !DEFER)) ? 1 : 2;         // frames of a wave in flight (registers!)
     for (int t0 = lo + w; t0 < hi; t0 += FR * NW) {
       float dcf_l[FR][NF];
 #pragma unroll
@@ -794,8 +794,8 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
 // from the d scores (and location features) the chain's attention kernels saved: no dependency between steps here, one
 // launch of B x S workgroups instead of a read-modify-write of dkeys in every step.  grid (B, S), PT threads:
 // thread = (16-byte unit group u4, frame group fg); frames of a thread: lo + fg, lo + fg + NG, ...
-constexpr int PT = 512, PFR = 8, PNF = 12;      // threads; frames per thread (max); location filters held in registers (max)
-template <bool KIND>
+constexpr int PT = 512, PNF = 12, PSB = 4;   // threads; location filters in registers (max); steps per barrier pair
+template <bool KIND, int PFR>                // PFR = frames per thread (max)
 __global__ __launch_bounds__(PT) void attn_param_grads_kernel(int B, int Te, int U, int F, int L, const int32_t *dec_len,
                                                               const int32_t *enc_len, const float *keys, const float *q_all,
                                                               const float *v, const float *wf, const float *ds_all,
@@ -808,9 +808,9 @@ __global__ __launch_bounds__(PT) void attn_param_grads_kernel(int B, int Te, int
   const int U4 = U / 4, NG = PT / U4;            // frame groups
   const int u4 = tid % U4, fg = tid / U4;
   const bool act = fg < NG;
-  float *ds_s = psm;                              // [per] d scores of the step
-  float *cf_s = ds_s + ((per + 3) & ~3);          // [per][F]
-  float *red = cf_s + ((per * F + 3) & ~3);       // [NG][U] cross-group sums at the end
+  float *ds_s = psm;                              // [PSB][per] d scores of the steps in flight
+  float *cf_s = ds_s + PSB * ((per + 3) & ~3);    // [PSB][per][F]
+  float *red = cf_s + PSB * ((per * F + 3) & ~3); // [NG][U] cross-group sums at the end
   float4 kx[PFR], dk[PFR], wfr[KIND ? PNF : 1], dwf[KIND ? PNF : 1];
   float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 vv = act ? reinterpret_cast<const float4 *>(v)[u4] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -828,29 +828,48 @@ __global__ __launch_bounds__(PT) void attn_param_grads_kernel(int B, int Te, int
     }
   }
   const int steps = min(max(dec_len[b], 0), L);
-  for (int l = 0; l < steps; ++l) {
+  const int DSP = (per + 3) & ~3, CFP = (per * F + 3) & ~3;      // per-step strides of the staged d scores / features
+  for (int l0 = 0; l0 < steps; l0 += PSB) {
+    // PSB steps per barrier pair: their d scores, features and queries travel together
     __syncthreads();
-    for (int t = lo + tid; t < hi; t += PT) ds_s[t - lo] = ds_all[((size_t)l * B + b) * Te + t];
+    for (int i = tid; i < PSB * (hi - lo); i += PT) {
+      const int sb = i / (hi - lo), t = lo + i % (hi - lo);
+      ds_s[sb * DSP + t - lo] = l0 + sb < steps ? ds_all[((size_t)(l0 + sb) * B + b) * Te + t] : 0.f;
+    }
     if (KIND)
-      for (int i = lo * F + tid; i < hi * F; i += PT) cf_s[i - lo * F] = cf_all[((size_t)l * B + b) * Te * F + i];
+      for (int i = tid; i < PSB * (hi - lo) * F; i += PT) {
+        const int sb = i / ((hi - lo) * F), r = i % ((hi - lo) * F);
+        cf_s[sb * CFP + r] = l0 + sb < steps ? cf_all[((size_t)(l0 + sb) * B + b) * Te * F + lo * F + r] : 0.f;
+      }
+    float4 qs[PSB];
+#pragma unroll
+    for (int sb = 0; sb < PSB; ++sb)
+      qs[sb] = (act && l0 + sb < steps) ? reinterpret_cast<const float4 *>(q_all + ((size_t)(l0 + sb) * B + b) * U)[u4]
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     if (!act) continue;
-    const float4 qq = reinterpret_cast<const float4 *>(q_all + ((size_t)l * B + b) * U)[u4];
+#pragma unroll
+    for (int sb = 0; sb < PSB; ++sb) {
+    if (l0 + sb >= steps) break;
+    const float4 qq = qs[sb];
+    const float *ds_s_ = ds_s + sb * DSP, *cf_s_ = cf_s + sb * CFP;
 #pragma unroll
     for (int i = 0; i < PFR; ++i) {
       const int t = lo + fg + NG * i;
       if (t < hi) {
-        const float g = ds_s[t - lo];
+        const float g = ds_s_[t - lo];
         float x[4] = {kx[i].x + qq.x, kx[i].y + qq.y, kx[i].z + qq.z, kx[i].w + qq.w};
         if (KIND) {
 #pragma unroll
           for (int f = 0; f < PNF; ++f)
             if (f < F) {
-              const float c = cf_s[(t - lo) * F + f];
+              const float c = cf_s_[(t - lo) * F + f];
               x[0] = fmaf(c, wfr[f].x, x[0]); x[1] = fmaf(c, wfr[f].y, x[1]); x[2] = fmaf(c, wfr[f].z, x[2]); x[3] = fmaf(c, wfr[f].w, x[3]);
             }
         }
-        const float th0 = tanhf_(x[0]), th1 = tanhf_(x[1]), th2 = tanhf_(x[2]), th3 = tanhf_(x[3]);
+        // one exp + one rcp per tanh (as the persistent kernels; relative error ~1e-7)
+        const float th0 = 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x[0])) - 1.0f, th1 = 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x[1])) - 1.0f;
+        const float th2 = 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x[2])) - 1.0f, th3 = 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x[3])) - 1.0f;
         const float d0 = g * vv.x * (1.f - th0 * th0), d1 = g * vv.y * (1.f - th1 * th1);
         const float d2 = g * vv.z * (1.f - th2 * th2), d3 = g * vv.w * (1.f - th3 * th3);
         dk[i].x += d0; dk[i].y += d1; dk[i].z += d2; dk[i].w += d3;
@@ -859,12 +878,13 @@ __global__ __launch_bounds__(PT) void attn_param_grads_kernel(int B, int Te, int
 #pragma unroll
           for (int f = 0; f < PNF; ++f)
             if (f < F) {
-              const float c = cf_s[(t - lo) * F + f];
+              const float c = cf_s_[(t - lo) * F + f];
               dwf[f].x = fmaf(c, d0, dwf[f].x); dwf[f].y = fmaf(c, d1, dwf[f].y);
               dwf[f].z = fmaf(c, d2, dwf[f].z); dwf[f].w = fmaf(c, d3, dwf[f].w);
             }
         }
       }
+    }
     }
   }
   // d keys: my frames (frames >= enc_len keep the caller's zeros)
@@ -1287,20 +1307,26 @@ extern "C" int nabu_attn_bwd(const nabu_attn_desc *d, int step, const int32_t *d
                        ws_bytes, stream, nullptr);
 }
 
-// attn_param_grads_kernel: S = slices per utterance (the partition of nabu_attn_bwd for the same descriptor)
-static bool attn_defer_ok(const nabu_attn_desc *d, int S) {
-  if (d->U % 4 || d->U / 4 > PT || PT % (d->U / 4)) return false;
-  const int NG = PT / (d->U / 4), per = (d->Te + S - 1) / S;
-  if ((per + NG - 1) / NG > PFR) return false;
-  if (d->kind == 1 && d->F > PNF) return false;
-  return true;
+// attn_param_grads_kernel has its own frame partition: enough slices that a thread keeps at most 4 frames (more, smaller
+// workgroups balance utterances of different lengths better), at most 16
+static int attn_defer_slices(const nabu_attn_desc *d) {
+  if (d->U % 4 || d->U / 4 > PT || PT % (d->U / 4)) return 0;
+  if (d->kind == 1 && d->F > PNF) return 0;
+  const int NG = PT / (d->U / 4);
+  int S = (d->Te + 4 * NG - 1) / (4 * NG);
+  if (S < 1) S = 1;
+  if (S > 16) S = 16;
+  const int per = (d->Te + S - 1) / S;
+  return (per + NG - 1) / NG <= 8 ? S : 0;
 }
 static int attn_param_grads(const nabu_attn_desc *d, int S, int L, const int32_t *dec_len, const int32_t *enc_len,
                             const float *keys, const float *q_all, const float *v, const float *wf, const float *ds_all,
                             const float *cf_all, float *dkeys, float *dv_part, float *dwf_part, hipStream_t s) {
   const int per = (d->Te + S - 1) / S, NG = PT / (d->U / 4);
-  const size_t shm = (((size_t)per + 3) / 4 * 4 + ((size_t)per * (d->kind == 1 ? d->F : 0) + 3) / 4 * 4 + (size_t)NG * d->U + 4) * sizeof(float);
-  auto kern = d->kind == 1 ? attn_param_grads_kernel<true> : attn_param_grads_kernel<false>;
+  const size_t shm = (PSB * (((size_t)per + 3) / 4 * 4 + ((size_t)per * (d->kind == 1 ? d->F : 0) + 3) / 4 * 4) + (size_t)NG * d->U + 4) * sizeof(float);
+  const bool four = (per + NG - 1) / NG <= 4;
+  auto kern = d->kind == 1 ? (four ? attn_param_grads_kernel<true, 4> : attn_param_grads_kernel<true, 8>)
+                           : (four ? attn_param_grads_kernel<false, 4> : attn_param_grads_kernel<false, 8>);
   if (shm > 64 * 1024)
     NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   hipLaunchKernelGGL(kern, dim3(d->B, S), dim3(PT), shm, s, d->B, d->Te, d->U, d->kind == 1 ? d->F : 0, L, dec_len, enc_len,
@@ -1384,6 +1410,7 @@ struct SpWs {
   size_t status, persist, persist_bytes;   // persistent decoder kernel: status word (ws[0]), XCC table + exchange rings
   size_t dv8;                              // its d attention_v partial rows [B*8, U]
   size_t ds_all, cf_all;                   // deferred attention gradients: d scores [L,B,Te], location features [L,B,Te,F]
+  size_t dv16, dwf16;                      // ... and the partial rows of attn_param_grads_kernel [B*Sp, U], [B*Sp, F*U]
   // the decoder steps run as NS independent sub-batches on NS streams: per sub-batch slices of
   // the scratch that a step's kernels share
   int NS, S;               // sub-batches; attention-backward slices per utterance (of a sub-batch)
@@ -1490,6 +1517,8 @@ static SpWs sp_ws(const nabu_speller_desc *d) {
     s.dv8 = take(speller_persist_bwd_ws_bytes(pd) ? B * 8 * U : 0);
     s.ds_all = take(L * B * Te);
     s.cf_all = take(d->kind == 1 ? L * B * Te * F : 0);
+    s.dv16 = take(B * 16 * U);
+    s.dwf16 = take(d->kind == 1 ? B * 16 * F * U : 0);
   }
   s.z_each = Bn * 4 * U;
   s.z = take(B * 4 * U);
@@ -1542,7 +1571,7 @@ static SpWs sp_ws(const nabu_speller_desc *d) {
   mx(nabu_gemm_ws_bytes(BL, (int)U, (int)C)); mx(nabu_gemm_ws_bytes(BL, (int)E, (int)C));
   mx(nabu_gemm_ws_bytes((int)U, (int)U, BL)); mx(nabu_gemm_ws_bytes((int)E, (int)(4 * U), BL));
   mx(nabu_gemm_ws_bytes((int)U, (int)(4 * U), BL)); mx(nabu_gemm_ws_bytes((int)Te, (int)E, (int)L));
-  mx(nabu_colsum_ws_bytes(BL, (int)(4 * U))); mx(nabu_colsum_ws_bytes((int)(B * 8), (int)(F * U + K * F + U)));
+  mx(nabu_colsum_ws_bytes(BL, (int)(4 * U))); mx(nabu_colsum_ws_bytes((int)(B * 16), (int)(F * U + K * F + U)));
   s.gemm_bytes = (g + 255) / 256 * 256;
   s.gemm_each = s.gemm_bytes / 4 + 4;
   s.gemm = take(NS * s.gemm_each);
@@ -1827,7 +1856,10 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
     SP_TRY(sub_fork(ss));
   }
   // d keys / d attention_v / d conv_proj of all steps in ONE launch after the chain (attn_param_grads_kernel)
-  const bool defer = !persist && env_int("NABU_SPELLER_DEFER", 1) && attn_defer_ok(&adn, S);
+  nabu_attn_desc adb = adn;      // the whole batch
+  adb.B = B;
+  const int Sp = (!persist && env_int("NABU_SPELLER_DEFER", 1)) ? attn_defer_slices(&adb) : 0;
+  const bool defer = Sp > 0;
   unsigned *atk = env_int("NABU_SPELLER_ATTN_FUSED", 1) ? reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)NS * 1024 : nullptr;
   auto bwd_chain = [&](int sub) -> int {
   int cur = 0;   // index of the carries coming from step t+1
@@ -1932,13 +1964,9 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   SP_TRY(run_subs(NS, bwd_chain));
   SP_TRY(sub_join(ss));
   }
-  if (defer) {
-    // every sub-batch has the same slice partition (S slices of ceil(Te/S) frames): one launch over the whole batch
-    nabu_attn_desc adb = adn;
-    adb.B = B;
-    SP_TRY(attn_param_grads(&adb, S, L, dec_len, enc_len, r + R.keys, r + R.q, p->attention_v, p->conv_proj, w + W.ds_all,
-                            w + W.cf_all, dkeys, w + W.dv, w + W.dwf, s));
-  }
+  if (defer)
+    SP_TRY(attn_param_grads(&adb, Sp, L, dec_len, enc_len, r + R.keys, r + R.q, p->attention_v, p->conv_proj, w + W.ds_all,
+                            w + W.cf_all, dkeys, w + W.dv16, w + W.dwf16, s));
   // sums over steps as single GEMMs
   SP_TRY(mm(true, false, U, U, BL, htop_all, U, dq, U, 0.f, g->query_kernel, U, nullptr, gw, gwb, stream));
   for (int n = 0; n < nl; ++n) {
@@ -1954,10 +1982,12 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
     }
     SP_TRY(nabu_colsum_f32(BL, 4 * U, dzn, 4 * U, 0.f, g->lstm_bias[n], gw, gwb, stream));
   }
-  if (persist) SP_TRY(nabu_colsum_f32(B * 8, U, w + W.dv8, U, 0.f, g->attention_v, gw, gwb, stream));
-  else         SP_TRY(nabu_colsum_f32(B * S, U, w + W.dv, U, 0.f, g->attention_v, gw, gwb, stream));
+  if (persist)    SP_TRY(nabu_colsum_f32(B * 8, U, w + W.dv8, U, 0.f, g->attention_v, gw, gwb, stream));
+  else if (defer) SP_TRY(nabu_colsum_f32(B * Sp, U, w + W.dv16, U, 0.f, g->attention_v, gw, gwb, stream));
+  else            SP_TRY(nabu_colsum_f32(B * S, U, w + W.dv, U, 0.f, g->attention_v, gw, gwb, stream));
   if (d->kind == 1) {
-    SP_TRY(nabu_colsum_f32(B * S, F * U, w + W.dwf, F * U, 0.f, g->conv_proj, gw, gwb, stream));
+    if (defer) SP_TRY(nabu_colsum_f32(B * Sp, F * U, w + W.dwf16, F * U, 0.f, g->conv_proj, gw, gwb, stream));
+    else       SP_TRY(nabu_colsum_f32(B * S, F * U, w + W.dwf, F * U, 0.f, g->conv_proj, gw, gwb, stream));
     SP_TRY(nabu_colsum_f32(B, K * F, w + W.dck, K * F, 0.f, g->conv_kernel, gw, gwb, stream));
   }
   // keys = values·Wmem ; context_t = align_t^T·values
