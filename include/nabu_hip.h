@@ -115,6 +115,50 @@ int nabu_gemm_bf16_nt(int M, int N, int K, float alpha, const void *A_bf16, int 
                       float beta, float *C, int ldc, const float *bias, void *ws, size_t ws_bytes,
                       nabu_stream_t stream);
 
+/* PACKED bf16-plane operands (gemm_pk.hip) — the time-batched input-to-hidden products and their
+ * gradients on the bf16 matrix pipe at fp32-equivalent accuracy ("bf16x6", planes = 3) or in plain bf16
+ * (planes = 1, BASELINE.json configs[4]).  An fp32 operand is converted ONCE per use-site into
+ *     packed[kb][plane][row][16 k]   bf16; row = the operand's M (A) or N (B) index, padded to a multiple
+ *                                    of 256 (nabu_pk_rows_pad); kb = k / 16, padded with zero blocks to
+ *                                    nabu_pk_kblocks(K, planes); within a row's 32 bytes the two 16-byte
+ *                                    halves are swapped when bit 3 of the row index is set;
+ *     planes = 3: x = h + m + l with h = rne_bf16(x), m = rne_bf16(x - h), l = x - h - m (exact: the three
+ *                 8-bit significands hold the 24 bits of x);  planes = 1: h only.
+ * nabu_pk_pack writes one source matrix into a packed operand: rows [row_off, row_off + fill_rows) and
+ * k-blocks [kb_off, kb_off + fill_kb), zeros where the source (R x C valid elements, row stride ld) ends.
+ *   transposed = 0: packed row = source row, k = source column (fill_rows over R, fill_kb over ceil(C/16));
+ *   transposed = 1: packed row = source column, k = source row (fill_rows over C, fill_kb over ceil(R/16));
+ *                   with period > 0 the value at reduction index r is source row r + shift when
+ *                   0 <= r % period + shift < period and 0 otherwise (the h_{t-1}^T·dz_t pairs of the
+ *                   recurrent weight gradient: period = T, shift = -1 / +1 for the forward / backward cell).
+ * nabu_gemm_pk: C_b[M,N] = alpha * sum_k A_b[m,k]·B_b[n,k] + beta*C_b + bias[n] for b < nbatch (<= 2), fp32
+ * result; planes = 3 adds the six plane products h·h, h·m, m·h, m·m, h·l, l·h (v_mfma_f32_32x32x16_bf16, fp32
+ * accumulation).  Columns n >= n_split (a multiple of 256, 0 = off) are written to C2_b[m, n - n_split] with
+ * bias2 — one product fills the gate buffers of both directions.  Deterministic split-K through ws.
+ * An operand packed with 3 planes can be used by a planes = 1 product (a_planes / b_planes = planes stored).
+ * Replaces: the tf MatMul of LayerNormBasicLSTMCell._linear over all frames and its autodiff
+ * (nabu/neuralnetworks/components/layer.py:35-47, nabu/neuralnetworks/trainers/trainer.py:556-558). */
+typedef struct nabu_pk_gemm_desc {
+  uint32_t size;          /* = sizeof(nabu_pk_gemm_desc) */
+  int32_t planes;         /* 3 = bf16x6 (fp32-equivalent), 1 = bf16 */
+  int32_t M, N, nkb;      /* output size per batch entry; k-blocks of 16 to reduce over */
+  int32_t nbatch;         /* 1 or 2 independent products in one launch */
+  const void *A[2], *B[2];/* packed operands (first k-block of the reduction) */
+  int32_t a_rows_pad, b_rows_pad, a_planes, b_planes;
+  float *C[2], *C2[2];
+  int32_t ldc, n_split;
+  const float *bias, *bias2;
+  float alpha, beta;
+} nabu_pk_gemm_desc;
+int nabu_pk_rows_pad(int rows);
+int nabu_pk_kblocks(int K, int planes);
+size_t nabu_pk_bytes(int rows, int K, int planes);
+int nabu_pk_pack(int planes, int transposed, const float *src, long long ld, int R, int C, void *dst,
+                 int dst_rows_pad, int row_off, int kb_off, int fill_rows, int fill_kb, int period,
+                 int shift, nabu_stream_t stream);
+size_t nabu_gemm_pk_ws_bytes(const nabu_pk_gemm_desc *d);
+int nabu_gemm_pk(const nabu_pk_gemm_desc *d, void *ws, size_t ws_bytes, nabu_stream_t stream);
+
 /* out[n] = beta*out[n] + sum_m A[m*lda + n]  (bias gradients; deterministic
  * two-stage tree).  ws >= nabu_colsum_ws_bytes(M,N). */
 size_t nabu_colsum_ws_bytes(int M, int N);

@@ -21,6 +21,15 @@ class BlstmDesc(_c.Structure):
                 ('gemm_precision', _c.c_int32)]
 
 
+class PkGemmDesc(_c.Structure):
+    _fields_ = [('size', _c.c_uint32), ('planes', _c.c_int32), ('M', _c.c_int32), ('N', _c.c_int32),
+                ('nkb', _c.c_int32), ('nbatch', _c.c_int32), ('A', _c.c_void_p * 2), ('B', _c.c_void_p * 2),
+                ('a_rows_pad', _c.c_int32), ('b_rows_pad', _c.c_int32), ('a_planes', _c.c_int32),
+                ('b_planes', _c.c_int32), ('C', _c.c_void_p * 2), ('C2', _c.c_void_p * 2),
+                ('ldc', _c.c_int32), ('n_split', _c.c_int32), ('bias', _c.c_void_p), ('bias2', _c.c_void_p),
+                ('alpha', _c.c_float), ('beta', _c.c_float)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/nabu_hip.h
 SIGNATURES = {
     'nabu_version': (_i, []),
@@ -35,6 +44,12 @@ SIGNATURES = {
     'nabu_cvt_bf16': (_i, [_sz, _i, _vp, _i, _vp, _i, _i, _vp]),
     'nabu_gemm_bf16_nt_ws_bytes': (_sz, [_i, _i, _i]),
     'nabu_gemm_bf16_nt': (_i, [_i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i, _vp, _vp, _sz, _vp]),
+    'nabu_pk_rows_pad': (_i, [_i]),
+    'nabu_pk_kblocks': (_i, [_i, _i]),
+    'nabu_pk_bytes': (_sz, [_i, _i, _i]),
+    'nabu_pk_pack': (_i, [_i, _i, _vp, _ll, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'nabu_gemm_pk_ws_bytes': (_sz, [_c.POINTER(PkGemmDesc)]),
+    'nabu_gemm_pk': (_i, [_c.POINTER(PkGemmDesc), _vp, _sz, _vp]),
     'nabu_gemm_set_default_precision': (_i, [_i]),
     'nabu_gemm_get_default_precision': (_i, []),
     'nabu_colsum_ws_bytes': (_sz, [_i, _i]),

@@ -1,0 +1,641 @@
+// gemm_pk.hip — dense products on the bf16 matrix pipe over PACKED bf16-plane operands.
+//
+//   C[M,N] (fp32) = alpha * sum_k A[m,k] * B[n,k] + beta*C + bias[n]
+//
+// Two arithmetics on the same kernel (template parameter NP):
+//   NP = 3  "bf16x6": every fp32 operand value x is held as three bf16 planes x = h + m + l (h = rne(x),
+//           m = rne(x - h), l = x - h - m: the three significands hold all 24 bits of x, the split is exact),
+//           and a product is the six plane products h·h, h·m, m·h, m·m, h·l, l·h (what is dropped is below
+//           2^-26 |a||b| per term) on v_mfma_f32_32x32x16_bf16, the 16-k partial sums promoted to the fp32
+//           accumulators by the VALU (see PROMOTED ACCUMULATION in the kernel): fp32-equivalent results from
+//           the pipe that is 16 times faster than v_mfma_f32_32x32x2_f32;
+//   NP = 1  plain bf16 operands (plane h only), fp32 accumulation: BASELINE.json configs[4]'s "bf16 MFMA
+//           input-to-hidden GEMMs".
+//
+// Why packed operands.  Round 2's kernels either split fp32 operands inside the k-loop (gemm_bf16.hip:
+// 4-byte operand traffic and ~300 VALU instructions per tile on the critical path, 140-160 TF/s effective)
+// or used 128 x 128 tiles on row-major bf16 copies (gemm_bf16_pre.hip: 64 flop per operand byte, matrix pipe
+// 27 % busy, every operand panel fetched ~5 times).  Here every operand is converted ONCE per use-site into
+// the layout the tile loop wants (pack kernels below, HBM-streaming, ~10 bytes of traffic per element):
+//
+//   packed[kb][plane][row][16 k]   bf16, row = the operand's M (resp. N) index padded to a multiple of 256,
+//                                  kb = k / 16; inside a row's 32 bytes the two 16-byte halves are swapped
+//                                  when bit 3 of the row index is set (LDS bank swizzle baked into memory).
+//
+// A 256-row tile of one (kb, plane) is then ONE contiguous 8 KiB piece of memory, and it is exactly the LDS
+// image the MFMA operand reads want: staging is a linear LDS-DMA copy (buffer_load_dwordx4 ... lds, 1 KiB per
+// wave instruction, no registers, no address arithmetic beyond a scalar add per stage, every byte of every
+// 128-byte line used), and the operand reads are conflict-free ds_read_b128 (row stride 32 B + the half swap:
+// the 16 lanes of a read group cover all 64 banks).
+//
+// Tile loop: 256 x 256 output tile per 512-thread workgroup (8 waves: 2 along M x 4 along N, each
+// 128 x 64 = 4 x 2 MFMA tiles, 128 accumulator registers), one workgroup per CU.  A STAGE is 6 pieces of
+// 8 KiB (NP = 3: one k-block of 16 x 3 planes x {A, B}; NP = 1: three k-blocks x {A, B}) = 48 KiB, ring of
+// three stages = 144 KiB of LDS.  The two waves of a SIMD run half a stage apart (waves 4-7 pass one extra
+// barrier at the start): while one is in its COMPUTE phase (48 / 24 back-to-back MFMAs = 1536 / 768 cycles,
+// no memory instruction at all) its partner is in its LOAD phase (issue the 6 LDS-DMA pieces of stage t+2,
+// 18 operand reads of stage t) — matrix beside memory on every SIMD, two barriers per stage.
+// LDS-DMA completion is counted by hand (s_waitcnt vmcnt(6): everything but the pieces just issued), the
+// loads are invisible to hipcc (inline asm, no destination registers), so no compiler wait ever drains them.
+// Ring discipline (t = stage, barrier numbering in the kernel):
+//   RAW  pieces of stage t+2 are issued in LOAD(t), waited for at the end of LOAD(t+1) by the issuing wave,
+//        which then passes a barrier before anybody reads them in LOAD(t+2);
+//   WAR  stage t+2 lands in the buffer of stage t-1, whose last reads (LOAD(t-1) of the late half) are
+//        retired (lgkmcnt(0)) before the barrier that precedes LOAD(t) of the early half.
+//
+// XCD-aware order: workgroup id -> XCD is id % 8; every XCD walks a contiguous range of the tile sequence,
+// which goes row-fastest through bands of 4 row tiles, so the 32 tiles in flight on an XCD are ~4 x 8 tiles
+// that share 12 operand panels in that XCD's L2 and move along k together.
+//
+// Replaces: the tf MatMul of the LSTM cell's input part and its autodiff, time-batched
+// (nabu/neuralnetworks/components/layer.py:35-47, nabu/neuralnetworks/trainers/trainer.py:556-558).
+#include "gemm_args.h"
+
+#include <stdlib.h>
+
+namespace nabu {
+
+typedef __bf16 kbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 kbf16x2 __attribute__((ext_vector_type(2)));
+typedef float kf32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned ku32x4 __attribute__((ext_vector_type(4)));
+typedef int ki32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PK_T = 256;               // tile edge (rows of A = M index, rows of B = N index)
+constexpr int PK_CH = PK_T * 32;        // one piece: 256 rows x 16 k x 2 bytes
+constexpr int PK_STAGE = 6 * PK_CH;     // 48 KiB
+constexpr int PK_LDS = 3 * PK_STAGE;    // 144 KiB
+constexpr int PK_GM = 4;                // row tiles per band of the tile order
+
+struct PkOp {
+  const char *base[2];        // per batch entry
+  unsigned long long kb_stride;   // bytes from k-block kb to kb+1 (= planes stored * rows_pad * 32)
+  unsigned plane_stride;          // rows_pad * 32
+};
+
+struct PkArgs {
+  PkOp A, B;
+  int M, N;                   // logical output size per batch entry
+  int tiles_m, tiles_n, nbatch;
+  int nkb;                    // k-blocks to reduce over (multiple of the stage's k-blocks)
+  int nsplit, kb_per_split;
+  float *C[2], *C2[2];        // per batch entry; columns >= n_split go to C2 (column n - n_split)
+  int ldc, n_split;
+  const float *bias, *bias2;  // bias2: columns >= n_split
+  float alpha, beta;
+  float *partial;             // [nsplit][nbatch][M][N] when nsplit > 1
+};
+
+__device__ __forceinline__ ki32x4 pk_rsrc(unsigned long long a) {
+  return (ki32x4){(int)(unsigned)a, (int)(unsigned)((a >> 32) & 0xFFFFu), -1, 0x00020000};
+}
+
+// six LDS-DMA pieces of one stage: 1 KiB per wave and piece.  m0 = LDS byte address of this wave's part of
+// piece 0 (pieces are PK_CH apart); voff = tid * 16; A pieces at soffsets 0, sa1, sa2 of ra, B pieces of rb.
+__device__ __forceinline__ void pk_stage_issue(unsigned m0, unsigned voff, ki32x4 ra, ki32x4 rb, unsigned sa1,
+                                               unsigned sa2, unsigned sb1, unsigned sb2) {
+  const unsigned m1 = m0 + PK_CH, m2 = m0 + 2 * PK_CH, m3 = m0 + 3 * PK_CH, m4 = m0 + 4 * PK_CH, m5 = m0 + 5 * PK_CH;
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %7, 0 offen lds\n\t"
+      "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %7, %9 offen lds\n\t"
+      "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %7, %10 offen lds\n\t"
+      "s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %8, 0 offen lds\n\t"
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %8, %11 offen lds\n\t"
+      "s_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %8, %12 offen lds"
+      :
+      : "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(m4), "s"(m5), "v"(voff), "s"(ra), "s"(rb), "s"(sa1), "s"(sa2),
+        "s"(sb1), "s"(sb2)
+      : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void pk_wait() {   // LDS-DMA pieces but the last N landed; operand reads retired
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void pk_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int NP, int VAR>
+__global__ __launch_bounds__(512) void gemm_pk_kernel(PkArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char pk_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = w >> 2, wn = w & 3;
+
+  // ---- work item of this workgroup: XCD-contiguous ranges of (split, batch, band, column, row) ----
+  const int total = gridDim.x, wg = blockIdx.x;
+  int t;
+  {
+    const int per = total / 8, rem = total % 8, xcd = wg % 8, local = wg / 8;
+    t = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + local;
+  }
+  const int per_batch = p.tiles_m * p.tiles_n, ntiles = per_batch * p.nbatch;
+  const int split = t / ntiles;
+  int tile = t - split * ntiles;
+  const int batch = tile / per_batch;
+  tile -= batch * per_batch;
+  const int band = PK_GM * p.tiles_n, g = tile / band, first = g * PK_GM;
+  const int rows = min(p.tiles_m - first, PK_GM), r = tile - g * band;
+  const int tm = first + r % rows, tn = r / rows;
+
+  const int kb0 = split * p.kb_per_split;
+  const int kbn = min(p.nkb, kb0 + p.kb_per_split) - kb0;
+  constexpr int KBS = NP == 3 ? 1 : 3;          // k-blocks per stage
+  const int nst = kbn / KBS;
+
+  unsigned long long pa = reinterpret_cast<unsigned long long>(p.A.base[batch]) + (unsigned long long)tm * PK_CH +
+                          (unsigned long long)kb0 * p.A.kb_stride;
+  unsigned long long pb = reinterpret_cast<unsigned long long>(p.B.base[batch]) + (unsigned long long)tn * PK_CH +
+                          (unsigned long long)kb0 * p.B.kb_stride;
+  const unsigned long long step_a = (unsigned long long)KBS * p.A.kb_stride, step_b = (unsigned long long)KBS * p.B.kb_stride;
+  const unsigned sa1 = NP == 3 ? p.A.plane_stride : (unsigned)p.A.kb_stride, sa2 = 2 * sa1;
+  const unsigned sb1 = NP == 3 ? p.B.plane_stride : (unsigned)p.B.kb_stride, sb2 = 2 * sb1;
+  const unsigned voff = (unsigned)tid * 16u;
+  const unsigned wbase = (unsigned)w * 1024u;     // this wave's part of a piece
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  f32x16 tpend = acc[0][0];   // promoted accumulation: the partial sum whose add is still owed (0 at the start)
+
+  // operand read offsets inside a stage: row (lane & 31) of a 32-row MFMA tile, half (lane >> 5) swapped by
+  // bit 3 of the row (tile bases are multiples of 32 rows, so bit 3 of the row is bit 3 of the lane)
+  const unsigned laneoff = (unsigned)(lane & 31) * 32u + (unsigned)(((lane >> 5) ^ ((lane >> 3) & 1)) * 16);
+  const unsigned offA = laneoff + (unsigned)grp * (128u * 32u);
+  const unsigned offB = laneoff + 3u * PK_CH + (unsigned)wn * (64u * 32u);
+
+  // ---- prologue: stages 0 and 1 ----
+  if (nst > 0) {
+    pk_stage_issue(wbase, voff, pk_rsrc(pa), pk_rsrc(pb), sa1, sa2, sb1, sb2);
+    pa += step_a; pb += step_b;
+  }
+  if (nst > 1) {
+    pk_stage_issue(PK_STAGE + wbase, voff, pk_rsrc(pa), pk_rsrc(pb), sa1, sa2, sb1, sb2);
+    pa += step_a; pb += step_b;
+    pk_wait<6>();
+  } else {
+    pk_wait<0>();
+  }
+  pk_barrier();                 // barrier 0: stage 0 visible
+  if (grp == 1) pk_barrier();   // the late half runs one barrier interval behind
+
+  unsigned so_rd = 0, so_wr = 2 * PK_STAGE;
+  for (int st = 0; st < nst; ++st) {
+    // -------- LOAD(st) --------
+    const bool more = st + 2 < nst;
+    if (more) {
+      pk_stage_issue(so_wr + wbase, voff, pk_rsrc(pa), pk_rsrc(pb), sa1, sa2, sb1, sb2);
+      pa += step_a; pb += step_b;
+    }
+    kbf16x8 fa[4][3], fb[2][3];
+    {
+      const char *sA = pk_smem + so_rd + offA, *sB = pk_smem + so_rd + offB;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i][q] = *reinterpret_cast<const kbf16x8 *>(sA + q * PK_CH + i * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j][q] = *reinterpret_cast<const kbf16x8 *>(sB + q * PK_CH + j * 1024);
+      }
+    }
+    if (more) pk_wait<6>(); else pk_wait<0>();
+    pk_barrier();
+    // -------- COMPUTE(st) --------
+    __builtin_amdgcn_s_setprio(1);
+    if (NP == 3 && VAR == 0) {
+      // direct accumulation (kept for A/B measurements: NABU_PK_VAR=0)
+#define PK_PROD(qa, qb)                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][qa], fb[j][qb], acc[i][j], 0, 0, 0);
+      PK_PROD(2, 0) PK_PROD(0, 2) PK_PROD(1, 1) PK_PROD(1, 0) PK_PROD(0, 1) PK_PROD(0, 0)
+#undef PK_PROD
+    } else if (NP == 3 && VAR == 3) {
+      // direct accumulation, the six products of a tile back to back on the same accumulator (measures the
+      // dependent-issue cost of the matrix pipe: NABU_PK_VAR=3)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+        }
+    } else if (NP == 3) {
+      // PROMOTED ACCUMULATION.  The six plane products of one (tile, k-block) are chained in a scratch
+      // accumulator that starts at 0 (smallest terms first), and the finished 16-k partial sum is added to the
+      // tile's accumulator by the VALU: one RNE rounding at the accumulator's magnitude per 16 k, where the
+      // exact-fp32 kernel's fma chain has 16 and a direct MFMA chain 6 (each with the matrix pipe's own
+      // rounding).  Two scratch tiles rotate: the 16 adds of tile n are issued in the gaps between the MFMAs
+      // of tile n+1 (a wave issues ~5 independent instructions under one 32-cycle MFMA); the last tile's adds
+      // wait for the first chain of the NEXT stage (tpend is carried across the stage boundary).
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f32x16 t0;
+#define PK_CHAIN(T, i, j)                                                                   \
+  T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], zero, 0, 0, 0);            \
+  T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], T, 0, 0, 0);               \
+  T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], T, 0, 0, 0);               \
+  T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], T, 0, 0, 0);               \
+  T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], T, 0, 0, 0);               \
+  T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], T, 0, 0, 0);
+      const f32x16 tprev = tpend;
+      PK_CHAIN(t0, 0, 0) acc[3][1] += tprev;
+      PK_CHAIN(tpend, 0, 1) acc[0][0] += t0;
+      PK_CHAIN(t0, 1, 0) acc[0][1] += tpend;
+      PK_CHAIN(tpend, 1, 1) acc[1][0] += t0;
+      PK_CHAIN(t0, 2, 0) acc[1][1] += tpend;
+      PK_CHAIN(tpend, 2, 1) acc[2][0] += t0;
+      PK_CHAIN(t0, 3, 0) acc[2][1] += tpend;
+      PK_CHAIN(tpend, 3, 1) acc[3][0] += t0;
+#undef PK_CHAIN
+    } else {
+#define PK_PROD(qa, qb)                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][qa], fb[j][qb], acc[i][j], 0, 0, 0);
+      PK_PROD(0, 0) PK_PROD(1, 1) PK_PROD(2, 2)
+#undef PK_PROD
+    }
+    __builtin_amdgcn_s_setprio(0);
+    pk_barrier();
+    so_rd = so_rd == 2 * PK_STAGE ? 0 : so_rd + PK_STAGE;
+    so_wr = so_wr == 2 * PK_STAGE ? 0 : so_wr + PK_STAGE;
+  }
+  if (grp == 0) pk_barrier();
+  if (NP == 3 && VAR == 1) acc[3][1] += tpend;
+
+  // ---- epilogue: MFMA C layout: column lane & 31, rows (q & 3) + 8 (q >> 2) + 4 (lane >> 5) ----
+  const int col = lane & 31, rbase = 4 * (lane >> 5);
+  const int m_t = tm * PK_T + grp * 128, n_t = tn * PK_T + wn * 64;
+  if (p.nsplit == 1) {
+    float *Cb = p.C[batch];
+    const float *bias = p.bias;
+    int n_off = 0;
+    if (p.n_split > 0 && n_t >= p.n_split) { Cb = p.C2[batch]; bias = p.bias2; n_off = p.n_split; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n_t + j * 32 + col;
+      if (n >= p.N) continue;
+      const float bv = bias ? bias[n - n_off] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int m = m_t + i * 32 + (q & 3) + 8 * (q >> 2) + rbase;
+          if (m >= p.M) continue;
+          float *c = Cb + (size_t)m * p.ldc + (n - n_off);
+          float v = p.alpha * acc[i][j][q] + bv;
+          if (p.beta != 0.f) v += p.beta * *c;
+          *c = v;
+        }
+    }
+  } else {
+    float *P = p.partial + ((size_t)split * p.nbatch + batch) * (size_t)p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n_t + j * 32 + col;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int m = m_t + i * 32 + (q & 3) + 8 * (q >> 2) + rbase;
+          if (m >= p.M) continue;
+          P[(size_t)m * p.N + n] = acc[i][j][q];
+        }
+    }
+  }
+}
+
+// split-K: fixed-order sum of the partial slabs, then the same epilogue as above
+__global__ __launch_bounds__(256) void gemm_pk_reduce_kernel(PkArgs p) {
+  const size_t per = (size_t)p.M * p.N, total = per * p.nbatch, n4 = total / 4;   // N % 4 == 0 (checked by the host)
+  for (size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x; i4 < n4; i4 += (size_t)gridDim.x * 256) {
+    const size_t i = i4 * 4;
+    const int batch = (int)(i / per);
+    const size_t e = i - (size_t)batch * per;
+    const int m = (int)(e / p.N), n = (int)(e % p.N);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < p.nsplit; ++z) {
+      const float4 v = *reinterpret_cast<const float4 *>(p.partial + (size_t)z * total + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float *Cb = p.C[batch];
+    const float *bias = p.bias;
+    int n_off = 0;
+    if (p.n_split > 0 && n >= p.n_split) { Cb = p.C2[batch]; bias = p.bias2; n_off = p.n_split; }
+    float *c = Cb + (size_t)m * p.ldc + (n - n_off);
+    float4 o = make_float4(p.alpha * s.x, p.alpha * s.y, p.alpha * s.z, p.alpha * s.w);
+    if (bias) {
+      const float4 b = *reinterpret_cast<const float4 *>(bias + n - n_off);
+      o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+    }
+    if (p.beta != 0.f) {
+      const float4 old = *reinterpret_cast<const float4 *>(c);
+      o.x += p.beta * old.x; o.y += p.beta * old.y; o.z += p.beta * old.z; o.w += p.beta * old.w;
+    }
+    *reinterpret_cast<float4 *>(c) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pack kernels: fp32 -> bf16 planes in the layout above.
+__device__ __forceinline__ unsigned pk_cvt2(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((kf32x2){a, b}, kbf16x2));
+}
+__device__ __forceinline__ float pk_hi(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float pk_lo(unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
+
+// 16 consecutive k of one packed row -> NP planes of 32 bytes (halves swapped when bit 3 of the row is set)
+template <int NP>
+__device__ __forceinline__ void pk_split_store(const float *x, char *dst, unsigned plane_stride, int row) {
+  unsigned h[8], m[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float a = x[2 * i], b = x[2 * i + 1];
+    h[i] = pk_cvt2(a, b);
+    if (NP == 3) {
+      const float ra = a - pk_hi(h[i]), rb = b - pk_lo(h[i]);     // exact
+      m[i] = pk_cvt2(ra, rb);
+      l[i] = pk_cvt2(ra - pk_hi(m[i]), rb - pk_lo(m[i]));          // exact, fits 8 bits
+    }
+  }
+  const int sw = (row >> 3) & 1;
+  ku32x4 *d = reinterpret_cast<ku32x4 *>(dst);
+  d[sw] = (ku32x4){h[0], h[1], h[2], h[3]};
+  d[sw ^ 1] = (ku32x4){h[4], h[5], h[6], h[7]};
+  if (NP == 3) {
+    ku32x4 *d1 = reinterpret_cast<ku32x4 *>(dst + plane_stride), *d2 = reinterpret_cast<ku32x4 *>(dst + 2 * (size_t)plane_stride);
+    d1[sw] = (ku32x4){m[0], m[1], m[2], m[3]};
+    d1[sw ^ 1] = (ku32x4){m[4], m[5], m[6], m[7]};
+    d2[sw] = (ku32x4){l[0], l[1], l[2], l[3]};
+    d2[sw ^ 1] = (ku32x4){l[4], l[5], l[6], l[7]};
+  }
+}
+
+struct PackArgs {
+  const float *src;
+  long long ld;
+  int R, C;                   // valid source rows / columns
+  int fill_rows, fill_kb;     // packed rows / k-blocks written (zeros beyond the source)
+  char *dst;                  // packed buffer
+  unsigned long long kb_stride;
+  unsigned plane_stride;
+  int row_off, kb_off;        // where this matrix sits in the packed operand
+  int period, shift;          // transposed form: source row of reduction index r is r + shift when
+                              // 0 <= r % period + shift < period, else the value is 0 (period 0: no shift)
+};
+
+// reduction index contiguous in the source: packed row = source row, k = source column.
+// grid (ceil(fill_kb / 4), ceil(fill_rows / 64)), 256 threads: a 64 x 64 tile through LDS
+template <int NP>
+__global__ __launch_bounds__(256) void pk_pack_rows_kernel(PackArgs a) {
+  __shared__ __attribute__((aligned(16))) float tile[64][68];
+  const int tid = threadIdx.x, r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + 256 * j, r = i >> 4, c4 = (i & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < a.R) {
+      const float *s = a.src + (size_t)(r0 + r) * a.ld + c0 + c4;
+      if (c0 + c4 + 3 < a.C) v = *reinterpret_cast<const float4 *>(s);
+      else {
+        if (c0 + c4 < a.C) v.x = s[0];
+        if (c0 + c4 + 1 < a.C) v.y = s[1];
+        if (c0 + c4 + 2 < a.C) v.z = s[2];
+      }
+    }
+    *reinterpret_cast<float4 *>(&tile[r][c4]) = v;
+  }
+  __syncthreads();
+  const int r = tid & 63, kbl = tid >> 6;
+  const int row = r0 + r, kb = blockIdx.x * 4 + kbl;
+  if (row >= a.fill_rows || kb >= a.fill_kb) return;
+  float x[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 v = *reinterpret_cast<const float4 *>(&tile[r][kbl * 16 + 4 * i]);
+    x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+  }
+  const int prow = a.row_off + row;
+  pk_split_store<NP>(x, a.dst + (size_t)(a.kb_off + kb) * a.kb_stride + (size_t)prow * 32, a.plane_stride, prow);
+}
+
+// reduction index = source ROW: packed row = source column, k = source row (transposed copy).
+// grid (ceil(fill_rows / 64) over source columns, ceil(fill_kb / 4) over source rows)
+template <int NP>
+__global__ __launch_bounds__(256) void pk_pack_cols_kernel(PackArgs a) {
+  __shared__ float tile[64][65];
+  const int tid = threadIdx.x, c0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + 256 * j, kk = i >> 4, c4 = (i & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    long long sr = (long long)k0 + kk;
+    bool ok = sr < a.R;
+    if (a.period > 0) {
+      const int ph = (int)(sr % a.period) + a.shift;
+      ok = ok && ph >= 0 && ph < a.period;
+      sr += a.shift;
+    }
+    if (ok) {
+      const float *s = a.src + (size_t)sr * a.ld + c0 + c4;
+      if (c0 + c4 + 3 < a.C) v = *reinterpret_cast<const float4 *>(s);
+      else {
+        if (c0 + c4 < a.C) v.x = s[0];
+        if (c0 + c4 + 1 < a.C) v.y = s[1];
+        if (c0 + c4 + 2 < a.C) v.z = s[2];
+      }
+    }
+    tile[kk][c4] = v.x; tile[kk][c4 + 1] = v.y; tile[kk][c4 + 2] = v.z; tile[kk][c4 + 3] = v.w;
+  }
+  __syncthreads();
+  const int c = tid & 63, kbl = tid >> 6;
+  const int row = c0 + c, kb = blockIdx.y * 4 + kbl;
+  if (row >= a.fill_rows || kb >= a.fill_kb) return;
+  float x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = tile[kbl * 16 + i][c];
+  const int prow = a.row_off + row;
+  pk_split_store<NP>(x, a.dst + (size_t)(a.kb_off + kb) * a.kb_stride + (size_t)prow * 32, a.plane_stride, prow);
+}
+
+static int pk_cu_count() {
+  static thread_local int cached_dev = -1, cached = 256;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+  if (dev != cached_dev) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) {
+      (void)hipGetLastError();
+      v = 256;
+    }
+    cached = v;
+    cached_dev = dev;
+  }
+  return cached;
+}
+
+// split-K policy: one workgroup per CU; with few output tiles cut the reduction so that the number of
+// workgroups comes close to a multiple of the CU count (>= 24 stages per workgroup)
+static int pk_choose_split(int ntiles, int nkb, int kbs, int *kb_per_split) {
+  const int ncu = pk_cu_count(), nst = nkb / kbs;
+  int best = 1;
+  double best_eff = 0.0;
+  const int maxs = nst / 24 < 1 ? 1 : (nst / 24 > 32 ? 32 : nst / 24);
+  for (int s = 1; s <= maxs; ++s) {
+    const int per = (nst + s - 1) / s, ns = (nst + per - 1) / per;
+    if (ns != s) continue;
+    const long long wgs = (long long)ntiles * ns, rounds = (wgs + ncu - 1) / ncu;
+    double eff = (double)ntiles * nst / ((double)rounds * ncu * per);   // useful stages / stage slots
+    eff -= 0.01 * (ns - 1);                                             // the reduce pass is not free
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = ns; }
+  }
+  const int per = (nst + best - 1) / best;
+  *kb_per_split = per * kbs;
+  return (nst + per - 1) / per;
+}
+
+}  // namespace nabu
+
+using namespace nabu;
+
+extern "C" int nabu_pk_rows_pad(int rows) { return (rows + PK_T - 1) / PK_T * PK_T; }
+extern "C" int nabu_pk_kblocks(int K, int planes) {
+  const int kbs = planes == 3 ? 1 : 3, nkb = (K + 15) / 16;
+  return (nkb + kbs - 1) / kbs * kbs;
+}
+extern "C" size_t nabu_pk_bytes(int rows, int K, int planes) {
+  if (rows <= 0 || K <= 0 || (planes != 1 && planes != 3)) return 0;
+  return (size_t)nabu_pk_kblocks(K, planes) * planes * nabu_pk_rows_pad(rows) * 32;
+}
+
+extern "C" int nabu_pk_pack(int planes, int transposed, const float *src, long long ld, int R, int C, void *dst,
+                            int dst_rows_pad, int row_off, int kb_off, int fill_rows, int fill_kb, int period,
+                            int shift, nabu_stream_t stream) {
+  NABU_CHECK_ARG(planes == 1 || planes == 3, "pk_pack: planes must be 1 or 3");
+  NABU_CHECK_ARG(src && dst && R >= 0 && C >= 0 && ld >= 0, "pk_pack: bad source");
+  NABU_CHECK_ARG(dst_rows_pad > 0 && dst_rows_pad % PK_T == 0 && row_off >= 0 && kb_off >= 0 && fill_rows >= 0 &&
+                     fill_kb >= 0 && row_off + fill_rows <= dst_rows_pad,
+                 "pk_pack: bad destination geometry");
+  if (ld % 4 || (reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 15))
+    return fail(NABU_EUNSUP, "pk_pack: source rows and both buffers must be 16-byte aligned");
+  if (fill_rows == 0 || fill_kb == 0) return 0;
+  PackArgs a;
+  a.src = src; a.ld = ld; a.R = R; a.C = C; a.fill_rows = fill_rows; a.fill_kb = fill_kb;
+  a.dst = static_cast<char *>(dst);
+  a.plane_stride = (unsigned)dst_rows_pad * 32u;
+  a.kb_stride = (unsigned long long)planes * a.plane_stride;
+  a.row_off = row_off; a.kb_off = kb_off; a.period = period; a.shift = shift;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!transposed) {
+    NABU_CHECK_ARG(period == 0, "pk_pack: shift only in the transposed form");
+    const dim3 grid((fill_kb + 3) / 4, (fill_rows + 63) / 64);
+    if (planes == 3) hipLaunchKernelGGL(pk_pack_rows_kernel<3>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(pk_pack_rows_kernel<1>, grid, dim3(256), 0, s, a);
+  } else {
+    const dim3 grid((fill_rows + 63) / 64, (fill_kb + 3) / 4);
+    if (planes == 3) hipLaunchKernelGGL(pk_pack_cols_kernel<3>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(pk_pack_cols_kernel<1>, grid, dim3(256), 0, s, a);
+  }
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+static int pk_fill(PkArgs &p, const nabu_pk_gemm_desc *d, int *planes) {
+  if (!d || d->size != sizeof(nabu_pk_gemm_desc)) return fail(NABU_EINVAL, "gemm_pk: bad descriptor size");
+  *planes = d->planes;
+  if (d->planes != 1 && d->planes != 3) return fail(NABU_EINVAL, "gemm_pk: planes must be 1 or 3");
+  if (d->M <= 0 || d->N <= 0 || d->nkb <= 0 || d->nbatch < 1 || d->nbatch > 2)
+    return fail(NABU_EINVAL, "gemm_pk: bad dimensions");
+  const int kbs = d->planes == 3 ? 1 : 3;
+  if (d->nkb % kbs) return fail(NABU_EINVAL, "gemm_pk: nkb must be a multiple of %d", kbs);
+  if (d->a_rows_pad % PK_T || d->b_rows_pad % PK_T || d->a_rows_pad < nabu_pk_rows_pad(d->M) ||
+      d->b_rows_pad < nabu_pk_rows_pad(d->N))
+    return fail(NABU_EINVAL, "gemm_pk: packed row counts must be multiples of 256 covering M and N");
+  if (d->a_planes < d->planes || d->b_planes < d->planes)
+    return fail(NABU_EINVAL, "gemm_pk: operand holds fewer planes than the product needs");
+  if (d->n_split && (d->n_split % PK_T || !d->C2[0])) return fail(NABU_EINVAL, "gemm_pk: n_split must be a multiple of 256 with C2 set");
+  if (d->N % 4 || d->ldc % 4) return fail(NABU_EUNSUP, "gemm_pk: N and ldc must be multiples of 4");
+  for (int b = 0; b < d->nbatch; ++b)
+    if (!d->A[b] || !d->B[b] || !d->C[b]) return fail(NABU_EINVAL, "gemm_pk: null pointer");
+  p.A.plane_stride = (unsigned)d->a_rows_pad * 32u;
+  p.A.kb_stride = (unsigned long long)d->a_planes * p.A.plane_stride;
+  p.B.plane_stride = (unsigned)d->b_rows_pad * 32u;
+  p.B.kb_stride = (unsigned long long)d->b_planes * p.B.plane_stride;
+  if (2 * (unsigned long long)(d->planes == 3 ? p.A.plane_stride : p.A.kb_stride) >= (1ull << 32) ||
+      2 * (unsigned long long)(d->planes == 3 ? p.B.plane_stride : p.B.kb_stride) >= (1ull << 32))
+    return fail(NABU_EUNSUP, "gemm_pk: operand too tall for 32-bit piece offsets");
+  for (int b = 0; b < 2; ++b) {
+    const int s = b < d->nbatch ? b : 0;
+    p.A.base[b] = static_cast<const char *>(d->A[s]);
+    p.B.base[b] = static_cast<const char *>(d->B[s]);
+    p.C[b] = d->C[s];
+    p.C2[b] = d->C2[s];
+  }
+  p.M = d->M; p.N = d->N;
+  p.tiles_m = (d->M + PK_T - 1) / PK_T; p.tiles_n = (d->N + PK_T - 1) / PK_T; p.nbatch = d->nbatch;
+  p.nkb = d->nkb;
+  p.ldc = d->ldc; p.n_split = d->n_split; p.bias = d->bias; p.bias2 = d->bias2;
+  p.alpha = d->alpha; p.beta = d->beta; p.partial = nullptr;
+  static int force = -2;
+  if (force == -2) { const char *e = getenv("NABU_PK_SPLIT"); force = e ? atoi(e) : -1; }
+  p.nsplit = pk_choose_split(p.tiles_m * p.tiles_n * p.nbatch, p.nkb, kbs, &p.kb_per_split);
+  if (force > 0) {
+    const int nst = p.nkb / kbs, per = (nst + force - 1) / force;
+    p.kb_per_split = per * kbs;
+    p.nsplit = (nst + per - 1) / per;
+  }
+  return 0;
+}
+
+extern "C" size_t nabu_gemm_pk_ws_bytes(const nabu_pk_gemm_desc *d) {
+  PkArgs p;
+  int planes;
+  if (pk_fill(p, d, &planes)) return 0;
+  return p.nsplit > 1 ? (size_t)p.nsplit * p.nbatch * p.M * p.N * sizeof(float) : 0;
+}
+
+extern "C" int nabu_gemm_pk(const nabu_pk_gemm_desc *d, void *ws, size_t ws_bytes, nabu_stream_t stream) {
+  PkArgs p;
+  int planes;
+  if (int e = pk_fill(p, d, &planes)) return e;
+  if (p.nsplit > 1) {
+    const size_t need = (size_t)p.nsplit * p.nbatch * p.M * p.N * sizeof(float);
+    if (!ws || ws_bytes < need) return fail(NABU_EWS, "gemm_pk: workspace %zu < %zu", ws_bytes, need);
+    p.partial = static_cast<float *>(ws);
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  static int var = -1;
+  if (var < 0) { const char *e = getenv("NABU_PK_VAR"); var = e ? atoi(e) : 1; }
+  const int grid = p.tiles_m * p.tiles_n * p.nbatch * p.nsplit;
+#define PK_LAUNCH(NP_, VAR_)                                                                                         \
+  {                                                                                                                   \
+    NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pk_kernel<NP_, VAR_>),                           \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, PK_LDS));                                \
+    hipLaunchKernelGGL((gemm_pk_kernel<NP_, VAR_>), dim3(grid), dim3(512), PK_LDS, s, p);                              \
+  }
+  if (planes == 1) PK_LAUNCH(1, 0)
+  else if (var == 0) PK_LAUNCH(3, 0)
+  else if (var == 3) PK_LAUNCH(3, 3)
+  else PK_LAUNCH(3, 1)
+#undef PK_LAUNCH
+  NABU_LAUNCH_CHECK();
+  if (p.nsplit > 1) {
+    const size_t n4 = (size_t)p.M * p.N * p.nbatch / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gemm_pk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
+    NABU_LAUNCH_CHECK();
+  }
+  return 0;
+}

@@ -188,6 +188,14 @@ struct Layout {
   // bf16-resident input products (gemm_precision = bf16): converted copies of the operands
   bool bf16_pre, bf16_fwd;
   size_t bf16_off, bf16_bytes;
+  // packed bf16-plane operands (gemm_pk.hip): planes = 3 (bf16x6) or 1 (bf16); pk_in = the input products
+  // X·Wx, dZ·Wx^T, X^T·dZ, pk_rec = the recurrent weight gradient h_{t-1}^T·dZ
+  int pk_planes;
+  bool pk_in, pk_rec;
+  size_t pk_off, pk_bytes;
+  // forward: X [BT, D], W^T of both cells [8H, D]; backward: dZ^T [8H, BT], X^T [D, BT], h^T per cell [H, BT],
+  // dZ [BT, 8H], Wx of both cells [D, 8H] (byte offsets inside the pk region)
+  size_t pk_x, pk_w, pk_dzT, pk_xT, pk_hT[2], pk_dz, pk_w2;
 };
 
 // the input-to-hidden products X·Wx, dZ·Wx^T, X^T·dZ run on bf16 copies of their operands (converted once per
@@ -210,6 +218,25 @@ static bool bf16_resident_fwd(const nabu_blstm_desc *d) {
   return env && prec == NABU_GEMM_BF16 && d->D % 8 == 0 && (4 * d->H) % 64 == 0 && BT < (1ll << 31) && BT >= 2048;
 }
 static int pad64(int x) { return (x + 63) / 64 * 64; }
+
+// planes of the packed-operand path for this layer (0 = not taken): bf16x6 -> 3, bf16 -> 1
+static int pk_planes_of(const nabu_blstm_desc *d) {
+  const int prec = d->gemm_precision == NABU_GEMM_DEFAULT ? nabu_gemm_get_default_precision() : d->gemm_precision;
+  static int env = -1;
+  if (env < 0) { const char *e = getenv("NABU_PK"); env = e ? atoi(e) : 1; }
+  if (!env) return 0;
+  const long long BT = (long long)d->B * d->T;
+  if (BT < 1024 || BT >= (1ll << 31) - 512 || d->H % 64) return 0;   // n_split = 4H must be a multiple of 256
+  return prec == NABU_GEMM_BF16X6 ? 3 : prec == NABU_GEMM_BF16 ? 1 : 0;
+}
+static nabu_pk_gemm_desc pk_desc(int planes, int M, int N, int nkb, const void *A, int a_rows_pad, const void *B,
+                                 int b_rows_pad, float *C, int ldc) {
+  nabu_pk_gemm_desc g = {};
+  g.size = sizeof(g); g.planes = planes; g.M = M; g.N = N; g.nkb = nkb; g.nbatch = 1;
+  g.A[0] = A; g.B[0] = B; g.a_rows_pad = a_rows_pad; g.b_rows_pad = b_rows_pad; g.a_planes = g.b_planes = planes;
+  g.C[0] = C; g.ldc = ldc; g.alpha = 1.f; g.beta = 0.f;
+  return g;
+}
 
 static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 
@@ -248,6 +275,44 @@ static Layout make_layout(const nabu_blstm_desc *d) {
     const size_t fwd = 2 * (BT * Dp + G * Dp), bwd = L.bf16_pre ? 2 * (BT * G + G * BT + D * BT + D * G) : 0;
     L.bf16_bytes = align_up(max_sz(fwd, bwd), 256);
     off += L.bf16_bytes;
+  }
+  L.pk_planes = pk_planes_of(d);
+  L.pk_in = L.pk_planes && D >= 256 && D % 4 == 0;
+  L.pk_rec = L.pk_planes && T > 1;
+  L.pk_off = off; L.pk_bytes = 0;
+  if (L.pk_planes) {
+    const int P = L.pk_planes, BT = (int)(B * T), G = (int)(4 * H);
+    size_t fwd = 0, bwd = 0;
+    auto take = [](size_t &o, size_t bytes) { const size_t at = o; o += align_up(bytes, 256); return at; };
+    if (L.pk_in) { L.pk_x = take(fwd, nabu_pk_bytes(BT, (int)D, P)); L.pk_w = take(fwd, nabu_pk_bytes(2 * G, (int)D, P)); }
+    L.pk_dzT = take(bwd, nabu_pk_bytes(2 * G, BT, P));
+    if (L.pk_in) L.pk_xT = take(bwd, nabu_pk_bytes((int)D, BT, P));
+    for (int dir = 0; dir < 2; ++dir) L.pk_hT[dir] = take(bwd, L.pk_rec ? nabu_pk_bytes((int)H, BT, P) : 0);
+    if (L.pk_in) { L.pk_dz = take(bwd, nabu_pk_bytes(BT, 2 * G, P)); L.pk_w2 = take(bwd, nabu_pk_bytes((int)D, 2 * G, P)); }
+    L.pk_bytes = max_sz(fwd, bwd);
+    off += L.pk_bytes;
+    // split-K slabs of the four products
+    size_t gws = 0;
+    nabu_pk_gemm_desc g;
+    const int rpBT = nabu_pk_rows_pad(BT), rpG = nabu_pk_rows_pad(2 * G), rpD = nabu_pk_rows_pad((int)D), rpH = nabu_pk_rows_pad((int)H);
+    float *dummy = reinterpret_cast<float *>(16);
+    if (L.pk_in) {
+      g = pk_desc(P, BT, 2 * G, nabu_pk_kblocks((int)D, P), dummy, rpBT, dummy, rpG, dummy, G); g.n_split = G; g.C2[0] = dummy;
+      gws = max_sz(gws, nabu_gemm_pk_ws_bytes(&g));
+      g = pk_desc(P, (int)D, 2 * G, nabu_pk_kblocks(BT, P), dummy, rpD, dummy, rpG, dummy, G); g.n_split = G; g.C2[0] = dummy;
+      gws = max_sz(gws, nabu_gemm_pk_ws_bytes(&g));
+      g = pk_desc(P, BT, (int)D, nabu_pk_kblocks(2 * G, P), dummy, rpBT, dummy, rpD, dummy, (int)D);
+      gws = max_sz(gws, nabu_gemm_pk_ws_bytes(&g));
+    }
+    if (L.pk_rec) {
+      g = pk_desc(P, (int)H, G, nabu_pk_kblocks(BT, P), dummy, rpH, dummy, rpG, dummy, G); g.nbatch = 2;
+      g.A[1] = g.B[1] = dummy; g.C[1] = dummy;
+      gws = max_sz(gws, nabu_gemm_pk_ws_bytes(&g));
+    }
+    if (gws > L.gemm_bytes) {   // the gemm region precedes the persist region: grow it in place
+      const size_t grow = align_up(gws, 256) - L.gemm_bytes;
+      L.gemm_bytes += grow; L.persist_off += grow; L.bf16_off += grow; L.pk_off += grow; off += grow;
+    }
   }
   L.total = off;
   return L;
@@ -328,7 +393,20 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const in
   const float *bias[2] = {bias_fw, bias_bw};
 
   // time-batched input projections (MFMA): gates_d = x·Wx_d + b_d
-  if (L.bf16_fwd) {
+  if (L.pk_in) {
+    // packed bf16-plane operands: X once, Wx^T of both cells as the rows of ONE operand; one product fills the
+    // gate buffers of both directions
+    const int P = L.pk_planes, BT = B * T, G = 4 * H;
+    char *pk = w + L.pk_off;
+    const int rpBT = nabu_pk_rows_pad(BT), rpG = nabu_pk_rows_pad(2 * G), nkb = nabu_pk_kblocks(D, P);
+    if (int e = nabu_pk_pack(P, 0, x, D, BT, D, pk + L.pk_x, rpBT, 0, 0, rpBT, nkb, 0, 0, stream)) return e;
+    for (int dir = 0; dir < 2; ++dir)
+      if (int e = nabu_pk_pack(P, 1, kern[dir], G, D, G, pk + L.pk_w, rpG, dir * G, 0, dir ? rpG - G : G, nkb, 0, 0, stream))
+        return e;
+    nabu_pk_gemm_desc g = pk_desc(P, BT, 2 * G, nkb, pk + L.pk_x, rpBT, pk + L.pk_w, rpG, gates[0], G);
+    g.C2[0] = gates[1]; g.n_split = G; g.bias = bias[0]; g.bias2 = bias[1];
+    if (int e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream)) return e;
+  } else if (L.bf16_fwd) {
     // bf16 copies: x once, Wx_d transposed ([4H, Dp]: the reduction index contiguous, zero-padded to a
     // multiple of 64), then 2-byte operands
     const int Dp = pad64(D);
@@ -437,8 +515,51 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
 
   // weight / input gradients from dz (now stored in gates[])
   const int M = B * T;
+  if (L.pk_planes) {
+    // packed bf16-plane operands (gemm_pk.hip).  dZ^T of both cells is one operand [8H, BT]: the weight
+    // gradients of both cells are column ranges of one product (input part) resp. a batch of two (recurrent part)
+    const int P = L.pk_planes, G = 4 * H;
+    char *pk = w + L.pk_off;
+    const int rpBT = nabu_pk_rows_pad(M), rpG = nabu_pk_rows_pad(2 * G), rpD = nabu_pk_rows_pad(D), rpH = nabu_pk_rows_pad(H);
+    const int nkbT = nabu_pk_kblocks(M, P);
+    int e;
+    for (int dir = 0; dir < 2; ++dir)
+      if ((e = nabu_pk_pack(P, 1, gates[dir], G, M, G, pk + L.pk_dzT, rpG, dir * G, 0, dir ? rpG - G : G, nkbT, 0, 0, stream)))
+        return e;
+    if (L.pk_in) {
+      if ((e = nabu_pk_pack(P, 1, x, D, M, D, pk + L.pk_xT, rpD, 0, 0, rpD, nkbT, 0, 0, stream))) return e;
+      nabu_pk_gemm_desc g = pk_desc(P, D, 2 * G, nkbT, pk + L.pk_xT, rpD, pk + L.pk_dzT, rpG, dkern[0], G);
+      g.C2[0] = dkern[1]; g.n_split = G;
+      if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
+    }
+    if (L.pk_rec) {
+      // h_{t-1}^T: the forward cell pairs dz[b,t] with out[b,t-1,:H], the backward cell with out[b,t+1,H:]
+      for (int dir = 0; dir < 2; ++dir)
+        if ((e = nabu_pk_pack(P, 1, out + (size_t)dir * H, 2 * H, M, H, pk + L.pk_hT[dir], rpH, 0, 0, rpH, nkbT, T,
+                              dir ? 1 : -1, stream)))
+          return e;
+      nabu_pk_gemm_desc g = pk_desc(P, H, G, nkbT, pk + L.pk_hT[0], rpH, pk + L.pk_dzT, rpG, dkern[0] + (size_t)D * G, G);
+      g.nbatch = 2; g.A[1] = pk + L.pk_hT[1]; g.B[1] = pk + L.pk_dzT + (size_t)G * 32; g.C[1] = dkern[1] + (size_t)D * G;
+      if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
+    }
+    if (d_x && L.pk_in) {
+      // dx = [dZ_fw | dZ_bw] · [Wx_fw | Wx_bw]^T: the two cells are two ranges of ONE reduction
+      const int nkb2 = nabu_pk_kblocks(2 * G, P), kbG = G / 16;
+      for (int dir = 0; dir < 2; ++dir) {
+        if ((e = nabu_pk_pack(P, 0, gates[dir], G, M, G, pk + L.pk_dz, rpBT, 0, dir * kbG, rpBT, dir ? nkb2 - kbG : kbG, 0, 0,
+                              stream)))
+          return e;
+        if ((e = nabu_pk_pack(P, 0, kern[dir], G, D, G, pk + L.pk_w2, rpD, 0, dir * kbG, rpD, dir ? nkb2 - kbG : kbG, 0, 0,
+                              stream)))
+          return e;
+      }
+      nabu_pk_gemm_desc g = pk_desc(P, M, D, nkb2, pk + L.pk_dz, rpBT, pk + L.pk_w2, rpD, d_x, D);
+      if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
+    }
+  }
   unsigned short *dzb = nullptr, *dzT = nullptr, *xT = nullptr, *wb = nullptr;
-  if (L.bf16_pre) {   // bf16 copies of this call's operands: x^T once; dz and dz^T, Wx per direction
+  const bool old_bf16 = L.bf16_pre && !L.pk_in;
+  if (old_bf16) {   // bf16 copies of this call's operands: x^T once; dz and dz^T, Wx per direction
     dzb = reinterpret_cast<unsigned short *>(w + L.bf16_off);
     dzT = dzb + (size_t)M * 4 * H;
     xT = dzT + (size_t)4 * H * M;
@@ -447,7 +568,8 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
   }
   for (int dir = 0; dir < 2; ++dir) {
     int e;
-    if (L.bf16_pre) {
+    if (L.pk_in) {
+    } else if (old_bf16) {
       if ((e = cvt_bf16_t(M, 4 * H, gates[dir], 4 * H, dzT, M, s))) return e;
       // dWx = x^T · dz = sum over frames of xT[d, k] * dzT[n, k]
       if ((e = gemm_bf16_pre(D, 4 * H, M, 1.f, xT, M, dzT, M, 0.f, dkern[dir], 4 * H, nullptr, w + L.gemm_off,
@@ -460,12 +582,14 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
     if (e) return e;
     }
     // dWh = h_{prev}^T · dz : fw pairs (out[b,t-1,:H], dz[b,t]); bw pairs (out[b,t+1,H:], dz[b,t])
+    if (!(L.pk_planes && L.pk_rec)) {
     const float *A = dir == 0 ? out : out + H + (size_t)2 * H;
     const float *Bm = dir == 0 ? gates[0] + (size_t)4 * H : gates[1];
     e = nabu_gemm_f32(1, 0, H, 4 * H, B * (T - 1), 1.f, A, 2 * H, Bm, 4 * H, 0.f,
                       dkern[dir] + (size_t)D * 4 * H, 4 * H, nullptr, T > 1 ? T - 1 : 0,
                       (long long)T * 2 * H, (long long)T * 4 * H, w + L.gemm_off, L.gemm_bytes, stream);
     if (e) return e;
+    }
     // db = column sums of dz: the persistent kernel already summed them per shard
     if (db_part)
       e = nabu_colsum_f32(db_rows, 4 * H, db_part + (size_t)dir * 4 * H, 2 * 4 * H, 0.f, dbias[dir], w + L.gemm_off,
@@ -474,7 +598,8 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
       e = nabu_colsum_f32(M, 4 * H, gates[dir], 4 * H, 0.f, dbias[dir], w + L.gemm_off, L.gemm_bytes, stream);
     if (e) return e;
     // dx (+)= dz · Wx^T
-    if (d_x && L.bf16_pre) {
+    if (L.pk_in) {
+    } else if (d_x && old_bf16) {
       if ((e = cvt_bf16((size_t)M, 4 * H, gates[dir], 4 * H, dzb, 4 * H, s))) return e;
       if ((e = cvt_bf16((size_t)D, 4 * H, kern[dir], 4 * H, wb, 4 * H, s))) return e;
       if ((e = gemm_bf16_pre(M, D, 4 * H, 1.f, dzb, 4 * H, wb, 4 * H, dir == 0 ? 0.f : 1.f, d_x, D, nullptr,

@@ -72,6 +72,69 @@ def gemm_bf16_nt(a_bf16, b_bf16, c, alpha=1.0, beta=0.0, bias=None):
     return c
 
 
+class PackedOperand(object):
+    """An fp32 matrix converted to the packed bf16-plane layout of gemm_pk.hip (include/nabu_hip.h,
+    nabu_pk_pack): `rows` = the operand's M (or N) index, `K` = the reduction length."""
+
+    def __init__(self, rows, K, planes, device):
+        L = _hip.lib()
+        self.rows, self.K, self.planes = rows, K, planes
+        self.rows_pad = L.nabu_pk_rows_pad(rows)
+        self.nkb = L.nabu_pk_kblocks(K, planes)
+        self.buf = torch.empty(L.nabu_pk_bytes(rows, K, planes), dtype=torch.uint8, device=device)
+
+    def kb_ptr(self, kb):
+        return self.buf.data_ptr() + kb * self.planes * self.rows_pad * 32
+
+    def row_ptr(self, row):
+        return self.buf.data_ptr() + row * 32
+
+
+def pk_pack(dst, src, transposed=False, row_off=0, kb_off=0, fill_rows=None, fill_kb=None, period=0, shift=0,
+            R=None, C=None, ld=None):
+    """write the 2-D fp32 tensor `src` into the packed operand `dst` (rows / k-blocks beyond the source are zero)"""
+    if R is None:
+        R, C = src.shape
+        ld = src.stride(0)
+    rows, kred = (C, R) if transposed else (R, C)
+    if fill_rows is None:
+        fill_rows = dst.rows_pad - row_off if row_off + rows >= dst.rows else rows
+    if fill_kb is None:
+        fill_kb = dst.nkb - kb_off if kb_off + (kred + 15) // 16 >= (dst.K + 15) // 16 else (kred + 15) // 16
+    check(_hip.lib().nabu_pk_pack(dst.planes, int(transposed), src.data_ptr(), ld, R, C, ptr(dst.buf), dst.rows_pad,
+                                  row_off, kb_off, fill_rows, fill_kb, period, shift, stream()), 'nabu_pk_pack')
+    return dst
+
+
+def gemm_pk(a, b, c, planes=None, alpha=1.0, beta=0.0, bias=None, c2=None, n_split=0, bias2=None, M=None, N=None,
+            nkb=None, a_ptrs=None, b_ptrs=None, cs=None, c2s=None):
+    """c[M,N] = alpha * a·b^T + beta*c + bias over packed operands (nabu_gemm_pk); batched form through
+    a_ptrs / b_ptrs / cs (lists of raw pointers / tensors, <= 2 entries)"""
+    L = _hip.lib()
+    planes = planes or min(a.planes, b.planes)
+    d = _hip.PkGemmDesc()
+    d.size = ctypes.sizeof(_hip.PkGemmDesc)
+    d.planes = planes
+    d.M = a.rows if M is None else M
+    d.N = b.rows if N is None else N
+    d.nkb = L.nabu_pk_kblocks(a.K, planes) if nkb is None else nkb
+    cs = cs or [c]
+    d.nbatch = len(cs)
+    for i in range(d.nbatch):
+        d.A[i] = a_ptrs[i] if a_ptrs else a.buf.data_ptr()
+        d.B[i] = b_ptrs[i] if b_ptrs else b.buf.data_ptr()
+        d.C[i] = ptr(cs[i])
+        d.C2[i] = ptr(c2s[i]) if c2s else ptr(c2)
+    d.a_rows_pad, d.b_rows_pad, d.a_planes, d.b_planes = a.rows_pad, b.rows_pad, a.planes, b.planes
+    d.ldc, d.n_split = cs[0].stride(0), n_split
+    d.bias, d.bias2 = ptr(bias), ptr(bias2)
+    d.alpha, d.beta = alpha, beta
+    ws_bytes = L.nabu_gemm_pk_ws_bytes(ctypes.byref(d))
+    ws = Workspace.get(ws_bytes, cs[0].device, 'gemm') if ws_bytes else None
+    check(L.nabu_gemm_pk(ctypes.byref(d), ptr(ws), ws_bytes, stream()), 'nabu_gemm_pk')
+    return c
+
+
 def set_gemm_precision(precision):
     """process default of every GEMM that does not name a precision ('f32' | 'bf16' | 'bf16x3' | 'bf16x6')"""
     check(_hip.lib().nabu_gemm_set_default_precision(_hip.GEMM_PRECISIONS[precision]), 'nabu_gemm_set_default_precision')

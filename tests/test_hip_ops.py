@@ -109,7 +109,7 @@ def _blstm_params(rng, D, H, scale=0.2):
                 bw_kernel=rng.normal(0, scale, (D + H, 4 * H)), bw_bias=rng.normal(0, scale, 4 * H))
 
 
-def _run_blstm(B, T, D, H, lens, mode, seed=0, need_dx=True):
+def _run_blstm(B, T, D, H, lens, mode, seed=0, need_dx=True, precision='default'):
     from nabu_amd import ops
     rng = np.random.default_rng(seed)
     x = rng.normal(size=(B, T, D)).astype(np.float32).astype(np.float64)
@@ -120,7 +120,7 @@ def _run_blstm(B, T, D, H, lens, mode, seed=0, need_dx=True):
     ref_out, cache = O.blstm_fwd(x, np.asarray(lens), p)
     ref_dx, ref_g = O.blstm_bwd(dout, cache)
 
-    plan = ops.BlstmPlan(B, T, D, H, int(max(lens)), mode)
+    plan = ops.BlstmPlan(B, T, D, H, int(max(lens)), mode, precision)
     xd, ld = dev(x), dev(np.asarray(lens), torch.int32)
     pd = {k: dev(v) for k, v in p.items()}
     out = torch.full((B, T, 2 * H), float('nan'), device='cuda')
