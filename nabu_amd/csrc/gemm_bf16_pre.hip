@@ -225,12 +225,8 @@ int gemm_bf16_pre(int M, int N, int K, float alpha, const unsigned short *A, int
   }
   PreArgs q = {A, B, lda, ldb};
   const size_t lds = 4 * (size_t)PTILE;
-  static bool configured = false;
-  if (!configured) {
-    NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16_pre_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
-  }
+  NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16_pre_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, a.nsplit);
   hipLaunchKernelGGL(gemm_bf16_pre_kernel, grid, dim3(256), lds, s, a, q);
   NABU_LAUNCH_CHECK();

@@ -264,12 +264,9 @@ int gemm_skinny_fused(int M, int N, int K1, const float *A, int lda, const float
   if (MT == 1) {
     hipLaunchKernelGGL(gemm_skinny_fused_kernel<1>, grid, dim3(256), lds, s, a, f);
   } else {
-    static bool configured = false;
-    if (!configured) {
-      NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_fused_kernel<2>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      configured = true;
-    }
+    // per call (cheap): the attribute is per device and this path is entered from several host threads
+    NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_fused_kernel<2>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     hipLaunchKernelGGL(gemm_skinny_fused_kernel<2>, grid, dim3(256), lds, s, a, f);
   }
   NABU_LAUNCH_CHECK();
@@ -292,12 +289,8 @@ int gemm_skinny_launch(const GemmArgs &a, hipStream_t s) {
   if (MT == 1) {
     hipLaunchKernelGGL(gemm_skinny_kernel<1>, grid, dim3(256), lds, s, a);
   } else {
-    static bool configured = false;
-    if (!configured) {
-      NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_kernel<2>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      configured = true;
-    }
+    NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_kernel<2>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     hipLaunchKernelGGL(gemm_skinny_kernel<2>, grid, dim3(256), lds, s, a);
   }
   NABU_LAUNCH_CHECK();

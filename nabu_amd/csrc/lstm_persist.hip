@@ -160,7 +160,7 @@ struct SpinGuard {
   __device__ __forceinline__ void start() { t0 = wall_clock64(); spins = 0; }
   __device__ __forceinline__ bool expired(const PersistArgs &p) {
     // back off between polls: 512 workgroups re-reading 8 KiB each as fast as the L2 answers
-    // (one way latency is ~50 ns, scratch/ub/pingpong.hip) would saturate the L2 they wait on
+    // (one way latency is ~50 ns, tools/experiments/ub/pingpong.hip) would saturate the L2 they wait on
     switch ((p.dbg >> 8) & 7) {
       case 1: __builtin_amdgcn_s_sleep(1); break;
       case 2: __builtin_amdgcn_s_sleep(2); break;

@@ -1473,8 +1473,12 @@ static int run_subs(int NS, F body) {
   int codes[8] = {0};
   std::string texts[8];
   if (!threads_env) {
-    for (int i = 0; i < NS; ++i) if (int e = body(i)) return e;
-    return 0;
+    int first = 0;                       // every chain is enqueued even after a failure: the caller joins the streams
+    for (int i = 0; i < NS; ++i) {
+      const int e = body(i);
+      if (e && !first) first = e;
+    }
+    return first;
   }
   int dev = 0;
   NABU_HIP(hipGetDevice(&dev));
@@ -1765,8 +1769,11 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
     return 0;
   };
   if (!persist) {
-  SP_TRY(run_subs(NS, fwd_chain));
-  SP_TRY(sub_join(ss));
+  {  // join the side streams before an error is propagated: chains already enqueued must not outlive the call
+    const int e_run = run_subs(NS, fwd_chain), e_join = sub_join(ss);
+    if (e_run) return e_run;
+    SP_TRY(e_join);
+  }
   }
   // output projection of all steps: [h_t, ctx_t]·W + b, then batch-major + impute_finished
   float *ltm = r + R.logits_tm;
@@ -1961,8 +1968,11 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   return 0;
   };
   if (!persist) {
-  SP_TRY(run_subs(NS, bwd_chain));
-  SP_TRY(sub_join(ss));
+  {
+    const int e_run = run_subs(NS, bwd_chain), e_join = sub_join(ss);
+    if (e_run) return e_run;
+    SP_TRY(e_join);
+  }
   }
   if (defer)
     SP_TRY(attn_param_grads(&adb, Sp, L, dec_len, enc_len, r + R.keys, r + R.q, p->attention_v, p->conv_proj, w + W.ds_all,

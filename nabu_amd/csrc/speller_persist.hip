@@ -1132,6 +1132,35 @@ size_t ring_bytes(const SpPersistDesc &d) {
 
 }  // namespace
 
+// The persistent decoder is sized for the whole MI355X: NU units of P workgroups, one per CU, formed per XCC, each
+// with up to 160 KiB of LDS.  On a partitioned (CPX/DPX) or smaller device the grid cannot be co-resident (every
+// call would spin to the time-out), so the geometry is checked against the CURRENT device and the step chain of
+// speller.hip is taken when it does not fit.
+static bool device_fits() {
+  static thread_local int cached_dev = -1;
+  static thread_local bool cached = false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (dev != cached_dev) {
+    int cus = 0, xcc = 0, lds = 0;
+    bool ok = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= NU * P;
+    ok = ok && hipDeviceGetAttribute(&xcc, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess && xcc == NU;
+    // the runtime reports the LDS a block may use under one of these names depending on its version
+    const hipDeviceAttribute_t names[3] = {hipDeviceAttributeMaxSharedMemoryPerBlock, hipDeviceAttributeSharedMemPerBlockOptin,
+                                           hipDeviceAttributeMaxSharedMemoryPerMultiprocessor};
+    for (hipDeviceAttribute_t n : names) {
+      int v = 0;
+      if (hipDeviceGetAttribute(&v, n, dev) == hipSuccess && v > lds) lds = v;
+    }
+    ok = ok && lds >= 160 * 1024 - 512;
+    (void)hipGetLastError();
+    if (getenv("NABU_PERSIST_DEBUG")) fprintf(stderr, "nabu: persistent decoder device check: %d CUs, %d XCCs, %d B LDS -> %s\n", cus, xcc, lds, ok ? "fits" : "step chain");
+    cached = ok;
+    cached_dev = dev;
+  }
+  return cached;
+}
+
 static bool shape_ok(const SpPersistDesc &d) {
   if ((d.B != NU * R && d.B != 2 * NU * R) || d.U % 32 || d.E % 32 || d.U < 32 || d.E < 32) return false;
   if (d.kind != 0 && d.kind != 1) return false;
@@ -1188,7 +1217,7 @@ static size_t bwd_ring_bytes(const SpPersistDesc &d) {
 bool speller_persist_bwd_ok(const SpPersistDesc &d) {
   const char *env = getenv("NABU_SPELLER_PERSIST_BWD");
   if (env && !atoi(env)) return false;
-  return bwd_shape_ok(d);
+  return bwd_shape_ok(d) && device_fits();
 }
 size_t speller_persist_bwd_ws_bytes(const SpPersistDesc &d) { return bwd_shape_ok(d) ? TABLE_BYTES + bwd_ring_bytes(d) : 0; }
 
@@ -1213,15 +1242,8 @@ int speller_persist_bwd(const SpPersistDesc &d, const int32_t *dec_len, const in
   NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + bwd_ring_bytes(d), stream));
   const size_t lds = bwd_lds_floats(d) * 4;
   auto kern = bwd_ks4(d) ? speller_persist_bwd_kernel<3, 128, 4, 8> : speller_persist_bwd_kernel<3, 8, 16, 8>;
-  static thread_local const void *configured[2] = {nullptr, nullptr};
-  const void *fn = reinterpret_cast<const void *>(kern);
-  bool done = false;
-  for (auto c : configured) done = done || c == fn;
-  if (!done) {
-    NABU_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-    for (auto &c : configured)
-      if (!c) { c = fn; break; }
-  }
+  // per call: the attribute is per device, a cache keyed by the function alone would miss a second device
+  NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
   hipLaunchKernelGGL(kern, dim3(NU * P), dim3(NT), lds, stream, a);
   NABU_LAUNCH_CHECK();
   return 0;
@@ -1230,7 +1252,7 @@ int speller_persist_bwd(const SpPersistDesc &d, const int32_t *dec_len, const in
 bool speller_persist_ok(const SpPersistDesc &d) {
   const char *env = getenv("NABU_SPELLER_PERSIST");     // 0 = the step chain of speller.hip
   if (env && !atoi(env)) return false;
-  return shape_ok(d);
+  return shape_ok(d) && device_fits();
 }
 
 size_t speller_persist_ws_bytes(const SpPersistDesc &d) {   // (independent of the switch: the workspace layout is)
@@ -1264,15 +1286,7 @@ int speller_persist_fwd(const SpPersistDesc &d, const int32_t *dec_len, const in
   const bool loc = d.kind == 1;
   auto kern = loc ? (KW <= 64 ? speller_persist_fwd_kernel<64, true> : KW <= 192 ? speller_persist_fwd_kernel<192, true> : speller_persist_fwd_kernel<384, true>)
                   : (KW <= 64 ? speller_persist_fwd_kernel<64, false> : KW <= 192 ? speller_persist_fwd_kernel<192, false> : speller_persist_fwd_kernel<384, false>);
-  static thread_local const void *configured[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  const void *fn = reinterpret_cast<const void *>(kern);
-  bool done = false;
-  for (auto c : configured) done = done || c == fn;
-  if (!done) {
-    NABU_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-    for (auto &c : configured)
-      if (!c) { c = fn; break; }
-  }
+  NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
   // 32 utterances per launch (4 per XCD): a batch of 64 runs as two launches on the stream
   for (int b0 = 0; b0 < d.B; b0 += NU * R) {
     a.b0 = b0;

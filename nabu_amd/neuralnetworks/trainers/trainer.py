@@ -18,6 +18,7 @@ underneath:
     as soon as its gradients are final and overlapped with the dense products of the
     next layer's backward pass — never with a persistent recurrent kernel."""
 import math
+import sys
 import os
 import pickle
 import time
@@ -223,6 +224,10 @@ class Trainer(object, metaclass=ABCMeta):
         finally:
             if self.buckets is not None:
                 self._end_backward()
+                failed = hip.take_phase_hook_error()      # raised inside the C -> Python hook of nabu_blstm_bwd
+                if failed is not None:
+                    self._join_comm()                     # no collective outlives the step
+                    raise failed
         self._update()
 
     def _init_optimizer(self):
@@ -270,6 +275,11 @@ class Trainer(object, metaclass=ABCMeta):
     def _end_backward(self):
         hip.set_phase_hook(None)
         hip.BEFORE_RECURRENT[0] = None
+        if sys.exc_info()[0] is not None:                 # the backward pass raised: drain what is in flight
+            try:
+                self._join_comm()
+            except Exception:                             # the original error is the one to report
+                pass
 
     def _launch_ready_buckets(self, everything=False):
         '''clip (per replica, before the aggregation: reference trainer.py:556-569) and start the

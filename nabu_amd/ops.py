@@ -351,9 +351,26 @@ def set_phase_hook(fn):
         _phase_hook[0] = None
         check(_hip.lib().nabu_blstm_set_phase_hook(None, None), 'nabu_blstm_set_phase_hook')
         return
-    _phase_hook[0] = _hip.PHASE_HOOK_T(lambda user: fn())
+    def trampoline(user):
+        # ctypes prints and swallows an exception raised inside a C callback: keep it and let the
+        # caller re-raise it once the C call has returned (take_phase_hook_error)
+        try:
+            fn()
+        except BaseException as exc:                     # noqa: B902 — re-raised by the caller
+            if _phase_hook_error[0] is None:
+                _phase_hook_error[0] = exc
+    _phase_hook[0] = _hip.PHASE_HOOK_T(trampoline)
     check(_hip.lib().nabu_blstm_set_phase_hook(ctypes.cast(_phase_hook[0], ctypes.c_void_p), None),
           'nabu_blstm_set_phase_hook')
+
+
+_phase_hook_error = [None]
+
+
+def take_phase_hook_error():
+    """the first exception a phase hook raised since the last call (None if none); clears it"""
+    exc, _phase_hook_error[0] = _phase_hook_error[0], None
+    return exc
 
 
 # called right before a recurrent launch is enqueued (forward and backward): the data-parallel

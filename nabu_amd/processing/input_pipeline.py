@@ -27,48 +27,50 @@ import numpy as np
 from nabu_amd.processing.tfreaders import tfreader_factory
 
 
-def get_filenames(dataconfs):
-    '''the utterances found in all data sets (reference input_pipeline.py:9-55)
+def _pointer_table(sections):
+    """utterance key -> record file of one data set; a data set may be spread over several
+    sections (directories), the key carries the section index so equal names do not collide"""
+    table = {}
+    for index, section in enumerate(sections):
+        with open(os.path.join(section['dir'], 'pointers.scp')) as scp:
+            for row in scp:
+                utt, path = row.strip().split('\t')
+                table['%s-%d' % (utt, index)] = path
+    return table
 
-    Args:
-        dataconfs: the database configurations as a list (one per data set) of lists of sections
-    Returns:
-        - a list of tuples with the filenames of an utterance, one per data set
-        - a list containing the names'''
-    files = []
-    for dataconfset in dataconfs:
-        setfiles = dict()
-        for i, dataconf in enumerate(dataconfset):
-            with open(os.path.join(dataconf['dir'], 'pointers.scp')) as fid:
-                for line in fid:
-                    (n, f) = line.strip().split('\t')
-                    setfiles['%s-%d' % (n, i)] = f
-        files.append(setfiles)
-    elements, names = [], []
-    for name in files[0]:
-        if all(name in setfile for setfile in files):
-            elements.append(tuple(setfile[name] for setfile in files))
-            names.append(name)
-        else:
-            print('%s was not found in all sets of data, ignoring this example' % name)
-    return elements, names
+
+def get_filenames(dataconfs):
+    """The utterances that every data set holds (reference input_pipeline.py:9-55).
+
+    dataconfs: one list of database sections per data set.  Returns (per-utterance tuples of record
+    files, one entry per data set; the utterance keys), in the order of the first data set."""
+    tables = [_pointer_table(sections) for sections in dataconfs]
+    shared = set(tables[0]).intersection(*tables[1:])
+    for key in tables[0]:
+        if key not in shared:
+            print('%s was not found in all sets of data, ignoring this example' % key)
+    names = [key for key in tables[0] if key in shared]
+    return [tuple(t[key] for t in tables) for key in names], names
 
 
 def bucket_boundaries(histogram, numbuckets):
-    '''bucket boundaries that divide the number of elements uniformly — the reference's greedy
-    algorithm (input_pipeline.py:176-202)'''
-    boundaries = [0] * numbuckets
-    for i in range(numbuckets - 1):
-        numelements = int(histogram[boundaries[i]:].sum() / (numbuckets - i))
-        if numelements == 0:
-            print('%d buckets could not be reached, using %d buckets' % (numbuckets, i))
-        j = boundaries[i] + 1
-        while (j + 1 < len(histogram) and
-               abs(histogram[boundaries[i]:j].sum() - numelements) >=
-               abs(histogram[boundaries[i]:j + 1].sum() - numelements)):
-            j += 1
-        boundaries[i + 1] = j
-    return boundaries[1:]
+    """Length boundaries that spread the utterances evenly over numbuckets buckets — the greedy rule
+    of the reference (input_pipeline.py:176-202): every bucket aims at an equal share of what is
+    left and its end moves right for as long as the next length brings the count at least as close."""
+    counts = np.concatenate([[0], np.cumsum(np.asarray(histogram))])     # counts[j] = elements shorter than j
+    top = len(histogram) - 1
+    edges, start = [], 0
+    for done in range(numbuckets - 1):
+        below = counts[min(start, top + 1)]
+        share = int((counts[-1] - below) / (numbuckets - done))
+        if share == 0:
+            print('%d buckets could not be reached, using %d buckets' % (numbuckets, done))
+        miss = np.abs(counts[start + 1:top + 1] - below - share)          # miss[k]: bucket ends at start + 1 + k
+        closer = np.nonzero(miss[:-1] < miss[1:])[0]                      # first end the next length does not improve
+        end = start + 1 + (int(closer[0]) if len(closer) else max(len(miss) - 1, 0))
+        edges.append(end)
+        start = end
+    return edges
 
 
 class RecordData(object):
@@ -109,6 +111,7 @@ class RecordData(object):
         self._pool = ThreadPoolExecutor(max_workers=1)
         self._lock = threading.Lock()
         self._ahead = {}           # step -> Future of its batch
+        self.lookahead = True      # bounded consumers (validation) switch it off: no batch past the last one
         self._last_step = None
         self._epochs = []          # per epoch: list of batches (lists of utterance indices)
         self._carry = [[] for _ in self.batch_sizes]
@@ -153,32 +156,55 @@ class RecordData(object):
             e += 1
 
     def _read(self, u):
-        if u not in self._cache:
+        hit = self._cache.get(u)
+        if hit is None:
+            hit = [r(f) for r, f in zip(self.readers, self.elements[u])]
             if len(self._cache) > 4096:
                 self._cache.clear()
-            self._cache[u] = [r(f) for r, f in zip(self.readers, self.elements[u])]
-        return self._cache[u]
+            self._cache[u] = hit
+        return hit
 
     def batch(self, step):
         '''batch number `step` of the never-ending stream (A0 contract, numpy).  The batch the caller
         will most likely ask for next (same stride as the last two requests) is read and padded by a
         background thread meanwhile.'''
         fut = self._ahead.pop(step, None)
+        for stale in self._ahead.values():                 # guesses that were wrong: do not let them run
+            stale.cancel()
+        self._ahead = {}
         out = fut.result() if fut is not None else self._assemble(step)
         stride = step - self._last_step if self._last_step is not None and step > self._last_step else 1
         self._last_step = step
         nxt = step + stride
-        self._ahead = {nxt: self._ahead[nxt]} if nxt in self._ahead else {}      # drop guesses that were wrong
-        if nxt not in self._ahead:
+        if self.lookahead and self._pool is not None:
             self._ahead[nxt] = self._pool.submit(self._assemble, nxt)
         return out
 
-    def _assemble(self, step):
-        with self._lock:                                   # schedule, carries and cache are shared state
-            return self._assemble_locked(step)
+    def close(self):
+        """stop the look-ahead thread (pending guesses are dropped)"""
+        pool, self._pool = self._pool, None
+        for fut in self._ahead.values():
+            fut.cancel()
+        self._ahead = {}
+        if pool is not None:
+            pool.shutdown(wait=False)
 
-    def _assemble_locked(self, step):
-        utts = [self._read(u) for u in self._indices(step)]
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _assemble(self, step):
+        with self._lock:                                   # the schedule and the carries are shared state
+            indices = list(self._indices(step))
+        # file reads and padding run outside the lock: a wrong look-ahead guess does not hold up the
+        # batch that was actually asked for (the utterance cache takes whole entries, a lost race
+        # only reads a file twice)
+        return self._pad(indices)
+
+    def _pad(self, indices):
+        utts = [self._read(u) for u in indices]
         names = self.input_names + self.target_names
         out = dict(inputs={}, input_seq_length={}, targets={}, target_seq_length={})
         for i, name in enumerate(names):

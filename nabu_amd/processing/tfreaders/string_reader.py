@@ -10,18 +10,20 @@ from nabu_amd.processing.tfreaders import tfreader
 class StringReader(tfreader.TfReader):
     '''a reader for reading and encoding text data'''
 
+    @staticmethod
+    def _symbols_of(datadir):
+        with open(os.path.join(datadir, 'alphabet')) as fid:
+            return fid.read().split()
+
     def _read_metadata(self, datadirs):
         metadata = dict()
         self._lengths(datadirs, metadata)
+        alphabets = [self._symbols_of(d) for d in datadirs]
+        if any(a != alphabets[0] for a in alphabets[1:]):
+            raise Exception('string data sets with different alphabets cannot be read together: %s' % (datadirs,))
         with open(os.path.join(datadirs[0], 'nonesymbol')) as fid:
-            nonesymbol = fid.read()
-        with open(os.path.join(datadirs[0], 'alphabet')) as fid:
-            alphabet = fid.read().split()
-        for datadir in datadirs:
-            with open(os.path.join(datadir, 'alphabet')) as fid:
-                if alphabet != fid.read().split():
-                    raise Exception('all string reader alphabets must be the same')
-        metadata['alphabet'] = [nonesymbol] + alphabet
+            padding_symbol = fid.read()
+        metadata['alphabet'] = [padding_symbol] + alphabets[0]
         metadata['index'] = {s: i for i, s in reversed(list(enumerate(metadata['alphabet'])))}
         return metadata
 
