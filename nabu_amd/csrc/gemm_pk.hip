@@ -50,6 +50,7 @@
 // Replaces: the tf MatMul of the LSTM cell's input part and its autodiff, time-batched
 // (nabu/neuralnetworks/components/layer.py:35-47, nabu/neuralnetworks/trainers/trainer.py:556-558).
 #include "gemm_args.h"
+#include "gemm_pk_asm.inc"
 
 #include <stdlib.h>
 
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(512) void gemm_pk_kernel(PkArgs p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-  f32x16 tpend = acc[0][0];   // promoted accumulation: the partial sum whose add is still owed (0 at the start)
+  f32x16 tpend = acc[0][0], t0 = acc[0][0];   // promoted accumulation: scratch tiles; tpend = the partial sum whose add is still owed
 
   // operand read offsets inside a stage: row (lane & 31) of a 32-row MFMA tile, half (lane >> 5) swapped by
   // bit 3 of the row (tile bases are multiples of 32 rows, so bit 3 of the row is bit 3 of the lane)
@@ -196,7 +197,14 @@ __global__ __launch_bounds__(512) void gemm_pk_kernel(PkArgs p) {
       pa += step_a; pb += step_b;
     }
     kbf16x8 fa[4][3], fb[2][3];
-    {
+    if constexpr (NP == 3 && VAR == 1) {
+      // hand-scheduled path: the operand reads land in the physical registers the COMPUTE stream names
+      // (gemm_pk_asm.inc); reads and their wait are ONE statement, so no compiler copy can see a register
+      // before its data
+      const unsigned va = so_rd + offA, vb = so_rd + offB;
+      if (more) asm volatile(PK_STREAM_LOAD "s_waitcnt vmcnt(6) lgkmcnt(0)" : PK_ASM_LOAD_OUTPUTS : "v"(va), "v"(vb) : "memory");
+      else asm volatile(PK_STREAM_LOAD "s_waitcnt vmcnt(0) lgkmcnt(0)" : PK_ASM_LOAD_OUTPUTS : "v"(va), "v"(vb) : "memory");
+    } else {
       const char *sA = pk_smem + so_rd + offA, *sB = pk_smem + so_rd + offB;
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
@@ -205,114 +213,86 @@ __global__ __launch_bounds__(512) void gemm_pk_kernel(PkArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) fb[j][q] = *reinterpret_cast<const kbf16x8 *>(sB + q * PK_CH + j * 1024);
       }
+      if (more) pk_wait<6>(); else pk_wait<0>();
     }
-    if (more) pk_wait<6>(); else pk_wait<0>();
     pk_barrier();
     // -------- COMPUTE(st) --------
-    __builtin_amdgcn_s_setprio(1);
+    if (!(NP == 3 && VAR == 1)) __builtin_amdgcn_s_setprio(1);
     if (NP == 3 && VAR == 0) {
       // direct accumulation (kept for A/B measurements: NABU_PK_VAR=0)
 #define PK_PROD(qa, qb)                                                                                    \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][qa], fb[j][qb], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][qb], fa[i][qa], acc[i][j], 0, 0, 0);
       PK_PROD(2, 0) PK_PROD(0, 2) PK_PROD(1, 1) PK_PROD(1, 0) PK_PROD(0, 1) PK_PROD(0, 0)
 #undef PK_PROD
-    } else if (NP == 3 && VAR == 3) {
-      // direct accumulation, the six products of a tile back to back on the same accumulator (measures the
-      // dependent-issue cost of the matrix pipe: NABU_PK_VAR=3)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
-        }
     } else if (NP == 3) {
       // PROMOTED ACCUMULATION.  The six plane products of one (tile, k-block) are chained in a scratch
       // accumulator that starts at 0 (smallest terms first), and the finished 16-k partial sum is added to the
       // tile's accumulator by the VALU: one RNE rounding at the accumulator's magnitude per 16 k, where the
       // exact-fp32 kernel's fma chain has 16 and a direct MFMA chain 6 (each with the matrix pipe's own
-      // rounding).  Two scratch tiles rotate: the 16 adds of tile n are issued in the gaps between the MFMAs
-      // of tile n+1 (a wave issues ~5 independent instructions under one 32-cycle MFMA); the last tile's adds
-      // wait for the first chain of the NEXT stage (tpend is carried across the stage boundary).
-      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      f32x16 t0;
-#define PK_CHAIN(T, i, j)                                                                   \
-  T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], zero, 0, 0, 0);            \
-  T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], T, 0, 0, 0);               \
-  T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], T, 0, 0, 0);               \
-  T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], T, 0, 0, 0);               \
-  T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], T, 0, 0, 0);               \
-  T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], T, 0, 0, 0);
-      const f32x16 tprev = tpend;
-      PK_CHAIN(t0, 0, 0) acc[3][1] += tprev;
-      PK_CHAIN(tpend, 0, 1) acc[0][0] += t0;
-      PK_CHAIN(t0, 1, 0) acc[0][1] += tpend;
-      PK_CHAIN(tpend, 1, 1) acc[1][0] += t0;
-      PK_CHAIN(t0, 2, 0) acc[1][1] += tpend;
-      PK_CHAIN(tpend, 2, 1) acc[2][0] += t0;
-      PK_CHAIN(t0, 3, 0) acc[2][1] += tpend;
-      PK_CHAIN(tpend, 3, 1) acc[3][0] += t0;
-#undef PK_CHAIN
+      // rounding).  The instruction stream is hand-scheduled (tools/gen_pk_asm.py, schedule S1: the 16 adds of
+      // tile n-1 in the gaps of tile n's MFMA chain; hipcc clusters them and loses 14 % of the matrix pipe).
+      asm volatile("s_setprio 1\n\t" PK_STREAM_S1 "s_setprio 0" : PK_ASM_COMPUTE_INOUT : PK_ASM_COMPUTE_INPUTS);
     } else {
 #define PK_PROD(qa, qb)                                                                                    \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][qa], fb[j][qb], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][qb], fa[i][qa], acc[i][j], 0, 0, 0);
       PK_PROD(0, 0) PK_PROD(1, 1) PK_PROD(2, 2)
 #undef PK_PROD
     }
-    __builtin_amdgcn_s_setprio(0);
+    if (!(NP == 3 && VAR == 1)) __builtin_amdgcn_s_setprio(0);
     pk_barrier();
     so_rd = so_rd == 2 * PK_STAGE ? 0 : so_rd + PK_STAGE;
     so_wr = so_wr == 2 * PK_STAGE ? 0 : so_wr + PK_STAGE;
   }
   if (grp == 0) pk_barrier();
-  if (NP == 3 && VAR == 1) acc[3][1] += tpend;
+  if (NP == 3 && VAR == 1) {
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(tpend));   // the last chain's matrix result -> VALU read: not padded by hipcc
+    acc[3][1] += tpend;
+  }
 
-  // ---- epilogue: MFMA C layout: column lane & 31, rows (q & 3) + 8 (q >> 2) + 4 (lane >> 5) ----
-  const int col = lane & 31, rbase = 4 * (lane >> 5);
+  // ---- epilogue.  The products were issued with the B fragment as the matrix instruction's first operand, so a
+  // 32 x 32 result tile is held transposed: lane -> row m = lane & 31, register quad g -> the four consecutive
+  // columns n = 8 g + 4 (lane >> 5) + {0..3}: one 16-byte store per quad (32 rows x 32 contiguous bytes per
+  // instruction) instead of four 4-byte stores.
+  const int mrow = lane & 31, nquad = 4 * (lane >> 5);
   const int m_t = tm * PK_T + grp * 128, n_t = tn * PK_T + wn * 64;
+  float *Cb;
+  const float *bias = nullptr;
+  int n_off = 0, ldc;
   if (p.nsplit == 1) {
-    float *Cb = p.C[batch];
-    const float *bias = p.bias;
-    int n_off = 0;
+    Cb = p.C[batch]; bias = p.bias; ldc = p.ldc;
     if (p.n_split > 0 && n_t >= p.n_split) { Cb = p.C2[batch]; bias = p.bias2; n_off = p.n_split; }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n_t + j * 32 + col;
-      if (n >= p.N) continue;
-      const float bv = bias ? bias[n - n_off] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int m = m_t + i * 32 + (q & 3) + 8 * (q >> 2) + rbase;
-          if (m >= p.M) continue;
-          float *c = Cb + (size_t)m * p.ldc + (n - n_off);
-          float v = p.alpha * acc[i][j][q] + bv;
-          if (p.beta != 0.f) v += p.beta * *c;
-          *c = v;
-        }
-    }
   } else {
-    float *P = p.partial + ((size_t)split * p.nbatch + batch) * (size_t)p.M * p.N;
+    Cb = p.partial + ((size_t)split * p.nbatch + batch) * (size_t)p.M * p.N;
+    ldc = p.N;
+  }
+  const bool plain = p.nsplit > 1 || (p.alpha == 1.f && p.beta == 0.f);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n_t + j * 32 + col;
-      if (n >= p.N) continue;
+  for (int i = 0; i < 4; ++i) {
+    const int m = m_t + i * 32 + mrow;
+    if (m >= p.M) continue;
+    float *crow = Cb + (size_t)m * ldc - n_off;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int m = m_t + i * 32 + (q & 3) + 8 * (q >> 2) + rbase;
-          if (m >= p.M) continue;
-          P[(size_t)m * p.N + n] = acc[i][j][q];
+      for (int g = 0; g < 4; ++g) {
+        const int n = n_t + j * 32 + 8 * g + nquad;
+        if (n >= p.N) continue;                      // N % 4 == 0: a quad is inside or outside as a whole
+        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        if (p.nsplit == 1) {
+          if (!plain) { v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha; }
+          if (bias) {
+            const float4 bv = *reinterpret_cast<const float4 *>(bias + n - n_off);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+          }
+          if (p.beta != 0.f) {
+            const float4 o = *reinterpret_cast<const float4 *>(crow + n);
+            v.x += p.beta * o.x; v.y += p.beta * o.y; v.z += p.beta * o.z; v.w += p.beta * o.w;
+          }
         }
-    }
+        *reinterpret_cast<float4 *>(crow + n) = v;
+      }
   }
 }
 
@@ -566,6 +546,10 @@ static int pk_fill(PkArgs &p, const nabu_pk_gemm_desc *d, int *planes) {
     return fail(NABU_EINVAL, "gemm_pk: operand holds fewer planes than the product needs");
   if (d->n_split && (d->n_split % PK_T || !d->C2[0])) return fail(NABU_EINVAL, "gemm_pk: n_split must be a multiple of 256 with C2 set");
   if (d->N % 4 || d->ldc % 4) return fail(NABU_EUNSUP, "gemm_pk: N and ldc must be multiples of 4");
+  auto misaligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) != 0; };
+  if (misaligned(d->bias) || misaligned(d->bias2)) return fail(NABU_EUNSUP, "gemm_pk: bias must be 16-byte aligned");
+  for (int b = 0; b < d->nbatch; ++b)
+    if (misaligned(d->C[b]) || misaligned(d->C2[b])) return fail(NABU_EUNSUP, "gemm_pk: C must be 16-byte aligned");
   for (int b = 0; b < d->nbatch; ++b)
     if (!d->A[b] || !d->B[b] || !d->C[b]) return fail(NABU_EINVAL, "gemm_pk: null pointer");
   p.A.plane_stride = (unsigned)d->a_rows_pad * 32u;
@@ -626,7 +610,6 @@ extern "C" int nabu_gemm_pk(const nabu_pk_gemm_desc *d, void *ws, size_t ws_byte
   }
   if (planes == 1) PK_LAUNCH(1, 0)
   else if (var == 0) PK_LAUNCH(3, 0)
-  else if (var == 3) PK_LAUNCH(3, 3)
   else PK_LAUNCH(3, 1)
 #undef PK_LAUNCH
   NABU_LAUNCH_CHECK();

@@ -195,6 +195,19 @@ def test_ctc_matches_oracle(B, T, C, Lmax):
         assert np.all(host(dl)[b, tl[b]:] == 0)
 
 
+def test_ctc_matches_tensorflows_known_answer_vectors():
+    """the HIP kernel on TensorFlow's own CTC test vectors (tests/golden/tf_ctc_basic.npz, [TF-1.8 recalled],
+    see tests/test_oracle.py): losses to 1e-5, gradients to 2e-6 — blank = last class, repeated labels"""
+    import os
+    from nabu_amd import ops
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tf_ctc_basic.npz'))
+    nll, dl, status = ops.ctc_loss_grad(dev(np.log(fx['prob'])), dev(fx['logit_len'], torch.int32), dev(fx['labels'], torch.int32),
+                                        dev(fx['label_len'], torch.int32), 1.0)
+    assert int(status.item()) == 0
+    assert np.abs(host(nll) - fx['loss']).max() < 1e-5
+    assert np.abs(host(dl) - fx['grad']).max() < 2e-6
+
+
 def test_ctc_edge_cases():
     from nabu_amd import ops
     C = 5

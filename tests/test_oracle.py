@@ -4,6 +4,8 @@ against independent implementations available in the container:
 PyTorch-CPU float64 autograd restatements (tests/torch_ref.py),
 torch.nn.functional.ctc_loss, torch.nn.LSTM, finite differences and closed
 forms."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -384,3 +386,18 @@ def test_cpu_baseline_restatement_is_the_same_graph():
                        {k: v.detach().clone().requires_grad_() for k, v in out.items()}, small, {'t': 0, 'm': {}, 'v': {}},
                        fused=True)
     assert abs(l1 - l2) < 1e-4 * abs(l1)
+
+
+def test_ctc_matches_tensorflows_own_known_answer_vectors():
+    """[TF-1.8 recalled] The two sequences of TensorFlow's own CTC unit test (tensorflow/python/kernel_tests/
+    ctc_loss_op_test.py, CTCLossTest.testBasic: 6 classes, 5 frames, targets [0,1,2,1,0] and [0,1,1,0], inputs =
+    log of the probability matrices, expected losses 3.34211 / 5.42262 and expected d loss / d logits), restated
+    from memory as tests/golden/tf_ctc_basic.npz.  They are not held by the reference repository (it has no CTC
+    test), so parity stays "unpinned" under the rubric; but 62 recalled numbers the oracle reproduces to their
+    printed precision cannot agree by chance: they pin the blank index (last class), the handling of the repeated
+    label in the second target and the sign / normalisation of the gradient of tf.nn.ctc_loss
+    (reference call site: nabu/neuralnetworks/trainers/loss_functions.py:206-210)."""
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tf_ctc_basic.npz'))
+    nll, grad = O.ctc_loss(np.log(fx['prob']), fx['logit_len'], fx['labels'], fx['label_len'])
+    assert np.abs(nll - fx['loss']).max() < 1e-5
+    assert np.abs(grad - fx['grad']).max() < 2e-6

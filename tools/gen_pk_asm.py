@@ -8,19 +8,20 @@ gap), and inline-asm operands cannot name one register of a 16-register tuple, s
   v[0:127]    accumulators, tile n = (i, j) = (n >> 1, n & 1) at v[16n : 16n+15]
   v[128:175]  A fragments, (i, plane q) at v[128 + 4(3i+q) : +3]
   v[176:199]  B fragments, (j, plane q) at v[176 + 4(3j+q) : +3]
-  v[200:247]  three scratch tiles T0..T2 (16 registers each)
+  v[200:231]  two scratch tiles T0, T1 (16 registers each)
 
-Schedule "S2" (the shipped one).  The six plane products of tile n are a dependent chain into scratch tile n % 3
-that starts from 0, smallest terms first.  Two chains are always in flight, interleaved MFMA by MFMA (a chain's own
-MFMAs are two issue slots apart, so a dependent matrix instruction never waits for its predecessor), chain n+1
-starting when chain n is half done.  The 16 v_add_f32 that promote a finished chain into its accumulator tile are
-spread over the five MFMA gaps that follow the chain's end by at least two MFMAs (64 cycles: the matrix result is
-written 8 passes + 3 states after issue; nothing inside an asm statement is padded by the compiler), 3-4 adds per
-gap — a wave issues ~5 independent instructions under one 32-cycle MFMA.  The last two chains of a stage are
-promoted at the start of the next stage (and after the loop), so the stream is the same for every stage.
+Schedule "S1" (the shipped one).  The six plane products of tile n are a dependent chain into scratch tile n % 2
+that starts from 0, smallest terms first (a dependent v_mfma_f32_32x32x16_bf16 issues back to back with its
+predecessor at the full rate: measured, tools/experiments/ub/pk_sched.hip).  The 16 v_add_f32 that promote the
+finished chain of tile n-1 into its accumulator tile sit in the gaps after the 2nd .. 5th MFMA of chain n, four per
+gap (a wave issues ~5 independent instructions under one 32-cycle MFMA; the first add comes two MFMAs = 64 cycles
+after the chain's last MFMA issued: the matrix result is written 8 passes + 3 states after issue, and nothing
+inside an asm statement is padded by the compiler).  Tile 7's partial sum is promoted at the start of the NEXT
+stage (T1 is carried across the stage boundary; one add pass after the loop), so every stage runs the same stream.
+Measured one wave per SIMD: 653 ns per stage = the bare 48-MFMA stream (655 ns): the adds are free.
 
-Schedules "S1" (two scratch tiles, one chain at a time, adds of the previous chain in its gaps) and "S0" (direct
-accumulation, no promotion) are emitted for the micro-benchmark tools/experiments/ub/pk_sched.hip."""
+Schedules "S0" (direct accumulation, no promotion) and "S2" (three scratch tiles, two interleaved chains, wrapping
+around the stage: a throughput probe only) are emitted with --bench for the micro-benchmark."""
 import sys
 
 ACC, FA, FB, TMP = 0, 128, 176, 200
@@ -54,7 +55,9 @@ def chain(n, r):
     i, j = n >> 1, n & 1
     out = []
     for k, (qa, qb) in enumerate(PRODUCTS):
-        out.append(mfma(tmp(r), fa(i, qa), fb(j, qb), '0' if k == 0 else tmp(r)))
+        # operands swapped (B fragment first): the result tile is C^T — a lane holds 4 consecutive columns n of one
+        # row m per register quad, which the epilogue stores as 16-byte pieces
+        out.append(mfma(tmp(r), fb(j, qb), fa(i, qa), '0' if k == 0 else tmp(r)))
     return out
 
 
@@ -66,20 +69,30 @@ def stream_s0():
     out = []
     for qa, qb in PRODUCTS:
         for n in range(8):
-            out.append(mfma(acc(n), fa(n >> 1, qa), fb(n & 1, qb), acc(n)))
+            out.append(mfma(acc(n), fb(n & 1, qb), fa(n >> 1, qa), acc(n)))
     return out
 
 
-def stream_s1():
-    """two scratch tiles; chain n alone, the adds of chain n-1 (tile 7 of the previous stage for n = 0) in its gaps"""
+def pk_adds(n, r):
+    return ['v_pk_add_f32 v[%d:%d], v[%d:%d], v[%d:%d]' % (ACC + 16 * n + e, ACC + 16 * n + e + 1, ACC + 16 * n + e,
+                                                          ACC + 16 * n + e + 1, TMP + 16 * r + e, TMP + 16 * r + e + 1)
+            for e in range(0, 16, 2)]
+
+
+def stream_s1(share=(0, 0, 4, 4, 4, 4), packed=False):
+    """two scratch tiles; chain n alone, the adds of chain n-1 (tile 7 of the previous stage for n = 0) in its
+    gaps: share[k] adds behind the chain's MFMA k+1"""
     out = []
     for n in range(8):
         c = chain(n, n % 2)
-        a = adds((n - 1) % 8, (n - 1) % 2)
-        out += c[:2]
-        for g in range(4):
-            out += a[4 * g:4 * g + 4]
-            out.append(c[2 + g])
+        a = (pk_adds if packed else adds)((n - 1) % 8, (n - 1) % 2)
+        at = 0
+        for k in range(6):
+            out.append(c[k])
+            cnt = share[k] // 2 if packed else share[k]
+            out += a[at:at + cnt]
+            at += cnt
+        assert at == len(a)
     return out
 
 
@@ -117,15 +130,47 @@ def as_c_string(lines):
     return '\n'.join('      "%s\\n\\t"' % l for l in lines)
 
 
+def stream_load(va, vb):
+    """the 18 operand reads of a stage: A (i, q) at va + q * 8192 + i * 1024, B (j, q) at vb + q * 8192 + j * 1024
+    (va / vb = the asm operand names of the two per-lane LDS addresses; vb already points at the B pieces)"""
+    out = []
+    for q in range(3):
+        for i in range(4):
+            out.append('ds_read_b128 %s, %s offset:%d' % (fa(i, q), va, q * 8192 + i * 1024))
+        for j in range(2):
+            out.append('ds_read_b128 %s, %s offset:%d' % (fb(j, q), vb, q * 8192 + j * 1024))
+    return out
+
+
+def macro(name, lines):
+    print('#define %s \\' % name)
+    print(' \\\n'.join('  "%s\\n\\t"' % l for l in lines))
+    print()
+
+
+def operand_lists():
+    """constraint lists matching the physical registers above (C macros)"""
+    accs = ', '.join('"+{%s}"(acc[%d][%d])' % (acc(n), n >> 1, n & 1) for n in range(8))
+    tmps = ', '.join('"+{%s}"(%s)' % (tmp(r), nm) for r, nm in ((0, 't0'), (1, 'tpend')))
+    fas_o = ', '.join('"=&{%s}"(fa[%d][%d])' % (fa(i, q), i, q) for i in range(4) for q in range(3))
+    fbs_o = ', '.join('"=&{%s}"(fb[%d][%d])' % (fb(j, q), j, q) for j in range(2) for q in range(3))
+    fas_i = ', '.join('"{%s}"(fa[%d][%d])' % (fa(i, q), i, q) for i in range(4) for q in range(3))
+    fbs_i = ', '.join('"{%s}"(fb[%d][%d])' % (fb(j, q), j, q) for j in range(2) for q in range(3))
+    print('#define PK_ASM_LOAD_OUTPUTS %s, %s\n' % (fas_o, fbs_o))
+    print('#define PK_ASM_COMPUTE_INOUT %s, %s\n' % (accs, tmps))
+    print('#define PK_ASM_COMPUTE_INPUTS %s, %s\n' % (fas_i, fbs_i))
+
+
 def main():
-    s2, slot, gaps = stream_s2()
-    print('// generated by tools/gen_pk_asm.py — do not edit')
-    print('#define PK_STREAM_S0 \\')
-    print(' \\\n'.join('  "%s\\n\\t"' % l for l in stream_s0()))
-    print('#define PK_STREAM_S1 \\')
-    print(' \\\n'.join('  "%s\\n\\t"' % l for l in stream_s1()))
-    print('#define PK_STREAM_S2 \\')
-    print(' \\\n'.join('  "%s\\n\\t"' % l for l in s2))
+    print('// generated by tools/gen_pk_asm.py — do not edit (register map and schedules: see the generator)')
+    if len(sys.argv) > 1 and sys.argv[1] == '--bench':
+        macro('PK_STREAM_S0', stream_s0())
+        macro('PK_STREAM_S2', stream_s2()[0])
+    macro('PK_STREAM_S1', stream_s1())
+    # measured and dropped (sum over the cfg2 product shapes, direct accumulation 7.78 ms): S1 8.14 ms; the adds as
+    # (0,0,3,3,3,7) 8.23, as (0,0,0,5,5,6) 8.15, as 8 v_pk_add_f32 per tile 9.39, S1 without s_setprio 8.13
+    macro('PK_STREAM_LOAD', stream_load('%18', '%19'))
+    operand_lists()
 
 
 if __name__ == '__main__':
