@@ -284,6 +284,11 @@ def parse_args(argv=None):
                     help='cfg2 (default) is the BASELINE.json metric; cfg3 = same encoder + Speller; cfg5 = '
                          'location-aware LAS, batch 64x1600x80, bf16 input GEMMs (BASELINE.json configs[2]/[4]), '
                          'for information')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='first-contact check of the multi-rank path: start / join the ranks exactly as a measurement '
+                         'would (self-launch or the given environment, rendezvous over 127.0.0.1, device assignment), '
+                         'run one collective, print one JSON line and stop before the workload.  With fewer visible '
+                         'GPUs than ranks the process group is gloo and the ranks share the devices round-robin.')
     ap.add_argument('--allreduce', default='flat', choices=['flat', 'bucketed'],
                     help='gradient exchange of the data-parallel mode (trainer cfg key allreduce_buckets)')
     return ap.parse_args(argv)
@@ -320,6 +325,30 @@ def self_launch(argv, nproc, script=None):
 def make_server():
     from nabu_amd.computing import dist
     return dist.create_server()
+
+
+def dry_run(args):
+    """everything a measurement does up to and including init_process_group + one collective"""
+    import torch
+    from nabu_amd.computing import dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    ngpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    shared = world > max(ngpu, 0)
+    if shared and ngpu:
+        os.environ['LOCAL_RANK'] = str(int(os.environ.get('LOCAL_RANK', '0')) % ngpu)
+    server = dist.create_server(backend='gloo' if shared else None)
+    dev = torch.device('cuda', torch.cuda.current_device()) if ngpu else torch.device('cpu')
+    t = torch.full((4,), float(server.rank + 1), device='cpu' if server.backend == 'gloo' else dev)
+    server.all_reduce_sum_(t)
+    expect = world * (world + 1) / 2.0
+    ok = bool((t == expect).all().item())
+    server.barrier()
+    if server.rank == 0:
+        print(json.dumps({'dry_run': True, 'ok': ok, 'world_size_seen': server.world_size, 'backend': server.backend,
+                          'visible_gpus': ngpu, 'ranks_share_devices': shared, 'all_reduce_sum': float(t[0].item()),
+                          'master': '%s:%s' % (os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT'))}), flush=True)
+    server.shutdown()
+    return 0 if ok else 1
 
 
 # ------------------------------------------------------------------ the workload on the GPU
@@ -549,6 +578,8 @@ def main(argv=None):
     if args.gpus > 1 and env_world == 1:
         # no ranks in the environment: start them ourselves
         sys.exit(self_launch(argv, args.gpus))
+    if args.dry_run:
+        sys.exit(dry_run(args))
     server = make_server()
     if server.world_size != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, server.world_size))

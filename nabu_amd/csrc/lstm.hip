@@ -435,9 +435,12 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const in
     NABU_PROFILE_MARK(g_ev_begin, s);
     int e = lstm_persist_fwd(B, T, D, H, max_len, len, kern, gates, cs, out, reinterpret_cast<int *>(w), w + L.persist_off,
                              L.persist_bytes, s);
-    if (e) return e;
-    NABU_PROFILE_MARK(g_ev_end, s);
-    return 0;
+    // the grid cannot be co-resident on this device (occupancy check before the launch): LSTM_AUTO steps instead
+    if (!(e == NABU_EUNSUP && d->mode == NABU_LSTM_AUTO)) {
+      if (e) return e;
+      NABU_PROFILE_MARK(g_ev_end, s);
+      return 0;
+    }
   }
   StepArgs p;
   p.B = B; p.T = T; p.D = D; p.H = H; p.max_len = max_len; p.len = len;
@@ -493,11 +496,14 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
   NABU_PROFILE_MARK(g_ev_begin, s);
   float *db_part = nullptr;   // persistent path: bias-gradient partials [db_rows][2][4H]
   int db_rows = 0;
-  if (use_persistent(d)) {
+  bool stepwise = !use_persistent(d);
+  if (!stepwise) {
     int e = lstm_persist_bwd(B, T, D, H, max_len, len, kern, gates, cs, d_out, reinterpret_cast<int *>(w), w + L.persist_off,
                              L.persist_bytes, &db_part, &db_rows, s);
-    if (e) return e;
-  } else {
+    if (e == NABU_EUNSUP && d->mode == NABU_LSTM_AUTO) { stepwise = true; db_part = nullptr; db_rows = 0; }
+    else if (e) return e;
+  }
+  if (stepwise) {
     StepArgs p;
     p.B = B; p.T = T; p.D = D; p.H = H; p.max_len = max_len; p.len = len;
     for (int i = 0; i < 2; ++i) { p.kernel[i] = kern[i]; p.gates[i] = gates[i]; p.cs[i] = cs[i]; }

@@ -857,17 +857,32 @@ size_t lstm_persist_ws_bytes(int B, int T, int H) {
   return TABLE_BYTES + m + db_part_bytes(B, H);
 }
 
+// Co-residency is a REQUIREMENT of these kernels (every workgroup of a unit polls its peers): the grid is
+// validated against the runtime's occupancy answer for this kernel, block size and LDS request on the current
+// device before it is launched — what hipLaunchCooperativeKernel would check, without its +15-19 us per launch
+// (MI355X_MICROARCH.md, coop-launch row).  The answer can be one block per CU too high at 81-112 SGPRs with
+// 256-thread blocks (same guide); the grids here need at most 2 per CU where the register file admits 2 and the
+// LDS request is sized for exactly that, and every spin is bounded, so an optimistic answer costs a time-out,
+// never a hang.  NABU_EUNSUP makes LSTM_AUTO take the step-wise kernels.
 template <typename K>
 static int launch(K kernel, const PersistArgs &a, int grid, int threads, size_t lds, hipStream_t stream) {
-  static thread_local const void *configured[32] = {nullptr};
   const void *fn = reinterpret_cast<const void *>(kernel);
-  bool done = false;
-  for (auto c : configured) done = done || c == fn;
-  if (!done) {
+  struct Seen { const void *fn; int dev, threads, blocks; size_t lds; };
+  static thread_local Seen seen[32] = {};
+  int dev = 0;
+  NABU_HIP(hipGetDevice(&dev));
+  int blocks = -1;
+  for (const Seen &c : seen)
+    if (c.fn == fn && c.dev == dev && c.threads == threads && c.lds == lds) blocks = c.blocks;
+  if (blocks < 0) {
     NABU_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    for (auto &c : configured)
-      if (!c) { c = fn; break; }
+    NABU_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, threads, lds));
+    for (Seen &c : seen)
+      if (!c.fn) { c = Seen{fn, dev, threads, blocks, lds}; break; }
   }
+  if ((long long)blocks * cu_count() < grid)
+    return fail(NABU_EUNSUP, "persistent LSTM: %d workgroups cannot be co-resident (%d per CU x %d CUs on this device)",
+                grid, blocks, cu_count());
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, stream, a);
   NABU_LAUNCH_CHECK();
   return 0;

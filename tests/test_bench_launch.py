@@ -101,3 +101,17 @@ def test_driver_style_launch_and_single_rank():
                         'type("S", (), {"world_size": 2, "rank": 0})(); bench.main(["--gpus", "4"])' % ROOT],
                        env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and 'WORLD_SIZE=2' in (r.stderr + r.stdout)
+
+
+def test_dry_run_starts_two_ranks_and_runs_a_collective():
+    """`python bench.py --gpus 2 --dry-run`: self-launch, rendezvous on 127.0.0.1, process group, one all-reduce,
+    one JSON line — without the workload (on this CPU box: gloo; the GPU twin is tests/test_hip_dist.py)"""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['ok'] and out['world_size_seen'] == 2 and out['all_reduce_sum'] == 3.0
