@@ -449,6 +449,55 @@ __global__ __launch_bounds__(256) void pk_pack_cols_kernel(PackArgs a) {
   pk_split_store<NP>(x, a.dst + (size_t)(a.kb_off + kb) * a.kb_stride + (size_t)prow * 32, a.plane_stride, prow);
 }
 
+// BOTH layouts of one source matrix from ONE read (the backward pass needs dz as [BT rows, k = gate column] for the
+// input gradient and as [gate-column rows, k = frame] for the weight gradients): a 64 x 64 tile through LDS, then the
+// natural pack (row = source row) and the transposed pack (row = source column) of it.
+// grid (ceil(C / 64), ceil(R / 64)); a = natural destination, b = transposed destination (their src/ld/R/C are equal)
+template <int NP>
+__global__ __launch_bounds__(256) void pk_pack_both_kernel(PackArgs a, PackArgs b) {
+  __shared__ __attribute__((aligned(16))) float tile[64][68];
+  const int tid = threadIdx.x, r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + 256 * j, r = i >> 4, c4 = (i & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < a.R) {
+      const float *s = a.src + (size_t)(r0 + r) * a.ld + c0 + c4;
+      if (c0 + c4 + 3 < a.C) v = *reinterpret_cast<const float4 *>(s);
+      else {
+        if (c0 + c4 < a.C) v.x = s[0];
+        if (c0 + c4 + 1 < a.C) v.y = s[1];
+        if (c0 + c4 + 2 < a.C) v.z = s[2];
+      }
+    }
+    *reinterpret_cast<float4 *>(&tile[r][c4]) = v;
+  }
+  __syncthreads();
+  const int l = tid & 63, kbl = tid >> 6;
+  float x[16];
+  {   // natural: packed row = source row r0 + l, k-block = source columns c0 + 16 kbl ...
+    const int row = r0 + l, kb = blockIdx.x * 4 + kbl;
+    if (row < a.fill_rows && kb < a.fill_kb) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 v = *reinterpret_cast<const float4 *>(&tile[l][kbl * 16 + 4 * i]);
+        x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+      }
+      const int prow = a.row_off + row;
+      pk_split_store<NP>(x, a.dst + (size_t)(a.kb_off + kb) * a.kb_stride + (size_t)prow * 32, a.plane_stride, prow);
+    }
+  }
+  {   // transposed: packed row = source column c0 + l, k-block = source rows r0 + 16 kbl ...
+    const int row = c0 + l, kb = blockIdx.y * 4 + kbl;
+    if (row < b.fill_rows && kb < b.fill_kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) x[i] = tile[kbl * 16 + i][l];
+      const int prow = b.row_off + row;
+      pk_split_store<NP>(x, b.dst + (size_t)(b.kb_off + kb) * b.kb_stride + (size_t)prow * 32, b.plane_stride, prow);
+    }
+  }
+}
+
 static int pk_cu_count() {
   static thread_local int cached_dev = -1, cached = 256;
   int dev = 0;
@@ -530,6 +579,31 @@ extern "C" int nabu_pk_pack(int planes, int transposed, const float *src, long l
   NABU_LAUNCH_CHECK();
   return 0;
 }
+
+// internal (lstm.hip): natural pack into (dst_n: rows_pad_n, kb_off_n, fill_kb_n) AND transposed pack into
+// (dst_t: rows_pad_t, row_off_t, fill_rows_t) of the same [R x C] source in one pass.  The natural pack fills rows
+// [0, fill_rows_n), the transposed pack k-blocks [0, fill_kb_t).
+namespace nabu {
+int pk_pack_both(int planes, const float *src, long long ld, int R, int C, void *dst_n, int rows_pad_n, int kb_off_n,
+                 int fill_rows_n, int fill_kb_n, void *dst_t, int rows_pad_t, int row_off_t, int fill_rows_t,
+                 int fill_kb_t, hipStream_t s) {
+  if (ld % 4 || (reinterpret_cast<uintptr_t>(src) & 15)) return fail(NABU_EUNSUP, "pk_pack_both: unaligned source");
+  PackArgs a, b;
+  a.src = b.src = src; a.ld = b.ld = ld; a.R = b.R = R; a.C = b.C = C;
+  a.fill_rows = fill_rows_n; a.fill_kb = fill_kb_n; a.dst = static_cast<char *>(dst_n);
+  a.plane_stride = (unsigned)rows_pad_n * 32u; a.kb_stride = (unsigned long long)planes * a.plane_stride;
+  a.row_off = 0; a.kb_off = kb_off_n; a.period = 0; a.shift = 0;
+  b.fill_rows = fill_rows_t; b.fill_kb = fill_kb_t; b.dst = static_cast<char *>(dst_t);
+  b.plane_stride = (unsigned)rows_pad_t * 32u; b.kb_stride = (unsigned long long)planes * b.plane_stride;
+  b.row_off = row_off_t; b.kb_off = 0; b.period = 0; b.shift = 0;
+  const int gx = ((fill_kb_n + 3) / 4 > (fill_rows_t + 63) / 64) ? (fill_kb_n + 3) / 4 : (fill_rows_t + 63) / 64;
+  const int gy = ((fill_rows_n + 63) / 64 > (fill_kb_t + 3) / 4) ? (fill_rows_n + 63) / 64 : (fill_kb_t + 3) / 4;
+  if (planes == 3) hipLaunchKernelGGL(pk_pack_both_kernel<3>, dim3(gx, gy), dim3(256), 0, s, a, b);
+  else hipLaunchKernelGGL(pk_pack_both_kernel<1>, dim3(gx, gy), dim3(256), 0, s, a, b);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace nabu
 
 static int pk_fill(PkArgs &p, const nabu_pk_gemm_desc *d, int *planes) {
   if (!d || d->size != sizeof(nabu_pk_gemm_desc)) return fail(NABU_EINVAL, "gemm_pk: bad descriptor size");

@@ -529,9 +529,16 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
     const int rpBT = nabu_pk_rows_pad(M), rpG = nabu_pk_rows_pad(2 * G), rpD = nabu_pk_rows_pad(D), rpH = nabu_pk_rows_pad(H);
     const int nkbT = nabu_pk_kblocks(M, P);
     int e;
-    for (int dir = 0; dir < 2; ++dir)
-      if ((e = nabu_pk_pack(P, 1, gates[dir], G, M, G, pk + L.pk_dzT, rpG, dir * G, 0, dir ? rpG - G : G, nkbT, 0, 0, stream)))
-        return e;
+    const bool both = d_x && L.pk_in;    // dz is also needed row-major (dx): both packs from one read of dz
+    const int nkb2 = nabu_pk_kblocks(2 * G, P), kbG = G / 16;
+    for (int dir = 0; dir < 2; ++dir) {
+      if (both)
+        e = pk_pack_both(P, gates[dir], G, M, G, pk + L.pk_dz, rpBT, dir * kbG, rpBT, dir ? nkb2 - kbG : kbG, pk + L.pk_dzT,
+                         rpG, dir * G, dir ? rpG - G : G, nkbT, s);
+      else
+        e = nabu_pk_pack(P, 1, gates[dir], G, M, G, pk + L.pk_dzT, rpG, dir * G, 0, dir ? rpG - G : G, nkbT, 0, 0, stream);
+      if (e) return e;
+    }
     if (L.pk_in) {
       if ((e = nabu_pk_pack(P, 1, x, D, M, D, pk + L.pk_xT, rpD, 0, 0, rpD, nkbT, 0, 0, stream))) return e;
       nabu_pk_gemm_desc g = pk_desc(P, D, 2 * G, nkbT, pk + L.pk_xT, rpD, pk + L.pk_dzT, rpG, dkern[0], G);
@@ -550,15 +557,10 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
     }
     if (d_x && L.pk_in) {
       // dx = [dZ_fw | dZ_bw] · [Wx_fw | Wx_bw]^T: the two cells are two ranges of ONE reduction
-      const int nkb2 = nabu_pk_kblocks(2 * G, P), kbG = G / 16;
-      for (int dir = 0; dir < 2; ++dir) {
-        if ((e = nabu_pk_pack(P, 0, gates[dir], G, M, G, pk + L.pk_dz, rpBT, 0, dir * kbG, rpBT, dir ? nkb2 - kbG : kbG, 0, 0,
-                              stream)))
-          return e;
+      for (int dir = 0; dir < 2; ++dir)
         if ((e = nabu_pk_pack(P, 0, kern[dir], G, D, G, pk + L.pk_w2, rpD, 0, dir * kbG, rpD, dir ? nkb2 - kbG : kbG, 0, 0,
                               stream)))
           return e;
-      }
       nabu_pk_gemm_desc g = pk_desc(P, M, D, nkb2, pk + L.pk_dz, rpBT, pk + L.pk_w2, rpD, d_x, D);
       if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
     }
