@@ -396,6 +396,10 @@ int nabu_speller_decoder_inputs(const nabu_speller_desc *d, const void *reserve,
                                 nabu_stream_t stream);
 size_t nabu_speller_reserve_bytes(const nabu_speller_desc *d);
 size_t nabu_speller_ws_bytes(const nabu_speller_desc *d);
+/* 1 when the decoder steps of this descriptor run as ONE persistent launch (speller_persist.hip) in the forward
+ * (backward = 0) resp. backward pass on the current device, 0 when they take the step chain.  Diagnostic: the two
+ * paths compute the same function (tests/test_hip_speller.py compares them). */
+int nabu_speller_uses_persistent(const nabu_speller_desc *d, int backward);
 int nabu_speller_fwd(const nabu_speller_desc *d, const float *values, const int32_t *enc_len,
                      const int32_t *ids, const int32_t *dec_len, const nabu_speller_params *p,
                      float *logits, void *reserve, void *ws, size_t ws_bytes, nabu_stream_t stream);

@@ -79,6 +79,7 @@ SIGNATURES = {
     'nabu_speller_decoder_inputs': (_i, [_vp, _vp, _vp, _vp]),
     'nabu_speller_reserve_bytes': (_sz, [_vp]),
     'nabu_speller_ws_bytes': (_sz, [_vp]),
+    'nabu_speller_uses_persistent': (_i, [_vp, _i]),
     'nabu_speller_fwd': (_i, [_vp] * 9 + [_sz, _vp]),
     'nabu_speller_bwd': (_i, [_vp] * 11 + [_sz, _vp]),
     'nabu_mask_time_f32': (_i, [_i, _i, _i, _vp, _vp, _vp]),

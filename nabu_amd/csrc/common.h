@@ -48,4 +48,31 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 // tanh through one exp: 2*sigmoid(2x)-1 (abs error ~1e-7)
 __device__ __forceinline__ float tanhf_(float x) { return 2.0f / (1.0f + __expf(-2.0f * x)) - 1.0f; }
 
+// counter-based RNG (Philox4x32-10) for dropout masks, scheduled sampling and Gaussian input noise:
+// element i uses counter (i/4, offset) and key seed, so the backward pass
+// regenerates the forward mask instead of storing it.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+  const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+    const unsigned hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u;
+    k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+__device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+// dropout scale factors (0 or 1/keep) of the 4-element group `group` of the array the stream is defined on
+// (dropout_kernel of elementwise.hip: element e = 4 group + j keeps its value when u01(r[j]) < keep)
+__device__ __forceinline__ float4 dropout_scale4(unsigned long long group, float keep, unsigned long long seed,
+                                                 unsigned long long offset) {
+  const uint4 r = philox4x32_10(make_uint4((unsigned)group, (unsigned)(group >> 32), (unsigned)offset, (unsigned)(offset >> 32)),
+                                make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+  const float inv = 1.0f / keep;
+  return make_float4(u01(r.x) < keep ? inv : 0.f, u01(r.y) < keep ? inv : 0.f, u01(r.z) < keep ? inv : 0.f,
+                     u01(r.w) < keep ? inv : 0.f);
+}
+
 }  // namespace nabu

@@ -119,23 +119,7 @@ __global__ __launch_bounds__(256) void pad_time_kernel(int B, int T, int Tp, int
 }
 
 
-// ---------------------------------------------------------------------------
-// counter-based RNG (Philox4x32-10) for dropout masks and Gaussian input noise:
-// element i uses counter (i/4, offset) and key seed, so the backward pass
-// regenerates the forward mask instead of storing it.
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
-  const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const unsigned hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
-    const unsigned hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
-    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-    k.x += 0x9E3779B9u;
-    k.y += 0xBB67AE85u;
-  }
-  return c;
-}
-__device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+// counter-based RNG (Philox4x32-10): philox4x32_10 / u01 in common.h (shared with the persistent decoder)
 
 // i0: index of the first 4-element group of x inside the array the random stream is defined on (a
 // sub-batch of rows draws exactly the numbers the whole batch would draw for those rows)

@@ -1639,6 +1639,31 @@ extern "C" size_t nabu_speller_ws_bytes(const nabu_speller_desc *d) {
   return sp_ws(d).total * sizeof(float);
 }
 
+// Which decoder steps run as ONE persistent launch (speller_persist.hip) instead of the step chain; the same
+// predicates drive nabu_speller_fwd / _bwd and the query nabu_speller_uses_persistent.
+static bool fwd_takes_persistent(const nabu_speller_desc *d, const SpWs &W) {
+  const int B = d->B, U = d->U, E = d->E, Bn = B / W.NS;
+  const bool cell_epi0 = env_int("NABU_SPELLER_EPILOGUE", 1) && fused_ok(Bn, 4 * U, E, E, U, U);
+  SpPersistDesc pd = {B, d->L, U, E, d->Te, d->C};
+  pd.kind = d->kind; pd.K = d->K; pd.F = d->F;
+  pd.sample_prob = d->sample_prob;
+  return d->num_layers == 1 && (d->kind == 0 || d->kind == 1) && d->prob_fn == 0 && cell_epi0 &&
+         W.persist_bytes > 0 && speller_persist_ok(pd);
+}
+static bool bwd_takes_persistent(const nabu_speller_desc *d, const SpWs &W) {
+  const int B = d->B, U = d->U, E = d->E, Bn = B / W.NS;
+  const bool fuse_shapes = env_int("NABU_SPELLER_EPILOGUE", 1) && d->num_layers == 1 && fused_ok(Bn, U, U, U, 0, 0) &&
+                           fused_ok(Bn, E + U, 4 * U, 4 * U, 0, 0) && (E + U) / 32 <= 1024;
+  SpPersistDesc pd = {B, d->L, U, E, d->Te, d->C};
+  pd.kind = d->kind; pd.K = d->K; pd.F = d->F;
+  return fuse_shapes && d->kind == 0 && d->prob_fn == 0 && W.persist_bytes > 0 && speller_persist_bwd_ok(pd);
+}
+extern "C" int nabu_speller_uses_persistent(const nabu_speller_desc *d, int backward) {
+  if (check_sp(d)) return 0;
+  const SpWs W = sp_ws(d);
+  return (backward ? bwd_takes_persistent(d, W) : fwd_takes_persistent(d, W)) ? 1 : 0;
+}
+
 extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values, const int32_t *enc_len,
                                 const int32_t *ids, const int32_t *dec_len, const nabu_speller_params *p,
                                 float *logits, void *reserve, void *ws, size_t ws_bytes,
@@ -1692,13 +1717,15 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
   // one LSTM layer, vanilla softmax attention, teacher forcing, no dropout, B = 32 (cfg3)
   SpPersistDesc pd = {B, L, U, E, Te, C};
   pd.kind = d->kind; pd.K = d->K; pd.F = d->F;
-  const bool persist = nl == 1 && !drop && !sampling && (d->kind == 0 || d->kind == 1) && d->prob_fn == 0 && cell_epi[0] &&
-                       W.persist_bytes > 0 && speller_persist_ok(pd);
+  pd.keep_prob = d->keep_prob; pd.seed = d->seed; pd.seed_offset = d->seed_offset;     // nl == 1: offset + t*nl + n = offset + t
+  pd.sample_prob = d->sample_prob; pd.sample_seed = d->sample_seed; pd.sample_offset = d->sample_offset;
+  const bool persist = fwd_takes_persistent(d, W);
   if (persist)
     SP_TRY(speller_persist_fwd(pd, dec_len, enc_len, ids_used, w + W.kperm[0], p->lstm_bias[0], p->lstm_kernel[0],
-                               p->query_kernel, p->attention_v, r + R.keys, values, p->conv_kernel, p->conv_proj, r + R.H[0], r + R.Cs[0],
-                               r + R.acts[0], r + R.q, r + R.ctx, r + R.align, reinterpret_cast<int *>(w + W.status),
-                               w + W.persist, W.persist_bytes, s));
+                               p->query_kernel, p->attention_v, r + R.keys, values, p->conv_kernel, p->conv_proj, r + R.H[0],
+                               drop ? r + R.Ho[0] : nullptr, r + R.Cs[0], r + R.acts[0], r + R.q, r + R.ctx, r + R.align,
+                               reinterpret_cast<int *>(w + W.status), w + W.persist, W.persist_bytes, s, p->out_kernel,
+                               p->out_bias, ids_used));
   unsigned *atk = env_int("NABU_SPELLER_ATTN_FUSED", 1) ? reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)NS * 1024 : nullptr;
   SubStreams ss;
   if (!persist) {
@@ -1845,15 +1872,17 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   // last workgroup of dq·Wq^T, and dz·[Kx^T | Kh^T] is ONE product whose [B, E+U] result carries d context and
   // d h to the next step — 4 dependent launches per step instead of 7
   const int epi_env_b = env_int("NABU_SPELLER_EPILOGUE", 1);
-  const bool fuse_b = epi_env_b && nl == 1 && !drop && fused_ok(Bn, U, U, U, 0, 0) && fused_ok(Bn, E + U, 4 * U, 4 * U, 0, 0) &&
-                      (E + U) / 32 <= 1024;
-  if (fuse_b) SP_TRY(transpose(E + U, 4 * U, p->lstm_kernel[0] + (size_t)C * 4 * U, 4 * U, w + W.kxhT, s));
-  const bool split_b = fuse_b && E % 32 == 0 && env_int("NABU_SPELLER_SPLIT", 1);
-  // the whole step loop as ONE persistent launch (speller_persist.hip), as in the forward pass
+  const bool fuse_shapes = epi_env_b && nl == 1 && fused_ok(Bn, U, U, U, 0, 0) && fused_ok(Bn, E + U, 4 * U, 4 * U, 0, 0) &&
+                           (E + U) / 32 <= 1024;
+  // the whole step loop as ONE persistent launch (speller_persist.hip), as in the forward pass (output dropout is
+  // applied inside it: the mask is recomputed from the Philox stream)
   SpPersistDesc pd = {B, L, U, E, Te, C};
   pd.kind = d->kind; pd.K = d->K; pd.F = d->F;
-  const bool persist = fuse_b && d->kind == 0 && d->prob_fn == 0 && W.persist_bytes > 0 &&
-                       speller_persist_bwd_ok(pd);
+  pd.keep_prob = d->keep_prob; pd.seed = d->seed; pd.seed_offset = d->seed_offset;
+  const bool persist = bwd_takes_persistent(d, W);
+  const bool fuse_b = fuse_shapes && (!drop || persist);      // the chain's cell epilogue has no dropout
+  if (fuse_b) SP_TRY(transpose(E + U, 4 * U, p->lstm_kernel[0] + (size_t)C * 4 * U, 4 * U, w + W.kxhT, s));
+  const bool split_b = fuse_b && E % 32 == 0 && env_int("NABU_SPELLER_SPLIT", 1);
   if (persist)
     SP_TRY(speller_persist_bwd(pd, dec_len, enc_len, w + W.kxhT, p->query_kernel, p->attention_v, r + R.keys, values,
                                r + R.acts[0], r + R.Cs[0], r + R.q, r + R.ctx, r + R.align, dH, dCtx, dq, w + W.dz[0],

@@ -7,6 +7,15 @@ namespace nabu {
 struct SpPersistDesc {
   int B, L, U, E, Te, C;
   int kind = 0, K = 0, F = 0;      // attention: 0 vanilla, 1 location-aware (filter taps, filters); softmax
+  // output dropout of the cell (speller.py:36-40: DropoutWrapper(output_keep_prob)): the mask of step t is the Philox
+  // stream dropout_rows draws for (seed, seed_offset + t) over [B, U]; 1 = off
+  float keep_prob = 1.f;
+  unsigned long long seed = 0, seed_offset = 0;
+  // scheduled sampling (rnn_decoder.py:59-66, ScheduledEmbeddingTrainingHelper): with probability sample_prob the
+  // next input of a row is drawn from softmax(logits of this step) — the draws of nabu_sample_ids for
+  // (sample_seed, sample_offset + t, batch row); 0 = teacher forcing
+  float sample_prob = 0.f;
+  unsigned long long sample_seed = 0, sample_offset = 0;
 };
 
 // shapes the persistent forward kernel takes (single LSTM layer, vanilla softmax attention, no dropout, no
@@ -18,12 +27,16 @@ size_t speller_persist_ws_bytes(const SpPersistDesc &d);
 // kperm: [(E+U), 4U] gate-interleaved dense rows of the cell kernel (column 4u+g); emb: the kernel's first C rows
 // (gate-major columns g*U+u); bias [4U] gate-major; wq [U,U]; v [U]; keys [B,Te,U]; values [B,Te,E]; ids [L,B].
 // Writes the time-major reserve arrays of nabu_speller_fwd: H, Cs [(L+1),B,U] (index 0 = zero state, set by the
-// caller), acts [L,B,4U], q [L,B,U], ctx [(L+1),B,E], align [(L+1),B,Te].
+// caller), acts [L,B,4U], q [L,B,U], ctx [(L+1),B,E], align [(L+1),B,Te]; with d.keep_prob < 1 also Ho [(L+1),B,U],
+// the dropped cell outputs (what the query and the output projection see; the recurrence keeps h).
 int speller_persist_fwd(const SpPersistDesc &d, const int32_t *dec_len, const int32_t *enc_len, const int32_t *ids,
                         const float *kperm, const float *bias, const float *emb, const float *wq, const float *v,
                         const float *keys, const float *values, const float *conv_kernel, const float *conv_proj, float *H,
-                        float *Cs, float *acts, float *q, float *ctx, float *align, int *status, void *ws, size_t ws_bytes,
-                        hipStream_t stream);
+                        float *Ho, float *Cs, float *acts, float *q, float *ctx, float *align, int *status, void *ws,
+                        size_t ws_bytes, hipStream_t stream, const float *out_kernel = nullptr,
+                        const float *out_bias = nullptr, int32_t *ids_used = nullptr);
+// (scheduled sampling: out_kernel [(U+E), C], out_bias [C] = the output projection; ids_used [L,B] = `ids`, whose
+// rows 1.. the kernel overwrites with the inputs it actually used)
 
 // Backward pass of the step loop (same shapes; the caller has run the output projection's gradient into dH / dCtx).
 // kxhT [4U, E+U]: transposed dense rows of the cell kernel (k = gate-major column).  Writes dq [L,B,U], dz [L,B,4U]

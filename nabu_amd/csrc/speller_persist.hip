@@ -59,6 +59,14 @@ struct Args {
   const int32_t *dec_len, *enc_len, *ids;
   const float *kperm, *bias, *emb, *wq, *v, *keys, *values;
   float *H, *Cs, *acts, *q, *ctx, *align;
+  const float *wout, *bout;          // scheduled sampling: output projection [(U+E), C], [C]
+  int32_t *ids_w;                    // ... the inputs actually used (= ids), rows 1.. written here
+  int C;
+  float sprob;
+  unsigned long long sseed, soff;
+  float *Ho;                         // dropped cell outputs (keep < 1), else unused
+  float keep;                        // output dropout keep probability (1 = off)
+  unsigned long long seed, seed_offset;
   unsigned *table;
   char *xbuf;
   int *status;
@@ -150,7 +158,9 @@ __device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(u
 // KR = weight registers per lane >= (E+U)/4
 // LOC: location-aware attention (attention.py:186-292): the score also takes conv1d(previous alignments)·conv_proj;
 // the normalised alignments travel in a fifth ring
-template <int KR, bool LOC>
+// REG: the regularised training recipes — output dropout and / or scheduled sampling (their code is compiled out of the
+// plain instantiations, whose register allocation is tight)
+template <int KR, bool LOC, bool REG>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void speller_persist_fwd_kernel(Args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int flag[2];
@@ -189,13 +199,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
   // ---- exchange rings of my unit: h [R][U], q [R][U], ctx [R][E], partials [R*S][E+4]
   const unsigned hb = (unsigned)(R * U * 4), cb = (unsigned)(R * E * 4), pb = (unsigned)(R * S * (E + 4) * 4);
   const unsigned lb = (unsigned)(R * TeP * 4);          // (LOC) alignments [R][S*FS]
-  const size_t unit_bytes = (size_t)RING * (2 * hb + cb + pb + (LOC ? lb : 0));
+  const size_t unit_bytes = (size_t)RING * (2 * hb + cb + pb + (LOC ? lb : 0) + 16);   // + 16: the sampled inputs [R]
   char *ub = p.xbuf + (size_t)unit * unit_bytes;
   __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)(RING * hb), 0x00020000);
   __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(ub + (size_t)RING * hb, 0, (int)(RING * hb), 0x00020000);
   __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(ub + (size_t)RING * 2 * hb, 0, (int)(RING * cb), 0x00020000);
   __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(ub + (size_t)RING * (2 * hb + cb), 0, (int)(RING * pb), 0x00020000);
   __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(ub + (size_t)RING * (2 * hb + cb + pb), 0, (int)(RING * lb), 0x00020000);
+  __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(ub + (size_t)RING * (2 * hb + cb + pb + (LOC ? lb : 0)), 0, RING * 16, 0x00020000);
+  const bool samp = REG && p.sprob > 0.f;
   const u32x4 sent4 = {SENT, SENT, SENT, SENT};
 
   // ---- LDS: keys / values slices of my (utterance, frame slice), my columns of Wq, scratch
@@ -272,13 +284,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
   // Saved tensors (what the backward pass reads): written one step late, right before the matrix product of the
   // next step — a poll loop waits for every older memory operation of its wave (one in-order counter), and an HBM
   // store in front of a poll put its acknowledgement (~4 us for the scattered 4-byte stores) on the critical path
-  float a_last = 0.f, q_last = 0.f;
+  float a_last = 0.f, q_last = 0.f, ho_last = 0.f;
+  const bool drop = REG && p.keep < 1.f;
   auto save_step = [&](int ts) {     // step ts is complete in my registers
     if (gate_thr) {
       p.acts[((size_t)ts * B + gb) * 4 * U + gg * U + gunit] = a_last;
       if (gg == 0) {
         p.Cs[((size_t)(ts + 1) * B + gb) * U + gunit] = c_state;
         p.H[((size_t)(ts + 1) * B + gb) * U + gunit] = h_state;
+        if (drop) p.Ho[((size_t)(ts + 1) * B + gb) * U + gunit] = ho_last;
       }
     }
     if (tid < R * UW) p.q[((size_t)ts * B + p.b0 + unit * R + tid / UW) * U + UW * slot + tid % UW] = q_last;
@@ -368,8 +382,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
 #pragma unroll
       for (int ww = 0; ww < NW; ++ww) z += red0[(size_t)ww * red_stride + gcol * 4 + grow];
       float a = 0.f;
+      int my_id = 0;
+      if (samp && t > 0) {
+        // the input of this step was decided at the end of the previous one (duty E): wave w = row w polls its word
+        unsigned idw;
+        Spin g;
+        g.start();
+        for (;;) {
+          idw = __builtin_amdgcn_raw_buffer_load_b32(ri, sp * 16 + (unsigned)(grow * 4), 0, 16);
+          if (__all(idw != SENT)) break;
+          if (g.expired(p)) { SP_TIMEOUT(1); idw = 0; break; }
+        }
+        my_id = (int)idw;
+      } else if (gate_thr) {
+        my_id = p.ids[(size_t)t * B + gb];
+      }
       if (gate_thr) {
-        z += gbias + p.emb[(size_t)p.ids[(size_t)t * B + gb] * 4 * U + gg * U + gunit];
+        z += gbias + p.emb[(size_t)my_id * 4 * U + gg * U + gunit];
         a = gg == 1 ? ftanh(z) : fsig(gg == 2 ? z + 1.0f : z);
       }
       const float gi = quad_bcast(a, 0), gj = quad_bcast(a, 1), gf = quad_bcast(a, 2), go = quad_bcast(a, 3);
@@ -379,6 +408,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
         h_state = ftanh(c_state) * go;
       }
       a_last = act ? a : 0.f;        // saved tensors of this step go to HBM under the NEXT step's product
+      if (drop && gate_thr && gg == 0) {   // what the query and the output projection see of h_t (the recurrence keeps h_t)
+        const size_t e = (size_t)gb * U + gunit;
+        const float4 sc = dropout_scale4(e >> 2, p.keep, p.seed, p.seed_offset + (unsigned long long)t);
+        const int j = (int)(e & 3);
+        ho_last = h_state * (j == 0 ? sc.x : j == 1 ? sc.y : j == 2 ? sc.z : sc.w);
+      }
       const bool pub = gate_thr && gg == 0;
       xst1(fbits(h_state), rh, pub ? so * hb + (unsigned)((grow * U + gunit) * 4) : OOB, coloc);
       xst1(SENT, rh, (pub && t >= 2) ? sr * hb + (unsigned)((grow * U + gunit) * 4) : OOB, coloc);
@@ -398,8 +433,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
         if (__all(!has_sentinel(v0) && !has_sentinel(v1))) break;
         if (g.expired(p)) { SP_TIMEOUT(1); break; }
       }
-      if (tid < NPC) *reinterpret_cast<f32x4 *>(hs + (4 * q0 / U) * (U + 4) + 4 * q0 % U) = __builtin_bit_cast(f32x4, v0);
-      if (NT + tid < NPC) *reinterpret_cast<f32x4 *>(hs + (4 * q1 / U) * (U + 4) + 4 * q1 % U) = __builtin_bit_cast(f32x4, v1);
+      f32x4 f0 = __builtin_bit_cast(f32x4, v0), f1 = __builtin_bit_cast(f32x4, v1);
+      if (drop) {
+        // the query is taken from the DROPPED output: piece q = 4 consecutive units of row 4q / U = one Philox group
+        // of the [B, U] stream (the mask is a function of (seed, step, element), recomputed by whoever needs it)
+        const unsigned long long off = p.seed_offset + (unsigned long long)t;
+        const size_t e0 = (size_t)(p.b0 + unit * R + 4 * q0 / U) * U + 4 * q0 % U, e1 = (size_t)(p.b0 + unit * R + 4 * q1 / U) * U + 4 * q1 % U;
+        const float4 s0 = dropout_scale4(e0 >> 2, p.keep, p.seed, off), s1 = dropout_scale4(e1 >> 2, p.keep, p.seed, off);
+        f0.x *= s0.x; f0.y *= s0.y; f0.z *= s0.z; f0.w *= s0.w;
+        f1.x *= s1.x; f1.y *= s1.y; f1.z *= s1.z; f1.w *= s1.w;
+      }
+      if (tid < NPC) *reinterpret_cast<f32x4 *>(hs + (4 * q0 / U) * (U + 4) + 4 * q0 % U) = f0;
+      if (NT + tid < NPC) *reinterpret_cast<f32x4 *>(hs + (4 * q1 / U) * (U + 4) + 4 * q1 % U) = f1;
     }
     SP_STAMP(4);
     __syncthreads();
@@ -634,6 +679,110 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
       }
     }
     SP_STAMP(10);
+    // =========================== E: scheduled sampling of the next input ===========================
+    // ScheduledEmbeddingTrainingHelper (rnn_decoder.py:59-66): with probability sprob the next input of a row is a
+    // sample of softmax(logits_t), logits_t = [ho_t | ctx_t] . Wout + b — exactly the draws of sample_ids_kernel
+    // (elementwise.hip) for (seed, offset + t, batch row).  The first slice's workgroup of an utterance decides for
+    // its row: it gathers the row of [ho | ctx] only when the row was selected, every workgroup of the unit learns the
+    // four inputs through a 16-byte ring at the next step's gate phase.
+    if (samp && t + 1 < L) {
+      __syncthreads();                                   // parts / mz have been read: aux is free
+      if (cs == 0) {
+        const unsigned long long off = p.soff + (unsigned long long)t;
+        const uint4 rr = philox4x32_10(make_uint4((unsigned)cbg, 0u, (unsigned)off, (unsigned)(off >> 32)),
+                                       make_uint2((unsigned)p.sseed, (unsigned)(p.sseed >> 32)));
+        int id = p.ids[(size_t)(t + 1) * B + cbg];       // teacher forcing
+        if (u01(rr.x) < p.sprob) {
+          const int C = p.C;
+          float *xrow = aux, *lred = aux + K, *e_s = lred + NW * 64;
+          int *id_s = reinterpret_cast<int *>(e_s + 64);
+          {
+            // my row of [h_t (U) | ctx_t (E)], published in this step (slot so): K/4 pieces, <= 2 per thread
+            const int NPC = K / 4;
+            u32x4 v[2];
+            unsigned offs[2];
+            bool isc[2];
+            int qq[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              qq[j] = min(j * NT + tid, NPC - 1);
+              isc[j] = 4 * qq[j] >= U;
+              offs[j] = isc[j] ? so * cb + (unsigned)((ci * E + 4 * qq[j] - U) * 4) : so * hb + (unsigned)((ci * U + 4 * qq[j]) * 4);
+            }
+            Spin g;
+            g.start();
+            for (;;) {
+              bool ok = true;
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const u32x4 a = xld4(rc, isc[j] ? offs[j] : OOB), b = xld4(rh, isc[j] ? OOB : offs[j]);
+                v[j] = isc[j] ? a : b;
+                ok = ok && !has_sentinel(v[j]);
+              }
+              if (__all(ok)) break;
+              if (g.expired(p)) { SP_TIMEOUT(1); break; }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (j * NT + tid < NPC) {
+                f32x4 f = __builtin_bit_cast(f32x4, v[j]);
+                if (drop && !isc[j]) {                   // the projection sees the DROPPED output
+                  const float4 sc = dropout_scale4(((size_t)cbg * U + 4 * qq[j]) >> 2, p.keep, p.seed, p.seed_offset + (unsigned long long)t);
+                  f.x *= sc.x; f.y *= sc.y; f.z *= sc.z; f.w *= sc.w;
+                }
+                *reinterpret_cast<f32x4 *>(xrow + 4 * qq[j]) = f;
+              }
+          }
+          __syncthreads();
+          if (flag[0]) return;
+          {
+            // lane = class, the waves split k; Wout is read from L2 (its rows are contiguous over the classes)
+            float part = 0.f;
+            if (lane < C) {
+              const int k0 = w * (K / NW);
+              const float *wp = p.wout + (size_t)k0 * C + lane;
+              for (int k = 0; k < K / NW; k += 4) {
+                const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xrow + k0 + k);
+                part = fmaf(x4.x, wp[(size_t)k * C], part);
+                part = fmaf(x4.y, wp[(size_t)(k + 1) * C], part);
+                part = fmaf(x4.z, wp[(size_t)(k + 2) * C], part);
+                part = fmaf(x4.w, wp[(size_t)(k + 3) * C], part);
+              }
+            }
+            lred[w * 64 + lane] = part;
+          }
+          __syncthreads();
+          if (w == 0) {
+            float l = -INFINITY;
+            if (lane < C) {
+              l = p.bout[lane];
+              for (int ww = 0; ww < NW; ++ww) l += lred[ww * 64 + lane];
+            }
+            const float m = wmax(l);
+            e_s[lane] = lane < C ? expf(l - m) : 0.f;
+            if (lane == 0) {                             // the sums in class order, as sample_ids_kernel adds them
+              float tot = 0.f;
+              for (int c = 0; c < C; ++c) tot += e_s[c];
+              const float target = u01(rr.y) * tot;
+              float acc = 0.f;
+              int pick = C - 1;
+              for (int c = 0; c < C; ++c) {
+                acc += e_s[c];
+                if (acc > target) { pick = c; break; }
+              }
+              id_s[0] = pick;
+            }
+          }
+          __syncthreads();
+          id = id_s[0];
+        }
+        if (tid == 0) {
+          p.ids_w[(size_t)(t + 1) * B + cbg] = id;
+          xst1((unsigned)id, ri, so * 16 + (unsigned)(ci * 4), coloc);
+          xst1(SENT, ri, t >= 2 ? sr * 16 + (unsigned)(ci * 4) : OOB, coloc);
+        }
+      }
+    }
     __syncthreads();     // the scratch is re-used by the next step's gather
   }
   save_step(L - 1);
@@ -661,6 +810,8 @@ struct BArgs {
   const float *wq, *v, *keys, *values;
   const float *acts, *Cs, *q, *ctx, *align;     // saved by the forward pass (time-major)
   const float *dH;         // [L][B][U] d h_t of the output projection
+  float keep;              // output dropout of the cell (1 = off): d h through the output = mask / keep * (dH + dq . Wq^T)
+  unsigned long long seed, seed_offset;
   float *dCtx;             // [L][B][E] in: the output projection's share; out: the whole d context_t
   float *dq, *dz;          // [L][B][U], [L][B][4U] (gate-major): inputs of the weight-gradient products
   float *dkeys;            // [B][Te][U]
@@ -695,7 +846,7 @@ struct SpinB {
 
 // NSETC sets of NKQC instructions per wave (weight registers per lane: NSETC * NKQC); KS = k phases in the 16 blocks
 // of an instruction (4: a set is 16 columns, 16: a set is 4 columns); DKR = frames per thread in D1
-template <int NSETC, int NKQC, int KS, int DKR>
+template <int NSETC, int NKQC, int KS, int DKR, bool DROP>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void speller_persist_bwd_kernel(BArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int flag[2];
@@ -982,7 +1133,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
         const float a = p.acts[((size_t)t * B + gb) * 4 * U + gg * U + gunit];
         const float gi = quad_bcast(a, 0), gj = quad_bcast(a, 1), gf = quad_bcast(a, 2), go = quad_bcast(a, 3);
         if (t < glen) {
-          const float dh = p.dH[sidx] + dhq + chs[grow * 16 + gu];
+          float dho = p.dH[sidx] + dhq;          // gradient of the cell OUTPUT (projection + query): through the dropout mask
+          if (DROP && p.keep < 1.f) {
+            const size_t e = (size_t)gb * U + gunit;
+            const float4 sc = dropout_scale4(e >> 2, p.keep, p.seed, p.seed_offset + (unsigned long long)t);
+            const int j = (int)(e & 3);
+            dho *= j == 0 ? sc.x : j == 1 ? sc.y : j == 2 ? sc.z : sc.w;
+          }
+          const float dh = dho + chs[grow * 16 + gu];          // + the recurrent carry (not dropped)
           const float cnew = p.Cs[sidx + (size_t)B * U], cprev = p.Cs[sidx];
           const float tc = ftanh(cnew);
           const float dct = dc_state + dh * go * (1.f - tc * tc);
@@ -1113,7 +1271,9 @@ size_t lds_floats(const SpPersistDesc &d, int FS, bool stream) {
   size_t scr = NW * R * KR;
   if (R * KR < 256) scr += NW * 256;
   const size_t need_c = (size_t)R * (d.U + 4) + NW * 64 + d.U + FS + 64, need_d = (size_t)S * (d.E / S) + 2 * S + 64;
-  const size_t aux = need_c > need_d ? need_c : need_d;
+  size_t aux = need_c > need_d ? need_c : need_d;
+  const size_t need_e = d.sample_prob > 0.f ? K + NW * 64 + 64 + 16 : 0;     // duty E: a row of [h | ctx], partial logits, exps
+  if (need_e > aux) aux = need_e;
   if (K / NW == KR) scr = scr > aux ? scr : aux;   // aliased
   else scr += aux;
   size_t loc = 0;
@@ -1127,7 +1287,7 @@ int frames_per_slice(const SpPersistDesc &d) { return (d.Te + S - 1) / S; }
 size_t ring_bytes(const SpPersistDesc &d) {
   const size_t hb = (size_t)R * d.U * 4, cb = (size_t)R * d.E * 4, pb = (size_t)R * S * (d.E + 4) * 4;
   const size_t lb = d.kind == 1 ? (size_t)R * S * frames_per_slice(d) * 4 : 0;
-  return (size_t)NU * RING * (2 * hb + cb + pb + lb);
+  return (size_t)NU * RING * (2 * hb + cb + pb + lb + 16);
 }
 
 }  // namespace
@@ -1164,6 +1324,7 @@ static bool device_fits() {
 static bool shape_ok(const SpPersistDesc &d) {
   if ((d.B != NU * R && d.B != 2 * NU * R) || d.U % 32 || d.E % 32 || d.U < 32 || d.E < 32) return false;
   if (d.kind != 0 && d.kind != 1) return false;
+  if (d.sample_prob > 0.f && (d.C > 64 || d.C < 1 || (d.E + d.U) / 4 > 2 * NT)) return false;   // duty E: one lane per class
   if (d.kind == 1 && (d.K < 1 || d.F < 1 || S * frames_per_slice(d) / 4 > NT)) return false;
   const int K = d.E + d.U;
   if (K % (NW * 4) || K / NW > 384) return false;      // k range of a wave: whole 16-byte pieces, <= 384 weight registers
@@ -1233,6 +1394,7 @@ int speller_persist_bwd(const SpPersistDesc &d, const int32_t *dec_len, const in
   a.dec_len = dec_len; a.enc_len = enc_len; a.kxhT = kxhT; a.wq = wq; a.v = v; a.keys = keys; a.values = values;
   a.acts = acts; a.Cs = Cs; a.q = q; a.ctx = ctx; a.align = align; a.dH = dH; a.dCtx = dCtx; a.dq = dq; a.dz = dz;
   a.dkeys = dkeys; a.dv_part = dv_part;
+  a.keep = d.keep_prob; a.seed = d.seed; a.seed_offset = d.seed_offset;
   a.table = static_cast<unsigned *>(ws);
   a.xbuf = static_cast<char *>(ws) + TABLE_BYTES;
   a.status = status;
@@ -1241,7 +1403,8 @@ int speller_persist_bwd(const SpPersistDesc &d, const int32_t *dec_len, const in
   a.dbg = e ? atoi(e) : 0;
   NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + bwd_ring_bytes(d), stream));
   const size_t lds = bwd_lds_floats(d) * 4;
-  auto kern = bwd_ks4(d) ? speller_persist_bwd_kernel<3, 128, 4, 8> : speller_persist_bwd_kernel<3, 8, 16, 8>;
+  auto kern = bwd_ks4(d) ? speller_persist_bwd_kernel<3, 128, 4, 8, false> : speller_persist_bwd_kernel<3, 8, 16, 8, false>;
+  if (d.keep_prob < 1.f) kern = bwd_ks4(d) ? speller_persist_bwd_kernel<3, 128, 4, 8, true> : speller_persist_bwd_kernel<3, 8, 16, 8, true>;
   // per call: the attribute is per device, a cache keyed by the function alone would miss a second device
   NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
   hipLaunchKernelGGL(kern, dim3(NU * P), dim3(NT), lds, stream, a);
@@ -1263,8 +1426,9 @@ size_t speller_persist_ws_bytes(const SpPersistDesc &d) {   // (independent of t
 int speller_persist_fwd(const SpPersistDesc &d, const int32_t *dec_len, const int32_t *enc_len, const int32_t *ids,
                         const float *kperm, const float *bias, const float *emb, const float *wq, const float *v,
                         const float *keys, const float *values, const float *conv_kernel, const float *conv_proj, float *H,
-                        float *Cs, float *acts, float *q, float *ctx, float *align, int *status, void *ws, size_t ws_bytes,
-                        hipStream_t stream) {
+                        float *Ho, float *Cs, float *acts, float *q, float *ctx, float *align, int *status, void *ws,
+                        size_t ws_bytes, hipStream_t stream, const float *out_kernel, const float *out_bias,
+                        int32_t *ids_used) {
   if (!speller_persist_ok(d)) return fail(NABU_EUNSUP, "persistent decoder: unsupported shape");
   if (ws_bytes < speller_persist_ws_bytes(d)) return fail(NABU_EWS, "persistent decoder: workspace too small");
   if (d.kind == 1 && !(conv_kernel && conv_proj)) return fail(NABU_EINVAL, "persistent decoder: location-aware attention needs its kernels");
@@ -1275,6 +1439,12 @@ int speller_persist_fwd(const SpPersistDesc &d, const int32_t *dec_len, const in
   a.dec_len = dec_len; a.enc_len = enc_len; a.ids = ids;
   a.kperm = kperm; a.bias = bias; a.emb = emb; a.wq = wq; a.v = v; a.keys = keys; a.values = values;
   a.H = H; a.Cs = Cs; a.acts = acts; a.q = q; a.ctx = ctx; a.align = align;
+  a.Ho = Ho; a.keep = d.keep_prob; a.seed = d.seed; a.seed_offset = d.seed_offset;
+  if (d.keep_prob < 1.f && !Ho) return fail(NABU_EINVAL, "persistent decoder: dropout needs the Ho array");
+  a.wout = out_kernel; a.bout = out_bias; a.ids_w = ids_used; a.C = d.C;
+  a.sprob = d.sample_prob; a.sseed = d.sample_seed; a.soff = d.sample_offset;
+  if (d.sample_prob > 0.f && !(out_kernel && out_bias && ids_used == ids))
+    return fail(NABU_EINVAL, "persistent decoder: scheduled sampling needs the output projection and a writable ids array");
   a.table = static_cast<unsigned *>(ws);
   a.xbuf = static_cast<char *>(ws) + TABLE_BYTES;
   a.status = status;
@@ -1284,8 +1454,12 @@ int speller_persist_fwd(const SpPersistDesc &d, const int32_t *dec_len, const in
   const size_t lds = lds_floats(d, a.FS, a.stream_vals != 0) * 4;
   const int KW = (d.E + d.U) / NW;
   const bool loc = d.kind == 1;
-  auto kern = loc ? (KW <= 64 ? speller_persist_fwd_kernel<64, true> : KW <= 192 ? speller_persist_fwd_kernel<192, true> : speller_persist_fwd_kernel<384, true>)
-                  : (KW <= 64 ? speller_persist_fwd_kernel<64, false> : KW <= 192 ? speller_persist_fwd_kernel<192, false> : speller_persist_fwd_kernel<384, false>);
+  const bool reg = d.keep_prob < 1.f || d.sample_prob > 0.f;
+  auto kern = loc ? (KW <= 64 ? speller_persist_fwd_kernel<64, true, false> : KW <= 192 ? speller_persist_fwd_kernel<192, true, false> : speller_persist_fwd_kernel<384, true, false>)
+                  : (KW <= 64 ? speller_persist_fwd_kernel<64, false, false> : KW <= 192 ? speller_persist_fwd_kernel<192, false, false> : speller_persist_fwd_kernel<384, false, false>);
+  if (reg)
+    kern = loc ? (KW <= 64 ? speller_persist_fwd_kernel<64, true, true> : KW <= 192 ? speller_persist_fwd_kernel<192, true, true> : speller_persist_fwd_kernel<384, true, true>)
+               : (KW <= 64 ? speller_persist_fwd_kernel<64, false, true> : KW <= 192 ? speller_persist_fwd_kernel<192, false, true> : speller_persist_fwd_kernel<384, false, true>);
   NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
   // 32 utterances per launch (4 per XCD): a batch of 64 runs as two launches on the stream
   for (int b0 = 0; b0 < d.B; b0 += NU * R) {

@@ -125,6 +125,8 @@ def dynamic_decode(cell, encoded, encoded_seq_length, targets, target_seq_length
 
     record([encoded], [logits], backward)
     dynamic_decode.last = (desc, reserve)           # for decoder_inputs() below (tests, diagnostics)
+    dynamic_decode.last_paths = (lib.nabu_speller_uses_persistent(ctypes.byref(desc), 0),
+                                 lib.nabu_speller_uses_persistent(ctypes.byref(desc), 1))
     return logits, tlen
 
 

@@ -159,6 +159,161 @@ def test_persistent_decoder_forward(U, E, Te):
     hip.check_persist_status()
 
 
+def _decoder_run(over, enc, enc_len, tg, tlen, C, seed):
+    """logits, d encoded, every parameter gradient and the decoder inputs actually used, for a decoder built from
+    the cfg3 recipe + over; the regularisation RNG starts from `seed`"""
+    from nabu_amd import variables as vs
+    from nabu_amd.autodiff import Tape, SeqLen, record
+    from nabu_amd.neuralnetworks.components import ops as nops
+    from nabu_amd.neuralnetworks.models.ed_decoders import ed_decoder_factory, rnn_decoder
+    from nabu_amd.neuralnetworks.trainers import loss_functions
+    mc, _, _ = recipes.load_recipe('cfg3_las_vanilla', **over)
+    dec = ed_decoder_factory.factory('speller')(mc, {'text': C}, None)
+    store = vs.VariableStore(seed=3)
+    dev = torch.device('cuda')
+    nops.set_seed(seed)
+    enc_d, src, tgd = torch.tensor(enc, device=dev), torch.tensor(enc, device=dev), torch.tensor(tg, device=dev)
+    with vs.as_default(store), Tape() as tape:
+        record([src], [enc_d], lambda g: [g])
+        logits, lsl, _ = dec({'features': enc_d}, {'features': SeqLen(enc_len, dev)}, {'text': tgd},
+                             {'text': SeqLen(tlen, dev)}, True)
+        loss = loss_functions.average_cross_entropy({'text': tgd}, logits, lsl, {'text': SeqLen(tlen, dev)})
+    used = rnn_decoder.decoder_inputs().cpu().numpy().copy()
+    paths = rnn_decoder.dynamic_decode.last_paths                  # (forward, backward) took the persistent launch
+    got = {}
+
+    def capture(g):
+        got['denc'] = g.cpu().numpy()
+        return [None]
+    tape.ops[0].backward = capture
+    tape.backward(loss)
+    grads = {k: v.grad.cpu().numpy().copy() for k, v in store.vars.items() if v.grad is not None}
+    return logits['text'].cpu().numpy(), got['denc'], grads, used, paths
+
+
+@pytest.mark.parametrize('attention', ['vanilla', 'location_aware'])
+def test_persistent_decoder_with_output_dropout(attention):
+    """real training recipes (speller.py:36-40: DropoutWrapper(output_keep_prob)) on the persistent path: the mask
+    of a step is recomputed from the Philox stream inside the persistent kernels (query and projection see the
+    dropped output, the recurrence keeps h; backward: mask / keep on the output gradient only).  Same seed ->
+    same masks as the step chain (NABU_SPELLER_PERSIST=0): logits and every gradient agree to the tolerance of
+    the no-dropout persistent tests, and they differ from a run without dropout by O(1)."""
+    import os
+    from nabu_amd import ops as hip
+    rng = np.random.default_rng(31)
+    B, Te, E, C, U = 32, 40, 64, 8, 64
+    enc_len = rng.integers(Te // 2, Te + 1, B).astype(np.int32)
+    enc_len[0] = Te
+    tlen = rng.integers(1, 9, B).astype(np.int32)
+    tlen[3] = 8
+    enc = rng.normal(size=(B, Te, E)).astype(np.float32)
+    enc *= (np.arange(Te)[None, :, None] < enc_len[:, None, None])
+    tg = rng.integers(0, C - 1, (B, int(tlen.max()))).astype(np.int32)
+    for b in range(B):
+        tg[b, tlen[b] - 1] = C - 1
+        tg[b, tlen[b]:] = 0
+    over = {'decoder.num_layers': 1, 'decoder.num_units': U, 'decoder.attention': attention, 'decoder.dropout': 0.7}
+    if attention == 'location_aware':
+        over.update({'decoder.numfilt': 3, 'decoder.filtersize': 7})
+    got = _decoder_run(over, enc, enc_len, tg, tlen, C, seed=123)
+    assert got[4] == (1, 1 if attention == 'vanilla' else 0)           # the persistent kernels really ran
+    os.environ['NABU_SPELLER_PERSIST'] = os.environ['NABU_SPELLER_PERSIST_BWD'] = '0'
+    try:
+        ref = _decoder_run(over, enc, enc_len, tg, tlen, C, seed=123)
+        assert ref[4] == (0, 0)
+    finally:
+        del os.environ['NABU_SPELLER_PERSIST'], os.environ['NABU_SPELLER_PERSIST_BWD']
+    hip.check_persist_status()
+    plain = _decoder_run(dict(over, **{'decoder.dropout': 1.0}), enc, enc_len, tg, tlen, C, seed=123)
+    assert np.abs(got[0] - plain[0]).max() > 1e-2                      # dropout really acted
+    assert np.abs(got[0] - ref[0]).max() < 2e-5
+    rel = lambda a, b_: np.abs(a - b_).max() / (np.abs(b_).max() + 1e-12)
+    assert rel(got[1], ref[1]) < 2e-4
+    for k in ref[2]:
+        assert rel(got[2][k], ref[2][k]) < 2e-4, k
+
+
+@pytest.mark.parametrize('attention,dropout', [('vanilla', 1.0), ('location_aware', 1.0), ('vanilla', 0.8)])
+def test_persistent_decoder_with_scheduled_sampling(attention, dropout):
+    """sample_prob > 0 (the reference default is 0.1, defaults/speller.cfg:15; 0.5 here so that many inputs are drawn)
+    on the persistent path: the first slice's workgroup of every utterance evaluates the step's logits for its row and
+    draws exactly what nabu_sample_ids draws for (seed, offset + t, row); the inputs travel through a 16-byte ring.
+    Same seed -> the SAME decoder inputs as the step chain, logits and gradients to the tolerance of the other
+    persistent tests; also together with output dropout (the projection sees the dropped output)."""
+    import os
+    from nabu_amd import ops as hip
+    rng = np.random.default_rng(41)
+    B, Te, E, C, U = 32, 33, 64, 9, 64
+    enc_len = rng.integers(Te // 2, Te + 1, B).astype(np.int32)
+    enc_len[0] = Te
+    tlen = rng.integers(2, 10, B).astype(np.int32)
+    tlen[3] = 9
+    enc = rng.normal(size=(B, Te, E)).astype(np.float32)
+    enc *= (np.arange(Te)[None, :, None] < enc_len[:, None, None])
+    tg = rng.integers(0, C - 1, (B, int(tlen.max()))).astype(np.int32)
+    for b in range(B):
+        tg[b, tlen[b] - 1] = C - 1
+        tg[b, tlen[b]:] = 0
+    over = {'decoder.num_layers': 1, 'decoder.num_units': U, 'decoder.attention': attention, 'decoder.dropout': dropout,
+            'decoder.sample_prob': 0.5}
+    if attention == 'location_aware':
+        over.update({'decoder.numfilt': 3, 'decoder.filtersize': 7})
+    got = _decoder_run(over, enc, enc_len, tg, tlen, C, seed=77)
+    assert got[4][0] == 1                                             # the persistent forward kernel ran
+    os.environ['NABU_SPELLER_PERSIST'] = os.environ['NABU_SPELLER_PERSIST_BWD'] = '0'
+    try:
+        ref = _decoder_run(over, enc, enc_len, tg, tlen, C, seed=77)
+        assert ref[4] == (0, 0)
+    finally:
+        del os.environ['NABU_SPELLER_PERSIST'], os.environ['NABU_SPELLER_PERSIST_BWD']
+    hip.check_persist_status()
+    teacher = np.concatenate([np.full((1, B), C - 1), tg[:, :int(tlen.max()) - 1].T], 0)
+    assert 0.2 < (ref[3][1:] != teacher[1:]).mean() < 0.8              # inputs really were drawn
+    np.testing.assert_array_equal(got[3], ref[3])                      # ... and the same ones on both paths
+    assert np.abs(got[0] - ref[0]).max() < 2e-5
+    rel = lambda a, b_: np.abs(a - b_).max() / (np.abs(b_).max() + 1e-12)
+    assert rel(got[1], ref[1]) < 2e-4
+    for k in ref[2]:
+        assert rel(got[2][k], ref[2][k]) < 2e-4, k
+
+
+def test_persistent_decoder_regularised_at_the_cfg3_geometry():
+    """the reference's training defaults (sample_prob 0.1, speller.cfg:15; output dropout 0.9) at the FULL decoder geometry
+    of BASELINE configs[2] — 32 utterances, 125 encoder frames of 1024 features, 512 units, 40 classes, up to 60 steps:
+    the 384-weight-register instantiation with the regularisation code compiled in — persistent launch against the step
+    chain on the same seed: identical decoder inputs, logits and gradients to the persistent tests' tolerance"""
+    import os
+    from nabu_amd import ops as hip
+    rng = np.random.default_rng(43)
+    B, Te, E, C, U = 32, 125, 1024, 40, 512
+    enc_len = rng.integers(Te // 2, Te + 1, B).astype(np.int32)
+    enc_len[0] = Te
+    tlen = rng.integers(20, 61, B).astype(np.int32)
+    tlen[3] = 60
+    enc = (0.3 * rng.normal(size=(B, Te, E))).astype(np.float32)
+    enc *= (np.arange(Te)[None, :, None] < enc_len[:, None, None])
+    tg = rng.integers(0, C - 1, (B, int(tlen.max()))).astype(np.int32)
+    for b in range(B):
+        tg[b, tlen[b] - 1] = C - 1
+        tg[b, tlen[b]:] = 0
+    over = {'decoder.num_layers': 1, 'decoder.num_units': U, 'decoder.attention': 'vanilla', 'decoder.dropout': 0.9,
+            'decoder.sample_prob': 0.1}
+    got = _decoder_run(over, enc, enc_len, tg, tlen, C, seed=5)
+    assert got[4] == (1, 1)
+    os.environ['NABU_SPELLER_PERSIST'] = os.environ['NABU_SPELLER_PERSIST_BWD'] = '0'
+    try:
+        ref = _decoder_run(over, enc, enc_len, tg, tlen, C, seed=5)
+    finally:
+        del os.environ['NABU_SPELLER_PERSIST'], os.environ['NABU_SPELLER_PERSIST_BWD']
+    hip.check_persist_status()
+    np.testing.assert_array_equal(got[3], ref[3])
+    assert np.abs(got[0] - ref[0]).max() < 5e-5
+    rel = lambda a, b_: np.abs(a - b_).max() / (np.abs(b_).max() + 1e-12)
+    assert rel(got[1], ref[1]) < 3e-4
+    for k in ref[2]:
+        assert rel(got[2][k], ref[2][k]) < 3e-4, k
+
+
 def test_persistent_decoder_status_word_is_sticky_and_reported():
     """the persistent decoder kernels' hang safety (include/nabu_hip.h, nabu_speller_fwd): ws[0] of the Speller
     workspace is their status word.  A non-zero word (what a timed-out launch leaves) makes the next launches return
