@@ -206,6 +206,21 @@ int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const int32_t *len,
                    const float *d_out, void *reserve, float *d_x, float *dkernel_fw,
                    float *dbias_fw, float *dkernel_bw, float *dbias_bw, void *ws,
                    size_t ws_bytes, nabu_stream_t stream);
+/* The same gradient in two calls: nabu_blstm_bwd_data runs the recurrence backwards and produces what the layer
+ * BELOW waits for (d_x) plus the bias gradients, leaving dz in `reserve`; nabu_blstm_bwd_weights turns that dz into
+ * dkernel_fw / dkernel_bw ([(D+H),4H], overwritten) and may run any time later on the same stream with the same
+ * x / out / reserve (a different ws is fine).  data + weights == nabu_blstm_bwd, bit for bit.  Why: nothing waits
+ * for the weight gradients, and a long burst of bf16 matrix work in front of a latency-bound persistent recurrent
+ * kernel slows that kernel down (the chip's clock recovers slowly: +0.5 ms on the 1000-frame layer of cfg2), so a
+ * trainer runs the weight-gradient products of all layers after the last recurrence (TF's scheduler was free to
+ * do the same with the MatMul gradients of trainers/trainer.py:556-558). */
+int nabu_blstm_bwd_data(const nabu_blstm_desc *d, const float *x, const int32_t *len,
+                        const float *kernel_fw, const float *kernel_bw, const float *out,
+                        const float *d_out, void *reserve, float *d_x, float *dbias_fw, float *dbias_bw,
+                        void *ws, size_t ws_bytes, nabu_stream_t stream);
+int nabu_blstm_bwd_weights(const nabu_blstm_desc *d, const float *x, const int32_t *len, const float *out,
+                           void *reserve, float *dkernel_fw, float *dkernel_bw, void *ws, size_t ws_bytes,
+                           nabu_stream_t stream);
 
 /* 1 if nabu_blstm_fwd/bwd will run the persistent whole-sequence kernel for d. */
 int nabu_blstm_uses_persistent(const nabu_blstm_desc *d);

@@ -59,6 +59,8 @@ SIGNATURES = {
     'nabu_blstm_fwd': (_i, [_c.POINTER(BlstmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nabu_blstm_bwd': (_i, [_c.POINTER(BlstmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp, _vp, _vp, _sz, _vp]),
+    'nabu_blstm_bwd_data': (_i, [_c.POINTER(BlstmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'nabu_blstm_bwd_weights': (_i, [_c.POINTER(BlstmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nabu_blstm_uses_persistent': (_i, [_c.POINTER(BlstmDesc)]),
     'nabu_blstm_set_profile_events': (_i, [_vp, _vp]),
     'nabu_persist_set_timeout_us': (_i, [_ll]),

@@ -22,6 +22,7 @@ class _Op(object):
 
 class Tape(object):
     current = None
+    current_backward = None        # the tape whose backward() is running (for Tape.defer from inside a closure)
 
     def __init__(self):
         self.ops = []
@@ -30,6 +31,7 @@ class Tape(object):
         # called with a Variable once the last recorded op that declared it (record(..., params=))
         # has run its backward closure: its gradient is final (bucketed gradient exchange)
         self.on_param_ready = None
+        self._deferred = None          # during backward(): [(callable, params)] to run after the last closure
 
     def __enter__(self):
         self._prev = Tape.current
@@ -45,11 +47,33 @@ class Tape(object):
         parameter); raw input features do not need an input gradient."""
         return id(tensor) in self.produced
 
+    def defer(self, fn, params=()):
+        """Called from inside a backward closure: run ``fn()`` after the LAST closure of this backward pass (work
+        nothing downstream waits for — the weight-gradient products of a recurrent layer).  ``params``: Variables
+        whose gradient ``fn`` completes; they are reported ready after it ran.  Outside backward(): runs at once."""
+        if self._deferred is None:
+            fn()
+            return
+        for v in params:
+            if id(v) in self._pending:
+                self._pending[id(v)] += 1
+        self._deferred.append((fn, tuple(params)))
+
     def backward(self, root):
         """Run the recorded backward closures from ``root`` (the scalar loss)."""
         grads = {id(root): None}
         seen = {id(root)}
         pending = {}
+        self._pending = pending
+        self._deferred = []
+        outer, Tape.current_backward = Tape.current_backward, self
+        try:
+            self._run_backward(grads, seen, pending)
+        finally:
+            Tape.current_backward = outer
+            self._deferred = None
+
+    def _run_backward(self, grads, seen, pending):
         if self.on_param_ready is not None:
             for op in self.ops:
                 for v in op.params:
@@ -83,6 +107,14 @@ class Tape(object):
                 else:
                     grads[key] = g
                     seen.add(key)
+        deferred, self._deferred = self._deferred, None
+        for fn, params in deferred:
+            fn()
+            for v in params:
+                if id(v) in pending:
+                    pending[id(v)] -= 1
+                    if pending[id(v)] == 0:
+                        self.on_param_ready(v)
         self.ops = []
         self.produced = set()
 

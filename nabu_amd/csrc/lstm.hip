@@ -195,7 +195,10 @@ struct Layout {
   size_t pk_off, pk_bytes;
   // forward: X [BT, D], W^T of both cells [8H, D]; backward: dZ^T [8H, BT], X^T [D, BT], h^T per cell [H, BT],
   // dZ [BT, 8H], Wx of both cells [D, 8H] (byte offsets inside the pk region)
-  size_t pk_x, pk_w, pk_dzT, pk_xT, pk_hT[2], pk_dz, pk_w2;
+  size_t pk_x, pk_w, pk_xT, pk_hT[2], pk_dz, pk_w2;
+  // dZ^T packed [8H, BT] lives in the layer's RESERVE (behind the activations): it is written by the data part of
+  // the backward pass and read by the weight-gradient part, which may run later (nabu_blstm_bwd_weights)
+  size_t res_dzT_off, res_dzT_bytes;
 };
 
 // the input-to-hidden products X·Wx, dZ·Wx^T, X^T·dZ run on bf16 copies of their operands (converted once per
@@ -246,6 +249,7 @@ static Layout make_layout(const nabu_blstm_desc *d) {
   L.gates_elems = B * T * 4 * H;
   L.cs_elems = B * T * H;
   L.reserve_bytes = (2 * L.gates_elems + 2 * L.cs_elems) * sizeof(float);
+  L.res_dzT_off = L.res_dzT_bytes = 0;
   size_t off = 2048;  // ws[0..4): persistent kernels' status word (0 = ok), zeroed by the caller once;
                       // ws[64..64+4*grid): XCC id of every block of the last forward launch (diagnostic)
   L.hstate_off = off; off += align_up(4 * B * H * sizeof(float), 256);
@@ -285,7 +289,9 @@ static Layout make_layout(const nabu_blstm_desc *d) {
     size_t fwd = 0, bwd = 0;
     auto take = [](size_t &o, size_t bytes) { const size_t at = o; o += align_up(bytes, 256); return at; };
     if (L.pk_in) { L.pk_x = take(fwd, nabu_pk_bytes(BT, (int)D, P)); L.pk_w = take(fwd, nabu_pk_bytes(2 * G, (int)D, P)); }
-    L.pk_dzT = take(bwd, nabu_pk_bytes(2 * G, BT, P));
+    L.res_dzT_off = align_up(L.reserve_bytes, 256);
+    L.res_dzT_bytes = nabu_pk_bytes(2 * G, BT, P);
+    L.reserve_bytes = L.res_dzT_off + L.res_dzT_bytes;
     if (L.pk_in) L.pk_xT = take(bwd, nabu_pk_bytes((int)D, BT, P));
     for (int dir = 0; dir < 2; ++dir) L.pk_hT[dir] = take(bwd, L.pk_rec ? nabu_pk_bytes((int)H, BT, P) : 0);
     if (L.pk_in) { L.pk_dz = take(bwd, nabu_pk_bytes(BT, 2 * G, P)); L.pk_w2 = take(bwd, nabu_pk_bytes((int)D, 2 * G, P)); }
@@ -464,14 +470,17 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const in
   return 0;
 }
 
-extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const int32_t *len,
-                              const float *kernel_fw, const float *kernel_bw, const float *out,
-                              const float *d_out, void *reserve, float *d_x, float *dkernel_fw,
-                              float *dbias_fw, float *dkernel_bw, float *dbias_bw, void *ws,
-                              size_t ws_bytes, nabu_stream_t stream) {
+// parts: 1 = data (recurrence backward, bias gradients, input gradient, the packs of dz), 2 = weights (dWx, dWh from
+// the dz the data part left in the reserve), 3 = both (nabu_blstm_bwd)
+static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, const int32_t *len,
+                           const float *kernel_fw, const float *kernel_bw, const float *out,
+                           const float *d_out, void *reserve, float *d_x, float *dkernel_fw,
+                           float *dbias_fw, float *dkernel_bw, float *dbias_bw, void *ws,
+                           size_t ws_bytes, nabu_stream_t stream) {
   if (int e = check_desc(d)) return e;
-  NABU_CHECK_ARG(x && len && kernel_fw && kernel_bw && out && d_out && reserve && dkernel_fw &&
-                     dbias_fw && dkernel_bw && dbias_bw && ws, "blstm_bwd: null pointer");
+  NABU_CHECK_ARG(x && len && out && reserve && ws, "blstm_bwd: null pointer");
+  if (parts & 1) NABU_CHECK_ARG(kernel_fw && kernel_bw && d_out && dbias_fw && dbias_bw, "blstm_bwd: null pointer");
+  if (parts & 2) NABU_CHECK_ARG(dkernel_fw && dkernel_bw, "blstm_bwd: null pointer");
   const Layout L = make_layout(d);
   if (ws_bytes < L.total) return fail(NABU_EWS, "blstm_bwd: workspace %zu < %zu", ws_bytes, L.total);
   if (d->mode == NABU_LSTM_PERSISTENT && !lstm_persist_supported(d->B, d->T, d->H))
@@ -487,6 +496,9 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
   float *dkern[2] = {dkernel_fw, dkernel_bw};
   float *dbias[2] = {dbias_fw, dbias_bw};
 
+  float *db_part = nullptr;   // persistent path: bias-gradient partials [db_rows][2][4H]
+  int db_rows = 0;
+  if (parts & 1) {
   // dz rows of frames never visited by the recurrence must be zero
   if (max_len < T)
     for (int dir = 0; dir < 2; ++dir)
@@ -494,8 +506,6 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
                                 0, (size_t)(T - max_len) * 4 * H * sizeof(float), B, s));
 
   NABU_PROFILE_MARK(g_ev_begin, s);
-  float *db_part = nullptr;   // persistent path: bias-gradient partials [db_rows][2][4H]
-  int db_rows = 0;
   bool stepwise = !use_persistent(d);
   if (!stepwise) {
     int e = lstm_persist_bwd(B, T, D, H, max_len, len, kern, gates, cs, d_out, reinterpret_cast<int *>(w), w + L.persist_off,
@@ -518,50 +528,54 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
   }
   NABU_PROFILE_MARK(g_ev_end, s);
   if (g_phase_hook) g_phase_hook(g_phase_user);
+  }
 
   // weight / input gradients from dz (now stored in gates[])
   const int M = B * T;
   if (L.pk_planes) {
-    // packed bf16-plane operands (gemm_pk.hip).  dZ^T of both cells is one operand [8H, BT]: the weight
-    // gradients of both cells are column ranges of one product (input part) resp. a batch of two (recurrent part)
+    // packed bf16-plane operands (gemm_pk.hip).  dZ^T of both cells is one operand [8H, BT] (in the reserve): the
+    // weight gradients of both cells are column ranges of one product (input part) resp. a batch of two (recurrent part)
     const int P = L.pk_planes, G = 4 * H;
     char *pk = w + L.pk_off;
+    char *dzTp = static_cast<char *>(reserve) + L.res_dzT_off;
     const int rpBT = nabu_pk_rows_pad(M), rpG = nabu_pk_rows_pad(2 * G), rpD = nabu_pk_rows_pad(D), rpH = nabu_pk_rows_pad(H);
     const int nkbT = nabu_pk_kblocks(M, P);
-    int e;
-    const bool both = d_x && L.pk_in;    // dz is also needed row-major (dx): both packs from one read of dz
     const int nkb2 = nabu_pk_kblocks(2 * G, P), kbG = G / 16;
-    for (int dir = 0; dir < 2; ++dir) {
-      if (both)
-        e = pk_pack_both(P, gates[dir], G, M, G, pk + L.pk_dz, rpBT, dir * kbG, rpBT, dir ? nkb2 - kbG : kbG, pk + L.pk_dzT,
-                         rpG, dir * G, dir ? rpG - G : G, nkbT, s);
-      else
-        e = nabu_pk_pack(P, 1, gates[dir], G, M, G, pk + L.pk_dzT, rpG, dir * G, 0, dir ? rpG - G : G, nkbT, 0, 0, stream);
-      if (e) return e;
+    int e;
+    if (parts & 1) {
+      const bool both = d_x && L.pk_in;    // dz is also needed row-major (dx): both packs from one read of dz
+      for (int dir = 0; dir < 2; ++dir) {
+        if (both)
+          e = pk_pack_both(P, gates[dir], G, M, G, pk + L.pk_dz, rpBT, dir * kbG, rpBT, dir ? nkb2 - kbG : kbG, dzTp,
+                           rpG, dir * G, dir ? rpG - G : G, nkbT, s);
+        else
+          e = nabu_pk_pack(P, 1, gates[dir], G, M, G, dzTp, rpG, dir * G, 0, dir ? rpG - G : G, nkbT, 0, 0, stream);
+        if (e) return e;
+      }
+      if (d_x && L.pk_in) {
+        // dx = [dZ_fw | dZ_bw] · [Wx_fw | Wx_bw]^T: the two cells are two ranges of ONE reduction
+        for (int dir = 0; dir < 2; ++dir)
+          if ((e = nabu_pk_pack(P, 0, kern[dir], G, D, G, pk + L.pk_w2, rpD, 0, dir * kbG, rpD, dir ? nkb2 - kbG : kbG, 0, 0,
+                                stream)))
+            return e;
+        nabu_pk_gemm_desc g = pk_desc(P, M, D, nkb2, pk + L.pk_dz, rpBT, pk + L.pk_w2, rpD, d_x, D);
+        if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
+      }
     }
-    if (L.pk_in) {
+    if ((parts & 2) && L.pk_in) {
       if ((e = nabu_pk_pack(P, 1, x, D, M, D, pk + L.pk_xT, rpD, 0, 0, rpD, nkbT, 0, 0, stream))) return e;
-      nabu_pk_gemm_desc g = pk_desc(P, D, 2 * G, nkbT, pk + L.pk_xT, rpD, pk + L.pk_dzT, rpG, dkern[0], G);
+      nabu_pk_gemm_desc g = pk_desc(P, D, 2 * G, nkbT, pk + L.pk_xT, rpD, dzTp, rpG, dkern[0], G);
       g.C2[0] = dkern[1]; g.n_split = G;
       if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
     }
-    if (L.pk_rec) {
+    if ((parts & 2) && L.pk_rec) {
       // h_{t-1}^T: the forward cell pairs dz[b,t] with out[b,t-1,:H], the backward cell with out[b,t+1,H:]
       for (int dir = 0; dir < 2; ++dir)
         if ((e = nabu_pk_pack(P, 1, out + (size_t)dir * H, 2 * H, M, H, pk + L.pk_hT[dir], rpH, 0, 0, rpH, nkbT, T,
                               dir ? 1 : -1, stream)))
           return e;
-      nabu_pk_gemm_desc g = pk_desc(P, H, G, nkbT, pk + L.pk_hT[0], rpH, pk + L.pk_dzT, rpG, dkern[0] + (size_t)D * G, G);
-      g.nbatch = 2; g.A[1] = pk + L.pk_hT[1]; g.B[1] = pk + L.pk_dzT + (size_t)G * 32; g.C[1] = dkern[1] + (size_t)D * G;
-      if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
-    }
-    if (d_x && L.pk_in) {
-      // dx = [dZ_fw | dZ_bw] · [Wx_fw | Wx_bw]^T: the two cells are two ranges of ONE reduction
-      for (int dir = 0; dir < 2; ++dir)
-        if ((e = nabu_pk_pack(P, 0, kern[dir], G, D, G, pk + L.pk_w2, rpD, 0, dir * kbG, rpD, dir ? nkb2 - kbG : kbG, 0, 0,
-                              stream)))
-          return e;
-      nabu_pk_gemm_desc g = pk_desc(P, M, D, nkb2, pk + L.pk_dz, rpBT, pk + L.pk_w2, rpD, d_x, D);
+      nabu_pk_gemm_desc g = pk_desc(P, H, G, nkbT, pk + L.pk_hT[0], rpH, dzTp, rpG, dkern[0] + (size_t)D * G, G);
+      g.nbatch = 2; g.A[1] = pk + L.pk_hT[1]; g.B[1] = dzTp + (size_t)G * 32; g.C[1] = dkern[1] + (size_t)D * G;
       if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
     }
   }
@@ -572,11 +586,12 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
     dzT = dzb + (size_t)M * 4 * H;
     xT = dzT + (size_t)4 * H * M;
     wb = xT + (size_t)D * M;
-    if (int e = cvt_bf16_t(M, D, x, D, xT, M, s)) return e;
+    if (parts & 2)
+      if (int e = cvt_bf16_t(M, D, x, D, xT, M, s)) return e;
   }
   for (int dir = 0; dir < 2; ++dir) {
-    int e;
-    if (L.pk_in) {
+    int e = 0;
+    if (L.pk_in || !(parts & 2)) {
     } else if (old_bf16) {
       if ((e = cvt_bf16_t(M, 4 * H, gates[dir], 4 * H, dzT, M, s))) return e;
       // dWx = x^T · dz = sum over frames of xT[d, k] * dzT[n, k]
@@ -590,7 +605,7 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
     if (e) return e;
     }
     // dWh = h_{prev}^T · dz : fw pairs (out[b,t-1,:H], dz[b,t]); bw pairs (out[b,t+1,H:], dz[b,t])
-    if (!(L.pk_planes && L.pk_rec)) {
+    if (!(L.pk_planes && L.pk_rec) && (parts & 2)) {
     const float *A = dir == 0 ? out : out + H + (size_t)2 * H;
     const float *Bm = dir == 0 ? gates[0] + (size_t)4 * H : gates[1];
     e = nabu_gemm_f32(1, 0, H, 4 * H, B * (T - 1), 1.f, A, 2 * H, Bm, 4 * H, 0.f,
@@ -598,6 +613,7 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
                       (long long)T * 2 * H, (long long)T * 4 * H, w + L.gemm_off, L.gemm_bytes, stream);
     if (e) return e;
     }
+    if (!(parts & 1)) continue;
     // db = column sums of dz: the persistent kernel already summed them per shard
     if (db_part)
       e = nabu_colsum_f32(db_rows, 4 * H, db_part + (size_t)dir * 4 * H, 2 * 4 * H, 0.f, dbias[dir], w + L.gemm_off,
@@ -620,4 +636,26 @@ extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const in
     }
   }
   return 0;
+}
+
+extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const int32_t *len,
+                              const float *kernel_fw, const float *kernel_bw, const float *out,
+                              const float *d_out, void *reserve, float *d_x, float *dkernel_fw,
+                              float *dbias_fw, float *dkernel_bw, float *dbias_bw, void *ws,
+                              size_t ws_bytes, nabu_stream_t stream) {
+  return blstm_bwd_parts(3, d, x, len, kernel_fw, kernel_bw, out, d_out, reserve, d_x, dkernel_fw, dbias_fw, dkernel_bw,
+                         dbias_bw, ws, ws_bytes, stream);
+}
+extern "C" int nabu_blstm_bwd_data(const nabu_blstm_desc *d, const float *x, const int32_t *len,
+                                   const float *kernel_fw, const float *kernel_bw, const float *out,
+                                   const float *d_out, void *reserve, float *d_x, float *dbias_fw, float *dbias_bw,
+                                   void *ws, size_t ws_bytes, nabu_stream_t stream) {
+  return blstm_bwd_parts(1, d, x, len, kernel_fw, kernel_bw, out, d_out, reserve, d_x, nullptr, dbias_fw, nullptr, dbias_bw,
+                         ws, ws_bytes, stream);
+}
+extern "C" int nabu_blstm_bwd_weights(const nabu_blstm_desc *d, const float *x, const int32_t *len, const float *out,
+                                      void *reserve, float *dkernel_fw, float *dkernel_bw, void *ws, size_t ws_bytes,
+                                      nabu_stream_t stream) {
+  return blstm_bwd_parts(2, d, x, len, nullptr, nullptr, out, nullptr, reserve, nullptr, dkernel_fw, nullptr, dkernel_bw,
+                         nullptr, ws, ws_bytes, stream);
 }

@@ -6,7 +6,7 @@ import torch
 
 from nabu_amd import ops as hip
 from nabu_amd import variables as vs
-from nabu_amd.autodiff import record, requires_grad, SeqLen
+from nabu_amd.autodiff import record, requires_grad, SeqLen, Tape
 from nabu_amd.neuralnetworks.components import ops
 
 # cell scope of tf.contrib.rnn.LayerNormBasicLSTMCell under bidirectional_dynamic_rnn
@@ -15,6 +15,11 @@ LSTM_MODE = [hip.LSTM_AUTO]      # tests flip this to compare the two recurrent 
 # arithmetic of the input-to-hidden GEMMs of the layers built next ('default' | 'f32' | 'bf16' |
 # 'bf16x3' | 'bf16x6'); set by the encoders from their `gemm_precision` cfg key
 GEMM_PRECISION = ['default']
+# the weight-gradient products of a layer run after the LAST recurrence of the backward pass (Tape.defer): nothing
+# waits for them, and bf16 matrix bursts in front of a persistent recurrent kernel slow it down (include/nabu_hip.h,
+# nabu_blstm_bwd_data).  NABU_DEFER_WGRAD=0: one fused nabu_blstm_bwd per layer as before.
+import os as _os
+DEFER_WEIGHT_GRADS = [_os.environ.get('NABU_DEFER_WGRAD', '1') != '0']
 
 
 def blstm(inputs, sequence_length, num_units, layer_norm=False, scope=None):
@@ -47,8 +52,13 @@ def blstm(inputs, sequence_length, num_units, layer_norm=False, scope=None):
             if v.grad is None:
                 v.grad = torch.zeros_like(v.data)
         dx = torch.empty_like(x) if need_dx else None
-        hip.blstm_bwd(plan, x, lens.dev, kf.data, kb.data, out, dout.contiguous(), reserve, dx,
-                      kf.grad, bf.grad, kb.grad, bb.grad)
+        tape = Tape.current_backward
+        if DEFER_WEIGHT_GRADS[0] and tape is not None:
+            hip.blstm_bwd_data(plan, x, lens.dev, kf.data, kb.data, out, dout.contiguous(), reserve, dx, bf.grad, bb.grad)
+            tape.defer(lambda: hip.blstm_bwd_weights(plan, x, lens.dev, out, reserve, kf.grad, kb.grad), params=(kf, kb))
+        else:
+            hip.blstm_bwd(plan, x, lens.dev, kf.data, kb.data, out, dout.contiguous(), reserve, dx,
+                          kf.grad, bf.grad, kb.grad, bb.grad)
         return [dx]
     record([inputs], [out], backward, params=(kf, bf, kb, bb))
     return out

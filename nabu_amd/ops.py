@@ -200,6 +200,30 @@ def blstm_bwd(plan, x, lens_dev, k_fw, k_bw, out, d_out, reserve, d_x, dk_fw, db
     return d_x
 
 
+def blstm_bwd_data(plan, x, lens_dev, k_fw, k_bw, out, d_out, reserve, d_x, db_fw, db_bw):
+    """first half of blstm_bwd (nabu_blstm_bwd_data): recurrence backward, bias gradients, d_x; dz stays in `reserve`"""
+    L = _hip.lib()
+    ws = Workspace.get(plan.ws_bytes, x.device, 'blstm')
+    if BEFORE_RECURRENT[0] is not None:
+        BEFORE_RECURRENT[0]()
+    if PROFILER is not None:
+        PROFILER.arm('bwd', plan)
+    check(L.nabu_blstm_bwd_data(ctypes.byref(plan.desc), ptr(x), ptr(lens_dev), ptr(k_fw), ptr(k_bw), ptr(out),
+                                ptr(d_out), ptr(reserve), ptr(d_x), ptr(db_fw), ptr(db_bw), ptr(ws), plan.ws_bytes,
+                                stream()), 'nabu_blstm_bwd_data')
+    if PROFILER is not None:
+        PROFILER.disarm()
+    return d_x
+
+
+def blstm_bwd_weights(plan, x, lens_dev, out, reserve, dk_fw, dk_bw):
+    """second half (nabu_blstm_bwd_weights): the kernel gradients from the dz blstm_bwd_data left in `reserve`"""
+    ws = Workspace.get(plan.ws_bytes, x.device, 'blstm')
+    check(_hip.lib().nabu_blstm_bwd_weights(ctypes.byref(plan.desc), ptr(x), ptr(lens_dev), ptr(out), ptr(reserve),
+                                            ptr(dk_fw), ptr(dk_bw), ptr(ws), plan.ws_bytes, stream()),
+          'nabu_blstm_bwd_weights')
+
+
 def pad_time(x, Tp):
     B, T, F = x.shape
     y = torch.empty((B, Tp, F), dtype=x.dtype, device=x.device)

@@ -206,3 +206,39 @@ def test_blstm_layer_on_packed_products_matches_oracle(precision, tol, B, T, D, 
     assert rel_err(dx, rdx) < tol
     for k in rg:
         assert rel_err(g[k], rg[k]) < tol, k
+
+
+@pytest.mark.parametrize('precision', ['f32', 'bf16x6', 'bf16'])
+@pytest.mark.parametrize('B,T,D,H', [(16, 64, 256, 64), (8, 160, 40, 64)])
+def test_blstm_backward_in_two_calls_equals_one(precision, B, T, D, H):
+    """nabu_blstm_bwd_data + nabu_blstm_bwd_weights (the weight-gradient products deferred behind the last recurrence of
+    a backward pass) == nabu_blstm_bwd, bit for bit, on every arithmetic of the products"""
+    from nabu_amd import ops
+    rng = np.random.default_rng(B + T)
+    lens = rng.integers(T // 2, T + 1, B).astype(np.int32)
+    lens[0] = T
+    x = torch.tensor(rng.normal(size=(B, T, D)).astype(np.float32), device='cuda')
+    for b in range(B):
+        x[b, lens[b]:] = 0
+    ld = torch.tensor(lens, device='cuda')
+    p = [torch.tensor(rng.normal(0, 0.2, s).astype(np.float32), device='cuda') for s in [(D + H, 4 * H), (4 * H,), (D + H, 4 * H), (4 * H,)]]
+    dout = torch.tensor(rng.normal(size=(B, T, 2 * H)).astype(np.float32), device='cuda')
+    plan = ops.BlstmPlan(B, T, D, H, T, ops.LSTM_AUTO, precision)
+    res = []
+    for split in (False, True):
+        out = torch.zeros(B, T, 2 * H, device='cuda')
+        reserve = torch.empty(plan.reserve_bytes, dtype=torch.uint8, device='cuda')
+        ops.blstm_fwd(plan, x, ld, p[0], p[1], p[2], p[3], out, reserve)
+        g = [torch.full_like(q, float('nan')) for q in p]
+        dx = torch.full_like(x, float('nan'))
+        if split:
+            ops.blstm_bwd_data(plan, x, ld, p[0], p[2], out, dout, reserve, dx, g[1], g[3])
+            junk = torch.randn(1 << 20, device='cuda')          # other work in between
+            junk.mul_(2.0)
+            ops.blstm_bwd_weights(plan, x, ld, out, reserve, g[0], g[2])
+        else:
+            ops.blstm_bwd(plan, x, ld, p[0], p[2], out, dout, reserve, dx, g[0], g[1], g[2], g[3])
+        torch.cuda.synchronize()
+        res.append([dx] + g)
+    for a, b in zip(*res):
+        assert torch.isfinite(a).all() and torch.equal(a, b)

@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, '.')
 from nabu_amd import ops  # noqa: E402
 
-B, T, D, H = 32, 500, 2048, 512
+B, T, D, H = 32, int(os.environ.get('EXP_T', '500')), 2048, 512
 x = torch.randn(B, T, D, device='cuda') * 0.1
 lens = torch.full((B,), T, dtype=torch.int32).cuda()
 p = [torch.randn(s, device='cuda') * 0.03 for s in [(D + H, 4 * H), (4 * H,), (D + H, 4 * H), (4 * H,)]]
@@ -31,8 +31,9 @@ big = torch.randn(256 << 20, device='cuda')
 
 
 def burst(kind):
-    if kind == 'pk':
-        ops.gemm_pk(pa, pb, C, 3)
+    if kind.startswith('pk'):
+        for _ in range(int(kind[2:] or 1)):
+            ops.gemm_pk(pa, pb, C, 3)
     elif kind == 'f32':
         ops.gemm(A[:8000], Bm, C[:8000], False, True, precision='f32')
     elif kind == 'copy':
@@ -44,7 +45,7 @@ def burst(kind):
 
 
 prof = ops.enable_profiler()
-for kind in os.environ.get('EXP_BURST', 'none,pk,f32,copy,idle,none').split(','):
+for kind in os.environ.get('EXP_BURST', 'none,pk,pk2,pk3,f32,copy,idle,none').split(','):
     for it in range(8):
         burst(kind)
         ops.blstm_fwd(plan, x, lens, p[0], p[1], p[2], p[3], out, reserve)
