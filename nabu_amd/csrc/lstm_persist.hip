@@ -740,7 +740,9 @@ __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8
       //     workgroup meets at an execution barrier before anybody publishes.
       if (RINGB == 2) {
         wait_vm<3>();
+        NABU_STAMP(1, 7);
         __builtin_amdgcn_s_barrier();
+        NABU_STAMP(1, 8);
       }
 #pragma unroll
       for (int m = 0; m < GPW; ++m) {
@@ -752,6 +754,7 @@ __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8
         }
       }
     }
+    NABU_STAMP(1, 9);
     // claim the prefetched values here, in front of the dz store (see the forward kernel)
     if (s > 0) {
       wait_vm<GPW * RG>();   // N = the publish stores above

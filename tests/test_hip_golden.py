@@ -80,10 +80,19 @@ def test_ctc_recipes_match_golden(name, recipe):
     # weights after `steps` clip+Adam updates (an element whose gradient is rounding noise may
     # move by lr per step in either direction)
     wT = unpack(fx, 'wT:')
+    g0 = unpack(fx, 'g:')
     st = tr.model.store.state_dict()
     for k in wT:
         d = np.abs(st[k] - wT[k])
         assert d.max() < (steps + 0.5) * 1e-3 and d.mean() < 2e-5, (k, d.max(), d.mean())
+        # ... which only elements with a rounding-noise gradient may use: Adam's first steps move an element by
+        # ~lr * sign(g), so wherever the oracle's step-0 gradient is clearly non-zero (> 1e-3 of the variable's
+        # largest) the fp32 trajectory must stay within a small fraction of ONE step's travel of the float64 one
+        sure = np.abs(g0[k].reshape(wT[k].shape)) > 1e-3 * np.abs(g0[k]).max()
+        assert sure.mean() > 0.5, (k, sure.mean())                  # observed 65 - 100 % of the elements
+        print('\n%s: %.0f %% of the elements have a clear gradient; their final-weight error max %.2e (all: %.2e)'
+              % (k, 100 * sure.mean(), d[sure].max(), d.max()))
+        assert d[sure].max() < 5e-6, (k, d[sure].max())          # observed <= 1.1e-6; one step's travel is 1e-3
 
 
 @pytest.mark.parametrize('name,recipe', [('cfg3_small', 'cfg3_las_vanilla'), ('cfg5_small', 'cfg5_las_location')])

@@ -26,4 +26,5 @@ st = ws[4*320:4*(320+64)].view(torch.int32).cpu().numpy().astype(np.int64)
 for pas, name in ((0,'fwd'),(1,'bwd')):
     wal = st[32*pas:32*pas+(6 if pas==0 else 7)]
     print(name, 'phase times (ns)', [int((wal[i+1]-wal[i]) & 0xffffffff)*10 for i in range(len(wal)-1)])
+    if pas == 1: print('   bwd inner (ns): product end -> resets drained %d, -> barrier passed %d, -> publish issued %d, -> prefetch claimed %d' % tuple(int((st[32 + b] - st[32 + a]) & 0xffffffff) * 10 for a, b in ((4, 7), (7, 8), (8, 9), (9, 5))))
     if pas == 0: print('   fwd inner: stamp1->6 (prefetch issue) %d, 6->7 (LDS reads + FMAs) %d, 7->2 (quad reduce) %d' % tuple(int((st[b]-st[a]) & 0xffffffff)*10 for a,b in ((1,6),(6,7),(7,2))))
