@@ -32,6 +32,9 @@ class Tape(object):
         # has run its backward closure: its gradient is final (bucketed gradient exchange)
         self.on_param_ready = None
         self._deferred = None          # during backward(): [(callable, params)] to run after the last closure
+        # called after every deferred callable (its params have been reported ready): the data-parallel trainer
+        # starts the gradient buckets that became final — behind the last recurrence nothing needs the chip alone
+        self.after_deferred = None
 
     def __enter__(self):
         self._prev = Tape.current
@@ -115,6 +118,8 @@ class Tape(object):
                     pending[id(v)] -= 1
                     if pending[id(v)] == 0:
                         self.on_param_ready(v)
+            if self.after_deferred is not None:
+                self.after_deferred()
         self.ops = []
         self.produced = set()
 

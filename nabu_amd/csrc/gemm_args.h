@@ -102,7 +102,9 @@ int gemm_bf16_pre(int M, int N, int K, float alpha, const unsigned short *A, int
 int cvt_bf16(size_t R, int C, const float *src, int ld, unsigned short *dst, int ldd, hipStream_t s);
 int cvt_bf16_t(int R, int C, const float *src, int ld, unsigned short *dst, int ldd, hipStream_t s);
 
-// packed bf16-plane operands (gemm_pk.hip): natural AND transposed pack of one source in one pass
+// packed bf16-plane operands (gemm_pk.hip): does the current device offer the tile loop's 144 KiB of LDS?
+bool gemm_pk_device_ok();
+// natural AND transposed pack of one source in one pass
 int pk_pack_both(int planes, const float *src, long long ld, int R, int C, void *dst_n, int rows_pad_n, int kb_off_n,
                  int fill_rows_n, int fill_kb_n, void *dst_t, int rows_pad_t, int row_off_t, int fill_rows_t,
                  int fill_kb_t, hipStream_t s);

@@ -514,6 +514,27 @@ static int pk_cu_count() {
   return cached;
 }
 
+// the tile loop needs 144 KiB of LDS per workgroup: devices that do not offer it take the other GEMM kernels
+bool gemm_pk_device_ok() {
+  static thread_local int cached_dev = -1;
+  static thread_local bool cached = false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (dev != cached_dev) {
+    int lds = 0;
+    const hipDeviceAttribute_t names[3] = {hipDeviceAttributeMaxSharedMemoryPerBlock, hipDeviceAttributeSharedMemPerBlockOptin,
+                                           hipDeviceAttributeMaxSharedMemoryPerMultiprocessor};
+    for (hipDeviceAttribute_t n : names) {
+      int v = 0;
+      if (hipDeviceGetAttribute(&v, n, dev) == hipSuccess && v > lds) lds = v;
+    }
+    (void)hipGetLastError();
+    cached = lds >= PK_LDS;
+    cached_dev = dev;
+  }
+  return cached;
+}
+
 // split-K policy: one workgroup per CU; with few output tiles cut the reduction so that the number of
 // workgroups comes close to a multiple of the CU count (>= 24 stages per workgroup)
 static int pk_choose_split(int ntiles, int nkb, int kbs, int *kb_per_split) {
@@ -667,6 +688,7 @@ extern "C" int nabu_gemm_pk(const nabu_pk_gemm_desc *d, void *ws, size_t ws_byte
   PkArgs p;
   int planes;
   if (int e = pk_fill(p, d, &planes)) return e;
+  if (!gemm_pk_device_ok()) return fail(NABU_EUNSUP, "gemm_pk: the device offers less than %d bytes of LDS per workgroup", PK_LDS);
   if (p.nsplit > 1) {
     const size_t need = (size_t)p.nsplit * p.nbatch * p.M * p.N * sizeof(float);
     if (!ws || ws_bytes < need) return fail(NABU_EWS, "gemm_pk: workspace %zu < %zu", ws_bytes, need);

@@ -227,7 +227,7 @@ static int pk_planes_of(const nabu_blstm_desc *d) {
   const int prec = d->gemm_precision == NABU_GEMM_DEFAULT ? nabu_gemm_get_default_precision() : d->gemm_precision;
   static int env = -1;
   if (env < 0) { const char *e = getenv("NABU_PK"); env = e ? atoi(e) : 1; }
-  if (!env) return 0;
+  if (!env || !gemm_pk_device_ok()) return 0;
   const long long BT = (long long)d->B * d->T;
   if (BT < 1024 || BT >= (1ll << 31) - 512 || d->H % 64) return 0;   // n_split = 4H must be a multiple of 256
   return prec == NABU_GEMM_BF16X6 ? 3 : prec == NABU_GEMM_BF16 ? 1 : 0;

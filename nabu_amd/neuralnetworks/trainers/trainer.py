@@ -269,6 +269,9 @@ class Trainer(object, metaclass=ABCMeta):
         self._works = []
         self._declared = {id(v) for op in tape.ops for v in op.params}
         tape.on_param_ready = lambda v: self._ready.add(id(v))
+        # weight-gradient products deferred behind the last recurrence (layer.py, Tape.defer): a layer's bucket goes on
+        # the wire right after its products and travels under the next layer's
+        tape.after_deferred = self._launch_ready_buckets
         hip.set_phase_hook(self._launch_ready_buckets)
         hip.BEFORE_RECURRENT[0] = self._join_comm
 
