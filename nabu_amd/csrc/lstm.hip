@@ -192,6 +192,7 @@ struct Layout {
   // X·Wx, dZ·Wx^T, X^T·dZ, pk_rec = the recurrent weight gradient h_{t-1}^T·dZ
   int pk_planes;
   bool pk_in, pk_rec;
+  bool pk_whole;    // narrow input (D < 256): [x^T ; h^T] is ONE operand and the whole kernel gradient one product
   size_t pk_off, pk_bytes;
   // forward: X [BT, D], W^T of both cells [8H, D]; backward: dZ^T [8H, BT], X^T [D, BT], h^T per cell [H, BT],
   // dZ [BT, 8H], Wx of both cells [D, 8H] (byte offsets inside the pk region)
@@ -283,6 +284,7 @@ static Layout make_layout(const nabu_blstm_desc *d) {
   L.pk_planes = pk_planes_of(d);
   L.pk_in = L.pk_planes && D >= 256 && D % 4 == 0;
   L.pk_rec = L.pk_planes && T > 1;
+  L.pk_whole = L.pk_rec && !L.pk_in && D % 4 == 0;
   L.pk_off = off; L.pk_bytes = 0;
   if (L.pk_planes) {
     const int P = L.pk_planes, BT = (int)(B * T), G = (int)(4 * H);
@@ -293,14 +295,15 @@ static Layout make_layout(const nabu_blstm_desc *d) {
     L.res_dzT_bytes = nabu_pk_bytes(2 * G, BT, P);
     L.reserve_bytes = L.res_dzT_off + L.res_dzT_bytes;
     if (L.pk_in) L.pk_xT = take(bwd, nabu_pk_bytes((int)D, BT, P));
-    for (int dir = 0; dir < 2; ++dir) L.pk_hT[dir] = take(bwd, L.pk_rec ? nabu_pk_bytes((int)H, BT, P) : 0);
+    for (int dir = 0; dir < 2; ++dir)
+      L.pk_hT[dir] = take(bwd, L.pk_rec ? nabu_pk_bytes((int)(L.pk_whole ? D + H : H), BT, P) : 0);
     if (L.pk_in) { L.pk_dz = take(bwd, nabu_pk_bytes(BT, 2 * G, P)); L.pk_w2 = take(bwd, nabu_pk_bytes((int)D, 2 * G, P)); }
     L.pk_bytes = max_sz(fwd, bwd);
     off += L.pk_bytes;
     // split-K slabs of the four products
     size_t gws = 0;
     nabu_pk_gemm_desc g;
-    const int rpBT = nabu_pk_rows_pad(BT), rpG = nabu_pk_rows_pad(2 * G), rpD = nabu_pk_rows_pad((int)D), rpH = nabu_pk_rows_pad((int)H);
+    const int rpBT = nabu_pk_rows_pad(BT), rpG = nabu_pk_rows_pad(2 * G), rpD = nabu_pk_rows_pad((int)D);
     float *dummy = reinterpret_cast<float *>(16);
     if (L.pk_in) {
       g = pk_desc(P, BT, 2 * G, nabu_pk_kblocks((int)D, P), dummy, rpBT, dummy, rpG, dummy, G); g.n_split = G; g.C2[0] = dummy;
@@ -311,7 +314,8 @@ static Layout make_layout(const nabu_blstm_desc *d) {
       gws = max_sz(gws, nabu_gemm_pk_ws_bytes(&g));
     }
     if (L.pk_rec) {
-      g = pk_desc(P, (int)H, G, nabu_pk_kblocks(BT, P), dummy, rpH, dummy, rpG, dummy, G); g.nbatch = 2;
+      const int Mw = (int)(L.pk_whole ? D + H : H);
+      g = pk_desc(P, Mw, G, nabu_pk_kblocks(BT, P), dummy, nabu_pk_rows_pad(Mw), dummy, rpG, dummy, G); g.nbatch = 2;
       g.A[1] = g.B[1] = dummy; g.C[1] = dummy;
       gws = max_sz(gws, nabu_gemm_pk_ws_bytes(&g));
     }
@@ -538,7 +542,7 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
     const int P = L.pk_planes, G = 4 * H;
     char *pk = w + L.pk_off;
     char *dzTp = static_cast<char *>(reserve) + L.res_dzT_off;
-    const int rpBT = nabu_pk_rows_pad(M), rpG = nabu_pk_rows_pad(2 * G), rpD = nabu_pk_rows_pad(D), rpH = nabu_pk_rows_pad(H);
+    const int rpBT = nabu_pk_rows_pad(M), rpG = nabu_pk_rows_pad(2 * G), rpD = nabu_pk_rows_pad(D);
     const int nkbT = nabu_pk_kblocks(M, P);
     const int nkb2 = nabu_pk_kblocks(2 * G, P), kbG = G / 16;
     int e;
@@ -569,13 +573,18 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
       if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
     }
     if ((parts & 2) && L.pk_rec) {
-      // h_{t-1}^T: the forward cell pairs dz[b,t] with out[b,t-1,:H], the backward cell with out[b,t+1,H:]
-      for (int dir = 0; dir < 2; ++dir)
-        if ((e = nabu_pk_pack(P, 1, out + (size_t)dir * H, 2 * H, M, H, pk + L.pk_hT[dir], rpH, 0, 0, rpH, nkbT, T,
+      // h_{t-1}^T: the forward cell pairs dz[b,t] with out[b,t-1,:H], the backward cell with out[b,t+1,H:].
+      // Narrow input (the first layer, D = 40): x^T sits in front of h^T in the same operand and the whole kernel
+      // gradient [(D+H), 4H] of a cell is ONE product (its dWx alone cost more on the in-kernel-split kernel)
+      const int r0 = L.pk_whole ? D : 0, Mw = r0 + H, rpW = nabu_pk_rows_pad(Mw);
+      for (int dir = 0; dir < 2; ++dir) {
+        if (L.pk_whole && (e = nabu_pk_pack(P, 1, x, D, M, D, pk + L.pk_hT[dir], rpW, 0, 0, D, nkbT, 0, 0, stream))) return e;
+        if ((e = nabu_pk_pack(P, 1, out + (size_t)dir * H, 2 * H, M, H, pk + L.pk_hT[dir], rpW, r0, 0, rpW - r0, nkbT, T,
                               dir ? 1 : -1, stream)))
           return e;
-      nabu_pk_gemm_desc g = pk_desc(P, H, G, nkbT, pk + L.pk_hT[0], rpH, dzTp, rpG, dkern[0] + (size_t)D * G, G);
-      g.nbatch = 2; g.A[1] = pk + L.pk_hT[1]; g.B[1] = dzTp + (size_t)G * 32; g.C[1] = dkern[1] + (size_t)D * G;
+      }
+      nabu_pk_gemm_desc g = pk_desc(P, Mw, G, nkbT, pk + L.pk_hT[0], rpW, dzTp, rpG, dkern[0] + (size_t)(D - r0) * G, G);
+      g.nbatch = 2; g.A[1] = pk + L.pk_hT[1]; g.B[1] = dzTp + (size_t)G * 32; g.C[1] = dkern[1] + (size_t)(D - r0) * G;
       if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
     }
   }
@@ -591,7 +600,7 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
   }
   for (int dir = 0; dir < 2; ++dir) {
     int e = 0;
-    if (L.pk_in || !(parts & 2)) {
+    if (L.pk_in || L.pk_whole || !(parts & 2)) {
     } else if (old_bf16) {
       if ((e = cvt_bf16_t(M, 4 * H, gates[dir], 4 * H, dzT, M, s))) return e;
       // dWx = x^T · dz = sum over frames of xT[d, k] * dzT[n, k]
