@@ -81,7 +81,8 @@ def cpu_baseline():
     cores = min(sweep, key=sweep.get)
     c1 = cb.time_config('cfg1', 2, 5, threads=cores)
     c1f = cb.time_config('cfg1', 2, 5, fused=True, threads=cores)
-    c2 = cb.time_config('cfg2', 2, 5, threads=cores)
+    # (a slower host: the timed loop stops after >= 2 steps once 7 minutes are used; `sample` says how many ran)
+    c2 = cb.time_config('cfg2', 2, 5, threads=cores, budget_s=420.0)
     allc = {'cores': phys}
     if phys != cores:
         a1 = cb.time_config('cfg1', 2, 5, threads=phys, budget_s=60.0)
