@@ -234,16 +234,17 @@ def gemm_roofline_pk(B, T, D, H, planes):
     ms = timed(run, 3)
     ms_pack = timed(lambda: [ops.pk_pack(po, src) for po, src in packs], 2)
     flops = sum(2.0 * M * N * a.K * nb for a, _, M, N, nb in prods)
-    mult = 6 if planes == 3 else 1
+    mult = {3: 6, 2: 3, 1: 1}[planes]
     tf = flops * mult / ms / 1e9
     return {'bound': 'mfma', 'achieved': round(tf, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(tf / 2500.0, 4),
             'traffic': None, 'kernel': 'gemm_pk_kernel<%d,*> (+ split-K reduce)' % planes, 'ms_per_step': round(ms, 3),
             'flops_per_step': int(flops), 'effective_fp32_tflops': round(flops / ms / 1e9, 1),
             'pack_ms_per_step': round(ms_pack, 3),
             'note': 'the packed-operand products of a cfg2 step at their real shapes, back to back, timed with events on '
-                    'the launch stream; achieved = bf16 MFMA flops issued (%d plane products per product) against the '
-                    'dense bf16 peak of MI355X_MICROARCH.md; effective_fp32_tflops = 2MNK / time; pack_ms_per_step = '
-                    'the fp32 -> bf16-plane conversions of the same operands (HBM-bound, not part of ms_per_step)' % mult}
+                    'the launch stream; achieved = bf16 / fp16 MFMA flops issued (%d plane products per product) against the '
+                    'dense bf16 (= fp16) peak of MI355X_MICROARCH.md; effective_fp32_tflops = 2MNK / time; pack_ms_per_step = '
+                    'the fp32 -> plane conversions of the same operands (HBM-bound, not part of ms_per_step; planes = 2: '
+                    'with the row-maximum pass)' % mult}
 
 
 METRICS = {'cfg1': 'utterances/sec training step, 2x256 DBLSTM+CTC, batch 8x200x40 fbank',
@@ -258,10 +259,15 @@ WORKLOADS = {'cfg1': 'cfg1: DBLSTM 2 x 256, DNNDecoder, CTC, Adam+clip; 8 utt x 
                      'average cross-entropy; 32 utt x 1000 frames x 40 fbank per GPU',
              'cfg5': 'cfg5: Listener-512 (bf16 input GEMMs) + Speller (location-aware attention); '
                      '64 utt x 1600 frames x 80 fbank per GPU'}
+ALT_KEYS = {'f32': 'exact_fp32', 'bf16x6': 'alt_bf16x6', 'f16x3': 'alt_f16x3'}
 GEMM_ARITH = {'f32': 'f32 (v_mfma_f32_32x32x2_f32, exact fp32)',
               'bf16x6': 'fp32-equivalent on the bf16 matrix pipe: fp32 operands split exactly into 3 bf16 planes, 6 plane '
                         'products (v_mfma_f32_32x32x16_bf16), 16-k partial sums promoted to fp32 accumulators; error vs '
                         'float64 <= the exact-fp32 MFMA kernel\'s (tests/test_hip_gemm_pk.py)',
+              'f16x3': 'fp32-equivalent on the fp16 matrix pipe: every operand row scaled by a power of two (row maximum '
+                       'into [2^14, 2^15)) and held as two fp16 planes, 3 plane products (v_mfma_f32_32x32x16_f16), 16-k '
+                       'partial sums promoted to fp32 accumulators; error vs float64 <= the exact-fp32 MFMA kernel\'s on '
+                       'normal data, <= 1.25x on heavy-tailed data (tests/test_hip_gemm_pk.py)',
               'bf16x3': 'f32 operands split into 2 bf16 pieces, 3 bf16 MFMA products, f32 accumulate',
               'bf16': 'operands rounded to bf16, f32 accumulate'}
 
@@ -277,7 +283,7 @@ def parse_args(argv=None):
                     help='skip the second measurement of the same step with the other arithmetic (exact fp32 <-> bf16x6)')
     ap.add_argument('--no-gemm-roofline', action='store_true',
                     help='skip the roofline_gemm measurement (keeps a kernel trace of this command to the training steps)')
-    ap.add_argument('--gemm-precision', default='bf16x6', choices=['f32', 'bf16x6', 'bf16x3', 'bf16'],
+    ap.add_argument('--gemm-precision', default='bf16x6', choices=['f32', 'bf16x6', 'f16x3', 'bf16x3', 'bf16'],
                     help='arithmetic of the dense products (include/nabu_hip.h): bf16x6 (default) = fp32-equivalent '
                          'six-plane products on the bf16 matrix pipe, f32 = exact fp32 MFMA; the line names it in '
                          'config.gemm_arith and carries the other one as `exact_fp32` / `alt_bf16x6`')
@@ -449,10 +455,11 @@ class HipWorkload(object):
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
     def alt(self, steps):
-        if self.args.gemm_precision not in ('f32', 'bf16x6') or self.args.workload != 'cfg2' or self.args.no_alt:
-            return None
-        other = 'f32' if self.args.gemm_precision == 'bf16x6' else 'bf16x6'
-        return alt_gemm_arith(self.tr, self.batches, self.server, steps, other, self.args.gemm_precision)
+        """the same step under the other fp32-class arithmetics of the dense products: [(precision, seconds, loss)]"""
+        if self.args.gemm_precision not in ALT_KEYS or self.args.workload != 'cfg2' or self.args.no_alt:
+            return []
+        return [(o,) + alt_gemm_arith(self.tr, self.batches, self.server, steps, o, self.args.gemm_precision)
+                for o in ALT_KEYS if o != self.args.gemm_precision]
 
     def describe(self, dt):
         """workload-specific part of the JSON line (rank 0)"""
@@ -500,14 +507,15 @@ class HipWorkload(object):
                             'per recurrent launch from the rocprofv3 PMC passes under profiles/'}
         return {
             'metric': METRICS[args.workload],
-            'dtype': 'f32' if args.gemm_precision in ('f32', 'bf16x6') else 'f32 state / %s products' % args.gemm_precision,
+            'dtype': 'f32' if args.gemm_precision in ALT_KEYS else 'f32 state / %s products' % args.gemm_precision,
             'config': {'workload': WORKLOADS[args.workload], 'frames': T_,
                        'recurrent_path': 'persistent' if persistent else 'stepwise',
                        'gemm_arith': GEMM_ARITH[args.gemm_precision]},
             'roofline': roofline,
             'roofline_gemm': (None if args.workload != 'cfg2' or args.no_gemm_roofline
                               else gemm_roofline(B_, T_, D_, H_, args.gemm_precision) if args.gemm_precision == 'f32'
-                              else gemm_roofline_pk(B_, T_, D_, H_, 3) if args.gemm_precision == 'bf16x6' else None),
+                              else gemm_roofline_pk(B_, T_, D_, H_, 3) if args.gemm_precision == 'bf16x6'
+                              else gemm_roofline_pk(B_, T_, D_, H_, 2) if args.gemm_precision == 'f16x3' else None),
             'final_loss': round(self.final_loss, 4),
         }
 
@@ -539,7 +547,7 @@ def run(args, server, wl):
     wl.end_timed_region()
     wl.check()
     alt = wl.alt(min(args.steps, 5))
-    red = wl.reduce_max([dt_rank, alt[0] if alt else 0.0])
+    red = wl.reduce_max([dt_rank] + [a[1] for a in alt])
     per_rank = wl.gather(dt_rank)
     ar_ms = wl.allreduce_ms_per_step()
     ar_ranks = wl.gather(ar_ms if ar_ms is not None else 0.0)
@@ -556,17 +564,16 @@ def run(args, server, wl):
                     'ms_per_step_per_rank': [round(t / args.steps * 1e3, 3) for t in per_rank],
                     'allreduce': getattr(args, 'allreduce', 'flat') if world > 1 else None,
                     'allreduce_ms_per_step': [round(v, 3) for v in ar_ranks] if world > 1 else None}
-    if alt:
+    for i, (other, _, alt_loss) in enumerate(alt):
         n = min(args.steps, 5)
-        other = 'f32' if args.gemm_precision == 'bf16x6' else 'bf16x6'
         step_bytes_total = 2 * 2 * sum(wl.layer_t) * step_bytes(wl.B, wl.H)
-        out['exact_fp32' if other == 'f32' else 'alt_bf16x6'] = {
+        out[ALT_KEYS[other]] = {
             'note': 'the identical step (same weights stream, batches, protocol: 1 warm-up, barrier + sync bracket, MAX '
-                    'over ranks) with the dense products in the other arithmetic; not the headline value',
+                    'over ranks) with the dense products in another arithmetic; not the headline value',
             'gemm_arith': GEMM_ARITH[other],
-            'value': round(world * wl.units_per_step * n / red[1], 2), 'ms_per_step': round(red[1] / n * 1e3, 3),
-            'steps': n, 'final_loss': round(alt[1], 4),
-            'roofline_frac': round(step_bytes_total / (red[1] / n) / (HBM_PEAK_GBS * 1e9), 4)}
+            'value': round(world * wl.units_per_step * n / red[1 + i], 2), 'ms_per_step': round(red[1 + i] / n * 1e3, 3),
+            'steps': n, 'final_loss': round(alt_loss, 4),
+            'roofline_frac': round(step_bytes_total / (red[1 + i] / n) / (HBM_PEAK_GBS * 1e9), 4)}
     if not args.no_cpu_baseline and wl.wants_cpu_baseline():
         out['cpu_baseline'] = cpu_baseline() if world == 1 else cached_cpu_baseline()
     return out

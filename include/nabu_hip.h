@@ -65,12 +65,16 @@ size_t nabu_gemm_ws_bytes(int M, int N, int K);
  *                    v_mfma_f32_32x32x16_bf16 — the "bf16 MFMA input-to-hidden GEMMs" of
  *                    BASELINE.json configs[4];
  *   NABU_GEMM_BF16X3 / NABU_GEMM_BF16X6  each operand split into 2 / 3 bf16 pieces, 3 / 6 bf16
- *                    MFMA products: ~2^-16 / fp32-level (<= 2^-23) relative accuracy.
+ *                    MFMA products: ~2^-16 / fp32-level (<= 2^-23) relative accuracy;
+ *   NABU_GEMM_F16X3  fp32-level accuracy from three fp16 MFMA products of row-scaled two-plane operands
+ *                    (nabu_pk_pack_f16 below): the BLSTM layer's time-batched products take it on packed
+ *                    operands; a product on row-major operands (this function) computes bf16x6 instead.
  * NABU_GEMM_DEFAULT = the process default: NABU_GEMM_F32 unless changed by
  * nabu_gemm_set_default_precision() or the environment variable NABU_GEMM_PRECISION
- * (f32 | bf16 | bf16x3 | bf16x6).  Shapes the bf16 kernels do not take (K % 32, M % 4, N % 4,
+ * (f32 | bf16 | bf16x3 | bf16x6 | f16x3).  Shapes the bf16 kernels do not take (K % 32, M % 4, N % 4,
  * unaligned operands) silently use the exact fp32 kernel — never a lower precision than asked. */
-enum { NABU_GEMM_DEFAULT = 0, NABU_GEMM_F32 = 1, NABU_GEMM_BF16 = 2, NABU_GEMM_BF16X3 = 3, NABU_GEMM_BF16X6 = 4 };
+enum { NABU_GEMM_DEFAULT = 0, NABU_GEMM_F32 = 1, NABU_GEMM_BF16 = 2, NABU_GEMM_BF16X3 = 3, NABU_GEMM_BF16X6 = 4,
+       NABU_GEMM_F16X3 = 5 };
 int nabu_gemm_set_default_precision(int precision);
 int nabu_gemm_get_default_precision(void);
 int nabu_gemm_ex(int precision, int transA, int transB, int M, int N, int K, float alpha,
@@ -140,7 +144,7 @@ int nabu_gemm_bf16_nt(int M, int N, int K, float alpha, const void *A_bf16, int 
  * (nabu/neuralnetworks/components/layer.py:35-47, nabu/neuralnetworks/trainers/trainer.py:556-558). */
 typedef struct nabu_pk_gemm_desc {
   uint32_t size;          /* = sizeof(nabu_pk_gemm_desc) */
-  int32_t planes;         /* 3 = bf16x6 (fp32-equivalent), 1 = bf16 */
+  int32_t planes;         /* 3 = bf16x6 (fp32-equivalent), 2 = f16x3 (fp32-equivalent, scaled fp16 planes), 1 = bf16 */
   int32_t M, N, nkb;      /* output size per batch entry; k-blocks of 16 to reduce over */
   int32_t nbatch;         /* 1 or 2 independent products in one launch */
   const void *A[2], *B[2];/* packed operands (first k-block of the reduction) */
@@ -149,6 +153,7 @@ typedef struct nabu_pk_gemm_desc {
   int32_t ldc, n_split;
   const float *bias, *bias2;
   float alpha, beta;
+  const uint32_t *a_amax[2], *b_amax[2];  /* planes = 2: the row maxima the operands were packed with */
 } nabu_pk_gemm_desc;
 int nabu_pk_rows_pad(int rows);
 int nabu_pk_kblocks(int K, int planes);
@@ -156,6 +161,20 @@ size_t nabu_pk_bytes(int rows, int K, int planes);
 int nabu_pk_pack(int planes, int transposed, const float *src, long long ld, int R, int C, void *dst,
                  int dst_rows_pad, int row_off, int kb_off, int fill_rows, int fill_kb, int period,
                  int shift, nabu_stream_t stream);
+/* planes = 2, "f16x3": two scaled fp16 planes per operand and three plane products (l·h, h·l, h·h on
+ * v_mfma_f32_32x32x16_f16) — half the matrix instructions of bf16x6 at the same error level.  Every packed ROW
+ * (an M resp. N index, all its k) has a power-of-two scale 2^(14 - floor(log2 amax)) derived from `amax`, the
+ * bit pattern of the row's largest magnitude: x·scale = h + l with h = rne_f16(x·scale), l = rne_f16(x·scale - h);
+ * the product's epilogue divides the scales out.  amax[dst_rows_pad] (uint32, device) is indexed by packed row;
+ * it comes from nabu_pk_amax (atomic maxima of the rows and / or columns of a source matrix into ZEROED arrays:
+ * `rows[r]` for transposed = 0 packs, `cols[c]` for transposed = 1 packs) or from nabu_pk_amax_fill when a
+ * bound is known a priori (LSTM outputs: 1).  Any upper bound of the row's magnitudes is valid; a bound 2^j too
+ * large costs j bits of the l plane.  The same array goes into nabu_pk_gemm_desc.a_amax / b_amax. */
+int nabu_pk_amax(const float *src, long long ld, int R, int C, uint32_t *rows, uint32_t *cols, nabu_stream_t stream);
+int nabu_pk_amax_fill(uint32_t *dst, int n, float value, nabu_stream_t stream);
+int nabu_pk_pack_f16(int transposed, const float *src, long long ld, int R, int C, void *dst, int dst_rows_pad,
+                     int row_off, int kb_off, int fill_rows, int fill_kb, int period, int shift,
+                     const uint32_t *amax, nabu_stream_t stream);
 size_t nabu_gemm_pk_ws_bytes(const nabu_pk_gemm_desc *d);
 int nabu_gemm_pk(const nabu_pk_gemm_desc *d, void *ws, size_t ws_bytes, nabu_stream_t stream);
 

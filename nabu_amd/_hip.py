@@ -27,7 +27,7 @@ class PkGemmDesc(_c.Structure):
                 ('a_rows_pad', _c.c_int32), ('b_rows_pad', _c.c_int32), ('a_planes', _c.c_int32),
                 ('b_planes', _c.c_int32), ('C', _c.c_void_p * 2), ('C2', _c.c_void_p * 2),
                 ('ldc', _c.c_int32), ('n_split', _c.c_int32), ('bias', _c.c_void_p), ('bias2', _c.c_void_p),
-                ('alpha', _c.c_float), ('beta', _c.c_float)]
+                ('alpha', _c.c_float), ('beta', _c.c_float), ('a_amax', _c.c_void_p * 2), ('b_amax', _c.c_void_p * 2)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/nabu_hip.h
@@ -48,6 +48,9 @@ SIGNATURES = {
     'nabu_pk_kblocks': (_i, [_i, _i]),
     'nabu_pk_bytes': (_sz, [_i, _i, _i]),
     'nabu_pk_pack': (_i, [_i, _i, _vp, _ll, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'nabu_pk_amax': (_i, [_vp, _ll, _i, _i, _vp, _vp, _vp]),
+    'nabu_pk_amax_fill': (_i, [_vp, _i, _f, _vp]),
+    'nabu_pk_pack_f16': (_i, [_i, _vp, _ll, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'nabu_gemm_pk_ws_bytes': (_sz, [_c.POINTER(PkGemmDesc)]),
     'nabu_gemm_pk': (_i, [_c.POINTER(PkGemmDesc), _vp, _sz, _vp]),
     'nabu_gemm_set_default_precision': (_i, [_i]),
@@ -173,7 +176,7 @@ class Workspace(object):
 
 SPELLER_MAX_LAYERS = 4
 GEMM_DEFAULT, GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_BF16X6 = 0, 1, 2, 3, 4
-GEMM_PRECISIONS = {'default': 0, 'f32': 1, 'bf16': 2, 'bf16x3': 3, 'bf16x6': 4}
+GEMM_PRECISIONS = {'default': 0, 'f32': 1, 'bf16': 2, 'bf16x3': 3, 'bf16x6': 4, 'f16x3': 5}
 
 
 class SpellerDesc(_c.Structure):

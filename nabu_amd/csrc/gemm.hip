@@ -624,13 +624,14 @@ extern "C" int nabu_gemm_get_default_precision(void) {
       if (v == "bf16") g_default_precision = NABU_GEMM_BF16;
       else if (v == "bf16x3") g_default_precision = NABU_GEMM_BF16X3;
       else if (v == "bf16x6") g_default_precision = NABU_GEMM_BF16X6;
+      else if (v == "f16x3") g_default_precision = NABU_GEMM_F16X3;
     }
   }
   return g_default_precision;
 }
 
 extern "C" int nabu_gemm_set_default_precision(int precision) {
-  NABU_CHECK_ARG(precision >= NABU_GEMM_F32 && precision <= NABU_GEMM_BF16X6, "gemm: unknown precision");
+  NABU_CHECK_ARG(precision >= NABU_GEMM_F32 && precision <= NABU_GEMM_F16X3, "gemm: unknown precision");
   g_default_precision = precision;
   return 0;
 }
@@ -665,8 +666,11 @@ extern "C" int nabu_gemm_ex(int precision, int transA, int transB, int M, int N,
                             float *C, int ldc, const float *bias, int kseg,
                             long long a_seg_stride, long long b_seg_stride, void *ws,
                             size_t ws_bytes, nabu_stream_t stream) {
-  NABU_CHECK_ARG(precision >= NABU_GEMM_DEFAULT && precision <= NABU_GEMM_BF16X6, "gemm: unknown precision");
+  NABU_CHECK_ARG(precision >= NABU_GEMM_DEFAULT && precision <= NABU_GEMM_F16X3, "gemm: unknown precision");
   if (precision == NABU_GEMM_DEFAULT) precision = nabu_gemm_get_default_precision();
+  // f16x3 exists on packed operands only (gemm_pk.hip): products on row-major operands take the other
+  // fp32-equivalent arithmetic
+  if (precision == NABU_GEMM_F16X3) precision = NABU_GEMM_BF16X6;
   NABU_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "gemm: negative dimension");
   if (M == 0 || N == 0) return 0;
   NABU_CHECK_ARG(A && B && C, "gemm: null pointer");

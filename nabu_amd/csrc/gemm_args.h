@@ -107,7 +107,8 @@ bool gemm_pk_device_ok();
 // natural AND transposed pack of one source in one pass
 int pk_pack_both(int planes, const float *src, long long ld, int R, int C, void *dst_n, int rows_pad_n, int kb_off_n,
                  int fill_rows_n, int fill_kb_n, void *dst_t, int rows_pad_t, int row_off_t, int fill_rows_t,
-                 int fill_kb_t, hipStream_t s);
+                 int fill_kb_t, hipStream_t s, const unsigned *amax_n = nullptr, const unsigned *amax_t = nullptr);
+// (planes = 2, f16x3: amax_n / amax_t = the row maxima of the two destinations, indexed by packed row)
 
 // bf16-split kernels (gemm_bf16.hip); planes = 1 (bf16), 2 (bf16x3) or 3 (bf16x6)
 int gemm_bf16_launch(const GemmArgs &a, bool transA, bool transB, int planes, dim3 grid, hipStream_t stream);

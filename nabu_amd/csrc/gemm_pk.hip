@@ -11,6 +11,15 @@
 //           the pipe that is 16 times faster than v_mfma_f32_32x32x2_f32;
 //   NP = 1  plain bf16 operands (plane h only), fp32 accumulation: BASELINE.json configs[4]'s "bf16 MFMA
 //           input-to-hidden GEMMs".
+//   NP = 2  "f16x3": every operand ROW (an M resp. N index: all its k) carries a power-of-two scale s that
+//           puts the row's largest magnitude into [2^14, 2^15); the scaled value is held as two fp16 planes
+//           x·s = h + l (h = rne(x·s), l = rne(x·s - h): 22-24 significant bits, absolute error below
+//           2^-40 of the row's maximum) and a product is the three plane products l·h, h·l, h·h on
+//           v_mfma_f32_32x32x16_f16, promoted to the fp32 accumulators per 16 k as for NP = 3; the epilogue
+//           multiplies by 1 / (s_a[m] s_b[n]).  Half the matrix instructions of bf16x6 at the same error
+//           level against float64 (tests/test_hip_gemm_pk.py); a stage is 4 pieces (32 KiB), ring of three.
+//           The row maxima come from pk_amax_kernel (one read of the source) or are known a priori
+//           (LSTM outputs: |h| < 1).
 //
 // Why packed operands.  Round 2's kernels either split fp32 operands inside the k-loop (gemm_bf16.hip:
 // 4-byte operand traffic and ~300 VALU instructions per tile on the critical path, 140-160 TF/s effective)
@@ -57,6 +66,8 @@
 namespace nabu {
 
 typedef __bf16 kbf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 kf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 kf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 kbf16x2 __attribute__((ext_vector_type(2)));
 typedef float kf32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned ku32x4 __attribute__((ext_vector_type(4)));
@@ -66,6 +77,8 @@ constexpr int PK_T = 256;               // tile edge (rows of A = M index, rows 
 constexpr int PK_CH = PK_T * 32;        // one piece: 256 rows x 16 k x 2 bytes
 constexpr int PK_STAGE = 6 * PK_CH;     // 48 KiB
 constexpr int PK_LDS = 3 * PK_STAGE;    // 144 KiB
+constexpr int PK_STAGE2 = 4 * PK_CH;    // f16x3: 32 KiB
+constexpr int PK_LDS2 = 3 * PK_STAGE2;  // 96 KiB
 constexpr int PK_GM = 4;                // row tiles per band of the tile order
 
 struct PkOp {
@@ -85,7 +98,20 @@ struct PkArgs {
   const float *bias, *bias2;  // bias2: columns >= n_split
   float alpha, beta;
   float *partial;             // [nsplit][nbatch][M][N] when nsplit > 1
+  const unsigned *a_amax[2], *b_amax[2];   // f16x3: bit patterns of the packed rows' largest magnitudes (per batch entry)
 };
+
+// f16x3 row scales, derived from the bit pattern of the row's largest magnitude wherever they are needed:
+// scale = 2^(14 - floor(log2 amax)) puts amax into [2^14, 2^15) (fp16 overflows at 65504); exponent field clamped
+// so that scale and inverse are normal numbers; an all-zero row takes amax = 1; inf / NaN rows keep a finite scale
+// and propagate through the planes
+__device__ __forceinline__ unsigned pk_amax_exp(unsigned bits) {
+  unsigned e = (bits >> 23) & 0xFFu;
+  if ((bits & 0x7FFFFFFFu) == 0) e = 127;
+  return e < 15 ? 15 : (e > 253 ? 253 : e);
+}
+__device__ __forceinline__ float pk_scale_of(unsigned bits) { return __builtin_bit_cast(float, (268u - pk_amax_exp(bits)) << 23); }
+__device__ __forceinline__ float pk_inv_scale_of(unsigned bits) { return __builtin_bit_cast(float, (pk_amax_exp(bits) - 14u) << 23); }
 
 __device__ __forceinline__ ki32x4 pk_rsrc(unsigned long long a) {
   return (ki32x4){(int)(unsigned)a, (int)(unsigned)((a >> 32) & 0xFFFFu), -1, 0x00020000};
@@ -107,6 +133,21 @@ __device__ __forceinline__ void pk_stage_issue(unsigned m0, unsigned voff, ki32x
       :
       : "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(m4), "s"(m5), "v"(voff), "s"(ra), "s"(rb), "s"(sa1), "s"(sa2),
         "s"(sb1), "s"(sb2)
+      : "memory");
+}
+
+// f16x3: four pieces (A h, A l, B h, B l)
+__device__ __forceinline__ void pk_stage_issue4(unsigned m0, unsigned voff, ki32x4 ra, ki32x4 rb, unsigned sa1,
+                                                unsigned sb1) {
+  const unsigned m1 = m0 + PK_CH, m2 = m0 + 2 * PK_CH, m3 = m0 + 3 * PK_CH;
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %5, 0 offen lds\n\t"
+      "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %5, %7 offen lds\n\t"
+      "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %6, 0 offen lds\n\t"
+      "s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %6, %8 offen lds"
+      :
+      : "s"(m0), "s"(m1), "s"(m2), "s"(m3), "v"(voff), "s"(ra), "s"(rb), "s"(sa1), "s"(sb1)
       : "memory");
 }
 
@@ -145,7 +186,9 @@ __global__ __launch_bounds__(512) void gemm_pk_kernel(PkArgs p) {
 
   const int kb0 = split * p.kb_per_split;
   const int kbn = min(p.nkb, kb0 + p.kb_per_split) - kb0;
-  constexpr int KBS = NP == 3 ? 1 : 3;          // k-blocks per stage
+  constexpr int KBS = NP == 1 ? 3 : 1;          // k-blocks per stage
+  constexpr int NPIECE = NP == 2 ? 4 : 6;       // 8 KiB pieces per stage
+  constexpr unsigned STAGE = NPIECE * PK_CH;
   const int nst = kbn / KBS;
 
   unsigned long long pa = reinterpret_cast<unsigned long long>(p.A.base[batch]) + (unsigned long long)tm * PK_CH +
@@ -153,10 +196,15 @@ __global__ __launch_bounds__(512) void gemm_pk_kernel(PkArgs p) {
   unsigned long long pb = reinterpret_cast<unsigned long long>(p.B.base[batch]) + (unsigned long long)tn * PK_CH +
                           (unsigned long long)kb0 * p.B.kb_stride;
   const unsigned long long step_a = (unsigned long long)KBS * p.A.kb_stride, step_b = (unsigned long long)KBS * p.B.kb_stride;
-  const unsigned sa1 = NP == 3 ? p.A.plane_stride : (unsigned)p.A.kb_stride, sa2 = 2 * sa1;
-  const unsigned sb1 = NP == 3 ? p.B.plane_stride : (unsigned)p.B.kb_stride, sb2 = 2 * sb1;
+  const unsigned sa1 = NP != 1 ? p.A.plane_stride : (unsigned)p.A.kb_stride, sa2 = 2 * sa1;
+  const unsigned sb1 = NP != 1 ? p.B.plane_stride : (unsigned)p.B.kb_stride, sb2 = 2 * sb1;
   const unsigned voff = (unsigned)tid * 16u;
   const unsigned wbase = (unsigned)w * 1024u;     // this wave's part of a piece
+  auto issue = [&](unsigned m0) {
+    if constexpr (NP == 2) pk_stage_issue4(m0, voff, pk_rsrc(pa), pk_rsrc(pb), sa1, sb1);
+    else pk_stage_issue(m0, voff, pk_rsrc(pa), pk_rsrc(pb), sa1, sa2, sb1, sb2);
+    pa += step_a; pb += step_b;
+  };
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -166,37 +214,32 @@ __global__ __launch_bounds__(512) void gemm_pk_kernel(PkArgs p) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
   f32x16 tpend = acc[0][0], t0 = acc[0][0];   // promoted accumulation: scratch tiles; tpend = the partial sum whose add is still owed
+  f32x16 ts[4] = {acc[0][0], acc[0][0], acc[0][0], acc[0][0]};   // f16x3: four scratch tiles (gemm_pk_asm.inc)
 
   // operand read offsets inside a stage: row (lane & 31) of a 32-row MFMA tile, half (lane >> 5) swapped by
   // bit 3 of the row (tile bases are multiples of 32 rows, so bit 3 of the row is bit 3 of the lane)
   const unsigned laneoff = (unsigned)(lane & 31) * 32u + (unsigned)(((lane >> 5) ^ ((lane >> 3) & 1)) * 16);
   const unsigned offA = laneoff + (unsigned)grp * (128u * 32u);
-  const unsigned offB = laneoff + 3u * PK_CH + (unsigned)wn * (64u * 32u);
+  const unsigned offB = laneoff + (unsigned)(NPIECE / 2) * PK_CH + (unsigned)wn * (64u * 32u);
 
   // ---- prologue: stages 0 and 1 ----
-  if (nst > 0) {
-    pk_stage_issue(wbase, voff, pk_rsrc(pa), pk_rsrc(pb), sa1, sa2, sb1, sb2);
-    pa += step_a; pb += step_b;
-  }
+  if (nst > 0) issue(wbase);
   if (nst > 1) {
-    pk_stage_issue(PK_STAGE + wbase, voff, pk_rsrc(pa), pk_rsrc(pb), sa1, sa2, sb1, sb2);
-    pa += step_a; pb += step_b;
-    pk_wait<6>();
+    issue(STAGE + wbase);
+    pk_wait<NPIECE>();
   } else {
     pk_wait<0>();
   }
   pk_barrier();                 // barrier 0: stage 0 visible
   if (grp == 1) pk_barrier();   // the late half runs one barrier interval behind
 
-  unsigned so_rd = 0, so_wr = 2 * PK_STAGE;
+  unsigned so_rd = 0, so_wr = 2 * STAGE;
   for (int st = 0; st < nst; ++st) {
     // -------- LOAD(st) --------
     const bool more = st + 2 < nst;
-    if (more) {
-      pk_stage_issue(so_wr + wbase, voff, pk_rsrc(pa), pk_rsrc(pb), sa1, sa2, sb1, sb2);
-      pa += step_a; pb += step_b;
-    }
+    if (more) issue(so_wr + wbase);
     kbf16x8 fa[4][3], fb[2][3];
+    kf16x8 ha[4][2], hb[2][2];
     if constexpr (NP == 3 && VAR == 1) {
       // hand-scheduled path: the operand reads land in the physical registers the COMPUTE stream names
       // (gemm_pk_asm.inc); reads and their wait are ONE statement, so no compiler copy can see a register
@@ -204,6 +247,10 @@ __global__ __launch_bounds__(512) void gemm_pk_kernel(PkArgs p) {
       const unsigned va = so_rd + offA, vb = so_rd + offB;
       if (more) asm volatile(PK_STREAM_LOAD "s_waitcnt vmcnt(6) lgkmcnt(0)" : PK_ASM_LOAD_OUTPUTS : "v"(va), "v"(vb) : "memory");
       else asm volatile(PK_STREAM_LOAD "s_waitcnt vmcnt(0) lgkmcnt(0)" : PK_ASM_LOAD_OUTPUTS : "v"(va), "v"(vb) : "memory");
+    } else if constexpr (NP == 2) {
+      const unsigned va = so_rd + offA, vb = so_rd + offB;
+      if (more) asm volatile(PK2_STREAM_LOAD "s_waitcnt vmcnt(4) lgkmcnt(0)" : PK2_ASM_LOAD_OUTPUTS : "v"(va), "v"(vb) : "memory");
+      else asm volatile(PK2_STREAM_LOAD "s_waitcnt vmcnt(0) lgkmcnt(0)" : PK2_ASM_LOAD_OUTPUTS : "v"(va), "v"(vb) : "memory");
     } else {
       const char *sA = pk_smem + so_rd + offA, *sB = pk_smem + so_rd + offB;
 #pragma unroll
@@ -217,8 +264,20 @@ __global__ __launch_bounds__(512) void gemm_pk_kernel(PkArgs p) {
     }
     pk_barrier();
     // -------- COMPUTE(st) --------
-    if (!(NP == 3 && VAR == 1)) __builtin_amdgcn_s_setprio(1);
-    if (NP == 3 && VAR == 0) {
+    constexpr bool hand = (NP == 3 && VAR == 1) || (NP == 2 && VAR == 1);
+    if (!hand) __builtin_amdgcn_s_setprio(1);
+    if constexpr (NP == 2 && VAR == 0) {
+      // direct accumulation (A/B measurements: NABU_PK_VAR=0)
+#define PK_PROD(qa, qb)                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hb[j][qb], ha[i][qa], acc[i][j], 0, 0, 0);
+      PK_PROD(1, 0) PK_PROD(0, 1) PK_PROD(0, 0)
+#undef PK_PROD
+    } else if constexpr (NP == 2) {
+      // f16x3, promoted accumulation: chains of three MFMAs (l.h, h.l, h.h) from 0 in four rotating scratch tiles,
+      // the 16 adds of a tile spread over the next three MFMA gaps (tools/gen_pk_asm.py, stream_f16)
+      asm volatile("s_setprio 1\n\t" PK2_STREAM "s_setprio 0" : PK2_ASM_COMPUTE_INOUT : PK2_ASM_COMPUTE_INPUTS);
+    } else if (NP == 3 && VAR == 0) {
       // direct accumulation (kept for A/B measurements: NABU_PK_VAR=0)
 #define PK_PROD(qa, qb)                                                                                    \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
@@ -240,15 +299,22 @@ __global__ __launch_bounds__(512) void gemm_pk_kernel(PkArgs p) {
       PK_PROD(0, 0) PK_PROD(1, 1) PK_PROD(2, 2)
 #undef PK_PROD
     }
-    if (!(NP == 3 && VAR == 1)) __builtin_amdgcn_s_setprio(0);
+    if (!hand) __builtin_amdgcn_s_setprio(0);
     pk_barrier();
-    so_rd = so_rd == 2 * PK_STAGE ? 0 : so_rd + PK_STAGE;
-    so_wr = so_wr == 2 * PK_STAGE ? 0 : so_wr + PK_STAGE;
+    so_rd = so_rd == 2 * STAGE ? 0 : so_rd + STAGE;
+    so_wr = so_wr == 2 * STAGE ? 0 : so_wr + STAGE;
   }
   if (grp == 0) pk_barrier();
   if (NP == 3 && VAR == 1) {
     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(tpend));   // the last chain's matrix result -> VALU read: not padded by hipcc
     acc[3][1] += tpend;
+  }
+  if (NP == 2 && VAR == 1) {
+    // the adds the stream still owes: tile 6 = (3, 0) elements 10..15 out of T2, tile 7 = (3, 1) out of T3
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(ts[2]), "+v"(ts[3]));
+#pragma unroll
+    for (int q = 10; q < 16; ++q) acc[3][0][q] += ts[2][q];
+    acc[3][1] += ts[3];
   }
 
   // ---- epilogue.  The products were issued with the B fragment as the matrix instruction's first operand, so a
@@ -268,11 +334,13 @@ __global__ __launch_bounds__(512) void gemm_pk_kernel(PkArgs p) {
     ldc = p.N;
   }
   const bool plain = p.nsplit > 1 || (p.alpha == 1.f && p.beta == 0.f);
+  const bool scaled = NP == 2 && p.nsplit == 1;   // f16x3: undo the row scales here (split-K: in the reduce pass)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m_t + i * 32 + mrow;
     if (m >= p.M) continue;
     float *crow = Cb + (size_t)m * ldc - n_off;
+    const float ra = scaled ? pk_inv_scale_of(p.a_amax[batch][m]) : 1.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -280,6 +348,11 @@ __global__ __launch_bounds__(512) void gemm_pk_kernel(PkArgs p) {
         const int n = n_t + j * 32 + 8 * g + nquad;
         if (n >= p.N) continue;                      // N % 4 == 0: a quad is inside or outside as a whole
         float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        if (scaled) {
+          const ku32x4 bb = *reinterpret_cast<const ku32x4 *>(p.b_amax[batch] + n);
+          v.x *= ra * pk_inv_scale_of(bb.x); v.y *= ra * pk_inv_scale_of(bb.y);
+          v.z *= ra * pk_inv_scale_of(bb.z); v.w *= ra * pk_inv_scale_of(bb.w);
+        }
         if (p.nsplit == 1) {
           if (!plain) { v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha; }
           if (bias) {
@@ -309,6 +382,12 @@ __global__ __launch_bounds__(256) void gemm_pk_reduce_kernel(PkArgs p) {
       const float4 v = *reinterpret_cast<const float4 *>(p.partial + (size_t)z * total + i);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
+    if (p.a_amax[0]) {   // f16x3 operands: undo the row scales
+      const float ra = pk_inv_scale_of(p.a_amax[batch][m]);
+      const ku32x4 bb = *reinterpret_cast<const ku32x4 *>(p.b_amax[batch] + n);
+      s.x *= ra * pk_inv_scale_of(bb.x); s.y *= ra * pk_inv_scale_of(bb.y);
+      s.z *= ra * pk_inv_scale_of(bb.z); s.w *= ra * pk_inv_scale_of(bb.w);
+    }
     float *Cb = p.C[batch];
     const float *bias = p.bias;
     int n_off = 0;
@@ -335,9 +414,35 @@ __device__ __forceinline__ unsigned pk_cvt2(float a, float b) {
 __device__ __forceinline__ float pk_hi(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float pk_lo(unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
 
+// f16x3: 16 consecutive k of one packed row, scaled -> planes h, l (fp16, round to nearest even)
+__device__ __forceinline__ unsigned pk_cvt2h(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((kf32x2){a, b}, kf16x2));
+}
+__device__ __forceinline__ void pk_split_store_f16(const float *x, char *dst, unsigned plane_stride, int row, float scale) {
+  unsigned h[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float a = x[2 * i] * scale, b = x[2 * i + 1] * scale;       // exact (power of two)
+    h[i] = pk_cvt2h(a, b);
+    const kf16x2 hv = __builtin_bit_cast(kf16x2, h[i]);
+    l[i] = pk_cvt2h(a - (float)hv[0], b - (float)hv[1]);               // the difference is exact in fp32
+  }
+  const int sw = (row >> 3) & 1;
+  ku32x4 *d = reinterpret_cast<ku32x4 *>(dst), *d1 = reinterpret_cast<ku32x4 *>(dst + plane_stride);
+  d[sw] = (ku32x4){h[0], h[1], h[2], h[3]};
+  d[sw ^ 1] = (ku32x4){h[4], h[5], h[6], h[7]};
+  d1[sw] = (ku32x4){l[0], l[1], l[2], l[3]};
+  d1[sw ^ 1] = (ku32x4){l[4], l[5], l[6], l[7]};
+}
+
 // 16 consecutive k of one packed row -> NP planes of 32 bytes (halves swapped when bit 3 of the row is set)
 template <int NP>
-__device__ __forceinline__ void pk_split_store(const float *x, char *dst, unsigned plane_stride, int row) {
+__device__ __forceinline__ void pk_split_store(const float *x, char *dst, unsigned plane_stride, int row,
+                                               const unsigned *amax = nullptr) {
+  if constexpr (NP == 2) {
+    pk_split_store_f16(x, dst, plane_stride, row, pk_scale_of(amax[row]));
+    return;
+  }
   unsigned h[8], m[8], l[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -363,6 +468,7 @@ __device__ __forceinline__ void pk_split_store(const float *x, char *dst, unsign
 }
 
 struct PackArgs {
+  const unsigned *amax;       // f16x3: largest magnitude (bit pattern) of every packed row of the destination
   const float *src;
   long long ld;
   int R, C;                   // valid source rows / columns
@@ -407,7 +513,7 @@ __global__ __launch_bounds__(256) void pk_pack_rows_kernel(PackArgs a) {
     x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
   }
   const int prow = a.row_off + row;
-  pk_split_store<NP>(x, a.dst + (size_t)(a.kb_off + kb) * a.kb_stride + (size_t)prow * 32, a.plane_stride, prow);
+  pk_split_store<NP>(x, a.dst + (size_t)(a.kb_off + kb) * a.kb_stride + (size_t)prow * 32, a.plane_stride, prow, a.amax);
 }
 
 // reduction index = source ROW: packed row = source column, k = source row (transposed copy).
@@ -446,7 +552,7 @@ __global__ __launch_bounds__(256) void pk_pack_cols_kernel(PackArgs a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) x[i] = tile[kbl * 16 + i][c];
   const int prow = a.row_off + row;
-  pk_split_store<NP>(x, a.dst + (size_t)(a.kb_off + kb) * a.kb_stride + (size_t)prow * 32, a.plane_stride, prow);
+  pk_split_store<NP>(x, a.dst + (size_t)(a.kb_off + kb) * a.kb_stride + (size_t)prow * 32, a.plane_stride, prow, a.amax);
 }
 
 // BOTH layouts of one source matrix from ONE read (the backward pass needs dz as [BT rows, k = gate column] for the
@@ -484,7 +590,7 @@ __global__ __launch_bounds__(256) void pk_pack_both_kernel(PackArgs a, PackArgs 
         x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
       }
       const int prow = a.row_off + row;
-      pk_split_store<NP>(x, a.dst + (size_t)(a.kb_off + kb) * a.kb_stride + (size_t)prow * 32, a.plane_stride, prow);
+      pk_split_store<NP>(x, a.dst + (size_t)(a.kb_off + kb) * a.kb_stride + (size_t)prow * 32, a.plane_stride, prow, a.amax);
     }
   }
   {   // transposed: packed row = source column c0 + l, k-block = source rows r0 + 16 kbl ...
@@ -493,9 +599,60 @@ __global__ __launch_bounds__(256) void pk_pack_both_kernel(PackArgs a, PackArgs 
 #pragma unroll
       for (int i = 0; i < 16; ++i) x[i] = tile[kbl * 16 + i][l];
       const int prow = b.row_off + row;
-      pk_split_store<NP>(x, b.dst + (size_t)(b.kb_off + kb) * b.kb_stride + (size_t)prow * 32, b.plane_stride, prow);
+      pk_split_store<NP>(x, b.dst + (size_t)(b.kb_off + kb) * b.kb_stride + (size_t)prow * 32, b.plane_stride, prow, b.amax);
     }
   }
+}
+
+// largest magnitudes of the rows and / or the columns of a source matrix, as bit patterns (|x| compares like its
+// bits; NaN compares largest, so a NaN row keeps its NaN): atomicMax into zero-initialised arrays.
+// grid (ceil(C / 64), ceil(R / 256)), 256 threads: 64 columns x 256 rows per workgroup
+__global__ __launch_bounds__(256) void pk_amax_kernel(const float *src, long long ld, int R, int C, unsigned *rows,
+                                                      unsigned *cols) {
+  __shared__ unsigned cm[16][64];
+  const int tid = threadIdx.x, c0 = blockIdx.x * 64, r0 = blockIdx.y * 256;
+  const int c4 = (tid & 15) * 4, rl = tid >> 4;
+  unsigned cmax[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 4
+  for (int j = 0; j < 16; ++j) {
+    const int r = r0 + rl + 16 * j;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < R) {
+      const float *s = src + (size_t)r * ld + c0 + c4;
+      if (c0 + c4 + 3 < C) v = *reinterpret_cast<const float4 *>(s);
+      else {
+        if (c0 + c4 < C) v.x = s[0];
+        if (c0 + c4 + 1 < C) v.y = s[1];
+        if (c0 + c4 + 2 < C) v.z = s[2];
+      }
+    }
+    const unsigned b0 = __builtin_bit_cast(unsigned, v.x) & 0x7FFFFFFFu, b1 = __builtin_bit_cast(unsigned, v.y) & 0x7FFFFFFFu;
+    const unsigned b2 = __builtin_bit_cast(unsigned, v.z) & 0x7FFFFFFFu, b3 = __builtin_bit_cast(unsigned, v.w) & 0x7FFFFFFFu;
+    cmax[0] = max(cmax[0], b0); cmax[1] = max(cmax[1], b1); cmax[2] = max(cmax[2], b2); cmax[3] = max(cmax[3], b3);
+    if (rows) {
+      unsigned rm = max(max(b0, b1), max(b2, b3));
+      rm = max(rm, (unsigned)__shfl_xor((int)rm, 1));
+      rm = max(rm, (unsigned)__shfl_xor((int)rm, 2));
+      rm = max(rm, (unsigned)__shfl_xor((int)rm, 4));
+      rm = max(rm, (unsigned)__shfl_xor((int)rm, 8));
+      if ((tid & 15) == 0 && r < R && rm) atomicMax(rows + r, rm);
+    }
+  }
+  if (!cols) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) cm[rl][c4 + q] = cmax[q];
+  __syncthreads();
+  if (tid < 64 && c0 + tid < C) {
+    unsigned m = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) m = max(m, cm[q][tid]);
+    if (m) atomicMax(cols + c0 + tid, m);
+  }
+}
+
+__global__ void pk_fill_u32_kernel(unsigned *dst, int n, unsigned v) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = v;
 }
 
 static int pk_cu_count() {
@@ -536,12 +693,12 @@ bool gemm_pk_device_ok() {
 }
 
 // split-K policy: one workgroup per CU; with few output tiles cut the reduction so that the number of
-// workgroups comes close to a multiple of the CU count (>= 24 stages per workgroup)
-static int pk_choose_split(int ntiles, int nkb, int kbs, int *kb_per_split) {
+// workgroups comes close to a multiple of the CU count (>= 24 stages per workgroup; 48 of f16x3's half-length stages)
+static int pk_choose_split(int ntiles, int nkb, int kbs, int min_stages, int *kb_per_split) {
   const int ncu = pk_cu_count(), nst = nkb / kbs;
   int best = 1;
   double best_eff = 0.0;
-  const int maxs = nst / 24 < 1 ? 1 : (nst / 24 > 32 ? 32 : nst / 24);
+  const int maxs = nst / min_stages < 1 ? 1 : (nst / min_stages > 32 ? 32 : nst / min_stages);
   for (int s = 1; s <= maxs; ++s) {
     const int per = (nst + s - 1) / s, ns = (nst + per - 1) / per;
     if (ns != s) continue;
@@ -561,18 +718,19 @@ using namespace nabu;
 
 extern "C" int nabu_pk_rows_pad(int rows) { return (rows + PK_T - 1) / PK_T * PK_T; }
 extern "C" int nabu_pk_kblocks(int K, int planes) {
-  const int kbs = planes == 3 ? 1 : 3, nkb = (K + 15) / 16;
+  const int kbs = planes == 1 ? 3 : 1, nkb = (K + 15) / 16;
   return (nkb + kbs - 1) / kbs * kbs;
 }
 extern "C" size_t nabu_pk_bytes(int rows, int K, int planes) {
-  if (rows <= 0 || K <= 0 || (planes != 1 && planes != 3)) return 0;
+  if (rows <= 0 || K <= 0 || planes < 1 || planes > 3) return 0;
   return (size_t)nabu_pk_kblocks(K, planes) * planes * nabu_pk_rows_pad(rows) * 32;
 }
 
-extern "C" int nabu_pk_pack(int planes, int transposed, const float *src, long long ld, int R, int C, void *dst,
-                            int dst_rows_pad, int row_off, int kb_off, int fill_rows, int fill_kb, int period,
-                            int shift, nabu_stream_t stream) {
-  NABU_CHECK_ARG(planes == 1 || planes == 3, "pk_pack: planes must be 1 or 3");
+static int pk_pack_impl(int planes, int transposed, const float *src, long long ld, int R, int C, void *dst,
+                        int dst_rows_pad, int row_off, int kb_off, int fill_rows, int fill_kb, int period, int shift,
+                        const unsigned *amax, nabu_stream_t stream) {
+  NABU_CHECK_ARG(planes >= 1 && planes <= 3, "pk_pack: planes must be 1, 2 (f16x3) or 3");
+  NABU_CHECK_ARG((planes == 2) == (amax != nullptr), "pk_pack: the row maxima belong to planes = 2 (nabu_pk_pack_f16)");
   NABU_CHECK_ARG(src && dst && R >= 0 && C >= 0 && ld >= 0, "pk_pack: bad source");
   NABU_CHECK_ARG(dst_rows_pad > 0 && dst_rows_pad % PK_T == 0 && row_off >= 0 && kb_off >= 0 && fill_rows >= 0 &&
                      fill_kb >= 0 && row_off + fill_rows <= dst_rows_pad,
@@ -585,18 +743,56 @@ extern "C" int nabu_pk_pack(int planes, int transposed, const float *src, long l
   a.dst = static_cast<char *>(dst);
   a.plane_stride = (unsigned)dst_rows_pad * 32u;
   a.kb_stride = (unsigned long long)planes * a.plane_stride;
-  a.row_off = row_off; a.kb_off = kb_off; a.period = period; a.shift = shift;
+  a.row_off = row_off; a.kb_off = kb_off; a.period = period; a.shift = shift; a.amax = amax;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!transposed) {
     NABU_CHECK_ARG(period == 0, "pk_pack: shift only in the transposed form");
     const dim3 grid((fill_kb + 3) / 4, (fill_rows + 63) / 64);
     if (planes == 3) hipLaunchKernelGGL(pk_pack_rows_kernel<3>, grid, dim3(256), 0, s, a);
+    else if (planes == 2) hipLaunchKernelGGL(pk_pack_rows_kernel<2>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(pk_pack_rows_kernel<1>, grid, dim3(256), 0, s, a);
   } else {
     const dim3 grid((fill_rows + 63) / 64, (fill_kb + 3) / 4);
     if (planes == 3) hipLaunchKernelGGL(pk_pack_cols_kernel<3>, grid, dim3(256), 0, s, a);
+    else if (planes == 2) hipLaunchKernelGGL(pk_pack_cols_kernel<2>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(pk_pack_cols_kernel<1>, grid, dim3(256), 0, s, a);
   }
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_pk_pack(int planes, int transposed, const float *src, long long ld, int R, int C, void *dst,
+                            int dst_rows_pad, int row_off, int kb_off, int fill_rows, int fill_kb, int period,
+                            int shift, nabu_stream_t stream) {
+  NABU_CHECK_ARG(planes == 1 || planes == 3, "pk_pack: planes must be 1 or 3 (f16x3 operands: nabu_pk_pack_f16)");
+  return pk_pack_impl(planes, transposed, src, ld, R, C, dst, dst_rows_pad, row_off, kb_off, fill_rows, fill_kb, period,
+                      shift, nullptr, stream);
+}
+
+extern "C" int nabu_pk_pack_f16(int transposed, const float *src, long long ld, int R, int C, void *dst, int dst_rows_pad,
+                                int row_off, int kb_off, int fill_rows, int fill_kb, int period, int shift,
+                                const uint32_t *amax, nabu_stream_t stream) {
+  NABU_CHECK_ARG(amax != nullptr && (reinterpret_cast<uintptr_t>(amax) & 15) == 0, "pk_pack_f16: amax missing or unaligned");
+  return pk_pack_impl(2, transposed, src, ld, R, C, dst, dst_rows_pad, row_off, kb_off, fill_rows, fill_kb, period, shift,
+                      amax, stream);
+}
+
+extern "C" int nabu_pk_amax(const float *src, long long ld, int R, int C, uint32_t *rows, uint32_t *cols,
+                            nabu_stream_t stream) {
+  NABU_CHECK_ARG(src && R >= 0 && C >= 0 && ld >= 0 && (rows || cols), "pk_amax: bad arguments");
+  if (ld % 4 || (reinterpret_cast<uintptr_t>(src) & 15)) return fail(NABU_EUNSUP, "pk_amax: source rows must be 16-byte aligned");
+  if (R == 0 || C == 0) return 0;
+  hipLaunchKernelGGL(pk_amax_kernel, dim3((C + 63) / 64, (R + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), src,
+                     ld, R, C, rows, cols);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nabu_pk_amax_fill(uint32_t *dst, int n, float value, nabu_stream_t stream) {
+  NABU_CHECK_ARG(dst && n >= 0 && value >= 0.f, "pk_amax_fill: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(pk_fill_u32_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), dst, n,
+                     __builtin_bit_cast(unsigned, value));
   NABU_LAUNCH_CHECK();
   return 0;
 }
@@ -607,19 +803,22 @@ extern "C" int nabu_pk_pack(int planes, int transposed, const float *src, long l
 namespace nabu {
 int pk_pack_both(int planes, const float *src, long long ld, int R, int C, void *dst_n, int rows_pad_n, int kb_off_n,
                  int fill_rows_n, int fill_kb_n, void *dst_t, int rows_pad_t, int row_off_t, int fill_rows_t,
-                 int fill_kb_t, hipStream_t s) {
+                 int fill_kb_t, hipStream_t s, const unsigned *amax_n, const unsigned *amax_t) {
   if (ld % 4 || (reinterpret_cast<uintptr_t>(src) & 15)) return fail(NABU_EUNSUP, "pk_pack_both: unaligned source");
   PackArgs a, b;
   a.src = b.src = src; a.ld = b.ld = ld; a.R = b.R = R; a.C = b.C = C;
   a.fill_rows = fill_rows_n; a.fill_kb = fill_kb_n; a.dst = static_cast<char *>(dst_n);
   a.plane_stride = (unsigned)rows_pad_n * 32u; a.kb_stride = (unsigned long long)planes * a.plane_stride;
   a.row_off = 0; a.kb_off = kb_off_n; a.period = 0; a.shift = 0;
+  a.amax = amax_n; b.amax = amax_t;
+  if (planes == 2 && (!amax_n || !amax_t)) return fail(NABU_EINVAL, "pk_pack_both: f16x3 operands need the row maxima");
   b.fill_rows = fill_rows_t; b.fill_kb = fill_kb_t; b.dst = static_cast<char *>(dst_t);
   b.plane_stride = (unsigned)rows_pad_t * 32u; b.kb_stride = (unsigned long long)planes * b.plane_stride;
   b.row_off = row_off_t; b.kb_off = 0; b.period = 0; b.shift = 0;
   const int gx = ((fill_kb_n + 3) / 4 > (fill_rows_t + 63) / 64) ? (fill_kb_n + 3) / 4 : (fill_rows_t + 63) / 64;
   const int gy = ((fill_rows_n + 63) / 64 > (fill_kb_t + 3) / 4) ? (fill_rows_n + 63) / 64 : (fill_kb_t + 3) / 4;
   if (planes == 3) hipLaunchKernelGGL(pk_pack_both_kernel<3>, dim3(gx, gy), dim3(256), 0, s, a, b);
+  else if (planes == 2) hipLaunchKernelGGL(pk_pack_both_kernel<2>, dim3(gx, gy), dim3(256), 0, s, a, b);
   else hipLaunchKernelGGL(pk_pack_both_kernel<1>, dim3(gx, gy), dim3(256), 0, s, a, b);
   NABU_LAUNCH_CHECK();
   return 0;
@@ -629,10 +828,18 @@ int pk_pack_both(int planes, const float *src, long long ld, int R, int C, void 
 static int pk_fill(PkArgs &p, const nabu_pk_gemm_desc *d, int *planes) {
   if (!d || d->size != sizeof(nabu_pk_gemm_desc)) return fail(NABU_EINVAL, "gemm_pk: bad descriptor size");
   *planes = d->planes;
-  if (d->planes != 1 && d->planes != 3) return fail(NABU_EINVAL, "gemm_pk: planes must be 1 or 3");
+  if (d->planes < 1 || d->planes > 3) return fail(NABU_EINVAL, "gemm_pk: planes must be 1, 2 or 3");
+  if (d->planes == 2) {
+    if (d->a_planes != 2 || d->b_planes != 2) return fail(NABU_EINVAL, "gemm_pk: an f16x3 product takes f16x3 operands (2 planes)");
+    for (int b = 0; b < d->nbatch; ++b)
+      if (!d->a_amax[b] || !d->b_amax[b] || (reinterpret_cast<uintptr_t>(d->b_amax[b]) & 15))
+        return fail(NABU_EINVAL, "gemm_pk: f16x3 operands need their row maxima (b_amax 16-byte aligned)");
+  } else if (d->a_planes == 2 || d->b_planes == 2) {
+    return fail(NABU_EINVAL, "gemm_pk: f16x3 operands only feed planes = 2 products");
+  }
   if (d->M <= 0 || d->N <= 0 || d->nkb <= 0 || d->nbatch < 1 || d->nbatch > 2)
     return fail(NABU_EINVAL, "gemm_pk: bad dimensions");
-  const int kbs = d->planes == 3 ? 1 : 3;
+  const int kbs = d->planes == 1 ? 3 : 1;
   if (d->nkb % kbs) return fail(NABU_EINVAL, "gemm_pk: nkb must be a multiple of %d", kbs);
   if (d->a_rows_pad % PK_T || d->b_rows_pad % PK_T || d->a_rows_pad < nabu_pk_rows_pad(d->M) ||
       d->b_rows_pad < nabu_pk_rows_pad(d->N))
@@ -651,8 +858,8 @@ static int pk_fill(PkArgs &p, const nabu_pk_gemm_desc *d, int *planes) {
   p.A.kb_stride = (unsigned long long)d->a_planes * p.A.plane_stride;
   p.B.plane_stride = (unsigned)d->b_rows_pad * 32u;
   p.B.kb_stride = (unsigned long long)d->b_planes * p.B.plane_stride;
-  if (2 * (unsigned long long)(d->planes == 3 ? p.A.plane_stride : p.A.kb_stride) >= (1ull << 32) ||
-      2 * (unsigned long long)(d->planes == 3 ? p.B.plane_stride : p.B.kb_stride) >= (1ull << 32))
+  if (2 * (unsigned long long)(d->planes != 1 ? p.A.plane_stride : p.A.kb_stride) >= (1ull << 32) ||
+      2 * (unsigned long long)(d->planes != 1 ? p.B.plane_stride : p.B.kb_stride) >= (1ull << 32))
     return fail(NABU_EUNSUP, "gemm_pk: operand too tall for 32-bit piece offsets");
   for (int b = 0; b < 2; ++b) {
     const int s = b < d->nbatch ? b : 0;
@@ -660,6 +867,8 @@ static int pk_fill(PkArgs &p, const nabu_pk_gemm_desc *d, int *planes) {
     p.B.base[b] = static_cast<const char *>(d->B[s]);
     p.C[b] = d->C[s];
     p.C2[b] = d->C2[s];
+    p.a_amax[b] = d->planes == 2 ? d->a_amax[s] : nullptr;
+    p.b_amax[b] = d->planes == 2 ? d->b_amax[s] : nullptr;
   }
   p.M = d->M; p.N = d->N;
   p.tiles_m = (d->M + PK_T - 1) / PK_T; p.tiles_n = (d->N + PK_T - 1) / PK_T; p.nbatch = d->nbatch;
@@ -668,7 +877,7 @@ static int pk_fill(PkArgs &p, const nabu_pk_gemm_desc *d, int *planes) {
   p.alpha = d->alpha; p.beta = d->beta; p.partial = nullptr;
   static int force = -2;
   if (force == -2) { const char *e = getenv("NABU_PK_SPLIT"); force = e ? atoi(e) : -1; }
-  p.nsplit = pk_choose_split(p.tiles_m * p.tiles_n * p.nbatch, p.nkb, kbs, &p.kb_per_split);
+  p.nsplit = pk_choose_split(p.tiles_m * p.tiles_n * p.nbatch, p.nkb, kbs, d->planes == 2 ? 48 : 24, &p.kb_per_split);
   if (force > 0) {
     const int nst = p.nkb / kbs, per = (nst + force - 1) / force;
     p.kb_per_split = per * kbs;
@@ -700,11 +909,14 @@ extern "C" int nabu_gemm_pk(const nabu_pk_gemm_desc *d, void *ws, size_t ws_byte
   const int grid = p.tiles_m * p.tiles_n * p.nbatch * p.nsplit;
 #define PK_LAUNCH(NP_, VAR_)                                                                                         \
   {                                                                                                                   \
+    const int lds = NP_ == 2 ? PK_LDS2 : PK_LDS;                                                                       \
     NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pk_kernel<NP_, VAR_>),                           \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, PK_LDS));                                \
-    hipLaunchKernelGGL((gemm_pk_kernel<NP_, VAR_>), dim3(grid), dim3(512), PK_LDS, s, p);                              \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                   \
+    hipLaunchKernelGGL((gemm_pk_kernel<NP_, VAR_>), dim3(grid), dim3(512), lds, s, p);                                 \
   }
   if (planes == 1) PK_LAUNCH(1, 0)
+  else if (planes == 2 && var == 0) PK_LAUNCH(2, 0)
+  else if (planes == 2) PK_LAUNCH(2, 1)
   else if (var == 0) PK_LAUNCH(3, 0)
   else PK_LAUNCH(3, 1)
 #undef PK_LAUNCH

@@ -197,6 +197,9 @@ struct Layout {
   // forward: X [BT, D], W^T of both cells [8H, D]; backward: dZ^T [8H, BT], X^T [D, BT], h^T per cell [H, BT],
   // dZ [BT, 8H], Wx of both cells [D, 8H] (byte offsets inside the pk region)
   size_t pk_x, pk_w, pk_xT, pk_hT[2], pk_dz, pk_w2;
+  // planes = 2 (f16x3): the row maxima (uint32 per packed row) of the operands above; those of one pass are
+  // contiguous (one memset): forward [x | w], backward [dz | w2 | xT | hT0 | hT1]; dZ^T's sit behind it in the reserve
+  size_t pk_ax, pk_aw, pk_adz, pk_aw2, pk_axT, pk_ahT[2], pk_abwd_bytes, res_adzT_off;
   // dZ^T packed [8H, BT] lives in the layer's RESERVE (behind the activations): it is written by the data part of
   // the backward pass and read by the weight-gradient part, which may run later (nabu_blstm_bwd_weights)
   size_t res_dzT_off, res_dzT_bytes;
@@ -223,7 +226,7 @@ static bool bf16_resident_fwd(const nabu_blstm_desc *d) {
 }
 static int pad64(int x) { return (x + 63) / 64 * 64; }
 
-// planes of the packed-operand path for this layer (0 = not taken): bf16x6 -> 3, bf16 -> 1
+// planes of the packed-operand path for this layer (0 = not taken): bf16x6 -> 3, f16x3 -> 2, bf16 -> 1
 static int pk_planes_of(const nabu_blstm_desc *d) {
   const int prec = d->gemm_precision == NABU_GEMM_DEFAULT ? nabu_gemm_get_default_precision() : d->gemm_precision;
   static int env = -1;
@@ -231,7 +234,17 @@ static int pk_planes_of(const nabu_blstm_desc *d) {
   if (!env || !gemm_pk_device_ok()) return 0;
   const long long BT = (long long)d->B * d->T;
   if (BT < 1024 || BT >= (1ll << 31) - 512 || d->H % 64) return 0;   // n_split = 4H must be a multiple of 256
-  return prec == NABU_GEMM_BF16X6 ? 3 : prec == NABU_GEMM_BF16 ? 1 : 0;
+  return prec == NABU_GEMM_BF16X6 ? 3 : prec == NABU_GEMM_F16X3 ? 2 : prec == NABU_GEMM_BF16 ? 1 : 0;
+}
+// one entry point for the bf16-plane and the scaled-fp16-plane packs (amax: the row maxima of planes = 2)
+static int pk_pack_any(int planes, int transposed, const float *src, long long ld, int R, int C, void *dst, int rows_pad,
+                       int row_off, int kb_off, int fill_rows, int fill_kb, int period, int shift, const uint32_t *amax,
+                       nabu_stream_t stream) {
+  if (planes == 2)
+    return nabu_pk_pack_f16(transposed, src, ld, R, C, dst, rows_pad, row_off, kb_off, fill_rows, fill_kb, period, shift,
+                            amax, stream);
+  return nabu_pk_pack(planes, transposed, src, ld, R, C, dst, rows_pad, row_off, kb_off, fill_rows, fill_kb, period, shift,
+                      stream);
 }
 static nabu_pk_gemm_desc pk_desc(int planes, int M, int N, int nkb, const void *A, int a_rows_pad, const void *B,
                                  int b_rows_pad, float *C, int ldc) {
@@ -239,6 +252,7 @@ static nabu_pk_gemm_desc pk_desc(int planes, int M, int N, int nkb, const void *
   g.size = sizeof(g); g.planes = planes; g.M = M; g.N = N; g.nkb = nkb; g.nbatch = 1;
   g.A[0] = A; g.B[0] = B; g.a_rows_pad = a_rows_pad; g.b_rows_pad = b_rows_pad; g.a_planes = g.b_planes = planes;
   g.C[0] = C; g.ldc = ldc; g.alpha = 1.f; g.beta = 0.f;
+  if (planes == 2) g.a_amax[0] = g.a_amax[1] = g.b_amax[0] = g.b_amax[1] = reinterpret_cast<const uint32_t *>(16);   // sizing calls
   return g;
 }
 
@@ -294,6 +308,17 @@ static Layout make_layout(const nabu_blstm_desc *d) {
     L.res_dzT_off = align_up(L.reserve_bytes, 256);
     L.res_dzT_bytes = nabu_pk_bytes(2 * G, BT, P);
     L.reserve_bytes = L.res_dzT_off + L.res_dzT_bytes;
+    L.pk_abwd_bytes = 0;
+    if (P == 2) {
+      const size_t aBT = 4 * (size_t)nabu_pk_rows_pad(BT), aG = 4 * (size_t)nabu_pk_rows_pad(2 * G), aD = 4 * (size_t)nabu_pk_rows_pad((int)D);
+      const size_t aW = 4 * (size_t)nabu_pk_rows_pad((int)(L.pk_whole ? D + H : H));
+      L.res_adzT_off = align_up(L.reserve_bytes, 256);
+      L.reserve_bytes = L.res_adzT_off + aG;
+      L.pk_ax = take(fwd, aBT); L.pk_aw = take(fwd, aG);
+      L.pk_adz = take(bwd, aBT); L.pk_aw2 = take(bwd, aD); L.pk_axT = take(bwd, aD);
+      L.pk_ahT[0] = take(bwd, aW); L.pk_ahT[1] = take(bwd, aW);
+      L.pk_abwd_bytes = bwd;
+    }
     if (L.pk_in) L.pk_xT = take(bwd, nabu_pk_bytes((int)D, BT, P));
     for (int dir = 0; dir < 2; ++dir)
       L.pk_hT[dir] = take(bwd, L.pk_rec ? nabu_pk_bytes((int)(L.pk_whole ? D + H : H), BT, P) : 0);
@@ -409,12 +434,22 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const in
     const int P = L.pk_planes, BT = B * T, G = 4 * H;
     char *pk = w + L.pk_off;
     const int rpBT = nabu_pk_rows_pad(BT), rpG = nabu_pk_rows_pad(2 * G), nkb = nabu_pk_kblocks(D, P);
-    if (int e = nabu_pk_pack(P, 0, x, D, BT, D, pk + L.pk_x, rpBT, 0, 0, rpBT, nkb, 0, 0, stream)) return e;
+    uint32_t *ax = reinterpret_cast<uint32_t *>(pk + L.pk_ax), *aw = reinterpret_cast<uint32_t *>(pk + L.pk_aw);
+    if (P == 2) {
+      // f16x3: the frames' and the gate columns' largest magnitudes first (one more read of x: nothing is assumed
+      // about the layer's input)
+      NABU_HIP(hipMemsetAsync(ax, 0, L.pk_aw - L.pk_ax + 4 * (size_t)rpG, s));
+      if (int e = nabu_pk_amax(x, D, BT, D, ax, nullptr, stream)) return e;
+      for (int dir = 0; dir < 2; ++dir)
+        if (int e = nabu_pk_amax(kern[dir], G, D, G, nullptr, aw + dir * G, stream)) return e;
+    }
+    if (int e = pk_pack_any(P, 0, x, D, BT, D, pk + L.pk_x, rpBT, 0, 0, rpBT, nkb, 0, 0, ax, stream)) return e;
     for (int dir = 0; dir < 2; ++dir)
-      if (int e = nabu_pk_pack(P, 1, kern[dir], G, D, G, pk + L.pk_w, rpG, dir * G, 0, dir ? rpG - G : G, nkb, 0, 0, stream))
+      if (int e = pk_pack_any(P, 1, kern[dir], G, D, G, pk + L.pk_w, rpG, dir * G, 0, dir ? rpG - G : G, nkb, 0, 0, aw, stream))
         return e;
     nabu_pk_gemm_desc g = pk_desc(P, BT, 2 * G, nkb, pk + L.pk_x, rpBT, pk + L.pk_w, rpG, gates[0], G);
     g.C2[0] = gates[1]; g.n_split = G; g.bias = bias[0]; g.bias2 = bias[1];
+    if (P == 2) { g.a_amax[0] = ax; g.b_amax[0] = aw; }
     if (int e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream)) return e;
   } else if (L.bf16_fwd) {
     // bf16 copies: x once, Wx_d transposed ([4H, Dp]: the reduction index contiguous, zero-padded to a
@@ -546,30 +581,48 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
     const int nkbT = nabu_pk_kblocks(M, P);
     const int nkb2 = nabu_pk_kblocks(2 * G, P), kbG = G / 16;
     int e;
+    // f16x3 (P = 2): row maxima of every operand — measured (dz, the weights, x) or known (|h| < 1)
+    uint32_t *adz = reinterpret_cast<uint32_t *>(pk + L.pk_adz), *aw2 = reinterpret_cast<uint32_t *>(pk + L.pk_aw2);
+    uint32_t *axT = reinterpret_cast<uint32_t *>(pk + L.pk_axT);
+    uint32_t *ahT[2] = {reinterpret_cast<uint32_t *>(pk + L.pk_ahT[0]), reinterpret_cast<uint32_t *>(pk + L.pk_ahT[1])};
+    uint32_t *adzT = reinterpret_cast<uint32_t *>(static_cast<char *>(reserve) + L.res_adzT_off);
     if (parts & 1) {
       const bool both = d_x && L.pk_in;    // dz is also needed row-major (dx): both packs from one read of dz
+      if (P == 2) {
+        // one read of dz per cell: its rows' maxima over BOTH cells (the row scale of dZ as [BT, 8H]) and its columns'
+        NABU_HIP(hipMemsetAsync(adz, 0, L.pk_axT - L.pk_adz, s));
+        NABU_HIP(hipMemsetAsync(adzT, 0, 4 * (size_t)rpG, s));
+        for (int dir = 0; dir < 2; ++dir) {
+          if ((e = nabu_pk_amax(gates[dir], G, M, G, both ? adz : nullptr, adzT + dir * G, stream))) return e;
+          if (both && (e = nabu_pk_amax(kern[dir], G, D, G, aw2, nullptr, stream))) return e;
+        }
+      }
       for (int dir = 0; dir < 2; ++dir) {
         if (both)
           e = pk_pack_both(P, gates[dir], G, M, G, pk + L.pk_dz, rpBT, dir * kbG, rpBT, dir ? nkb2 - kbG : kbG, dzTp,
-                           rpG, dir * G, dir ? rpG - G : G, nkbT, s);
+                           rpG, dir * G, dir ? rpG - G : G, nkbT, s, adz, adzT);
         else
-          e = nabu_pk_pack(P, 1, gates[dir], G, M, G, dzTp, rpG, dir * G, 0, dir ? rpG - G : G, nkbT, 0, 0, stream);
+          e = pk_pack_any(P, 1, gates[dir], G, M, G, dzTp, rpG, dir * G, 0, dir ? rpG - G : G, nkbT, 0, 0, adzT, stream);
         if (e) return e;
       }
       if (d_x && L.pk_in) {
         // dx = [dZ_fw | dZ_bw] · [Wx_fw | Wx_bw]^T: the two cells are two ranges of ONE reduction
         for (int dir = 0; dir < 2; ++dir)
-          if ((e = nabu_pk_pack(P, 0, kern[dir], G, D, G, pk + L.pk_w2, rpD, 0, dir * kbG, rpD, dir ? nkb2 - kbG : kbG, 0, 0,
-                                stream)))
+          if ((e = pk_pack_any(P, 0, kern[dir], G, D, G, pk + L.pk_w2, rpD, 0, dir * kbG, rpD, dir ? nkb2 - kbG : kbG, 0, 0,
+                               aw2, stream)))
             return e;
         nabu_pk_gemm_desc g = pk_desc(P, M, D, nkb2, pk + L.pk_dz, rpBT, pk + L.pk_w2, rpD, d_x, D);
+        if (P == 2) { g.a_amax[0] = adz; g.b_amax[0] = aw2; }
         if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
       }
     }
+    if ((parts & 2) && P == 2) NABU_HIP(hipMemsetAsync(axT, 0, L.pk_abwd_bytes - L.pk_axT, s));
     if ((parts & 2) && L.pk_in) {
-      if ((e = nabu_pk_pack(P, 1, x, D, M, D, pk + L.pk_xT, rpD, 0, 0, rpD, nkbT, 0, 0, stream))) return e;
+      if (P == 2 && (e = nabu_pk_amax(x, D, M, D, nullptr, axT, stream))) return e;
+      if ((e = pk_pack_any(P, 1, x, D, M, D, pk + L.pk_xT, rpD, 0, 0, rpD, nkbT, 0, 0, axT, stream))) return e;
       nabu_pk_gemm_desc g = pk_desc(P, D, 2 * G, nkbT, pk + L.pk_xT, rpD, dzTp, rpG, dkern[0], G);
       g.C2[0] = dkern[1]; g.n_split = G;
+      if (P == 2) { g.a_amax[0] = axT; g.b_amax[0] = adzT; }
       if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
     }
     if ((parts & 2) && L.pk_rec) {
@@ -578,13 +631,18 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
       // gradient [(D+H), 4H] of a cell is ONE product (its dWx alone cost more on the in-kernel-split kernel)
       const int r0 = L.pk_whole ? D : 0, Mw = r0 + H, rpW = nabu_pk_rows_pad(Mw);
       for (int dir = 0; dir < 2; ++dir) {
-        if (L.pk_whole && (e = nabu_pk_pack(P, 1, x, D, M, D, pk + L.pk_hT[dir], rpW, 0, 0, D, nkbT, 0, 0, stream))) return e;
-        if ((e = nabu_pk_pack(P, 1, out + (size_t)dir * H, 2 * H, M, H, pk + L.pk_hT[dir], rpW, r0, 0, rpW - r0, nkbT, T,
-                              dir ? 1 : -1, stream)))
+        if (P == 2) {   // |h| < 1 by construction (o · tanh c); the input features are measured
+          if (L.pk_whole && (e = nabu_pk_amax(x, D, M, D, nullptr, ahT[dir], stream))) return e;
+          if ((e = nabu_pk_amax_fill(ahT[dir] + r0, H, 1.0f, stream))) return e;
+        }
+        if (L.pk_whole && (e = pk_pack_any(P, 1, x, D, M, D, pk + L.pk_hT[dir], rpW, 0, 0, D, nkbT, 0, 0, ahT[dir], stream))) return e;
+        if ((e = pk_pack_any(P, 1, out + (size_t)dir * H, 2 * H, M, H, pk + L.pk_hT[dir], rpW, r0, 0, rpW - r0, nkbT, T,
+                             dir ? 1 : -1, ahT[dir], stream)))
           return e;
       }
       nabu_pk_gemm_desc g = pk_desc(P, Mw, G, nkbT, pk + L.pk_hT[0], rpW, dzTp, rpG, dkern[0] + (size_t)(D - r0) * G, G);
       g.nbatch = 2; g.A[1] = pk + L.pk_hT[1]; g.B[1] = dzTp + (size_t)G * 32; g.C[1] = dkern[1] + (size_t)(D - r0) * G;
+      if (P == 2) { g.a_amax[0] = ahT[0]; g.a_amax[1] = ahT[1]; g.b_amax[0] = adzT; g.b_amax[1] = adzT + G; }
       if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
     }
   }

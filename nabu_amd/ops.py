@@ -73,8 +73,10 @@ def gemm_bf16_nt(a_bf16, b_bf16, c, alpha=1.0, beta=0.0, bias=None):
 
 
 class PackedOperand(object):
-    """An fp32 matrix converted to the packed bf16-plane layout of gemm_pk.hip (include/nabu_hip.h,
-    nabu_pk_pack): `rows` = the operand's M (or N) index, `K` = the reduction length."""
+    """An fp32 matrix converted to the packed plane layout of gemm_pk.hip (include/nabu_hip.h, nabu_pk_pack):
+    `rows` = the operand's M (or N) index, `K` = the reduction length.  planes = 3 / 1: bf16 planes; planes = 2:
+    the scaled fp16 planes of f16x3, with `amax` = the bit patterns of the packed rows' largest magnitudes
+    (pk_pack measures them unless told a bound)."""
 
     def __init__(self, rows, K, planes, device):
         L = _hip.lib()
@@ -82,6 +84,7 @@ class PackedOperand(object):
         self.rows_pad = L.nabu_pk_rows_pad(rows)
         self.nkb = L.nabu_pk_kblocks(K, planes)
         self.buf = torch.empty(L.nabu_pk_bytes(rows, K, planes), dtype=torch.uint8, device=device)
+        self.amax = torch.zeros(self.rows_pad, dtype=torch.int32, device=device) if planes == 2 else None
 
     def kb_ptr(self, kb):
         return self.buf.data_ptr() + kb * self.planes * self.rows_pad * 32
@@ -90,9 +93,20 @@ class PackedOperand(object):
         return self.buf.data_ptr() + row * 32
 
 
+def pk_amax(src, rows=None, cols=None, R=None, C=None, ld=None):
+    """atomic maxima (bit patterns of |x|) of the rows / columns of the 2-D fp32 tensor `src` into the int32 device
+    arrays `rows` [>= R] / `cols` [>= C], which the caller zeroed or seeded (nabu_pk_amax)"""
+    if R is None:
+        R, C = src.shape
+        ld = src.stride(0)
+    check(_hip.lib().nabu_pk_amax(src.data_ptr(), ld, R, C, ptr(rows), ptr(cols), stream()), 'nabu_pk_amax')
+
+
 def pk_pack(dst, src, transposed=False, row_off=0, kb_off=0, fill_rows=None, fill_kb=None, period=0, shift=0,
-            R=None, C=None, ld=None):
-    """write the 2-D fp32 tensor `src` into the packed operand `dst` (rows / k-blocks beyond the source are zero)"""
+            R=None, C=None, ld=None, bound=None, measure=True):
+    """write the 2-D fp32 tensor `src` into the packed operand `dst` (rows / k-blocks beyond the source are zero).
+    f16x3 operands (dst.planes == 2): the row maxima of the packed rows are measured first (`measure`; they
+    accumulate when several sources share packed rows along k) or set to the a-priori `bound`."""
     if R is None:
         R, C = src.shape
         ld = src.stride(0)
@@ -101,13 +115,24 @@ def pk_pack(dst, src, transposed=False, row_off=0, kb_off=0, fill_rows=None, fil
         fill_rows = dst.rows_pad - row_off if row_off + rows >= dst.rows else rows
     if fill_kb is None:
         fill_kb = dst.nkb - kb_off if kb_off + (kred + 15) // 16 >= (dst.K + 15) // 16 else (kred + 15) // 16
+    if dst.planes == 2:
+        L = _hip.lib()
+        am = dst.amax[row_off:]
+        if bound is not None:
+            check(L.nabu_pk_amax_fill(ptr(am), rows, float(bound), stream()), 'nabu_pk_amax_fill')
+        elif measure:
+            check(L.nabu_pk_amax(src.data_ptr(), ld, R, C, None if transposed else ptr(am), ptr(am) if transposed else None,
+                                 stream()), 'nabu_pk_amax')
+        check(L.nabu_pk_pack_f16(int(transposed), src.data_ptr(), ld, R, C, ptr(dst.buf), dst.rows_pad, row_off, kb_off,
+                                 fill_rows, fill_kb, period, shift, ptr(dst.amax), stream()), 'nabu_pk_pack_f16')
+        return dst
     check(_hip.lib().nabu_pk_pack(dst.planes, int(transposed), src.data_ptr(), ld, R, C, ptr(dst.buf), dst.rows_pad,
                                   row_off, kb_off, fill_rows, fill_kb, period, shift, stream()), 'nabu_pk_pack')
     return dst
 
 
 def gemm_pk(a, b, c, planes=None, alpha=1.0, beta=0.0, bias=None, c2=None, n_split=0, bias2=None, M=None, N=None,
-            nkb=None, a_ptrs=None, b_ptrs=None, cs=None, c2s=None):
+            nkb=None, a_ptrs=None, b_ptrs=None, cs=None, c2s=None, a_amax=None, b_amax=None):
     """c[M,N] = alpha * a·b^T + beta*c + bias over packed operands (nabu_gemm_pk); batched form through
     a_ptrs / b_ptrs / cs (lists of raw pointers / tensors, <= 2 entries)"""
     L = _hip.lib()
@@ -129,6 +154,10 @@ def gemm_pk(a, b, c, planes=None, alpha=1.0, beta=0.0, bias=None, c2=None, n_spl
     d.ldc, d.n_split = cs[0].stride(0), n_split
     d.bias, d.bias2 = ptr(bias), ptr(bias2)
     d.alpha, d.beta = alpha, beta
+    if planes == 2:
+        for i in range(d.nbatch):
+            d.a_amax[i] = (a_amax[i] if a_amax else a.amax.data_ptr())
+            d.b_amax[i] = (b_amax[i] if b_amax else b.amax.data_ptr())
     ws_bytes = L.nabu_gemm_pk_ws_bytes(ctypes.byref(d))
     ws = Workspace.get(ws_bytes, cs[0].device, 'gemm') if ws_bytes else None
     check(L.nabu_gemm_pk(ctypes.byref(d), ptr(ws), ws_bytes, stream()), 'nabu_gemm_pk')

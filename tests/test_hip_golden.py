@@ -133,7 +133,7 @@ def test_cfg1_exact_matches_golden():
     assert rel.max() < 1e-3 and rel.max() < 5e-5, (losses, fx['losses'])
 
 
-@pytest.mark.parametrize('name', ['cfg2_exact', 'cfg2_exact:bf16x6', 'cfg3_exact', 'cfg5_exact'])
+@pytest.mark.parametrize('name', ['cfg2_exact', 'cfg2_exact:bf16x6', 'cfg2_exact:f16x3', 'cfg3_exact', 'cfg5_exact'])
 def test_full_size_configs_match_the_oracle_goldens(name):
     """BASELINE.json configs[1], [2] and (one GPU's share of) [4] at their FULL size — the headline
     config 32 x 1000 x 40, 4 x 512 included — against numbers the float64 oracle produced in the
@@ -146,7 +146,7 @@ def test_full_size_configs_match_the_oracle_goldens(name):
     the 1e-3 loss bar in test_cfg5_exact_bf16_loss)."""
     from tests.golden import make_golden as G       # generators only (seeded numpy); no oracle math runs
     name, _, prec = name.partition(':')              # 'cfg2_exact:bf16x6': the headline config with its dense products as
-    fx = load(name)                                  # six bf16 plane products (gemm_pk.hip) — same tolerances
+    fx = load(name)                                  # six bf16 / three scaled-fp16 plane products (gemm_pk.hip) — same tolerances
     names, data, _, loss_name, recipe, steps = G.exact_setup(name)
     w = G.draw_weights(names)
     over = {'encoder.gemm_precision': 'f32'} if name == 'cfg5_exact' else {}

@@ -1,7 +1,8 @@
 """Times the packed bf16-plane GEMM (gemm_pk.hip) and its pack kernels at the product shapes of a cfg2 / cfg5
 training step, next to the exact-fp32 MFMA kernel.  Run on the GPU box:
     python tools/experiments/gemm_pk_bench.py [--planes 3] [--reps 20]
-Prints one line per shape: ms, effective TF/s (2MNK / time), MFMA TF/s (x6 for planes = 3)."""
+Prints one line per shape: ms, effective TF/s (2MNK / time), MFMA TF/s (x6 for planes = 3, x3 for planes = 2 = f16x3;
+the pack times of planes = 2 include the row-maximum pass)."""
 import argparse
 import os
 import sys
@@ -59,7 +60,7 @@ def main():
         fl = 2.0 * M * N * K
         print('%-22s M=%6d N=%5d K=%6d  pk %7.3f ms  %7.1f TF/s eff  %7.1f TF/s mfma | pack A+B %6.3f ms, A^T %6.3f ms '
               '(%5.2f TB/s) | fp32 %7.3f ms %6.1f TF/s' %
-              (name, M, N, K, t, fl / t * 1e-9, fl * (6 if a.planes == 3 else 1) / t * 1e-9, tp, tpt,
+              (name, M, N, K, t, fl / t * 1e-9, fl * {3: 6, 2: 3, 1: 1}[a.planes] / t * 1e-9, tp, tpt,
                M * K * (4 + 2 * a.planes) / tpt * 1e-9, t32, fl / t32 * 1e-9 if t32 else 0.0), flush=True)
         tot += t
         tot32 += t32

@@ -126,6 +126,82 @@ def stream_s2():
     return out, slot, gaps
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# NP = 2 ("f16x3": two scaled fp16 planes x = (h + l) / scale, products l.h, h.l, h.h on v_mfma_f32_32x32x16_f16).
+#   v[0:127]    accumulators (as above)
+#   v[128:159]  A fragments, (i, plane q) at v[128 + 4(2i+q) : +3]
+#   v[160:175]  B fragments, (j, plane q) at v[160 + 4(2j+q) : +3]
+#   v[176:239]  four scratch tiles T0..T3, chain n runs in T[n % 4]
+# A chain is only three MFMAs long, so the 16 adds of a tile need all three gaps of a chain's length: the adds of
+# tile n-1 sit behind the 2nd and 3rd MFMA of chain n (5 + 5; the 2nd MFMA of chain n issues 64 cycles after the last
+# one of chain n-1, whose result is written 8 passes + 3 states after issue) and behind the 1st MFMA of chain n+1
+# (6).  T[(n-1) % 4] is rewritten by chain n+3 at the earliest.  Tiles 6 and 7 of a stage finish in the next stage's
+# first gaps (T2 elements 10..15, T3 whole: one partial add pass after the loop), so every stage runs one stream.
+FA2, FB2, TMP2 = 128, 160, 176
+PRODUCTS2 = [(1, 0), (0, 1), (0, 0)]
+
+
+def fa2(i, q):
+    b = FA2 + 4 * (2 * i + q)
+    return 'v[%d:%d]' % (b, b + 3)
+
+
+def fb2(j, q):
+    b = FB2 + 4 * (2 * j + q)
+    return 'v[%d:%d]' % (b, b + 3)
+
+
+def tmp2(r):
+    return 'v[%d:%d]' % (TMP2 + 16 * r, TMP2 + 16 * r + 15)
+
+
+def stream_f16(split=(6, 5, 5)):
+    """split = adds behind MFMA 1 (the LAST ones of tile n-2), behind MFMA 2 and MFMA 3 (the first ones of tile n-1)"""
+    assert sum(split) == 16
+    out = []
+    for n in range(8):
+        i, j = n >> 1, n & 1
+        r = n % 4
+        ms = []
+        for k, (qa, qb) in enumerate(PRODUCTS2):
+            ms.append('v_mfma_f32_32x32x16_f16 %s, %s, %s, %s' % (tmp2(r), fb2(j, qb), fa2(i, qa), '0' if k == 0 else tmp2(r)))
+        def add(tile, e):
+            t = tile % 8
+            return 'v_add_f32 v%d, v%d, v%d' % (ACC + 16 * t + e, ACC + 16 * t + e, TMP2 + 16 * (t % 4) + e)
+        first = split[1] + split[2]
+        out.append(ms[0])
+        out += [add(n - 2, e) for e in range(first, 16)]
+        out.append(ms[1])
+        out += [add(n - 1, e) for e in range(0, split[1])]
+        out.append(ms[2])
+        out += [add(n - 1, e) for e in range(split[1], first)]
+    return out
+
+
+def stream_load2(va, vb):
+    out = []
+    for q in range(2):
+        for i in range(4):
+            out.append('ds_read_b128 %s, %s offset:%d' % (fa2(i, q), va, q * 8192 + i * 1024))
+        for j in range(2):
+            out.append('ds_read_b128 %s, %s offset:%d' % (fb2(j, q), vb, q * 8192 + j * 1024))
+    return out
+
+
+def operand_lists2():
+    accs = ', '.join('"+{%s}"(acc[%d][%d])' % (acc(n), n >> 1, n & 1) for n in range(8))
+    tmps = ', '.join('"+{%s}"(ts[%d])' % (tmp2(r), r) for r in range(4))
+    fas_o = ', '.join('"=&{%s}"(ha[%d][%d])' % (fa2(i, q), i, q) for i in range(4) for q in range(2))
+    fbs_o = ', '.join('"=&{%s}"(hb[%d][%d])' % (fb2(j, q), j, q) for j in range(2) for q in range(2))
+    fas_i = ', '.join('"{%s}"(ha[%d][%d])' % (fa2(i, q), i, q) for i in range(4) for q in range(2))
+    fbs_i = ', '.join('"{%s}"(hb[%d][%d])' % (fb2(j, q), j, q) for j in range(2) for q in range(2))
+    print('#define PK2_ASM_LOAD_OUTPUTS %s, %s\n' % (fas_o, fbs_o))
+    print('#define PK2_ASM_COMPUTE_INOUT %s, %s\n' % (accs, tmps))
+    print('#define PK2_ASM_COMPUTE_INPUTS %s, %s\n' % (fas_i, fbs_i))
+    # number of asm operands in front of the two LDS addresses of the LOAD statement
+    print('// PK2_STREAM_LOAD: 12 outputs, then %12 = A address, %13 = B address\n')
+
+
 def as_c_string(lines):
     return '\n'.join('      "%s\\n\\t"' % l for l in lines)
 
@@ -171,6 +247,9 @@ def main():
     # (0,0,3,3,3,7) 8.23, as (0,0,0,5,5,6) 8.15, as 8 v_pk_add_f32 per tile 9.39, S1 without s_setprio 8.13
     macro('PK_STREAM_LOAD', stream_load('%18', '%19'))
     operand_lists()
+    macro('PK2_STREAM', stream_f16())
+    macro('PK2_STREAM_LOAD', stream_load2('%12', '%13'))
+    operand_lists2()
 
 
 if __name__ == '__main__':
