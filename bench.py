@@ -18,11 +18,13 @@ clipped gradients when N > 1, weak scaling: every rank has its own batch of 32).
 Inputs are resident in HBM before the timed region.
 
 Arithmetic of the dense products (--gemm-precision): the headline runs them as fp32-EQUIVALENT
-products on the bf16 matrix pipe (bf16x6: every fp32 operand split exactly into three bf16 planes,
-six plane products, 16-k partial sums promoted to fp32 accumulators; measured error against float64
-below the exact-fp32 MFMA kernel's, tests/test_hip_gemm_pk.py) — everything else of the step is
-fp32.  The same step with exact-fp32 products (v_mfma_f32_32x32x2_f32) is timed in the same run
-and printed as the `exact_fp32` object of the line.
+products on the 16-bit matrix pipe — f16x3: every operand row scaled by a power of two and held as
+two fp16 planes, three plane products, 16-k partial sums promoted to fp32 accumulators; measured
+error against float64 at or below the exact-fp32 MFMA kernel's (tests/test_hip_gemm_pk.py), per-step
+loss within 5e-5 of the float64 oracle at the full size (tests/test_hip_golden.py) — everything else
+of the step is fp32.  The same step with the exact six-plane split on the bf16 pipe (bf16x6) and with
+exact-fp32 products (v_mfma_f32_32x32x2_f32) is timed in the same run and printed as the `alt_bf16x6`
+and `exact_fp32` objects of the line.
 
 One JSON line is printed by rank 0.  Extra objects:
   roofline     — SURVEY.md 8(d): the recurrent LSTM step's ALGORITHMIC bytes (per timestep per
@@ -280,13 +282,14 @@ def parse_args(argv=None):
     ap.add_argument('--mode', default='auto', choices=['auto', 'stepwise', 'persistent'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true',
-                    help='skip the second measurement of the same step with the other arithmetic (exact fp32 <-> bf16x6)')
+                    help='skip the measurements of the same step with the other fp32-class arithmetics of the dense products')
     ap.add_argument('--no-gemm-roofline', action='store_true',
                     help='skip the roofline_gemm measurement (keeps a kernel trace of this command to the training steps)')
-    ap.add_argument('--gemm-precision', default='bf16x6', choices=['f32', 'bf16x6', 'f16x3', 'bf16x3', 'bf16'],
-                    help='arithmetic of the dense products (include/nabu_hip.h): bf16x6 (default) = fp32-equivalent '
-                         'six-plane products on the bf16 matrix pipe, f32 = exact fp32 MFMA; the line names it in '
-                         'config.gemm_arith and carries the other one as `exact_fp32` / `alt_bf16x6`')
+    ap.add_argument('--gemm-precision', default='f16x3', choices=['f32', 'bf16x6', 'f16x3', 'bf16x3', 'bf16'],
+                    help='arithmetic of the dense products (include/nabu_hip.h): f16x3 (default) = fp32-equivalent '
+                         'three-plane products of row-scaled fp16 operands, bf16x6 = fp32-equivalent six-plane products '
+                         'on the bf16 matrix pipe, f32 = exact fp32 MFMA; the line names it in config.gemm_arith and '
+                         'carries the other two as `exact_fp32` / `alt_bf16x6` / `alt_f16x3`')
     ap.add_argument('--workload', default='cfg2', choices=['cfg1', 'cfg2', 'cfg3', 'cfg5'],
                     help='cfg2 (default) is the BASELINE.json metric; cfg3 = same encoder + Speller; cfg5 = '
                          'location-aware LAS, batch 64x1600x80, bf16 input GEMMs (BASELINE.json configs[2]/[4]), '
@@ -600,7 +603,7 @@ def main(argv=None):
 
 
 def alt_gemm_arith(tr, batches, server, steps, precision, restore):
-    """the same step with the other arithmetic of the dense products (exact fp32 <-> bf16x6), timed with the
+    """the same step with another arithmetic of the dense products (exact fp32 / bf16x6 / f16x3), timed with the
     protocol of the headline; NOT the headline value"""
     import torch
     from nabu_amd import ops

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnabu_hip.so')
+LIB_PATH = os.environ.get('NABU_HIP_LIB') or os.path.join(_HERE, 'libnabu_hip.so')   # (the override: A/B builds in experiments)
 
 _c = ctypes
 _vp, _i, _f, _sz, _ll = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t, _c.c_longlong

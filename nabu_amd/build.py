@@ -22,7 +22,7 @@ def _sources():
 
 def _digest():
     h = hashlib.sha256(' '.join(FLAGS).encode())
-    files = _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h'))
+    files = _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h') or f.endswith('.inc'))
     files.append(os.path.join(os.path.dirname(HERE), 'include', 'nabu_hip.h'))
     for f in files:
         with open(f, 'rb') as fid:

@@ -77,8 +77,11 @@ constexpr int PK_T = 256;               // tile edge (rows of A = M index, rows 
 constexpr int PK_CH = PK_T * 32;        // one piece: 256 rows x 16 k x 2 bytes
 constexpr int PK_STAGE = 6 * PK_CH;     // 48 KiB
 constexpr int PK_LDS = 3 * PK_STAGE;    // 144 KiB
+#ifndef PK_RING2
+#define PK_RING2 3                      // f16x3: stages in the LDS ring (3 or 4)
+#endif
 constexpr int PK_STAGE2 = 4 * PK_CH;    // f16x3: 32 KiB
-constexpr int PK_LDS2 = 3 * PK_STAGE2;  // 96 KiB
+constexpr int PK_LDS2 = PK_RING2 * PK_STAGE2;
 constexpr int PK_GM = 4;                // row tiles per band of the tile order
 
 struct PkOp {
@@ -222,22 +225,23 @@ __global__ __launch_bounds__(512) void gemm_pk_kernel(PkArgs p) {
   const unsigned offA = laneoff + (unsigned)grp * (128u * 32u);
   const unsigned offB = laneoff + (unsigned)(NPIECE / 2) * PK_CH + (unsigned)wn * (64u * 32u);
 
-  // ---- prologue: stages 0 and 1 ----
+  // ---- prologue: stages 0 .. RING-2 ----
+  constexpr int RING = NP == 2 ? PK_RING2 : 3;
   if (nst > 0) issue(wbase);
-  if (nst > 1) {
-    issue(STAGE + wbase);
-    pk_wait<NPIECE>();
-  } else {
-    pk_wait<0>();
-  }
+  if (nst > 1) issue(STAGE + wbase);
+  if (RING == 4 && nst > 2) issue(2 * STAGE + wbase);
+  if (RING == 4 && nst > 2) pk_wait<2 * NPIECE>();
+  else if (nst > 1) pk_wait<NPIECE>();
+  else pk_wait<0>();
   pk_barrier();                 // barrier 0: stage 0 visible
   if (grp == 1) pk_barrier();   // the late half runs one barrier interval behind
 
-  unsigned so_rd = 0, so_wr = 2 * STAGE;
+  unsigned so_rd = 0, so_wr = (RING - 1) * STAGE;
   for (int st = 0; st < nst; ++st) {
     // -------- LOAD(st) --------
-    const bool more = st + 2 < nst;
-    if (more) issue(so_wr + wbase);
+    const bool more = st + 2 < nst;               // a stage beyond st+1 is (or is being) fetched
+    const bool more2 = RING == 4 && st + 3 < nst;   // ... two of them
+    if (st + RING - 1 < nst) issue(so_wr + wbase);
     kbf16x8 fa[4][3], fb[2][3];
     kf16x8 ha[4][2], hb[2][2];
     if constexpr (NP == 3 && VAR == 1) {
@@ -249,7 +253,9 @@ __global__ __launch_bounds__(512) void gemm_pk_kernel(PkArgs p) {
       else asm volatile(PK_STREAM_LOAD "s_waitcnt vmcnt(0) lgkmcnt(0)" : PK_ASM_LOAD_OUTPUTS : "v"(va), "v"(vb) : "memory");
     } else if constexpr (NP == 2) {
       const unsigned va = so_rd + offA, vb = so_rd + offB;
-      if (more) asm volatile(PK2_STREAM_LOAD "s_waitcnt vmcnt(4) lgkmcnt(0)" : PK2_ASM_LOAD_OUTPUTS : "v"(va), "v"(vb) : "memory");
+      // all but the stages beyond st+1 have landed when the reads of this one retire
+      if (more2) asm volatile(PK2_STREAM_LOAD "s_waitcnt vmcnt(8) lgkmcnt(0)" : PK2_ASM_LOAD_OUTPUTS : "v"(va), "v"(vb) : "memory");
+      else if (more) asm volatile(PK2_STREAM_LOAD "s_waitcnt vmcnt(4) lgkmcnt(0)" : PK2_ASM_LOAD_OUTPUTS : "v"(va), "v"(vb) : "memory");
       else asm volatile(PK2_STREAM_LOAD "s_waitcnt vmcnt(0) lgkmcnt(0)" : PK2_ASM_LOAD_OUTPUTS : "v"(va), "v"(vb) : "memory");
     } else {
       const char *sA = pk_smem + so_rd + offA, *sB = pk_smem + so_rd + offB;
@@ -301,8 +307,8 @@ __global__ __launch_bounds__(512) void gemm_pk_kernel(PkArgs p) {
     }
     if (!hand) __builtin_amdgcn_s_setprio(0);
     pk_barrier();
-    so_rd = so_rd == 2 * STAGE ? 0 : so_rd + STAGE;
-    so_wr = so_wr == 2 * STAGE ? 0 : so_wr + STAGE;
+    so_rd = so_rd == (RING - 1) * STAGE ? 0 : so_rd + STAGE;
+    so_wr = so_wr == (RING - 1) * STAGE ? 0 : so_wr + STAGE;
   }
   if (grp == 0) pk_barrier();
   if (NP == 3 && VAR == 1) {
@@ -310,10 +316,10 @@ __global__ __launch_bounds__(512) void gemm_pk_kernel(PkArgs p) {
     acc[3][1] += tpend;
   }
   if (NP == 2 && VAR == 1) {
-    // the adds the stream still owes: tile 6 = (3, 0) elements 10..15 out of T2, tile 7 = (3, 1) out of T3
+    // the adds the stream still owes: tile 6 = (3, 0) its last elements out of T2, tile 7 = (3, 1) out of T3
     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(ts[2]), "+v"(ts[3]));
 #pragma unroll
-    for (int q = 10; q < 16; ++q) acc[3][0][q] += ts[2][q];
+    for (int q = PK2_PEND_FIRST; q < 16; ++q) acc[3][0][q] += ts[2][q];
     acc[3][1] += ts[3];
   }
 

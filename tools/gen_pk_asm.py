@@ -22,6 +22,7 @@ Measured one wave per SIMD: 653 ns per stage = the bare 48-MFMA stream (655 ns):
 
 Schedules "S0" (direct accumulation, no promotion) and "S2" (three scratch tiles, two interleaved chains, wrapping
 around the stage: a throughput probe only) are emitted with --bench for the micro-benchmark."""
+import os
 import sys
 
 ACC, FA, FB, TMP = 0, 128, 176, 200
@@ -133,10 +134,10 @@ def stream_s2():
 #   v[160:175]  B fragments, (j, plane q) at v[160 + 4(2j+q) : +3]
 #   v[176:239]  four scratch tiles T0..T3, chain n runs in T[n % 4]
 # A chain is only three MFMAs long, so the 16 adds of a tile need all three gaps of a chain's length: the adds of
-# tile n-1 sit behind the 2nd and 3rd MFMA of chain n (5 + 5; the 2nd MFMA of chain n issues 64 cycles after the last
+# tile n-1 sit behind the 2nd and 3rd MFMA of chain n (6 + 5; the 2nd MFMA of chain n issues 64 cycles after the last
 # one of chain n-1, whose result is written 8 passes + 3 states after issue) and behind the 1st MFMA of chain n+1
-# (6).  T[(n-1) % 4] is rewritten by chain n+3 at the earliest.  Tiles 6 and 7 of a stage finish in the next stage's
-# first gaps (T2 elements 10..15, T3 whole: one partial add pass after the loop), so every stage runs one stream.
+# (5).  T[(n-1) % 4] is rewritten by chain n+3 at the earliest.  Tiles 6 and 7 of a stage finish in the next stage's
+# first gaps (T2 the last elements, T3 whole: one partial add pass after the loop), so every stage runs one stream.
 FA2, FB2, TMP2 = 128, 160, 176
 PRODUCTS2 = [(1, 0), (0, 1), (0, 0)]
 
@@ -155,7 +156,7 @@ def tmp2(r):
     return 'v[%d:%d]' % (TMP2 + 16 * r, TMP2 + 16 * r + 15)
 
 
-def stream_f16(split=(6, 5, 5)):
+def stream_f16(split=(6, 5, 5), packed=False):
     """split = adds behind MFMA 1 (the LAST ones of tile n-2), behind MFMA 2 and MFMA 3 (the first ones of tile n-1)"""
     assert sum(split) == 16
     out = []
@@ -165,16 +166,21 @@ def stream_f16(split=(6, 5, 5)):
         ms = []
         for k, (qa, qb) in enumerate(PRODUCTS2):
             ms.append('v_mfma_f32_32x32x16_f16 %s, %s, %s, %s' % (tmp2(r), fb2(j, qb), fa2(i, qa), '0' if k == 0 else tmp2(r)))
-        def add(tile, e):
+        def adds_of(tile, lo, hi):
             t = tile % 8
-            return 'v_add_f32 v%d, v%d, v%d' % (ACC + 16 * t + e, ACC + 16 * t + e, TMP2 + 16 * (t % 4) + e)
+            a, b = ACC + 16 * t, TMP2 + 16 * (t % 4)
+            if packed:      # v_pk_add_f32 on aligned register pairs (lo, hi even)
+                assert lo % 2 == 0 and hi % 2 == 0
+                return ['v_pk_add_f32 v[%d:%d], v[%d:%d], v[%d:%d]' % (a + e, a + e + 1, a + e, a + e + 1, b + e, b + e + 1)
+                        for e in range(lo, hi, 2)]
+            return ['v_add_f32 v%d, v%d, v%d' % (a + e, a + e, b + e) for e in range(lo, hi)]
         first = split[1] + split[2]
         out.append(ms[0])
-        out += [add(n - 2, e) for e in range(first, 16)]
+        out += adds_of(n - 2, first, 16)
         out.append(ms[1])
-        out += [add(n - 1, e) for e in range(0, split[1])]
+        out += adds_of(n - 1, 0, split[1])
         out.append(ms[2])
-        out += [add(n - 1, e) for e in range(split[1], first)]
+        out += adds_of(n - 1, split[1], first)
     return out
 
 
@@ -247,7 +253,12 @@ def main():
     # (0,0,3,3,3,7) 8.23, as (0,0,0,5,5,6) 8.15, as 8 v_pk_add_f32 per tile 9.39, S1 without s_setprio 8.13
     macro('PK_STREAM_LOAD', stream_load('%18', '%19'))
     operand_lists()
-    macro('PK2_STREAM', stream_f16())
+    # measured, sum over the cfg2 product shapes: adds as (6,5,5) 5.09 ms, (5,6,5) 5.04, (4,6,6) 5.37; direct accumulation
+    # (no adds, error 1.24 x exact fp32 at K = 2048) 4.56
+    split2 = tuple(int(v) for v in os.environ.get('PK2_SPLIT', '6,5,5').split(','))
+    macro('PK2_STREAM', stream_f16(split2, packed=os.environ.get('PK2_PACKED') == '1'))
+    print('#define PK2_PEND_FIRST %d   // adds of tile 6 the stream leaves to the next stage: elements PK2_PEND_FIRST..15\n'
+          % (split2[1] + split2[2]))
     macro('PK2_STREAM_LOAD', stream_load2('%12', '%13'))
     operand_lists2()
 
