@@ -102,6 +102,7 @@ struct PkArgs {
   float alpha, beta;
   float *partial;             // [nsplit][nbatch][M][N] when nsplit > 1
   const unsigned *a_amax[2], *b_amax[2];   // f16x3: bit patterns of the packed rows' largest magnitudes (per batch entry)
+  int throttle;               // experiment (NABU_PK_THROTTLE): s_sleep units per stage
 };
 
 // f16x3 row scales, derived from the bit pattern of the row's largest magnitude wherever they are needed:
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(512) void gemm_pk_kernel(PkArgs p) {
 #undef PK_PROD
     }
     if (!hand) __builtin_amdgcn_s_setprio(0);
+    for (int z = 0; z < p.throttle; ++z) __builtin_amdgcn_s_sleep(1);
     pk_barrier();
     so_rd = so_rd == (RING - 1) * STAGE ? 0 : so_rd + STAGE;
     so_wr = so_wr == (RING - 1) * STAGE ? 0 : so_wr + STAGE;
@@ -881,8 +883,14 @@ static int pk_fill(PkArgs &p, const nabu_pk_gemm_desc *d, int *planes) {
   p.nkb = d->nkb;
   p.ldc = d->ldc; p.n_split = d->n_split; p.bias = d->bias; p.bias2 = d->bias2;
   p.alpha = d->alpha; p.beta = d->beta; p.partial = nullptr;
-  static int force = -2;
-  if (force == -2) { const char *e = getenv("NABU_PK_SPLIT"); force = e ? atoi(e) : -1; }
+  static int force = -2, throttle = 0;
+  if (force == -2) {
+    const char *e = getenv("NABU_PK_SPLIT");
+    force = e ? atoi(e) : -1;
+    e = getenv("NABU_PK_THROTTLE");
+    throttle = e ? atoi(e) : 0;
+  }
+  p.throttle = throttle;
   p.nsplit = pk_choose_split(p.tiles_m * p.tiles_n * p.nbatch, p.nkb, kbs, d->planes == 2 ? 48 : 24, &p.kb_per_split);
   if (force > 0) {
     const int nst = p.nkb / kbs, per = (nst + force - 1) / force;

@@ -199,7 +199,9 @@ struct Layout {
   size_t pk_x, pk_w, pk_xT, pk_hT[2], pk_dz, pk_w2;
   // planes = 2 (f16x3): the row maxima (uint32 per packed row) of the operands above; those of one pass are
   // contiguous (one memset): forward [x | w], backward [dz | w2 | xT | hT0 | hT1]; dZ^T's sit behind it in the reserve
-  size_t pk_ax, pk_aw, pk_adz, pk_aw2, pk_axT, pk_ahT[2], pk_abwd_bytes, res_adzT_off;
+  // the column maxima of x and the row maxima of Wx (the backward pass's x^T and Wx operands) are measured by the
+  // forward pass in the same reads as its own and kept in the reserve (res_axT_off, res_aw2_off)
+  size_t pk_ax, pk_aw, pk_adz, pk_ahT[2], pk_abwd_bytes, res_adzT_off, res_axT_off, res_aw2_off;
   // dZ^T packed [8H, BT] lives in the layer's RESERVE (behind the activations): it is written by the data part of
   // the backward pass and read by the weight-gradient part, which may run later (nabu_blstm_bwd_weights)
   size_t res_dzT_off, res_dzT_bytes;
@@ -313,9 +315,11 @@ static Layout make_layout(const nabu_blstm_desc *d) {
       const size_t aBT = 4 * (size_t)nabu_pk_rows_pad(BT), aG = 4 * (size_t)nabu_pk_rows_pad(2 * G), aD = 4 * (size_t)nabu_pk_rows_pad((int)D);
       const size_t aW = 4 * (size_t)nabu_pk_rows_pad((int)(L.pk_whole ? D + H : H));
       L.res_adzT_off = align_up(L.reserve_bytes, 256);
-      L.reserve_bytes = L.res_adzT_off + aG;
+      L.res_axT_off = L.res_adzT_off + aG;
+      L.res_aw2_off = L.res_axT_off + aD;
+      L.reserve_bytes = L.res_aw2_off + aD;
       L.pk_ax = take(fwd, aBT); L.pk_aw = take(fwd, aG);
-      L.pk_adz = take(bwd, aBT); L.pk_aw2 = take(bwd, aD); L.pk_axT = take(bwd, aD);
+      L.pk_adz = take(bwd, aBT);
       L.pk_ahT[0] = take(bwd, aW); L.pk_ahT[1] = take(bwd, aW);
       L.pk_abwd_bytes = bwd;
     }
@@ -438,10 +442,13 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const in
     if (P == 2) {
       // f16x3: the frames' and the gate columns' largest magnitudes first (one more read of x: nothing is assumed
       // about the layer's input)
+      uint32_t *axT = reinterpret_cast<uint32_t *>(static_cast<char *>(reserve) + L.res_axT_off);
+      uint32_t *aw2 = reinterpret_cast<uint32_t *>(static_cast<char *>(reserve) + L.res_aw2_off);
       NABU_HIP(hipMemsetAsync(ax, 0, L.pk_aw - L.pk_ax + 4 * (size_t)rpG, s));
-      if (int e = nabu_pk_amax(x, D, BT, D, ax, nullptr, stream)) return e;
+      NABU_HIP(hipMemsetAsync(axT, 0, 8 * (size_t)nabu_pk_rows_pad(D), s));     // axT and aw2 are adjacent
+      if (int e = nabu_pk_amax(x, D, BT, D, ax, axT, stream)) return e;
       for (int dir = 0; dir < 2; ++dir)
-        if (int e = nabu_pk_amax(kern[dir], G, D, G, nullptr, aw + dir * G, stream)) return e;
+        if (int e = nabu_pk_amax(kern[dir], G, D, G, aw2, aw + dir * G, stream)) return e;
     }
     if (int e = pk_pack_any(P, 0, x, D, BT, D, pk + L.pk_x, rpBT, 0, 0, rpBT, nkb, 0, 0, ax, stream)) return e;
     for (int dir = 0; dir < 2; ++dir)
@@ -582,20 +589,19 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
     const int nkb2 = nabu_pk_kblocks(2 * G, P), kbG = G / 16;
     int e;
     // f16x3 (P = 2): row maxima of every operand — measured (dz, the weights, x) or known (|h| < 1)
-    uint32_t *adz = reinterpret_cast<uint32_t *>(pk + L.pk_adz), *aw2 = reinterpret_cast<uint32_t *>(pk + L.pk_aw2);
-    uint32_t *axT = reinterpret_cast<uint32_t *>(pk + L.pk_axT);
+    uint32_t *adz = reinterpret_cast<uint32_t *>(pk + L.pk_adz);
+    uint32_t *axT = reinterpret_cast<uint32_t *>(static_cast<char *>(reserve) + L.res_axT_off);    // from the forward pass
+    uint32_t *aw2 = reinterpret_cast<uint32_t *>(static_cast<char *>(reserve) + L.res_aw2_off);
     uint32_t *ahT[2] = {reinterpret_cast<uint32_t *>(pk + L.pk_ahT[0]), reinterpret_cast<uint32_t *>(pk + L.pk_ahT[1])};
     uint32_t *adzT = reinterpret_cast<uint32_t *>(static_cast<char *>(reserve) + L.res_adzT_off);
     if (parts & 1) {
       const bool both = d_x && L.pk_in;    // dz is also needed row-major (dx): both packs from one read of dz
       if (P == 2) {
         // one read of dz per cell: its rows' maxima over BOTH cells (the row scale of dZ as [BT, 8H]) and its columns'
-        NABU_HIP(hipMemsetAsync(adz, 0, L.pk_axT - L.pk_adz, s));
+        if (both) NABU_HIP(hipMemsetAsync(adz, 0, 4 * (size_t)rpBT, s));
         NABU_HIP(hipMemsetAsync(adzT, 0, 4 * (size_t)rpG, s));
-        for (int dir = 0; dir < 2; ++dir) {
+        for (int dir = 0; dir < 2; ++dir)
           if ((e = nabu_pk_amax(gates[dir], G, M, G, both ? adz : nullptr, adzT + dir * G, stream))) return e;
-          if (both && (e = nabu_pk_amax(kern[dir], G, D, G, aw2, nullptr, stream))) return e;
-        }
       }
       for (int dir = 0; dir < 2; ++dir) {
         if (both)
@@ -616,9 +622,8 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
         if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
       }
     }
-    if ((parts & 2) && P == 2) NABU_HIP(hipMemsetAsync(axT, 0, L.pk_abwd_bytes - L.pk_axT, s));
+    if ((parts & 2) && P == 2 && L.pk_whole) NABU_HIP(hipMemsetAsync(ahT[0], 0, L.pk_abwd_bytes - L.pk_ahT[0], s));
     if ((parts & 2) && L.pk_in) {
-      if (P == 2 && (e = nabu_pk_amax(x, D, M, D, nullptr, axT, stream))) return e;
       if ((e = pk_pack_any(P, 1, x, D, M, D, pk + L.pk_xT, rpD, 0, 0, rpD, nkbT, 0, 0, axT, stream))) return e;
       nabu_pk_gemm_desc g = pk_desc(P, D, 2 * G, nkbT, pk + L.pk_xT, rpD, dzTp, rpG, dkern[0], G);
       g.C2[0] = dkern[1]; g.n_split = G;
