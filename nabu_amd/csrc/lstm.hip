@@ -236,7 +236,10 @@ static int pk_planes_of(const nabu_blstm_desc *d) {
   if (!env || !gemm_pk_device_ok()) return 0;
   const long long BT = (long long)d->B * d->T;
   if (BT < 1024 || BT >= (1ll << 31) - 512 || d->H % 64) return 0;   // n_split = 4H must be a multiple of 256
-  return prec == NABU_GEMM_BF16X6 ? 3 : prec == NABU_GEMM_F16X3 ? 2 : prec == NABU_GEMM_BF16 ? 1 : 0;
+  // f16x3 pays for its row maxima with ~20 small launches per layer and step: below 2048 frames (cfg1: 1600) the
+  // other fp32-equivalent arithmetic is faster (2.06 against 2.16 ms per cfg1 step)
+  if (prec == NABU_GEMM_F16X3) return BT >= 2048 ? 2 : 3;
+  return prec == NABU_GEMM_BF16X6 ? 3 : prec == NABU_GEMM_BF16 ? 1 : 0;
 }
 // one entry point for the bf16-plane and the scaled-fp16-plane packs (amax: the row maxima of planes = 2)
 static int pk_pack_any(int planes, int transposed, const float *src, long long ld, int R, int C, void *dst, int rows_pad,

@@ -352,10 +352,11 @@ def test_gemm_pk_f16x3_non_finite_inputs_stay_visible():
 
 @pytest.mark.parametrize('precision,tol', [('bf16x6', 2e-4), ('f16x3', 2e-4), ('bf16', 5e-2)])
 @pytest.mark.parametrize('B,T,D,H,lens', [
-    (16, 64, 256, 64, None),                                       # every product on the packed path
-    (9, 130, 260, 128, [130, 7, 99, 130, 1, 64, 65, 129, 30]),     # ragged, edge tiles, B*T and D not multiples of 16
-    (8, 160, 40, 64, None),                                        # narrow input: only the recurrent gradient is packed
-])
+    (32, 64, 256, 64, None),                                       # every product on the packed path
+    (17, 130, 260, 128, [130, 7, 99, 130, 1, 64, 65, 129, 30, 130, 2, 77, 128, 13, 100, 55, 130]),   # ragged, edge tiles,
+                                                                   # B*T and D not multiples of 16
+    (16, 160, 40, 64, None),                                       # narrow input: only the recurrent gradient is packed
+])   # (B*T >= 2048: below that the layer computes f16x3 requests as bf16x6)
 def test_blstm_layer_on_packed_products_matches_oracle(precision, tol, B, T, D, H, lens):
     """nabu_blstm_fwd/_bwd with gemm_precision = bf16x6 / f16x3 (fp32-equivalent, same bounds as the exact-fp32 layer
     tests) and bf16 (operand rounding ~2^-9) against the float64 oracle; zero rows past each length stay exact"""
@@ -372,8 +373,19 @@ def test_blstm_layer_on_packed_products_matches_oracle(precision, tol, B, T, D, 
         assert rel_err(g[k], rg[k]) < tol, k
 
 
+def test_blstm_layer_f16x3_is_its_own_arithmetic_above_2048_frames():
+    """a layer asked for f16x3 runs the three-product kernel from 2048 frames on (its results differ from bf16x6's in
+    the last bits) and bf16x6 below (bit-identical results)"""
+    from nabu_amd import ops
+    from tests.test_hip_ops import _run_blstm
+    for B, T, same in ((32, 64, False), (16, 64, True)):
+        a = _run_blstm(B, T, 256, 64, [T] * B, ops.LSTM_AUTO, seed=5, precision='f16x3')
+        b = _run_blstm(B, T, 256, 64, [T] * B, ops.LSTM_AUTO, seed=5, precision='bf16x6')
+        assert np.array_equal(a[0], b[0]) == same and np.array_equal(a[2], b[2]) == same, (B, T)
+
+
 @pytest.mark.parametrize('precision', ['f32', 'bf16x6', 'f16x3', 'bf16'])
-@pytest.mark.parametrize('B,T,D,H', [(16, 64, 256, 64), (8, 160, 40, 64)])
+@pytest.mark.parametrize('B,T,D,H', [(32, 64, 256, 64), (16, 160, 40, 64)])
 def test_blstm_backward_in_two_calls_equals_one(precision, B, T, D, H):
     """nabu_blstm_bwd_data + nabu_blstm_bwd_weights (the weight-gradient products deferred behind the last recurrence of
     a backward pass) == nabu_blstm_bwd, bit for bit, on every arithmetic of the products"""
