@@ -154,6 +154,11 @@ typedef struct nabu_pk_gemm_desc {
   const float *bias, *bias2;
   float alpha, beta;
   const uint32_t *a_amax[2], *b_amax[2];  /* planes = 2: the row maxima the operands were packed with */
+  int32_t direct;         /* planes = 2: 1 = chain the three plane products into the accumulators directly (three
+                           * roundings of the matrix pipe per 16 k where the exact-fp32 instruction has eight; 10 %
+                           * faster) instead of promoting 16-k partial sums (0, the default: one rounding per 16 k);
+                           * 2 = direct when a workgroup's reduction is at most twice as long as the exact-fp32
+                           * kernel's would be for the same product (fewer roundings than that kernel), else promoted */
 } nabu_pk_gemm_desc;
 int nabu_pk_rows_pad(int rows);
 int nabu_pk_kblocks(int K, int planes);

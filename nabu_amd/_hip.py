@@ -27,7 +27,7 @@ class PkGemmDesc(_c.Structure):
                 ('a_rows_pad', _c.c_int32), ('b_rows_pad', _c.c_int32), ('a_planes', _c.c_int32),
                 ('b_planes', _c.c_int32), ('C', _c.c_void_p * 2), ('C2', _c.c_void_p * 2),
                 ('ldc', _c.c_int32), ('n_split', _c.c_int32), ('bias', _c.c_void_p), ('bias2', _c.c_void_p),
-                ('alpha', _c.c_float), ('beta', _c.c_float), ('a_amax', _c.c_void_p * 2), ('b_amax', _c.c_void_p * 2)]
+                ('alpha', _c.c_float), ('beta', _c.c_float), ('a_amax', _c.c_void_p * 2), ('b_amax', _c.c_void_p * 2), ('direct', _c.c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/nabu_hip.h

@@ -837,6 +837,7 @@ static int pk_fill(PkArgs &p, const nabu_pk_gemm_desc *d, int *planes) {
   if (!d || d->size != sizeof(nabu_pk_gemm_desc)) return fail(NABU_EINVAL, "gemm_pk: bad descriptor size");
   *planes = d->planes;
   if (d->planes < 1 || d->planes > 3) return fail(NABU_EINVAL, "gemm_pk: planes must be 1, 2 or 3");
+  if (d->direct < 0 || d->direct > 2) return fail(NABU_EINVAL, "gemm_pk: direct must be 0, 1 or 2");
   if (d->planes == 2) {
     if (d->a_planes != 2 || d->b_planes != 2) return fail(NABU_EINVAL, "gemm_pk: an f16x3 product takes f16x3 operands (2 planes)");
     for (int b = 0; b < d->nbatch; ++b)
@@ -918,8 +919,20 @@ extern "C" int nabu_gemm_pk(const nabu_pk_gemm_desc *d, void *ws, size_t ws_byte
     p.partial = static_cast<float *>(ws);
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  static int var = -1;
-  if (var < 0) { const char *e = getenv("NABU_PK_VAR"); var = e ? atoi(e) : 1; }
+  static int var_env = -2;
+  if (var_env == -2) { const char *e = getenv("NABU_PK_VAR"); var_env = e ? atoi(e) : -1; }
+  // promoted accumulation unless the caller asks for the direct chain (planes = 2, d->direct) or the environment
+  // overrides (A/B measurements).  direct = 2 decides by rounding count: the direct chain rounds 3 times per 16 k,
+  // v_mfma_f32_32x32x2_f32 8 times — so it is taken when a workgroup's reduction here is at most twice as long as the
+  // exact-fp32 kernel's would be for the same product (its split-K policy: nabu_gemm_ws_bytes)
+  bool direct = planes == 2 && d->direct == 1;
+  if (planes == 2 && d->direct == 2) {
+    const long long K = (long long)p.nkb * 16;
+    const size_t w32 = nabu_gemm_ws_bytes(p.M, p.N, (int)K);
+    const long long ns32 = w32 ? (long long)(w32 / ((size_t)p.M * p.N * sizeof(float))) : 1;
+    direct = (long long)p.kb_per_split * 16 <= 2 * (K / (ns32 > 0 ? ns32 : 1));
+  }
+  const int var = var_env >= 0 ? var_env : (direct ? 0 : 1);
   const int grid = p.tiles_m * p.tiles_n * p.nbatch * p.nsplit;
 #define PK_LAUNCH(NP_, VAR_)                                                                                         \
   {                                                                                                                   \

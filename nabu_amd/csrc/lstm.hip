@@ -459,7 +459,7 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const in
         return e;
     nabu_pk_gemm_desc g = pk_desc(P, BT, 2 * G, nkb, pk + L.pk_x, rpBT, pk + L.pk_w, rpG, gates[0], G);
     g.C2[0] = gates[1]; g.n_split = G; g.bias = bias[0]; g.bias2 = bias[1];
-    if (P == 2) { g.a_amax[0] = ax; g.b_amax[0] = aw; }
+    if (P == 2) { g.a_amax[0] = ax; g.b_amax[0] = aw; g.direct = 2; }
     if (int e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream)) return e;
   } else if (L.bf16_fwd) {
     // bf16 copies: x once, Wx_d transposed ([4H, Dp]: the reduction index contiguous, zero-padded to a
@@ -621,7 +621,7 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
                                aw2, stream)))
             return e;
         nabu_pk_gemm_desc g = pk_desc(P, M, D, nkb2, pk + L.pk_dz, rpBT, pk + L.pk_w2, rpD, d_x, D);
-        if (P == 2) { g.a_amax[0] = adz; g.b_amax[0] = aw2; }
+        if (P == 2) { g.a_amax[0] = adz; g.b_amax[0] = aw2; g.direct = 2; }
         if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
       }
     }
@@ -630,7 +630,9 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
       if ((e = pk_pack_any(P, 1, x, D, M, D, pk + L.pk_xT, rpD, 0, 0, rpD, nkbT, 0, 0, axT, stream))) return e;
       nabu_pk_gemm_desc g = pk_desc(P, D, 2 * G, nkbT, pk + L.pk_xT, rpD, dzTp, rpG, dkern[0], G);
       g.C2[0] = dkern[1]; g.n_split = G;
-      if (P == 2) { g.a_amax[0] = axT; g.b_amax[0] = adzT; }
+      // direct = 2: the three plane products chained directly into the accumulators wherever that rounds less often
+      // than the exact-fp32 kernel would (gemm_pk.hip; 0.6-0.8 x its error at these shapes, tests/test_hip_gemm_pk.py)
+      if (P == 2) { g.a_amax[0] = axT; g.b_amax[0] = adzT; g.direct = 2; }
       if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
     }
     if ((parts & 2) && L.pk_rec) {
@@ -650,7 +652,7 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
       }
       nabu_pk_gemm_desc g = pk_desc(P, Mw, G, nkbT, pk + L.pk_hT[0], rpW, dzTp, rpG, dkern[0] + (size_t)(D - r0) * G, G);
       g.nbatch = 2; g.A[1] = pk + L.pk_hT[1]; g.B[1] = dzTp + (size_t)G * 32; g.C[1] = dkern[1] + (size_t)(D - r0) * G;
-      if (P == 2) { g.a_amax[0] = ahT[0]; g.a_amax[1] = ahT[1]; g.b_amax[0] = adzT; g.b_amax[1] = adzT + G; }
+      if (P == 2) { g.a_amax[0] = ahT[0]; g.a_amax[1] = ahT[1]; g.b_amax[0] = adzT; g.b_amax[1] = adzT + G; g.direct = 2; }
       if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
     }
   }

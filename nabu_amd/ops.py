@@ -132,7 +132,7 @@ def pk_pack(dst, src, transposed=False, row_off=0, kb_off=0, fill_rows=None, fil
 
 
 def gemm_pk(a, b, c, planes=None, alpha=1.0, beta=0.0, bias=None, c2=None, n_split=0, bias2=None, M=None, N=None,
-            nkb=None, a_ptrs=None, b_ptrs=None, cs=None, c2s=None, a_amax=None, b_amax=None):
+            nkb=None, a_ptrs=None, b_ptrs=None, cs=None, c2s=None, a_amax=None, b_amax=None, direct=False):
     """c[M,N] = alpha * a·b^T + beta*c + bias over packed operands (nabu_gemm_pk); batched form through
     a_ptrs / b_ptrs / cs (lists of raw pointers / tensors, <= 2 entries)"""
     L = _hip.lib()
@@ -154,6 +154,7 @@ def gemm_pk(a, b, c, planes=None, alpha=1.0, beta=0.0, bias=None, c2=None, n_spl
     d.ldc, d.n_split = cs[0].stride(0), n_split
     d.bias, d.bias2 = ptr(bias), ptr(bias2)
     d.alpha, d.beta = alpha, beta
+    d.direct = int(direct)            # 0 promoted accumulation, 1 direct chain, 2 by rounding count (nabu_hip.h)
     if planes == 2:
         for i in range(d.nbatch):
             d.a_amax[i] = (a_amax[i] if a_amax else a.amax.data_ptr())

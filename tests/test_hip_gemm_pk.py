@@ -248,7 +248,7 @@ def test_pack_f16_bit_exact_and_row_maxima(transposed, rows, K):
     assert np.abs(xs).max() < 2.0 ** 15
 
 
-def _product_f16(a, b, bound_a=None, bound_b=None, **kw):
+def _product_f16(a, b, bound_a=None, bound_b=None, direct=False, **kw):
     from nabu_amd import ops
     M, K = a.shape
     N = b.shape[0]
@@ -258,7 +258,7 @@ def _product_f16(a, b, bound_a=None, bound_b=None, **kw):
     c = torch.tensor(kw.pop('c0'), device='cuda') if kw.get('c0') is not None else torch.full((M, N), 7.0, device='cuda')
     kw.pop('c0', None)
     bias = kw.pop('bias', None)
-    ops.gemm_pk(pa, pb, c, 2, bias=torch.tensor(bias, device='cuda') if bias is not None else None, **kw)
+    ops.gemm_pk(pa, pb, c, 2, bias=torch.tensor(bias, device='cuda') if bias is not None else None, direct=direct, **kw)
     return c.cpu().numpy()
 
 
@@ -334,6 +334,37 @@ def test_gemm_pk_f16x3_error_not_above_exact_fp32(K, sigma):
     bar = 1.0 if sigma == 0.0 else 1.25
     assert np.sqrt((e3 ** 2).mean()) <= bar * np.sqrt((e32 ** 2).mean())
     assert e3.max() <= (1.0 if sigma == 0.0 else 1.5) * e32.max()
+
+
+@pytest.mark.parametrize('M,N,K', [(2048, 4096, 16000), (2048, 4096, 4000), (552, 2048, 32000), (512, 2048, 8000),
+                                   (16000, 4096, 2048), (4000, 4096, 2048), (8000, 2048, 8192)])
+def test_gemm_pk_f16x3_direct_chain_at_the_layer_shapes(M, N, K):
+    """the BLSTM layer asks for direct = 2: the three plane products chained directly into the accumulators where that
+    rounds less often than the exact-fp32 kernel would.  At the shapes of cfg2's weight-gradient, forward and
+    input-gradient products the rule picks the direct chain and the error against float64 stays <= 1.0 x the
+    exact-fp32 MFMA kernel's; at 512 x 512 x 2048 (the fp32 kernel splits K there, this one barely) it picks the
+    promoted sums"""
+    from nabu_amd import ops
+    rng = np.random.default_rng(M + K)
+    a = rng.normal(size=(M, K)).astype(np.float32)
+    b = rng.normal(size=(N, K)).astype(np.float32)
+    ref = a.astype(np.float64) @ b.astype(np.float64).T
+    got = _product_f16(a, b, direct=1)
+    assert np.array_equal(got, _product_f16(a, b, direct=2))          # the rule takes the direct chain here
+    c = torch.zeros(M, N, device='cuda')
+    ops.gemm(torch.tensor(a, device='cuda'), torch.tensor(b, device='cuda'), c, False, True, precision='f32')
+    e3, e32 = got - ref, c.cpu().numpy() - ref
+    r = np.sqrt((e3 ** 2).mean()) / np.sqrt((e32 ** 2).mean())
+    print('\n%d x %d x %d  direct f16x3 / exact fp32: rms %.3f max %.3f' % (M, N, K, r, np.abs(e3).max() / np.abs(e32).max()))
+    assert r <= 1.0 and np.abs(e3).max() <= 1.0 * np.abs(e32).max()
+
+
+def test_gemm_pk_f16x3_direct_rule_keeps_promoted_sums_where_fp32_splits_finer():
+    rng = np.random.default_rng(8)
+    a = rng.normal(size=(512, 2048)).astype(np.float32)
+    b = rng.normal(size=(512, 2048)).astype(np.float32)
+    auto, promoted, direct = (_product_f16(a, b, direct=m) for m in (2, 0, 1))
+    assert np.array_equal(auto, promoted) and not np.array_equal(auto, direct)
 
 
 def test_gemm_pk_f16x3_non_finite_inputs_stay_visible():
