@@ -1409,6 +1409,7 @@ struct SpWs {
   size_t tickets, fpart;   // fused skinny products: per-column-slice tickets (zeroed per call), partial tiles
   size_t status, persist, persist_bytes;   // persistent decoder kernel: status word (ws[0]), XCC table + exchange rings
   size_t dv8;                              // its d attention_v partial rows [B*8, U]
+  size_t dck8;                             // ... location-aware: conv kernel gradient partial rows [B*8, K*F]
   size_t ds_all, cf_all;                   // deferred attention gradients: d scores [L,B,Te], location features [L,B,Te,F]
   size_t dv16, dwf16;                      // ... and the partial rows of attn_param_grads_kernel [B*Sp, U], [B*Sp, F*U]
   // the decoder steps run as NS independent sub-batches on NS streams: per sub-batch slices of
@@ -1519,6 +1520,7 @@ static SpWs sp_ws(const nabu_speller_desc *d) {
     if (speller_persist_bwd_ws_bytes(pd) > s.persist_bytes) s.persist_bytes = speller_persist_bwd_ws_bytes(pd);
     s.persist = take(s.persist_bytes / 4 + 4);
     s.dv8 = take(speller_persist_bwd_ws_bytes(pd) ? B * 8 * U : 0);
+    s.dck8 = take((speller_persist_bwd_ws_bytes(pd) && d->kind == 1) ? B * 8 * K * F : 0);
     s.ds_all = take(L * B * Te);
     s.cf_all = take(d->kind == 1 ? L * B * Te * F : 0);
     s.dv16 = take(B * 16 * U);
@@ -1656,7 +1658,12 @@ static bool bwd_takes_persistent(const nabu_speller_desc *d, const SpWs &W) {
                            fused_ok(Bn, E + U, 4 * U, 4 * U, 0, 0) && (E + U) / 32 <= 1024;
   SpPersistDesc pd = {B, d->L, U, E, d->Te, d->C};
   pd.kind = d->kind; pd.K = d->K; pd.F = d->F;
-  return fuse_shapes && d->kind == 0 && d->prob_fn == 0 && W.persist_bytes > 0 && speller_persist_bwd_ok(pd);
+  // (location-aware attention: the kernel leaves d keys / d attention_v / d conv_proj to attn_param_grads_kernel)
+  if (d->kind == 1) {
+    const nabu_attn_desc adb = sub_attn_desc(d, B);
+    if (!env_int("NABU_SPELLER_DEFER", 1) || attn_defer_slices(&adb) <= 0) return false;
+  }
+  return fuse_shapes && (d->kind == 0 || d->kind == 1) && d->prob_fn == 0 && W.persist_bytes > 0 && speller_persist_bwd_ok(pd);
 }
 extern "C" int nabu_speller_uses_persistent(const nabu_speller_desc *d, int backward) {
   if (check_sp(d)) return 0;
@@ -1886,7 +1893,9 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   if (persist)
     SP_TRY(speller_persist_bwd(pd, dec_len, enc_len, w + W.kxhT, p->query_kernel, p->attention_v, r + R.keys, values,
                                r + R.acts[0], r + R.Cs[0], r + R.q, r + R.ctx, r + R.align, dH, dCtx, dq, w + W.dz[0],
-                               dkeys, w + W.dv8, reinterpret_cast<int *>(w + W.status), w + W.persist, W.persist_bytes, s));
+                               dkeys, w + W.dv8, reinterpret_cast<int *>(w + W.status), w + W.persist, W.persist_bytes, s,
+                               p->conv_kernel, p->conv_proj, w + W.ds_all, d->kind == 1 ? w + W.cf_all : nullptr,
+                               d->kind == 1 ? w + W.dck8 : nullptr));
   if (!persist) {
     SP_TRY(sub_streams(NS, s, &ss));
     SP_TRY(sub_fork(ss));
@@ -1894,7 +1903,9 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   // d keys / d attention_v / d conv_proj of all steps in ONE launch after the chain (attn_param_grads_kernel)
   nabu_attn_desc adb = adn;      // the whole batch
   adb.B = B;
-  const int Sp = (!persist && env_int("NABU_SPELLER_DEFER", 1)) ? attn_defer_slices(&adb) : 0;
+  // (the persistent kernel accumulates them itself for vanilla attention and leaves them to that launch for
+  // location-aware attention)
+  const int Sp = ((!persist || d->kind == 1) && env_int("NABU_SPELLER_DEFER", 1)) ? attn_defer_slices(&adb) : 0;
   const bool defer = Sp > 0;
   unsigned *atk = env_int("NABU_SPELLER_ATTN_FUSED", 1) ? reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)NS * 1024 : nullptr;
   auto bwd_chain = [&](int sub) -> int {
@@ -2021,13 +2032,14 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
     }
     SP_TRY(nabu_colsum_f32(BL, 4 * U, dzn, 4 * U, 0.f, g->lstm_bias[n], gw, gwb, stream));
   }
-  if (persist)    SP_TRY(nabu_colsum_f32(B * 8, U, w + W.dv8, U, 0.f, g->attention_v, gw, gwb, stream));
-  else if (defer) SP_TRY(nabu_colsum_f32(B * Sp, U, w + W.dv16, U, 0.f, g->attention_v, gw, gwb, stream));
+  if (persist && !defer) SP_TRY(nabu_colsum_f32(B * 8, U, w + W.dv8, U, 0.f, g->attention_v, gw, gwb, stream));
+  else if (defer)        SP_TRY(nabu_colsum_f32(B * Sp, U, w + W.dv16, U, 0.f, g->attention_v, gw, gwb, stream));
   else            SP_TRY(nabu_colsum_f32(B * S, U, w + W.dv, U, 0.f, g->attention_v, gw, gwb, stream));
   if (d->kind == 1) {
     if (defer) SP_TRY(nabu_colsum_f32(B * Sp, F * U, w + W.dwf16, F * U, 0.f, g->conv_proj, gw, gwb, stream));
     else       SP_TRY(nabu_colsum_f32(B * S, F * U, w + W.dwf, F * U, 0.f, g->conv_proj, gw, gwb, stream));
-    SP_TRY(nabu_colsum_f32(B, K * F, w + W.dck, K * F, 0.f, g->conv_kernel, gw, gwb, stream));
+    if (persist) SP_TRY(nabu_colsum_f32(B * 8, K * F, w + W.dck8, K * F, 0.f, g->conv_kernel, gw, gwb, stream));
+    else         SP_TRY(nabu_colsum_f32(B, K * F, w + W.dck, K * F, 0.f, g->conv_kernel, gw, gwb, stream));
   }
   // keys = values·Wmem ; context_t = align_t^T·values
   SP_TRY(mm(true, false, E, U, B * Te, values, E, dkeys, U, 0.f, g->memory_kernel, U, nullptr, gw, gwb, stream));

@@ -38,7 +38,8 @@ int speller_persist_fwd(const SpPersistDesc &d, const int32_t *dec_len, const in
 // (scheduled sampling: out_kernel [(U+E), C], out_bias [C] = the output projection; ids_used [L,B] = `ids`, whose
 // rows 1.. the kernel overwrites with the inputs it actually used)
 
-// Backward pass of the step loop (same shapes; the caller has run the output projection's gradient into dH / dCtx).
+// Backward pass of the step loop (same shapes, B = 32 or 64; the caller has run the output projection's gradient into
+// dH / dCtx).
 // kxhT [4U, E+U]: transposed dense rows of the cell kernel (k = gate-major column).  Writes dq [L,B,U], dz [L,B,4U]
 // (gate-major), dkeys [B,Te,U] (overwritten), dv_part [B*8,U] (one row per utterance and frame slice), and adds the
 // carried d context into dCtx [L,B,E].
@@ -48,6 +49,11 @@ int speller_persist_bwd(const SpPersistDesc &d, const int32_t *dec_len, const in
                         const float *wq, const float *v, const float *keys, const float *values, const float *acts,
                         const float *Cs, const float *q, const float *ctx, const float *align, const float *dH, float *dCtx,
                         float *dq, float *dz, float *dkeys, float *dv_part, int *status, void *ws, size_t ws_bytes,
-                        hipStream_t stream);
+                        hipStream_t stream, const float *conv_kernel = nullptr, const float *conv_proj = nullptr,
+                        float *ds_all = nullptr, float *cf_all = nullptr, float *dck_part = nullptr);
+// location-aware attention (d.kind = 1): conv_kernel [K, F], conv_proj [F, U]; the kernel then writes the steps'
+// d scores ds_all [L, B, Te] and location features cf_all [L, B, Te, F] — the inputs of attn_param_grads_kernel
+// (speller.hip), which produces d keys / d attention_v / d conv_proj; dkeys and dv_part are NOT written — and the
+// conv kernel's gradient as one partial row per (utterance, frame slice): dck_part [B * 8, K * F].
 
 }  // namespace nabu

@@ -805,6 +805,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
 // pieces that all 32 workgroups published after reading what it now resets).
 struct BArgs {
   int L, U, E, Te, FS;
+  int Bt, b0;              // rows of the whole batch (strides of the time-major tensors); first row of this launch
+  // location-aware attention (LOCB): filter taps, filters; values slice read from L2 per step; conv kernel [K][F],
+  // feature projection [F][U]; outputs for attn_param_grads_kernel (d scores [L][B][Te], location features
+  // [L][B][Te][F]) and the conv kernel's gradient, one partial row per (utterance, slice) [B*S][K*F]
+  int K, F, stream_vals;
+  const float *ck, *wf;
+  float *ds_all, *cf_all, *dck_part;
   const int32_t *dec_len, *enc_len;
   const float *kxhT;       // [4U][E+U] (k = gate-major column of the cell kernel)
   const float *wq, *v, *keys, *values;
@@ -831,6 +838,13 @@ struct BArgs {
     }                                                                                                       \
   } while (0)
 
+// NABU_PERSIST_DEBUG bit 2: wall-clock stamps of the phases of step L/2 in block 0 (status[48 + i], 10 ns ticks)
+#define SPB_STAMP(i)                                                               \
+  do {                                                                             \
+    if ((p.dbg & 4) && blockIdx.x == 0 && tid == 0 && n == L / 2)                  \
+      p.status[48 + (i)] = (int)wall_clock64();                                    \
+  } while (0)
+
 struct SpinB {
   unsigned long long t0;
   unsigned n;
@@ -846,7 +860,19 @@ struct SpinB {
 
 // NSETC sets of NKQC instructions per wave (weight registers per lane: NSETC * NKQC); KS = k phases in the 16 blocks
 // of an instruction (4: a set is 16 columns, 16: a set is 4 columns); DKR = frames per thread in D1
-template <int NSETC, int NKQC, int KS, int DKR, bool DROP>
+// LOCB: location-aware attention (attention.py:186-292).  The score takes conv1d(a_{t-1})·conv_proj, so D1 also
+//   * recomputes the location features of its frames from the saved alignments of step t-1,
+//   * produces d features[f, c] = sum_u d[f, u] conv_proj[c, u] and hands them to the other slices of its utterance
+//     through a fifth ring: step t-1 needs d a_{t-1}[j] += sum_{f,c} d features_t[f, c] ck[j - f + pb, c] for ITS
+//     frames j (the filters reach (K-1)/2 frames into the neighbouring slices), and the softmax backward of step t-1
+//     needs sum_j a_{t-1}[j] (that carry)[j] over ALL frames = sum_{f,c} d features_t[f, c] features_t[f, c]: every
+//     slice appends its part of that sum to its ring piece, nobody needs the other slices' carries;
+//   * accumulates the conv kernel's gradient of its frames in registers (K F / 256 per thread) for the whole launch;
+//   * leaves d keys / d attention_v / d conv_proj to attn_param_grads_kernel (speller.hip), for which it saves the
+//     step's d scores and location features as the step chain does — no per-frame accumulators here.
+//   Thread map of the score backward: waves over frames, lanes over 16-byte unit groups (U <= 512), d features by
+//   wave reductions.
+template <int NSETC, int NKQC, int KS, int DKR, bool DROP, bool LOCB>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void speller_persist_bwd_kernel(BArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int flag[2];
@@ -856,8 +882,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
   const int KB = 4 * U, KBW = KB / NW;          // reduction index of D3 (gate columns), range of a wave
   const int NC = (E + U) / P;                  // my output columns of D3
   const int UW = U / P, UB = U / S;            // my units (D2); my dq block (D1b)
-  const int B = NU * R;
+  const int B = p.Bt;
   constexpr int CGS = 16 / KS;                 // column groups of 4 per instruction
+  const int Kc = LOCB ? p.K : 0, Fc = LOCB ? p.F : 0, pbc = (Kc - 1) / 2, TeP = S * FS, K4 = (Kc + 3) & ~3;
+  const int FF = FS * Fc, PF = (FF + 4) & ~3;  // d features of a slice; its ring piece (+ the partial sum, padded)
   constexpr int KR = NSETC * NKQC;
   const int NSET = NC / (4 * CGS);             // <= NSETC
 
@@ -885,41 +913,64 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
 
   // rings: carry [R][E+U], dq partials [R*S][U], dq [R][U], dz [R][4U]
   const unsigned kb = (unsigned)(R * (E + U) * 4), ab = (unsigned)(R * S * U * 4), qb = (unsigned)(R * U * 4), zb = (unsigned)(R * 4 * U * 4);
-  const size_t unit_bytes = (size_t)RING * (kb + ab + qb + zb);
+  const unsigned fbz = LOCB ? (unsigned)(R * S * PF * 4) : 0u;      // (LOCB) d features [R][S][PF]
+  const size_t unit_bytes = (size_t)RING * (kb + ab + qb + zb + fbz);
   char *ub = p.xbuf + (size_t)unit * unit_bytes;
   __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)(RING * kb), 0x00020000);
   __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(ub + (size_t)RING * kb, 0, (int)(RING * ab), 0x00020000);
   __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(ub + (size_t)RING * (kb + ab), 0, (int)(RING * qb), 0x00020000);
   __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(ub + (size_t)RING * (kb + ab + qb), 0, (int)(RING * zb), 0x00020000);
+  __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(ub + (size_t)RING * (kb + ab + qb + zb), 0, (int)(RING * fbz), 0x00020000);
   const u32x4 sent4 = {SENT, SENT, SENT, SENT};
 
   // LDS
+  const bool svals = LOCB && p.stream_vals;           // the values slice does not fit next to the keys: read from L2
   float *keys_s = smem;                               // [FS][U]
-  float *vals_s = keys_s + (size_t)FS * U;            // [FS][E]
-  float *wqr_s = vals_s + (size_t)FS * E;             // [UW][U + 4]: Wq rows of my units
+  float *vals_s = keys_s + (size_t)FS * U;            // [FS][E] (absent when streamed)
+  float *wqr_s = vals_s + (svals ? 0 : (size_t)FS * E);   // [UW][U + 4]: Wq rows of my units
   float *v_s = wqr_s + (size_t)UW * (U + 4);          // [U]
-  float *scr = v_s + U;                               // scratch
+  // (LOCB) feature projection [F][U], conv kernel [F][K4], padded alignments of step t-1 [pb + S*FS + K + 8], features
+  // and d features of my frames [FS][F], my frames' carry per filter [FS][F], every slice's d features [S*FS][F] and
+  // partial sums [S]
+  float *wf_s = v_s + U;
+  float *ck_s = wf_s + (size_t)Fc * U;
+  float *alp_s = ck_s + (size_t)K4 * Fc;
+  float *cf_s = alp_s + (LOCB ? ((pbc + TeP + Kc + 8) & ~3) : 0);
+  float *dcf_s = cf_s + ((FF + 3) & ~3);
+  float *cpart_s = dcf_s + ((FF + 3) & ~3);
+  float *dcfa_s = cpart_s + ((FF + 3) & ~3);
+  float *rpart_s = dcfa_s + (size_t)TeP * Fc;
+  float *scr = rpart_s + (LOCB ? 2 * S : 0);          // scratch
   // D3: my wave stages dz[4 rows][half of its k range] (two halves);  D1: dcx [E], red [NW] + da/ds [FS], dqh [2][U]
   // D1b: blk [S][UB];  D2: dqs [R][U + 4], chs [R][UW], qred [NW][64][4]
   const int HK = KBW / 2;
   float *Zs = scr + (size_t)w * R * HK;
   float *dcx = scr;
   float *redw = scr + E;                              // [NW] + [FS] + [FS]
-  float *dqh = redw + 64 + 2 * 64;                    // [2][U]
+  float *dqh = redw + 64 + 2 * 64;                    // [2][U] ([NW][U]: LOCB)
   float *blk = scr;
   float *dqs = scr;
   float *chs = dqs + R * (U + 4);
   float *qred = chs + 64;
   float *ored = scr + (size_t)NW * R * HK;            // D3 output tiles [NW][NC][4] (behind the staging)
 
-  const int ci = slot / S, cs = slot % S, cbg = unit * R + ci, f0 = cs * FS;
+  const int ci = slot / S, cs = slot % S, cbg = p.b0 + unit * R + ci, f0 = cs * FS;
   for (int i = tid; i < FS * U; i += NT) {
     const int f = f0 + i / U;
     keys_s[i] = f < Te ? p.keys[((size_t)cbg * Te + f) * U + i % U] : 0.f;
   }
-  for (int i = tid; i < FS * E; i += NT) {
-    const int f = f0 + i / E;
-    vals_s[i] = f < Te ? p.values[((size_t)cbg * Te + f) * E + i % E] : 0.f;
+  if (!svals)
+    for (int i = tid; i < FS * E; i += NT) {
+      const int f = f0 + i / E;
+      vals_s[i] = f < Te ? p.values[((size_t)cbg * Te + f) * E + i % E] : 0.f;
+    }
+  if (LOCB) {
+    for (int i = tid; i < Fc * U; i += NT) wf_s[i] = p.wf[i];
+    for (int i = tid; i < K4 * Fc; i += NT) {            // [filter][tap], taps padded with zeros
+      const int j = i / K4, d = i % K4;
+      ck_s[i] = d < Kc ? p.ck[d * Fc + j] : 0.f;
+    }
+    for (int i = tid; i < ((pbc + TeP + Kc + 8) & ~3); i += NT) alp_s[i] = 0.f;       // the pads stay zero
   }
   for (int i = tid; i < UW * U; i += NT) wqr_s[(i / U) * (U + 4) + i % U] = p.wq[(size_t)(UW * slot + i / U) * U + i % U];
   for (int i = tid; i < U; i += NT) v_s[i] = p.v[i];
@@ -938,7 +989,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
   // D2 identities: gate thread (row, col = 4*unit + gate)
   const int grow = tid >> 6, gcol = tid & 63, gu = gcol >> 2, gg = gcol & 3;
   const bool gate_thr = gcol < 4 * UW;
-  const int gb = unit * R + grow, gunit = UW * slot + gu;
+  const int gb = p.b0 + unit * R + grow, gunit = UW * slot + gu;
   const int glen = p.dec_len[gb];
   float dc_state = 0.f;
   // D1 identities: thread = (4 units uq, frame half fh)
@@ -951,6 +1002,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
 #pragma unroll
   for (int i = 0; i < DKR; ++i) dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 dvacc = {0.f, 0.f, 0.f, 0.f};
+  float dck_acc[4] = {0.f, 0.f, 0.f, 0.f};           // (LOCB) conv kernel gradient: elements tid + NT * m of [K][F]
   float dq_last = 0.f, dz_last = 0.f;
   f32x4 dcx_last = {0.f, 0.f, 0.f, 0.f};
   auto save_step = [&](int ts) {
@@ -964,6 +1016,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
     const int t = L - 1 - n;
     const unsigned so = (unsigned)(n % RING), sp = (unsigned)((n + RING - 1) % RING), sr = (unsigned)((n + RING - 2) % RING);
     const bool frozen = t >= clen;
+    SPB_STAMP(0);
     // =========================== D1: attention backward ===========================
     {
       // d context of (step t, my utterance) and its product with the context (softmax backward's sum)
@@ -990,9 +1043,175 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
       float rp = dc4.x * cx4.x + dc4.y * cx4.y + dc4.z * cx4.z + dc4.w * cx4.w;
       rp = wsum(rp);
       if (lane == 0) redw[w] = rp;
+      if (LOCB) {
+        if (n > 0) {
+          // d features of step t+1, every slice of my utterance (+ their partial sums): S * PF / 4 pieces, <= 2 per thread
+          const int NPC = S * PF / 4;
+          u32x4 v[2];
+          unsigned off[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) off[j] = sp * fbz + (unsigned)((ci * S * PF + 4 * min(j * NT + tid, NPC - 1)) * 4);
+          SpinB g;
+          g.start();
+          for (;;) {
+            v[0] = xld4(rf, off[0]);
+            v[1] = xld4(rf, off[1]);
+            if (__all(!has_sentinel(v[0]) && !has_sentinel(v[1]))) break;
+            if (g.expired(p)) { SPB_TIMEOUT(); break; }
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (j * NT + tid < NPC) {
+              const int qi = j * NT + tid, ii = 4 * qi / PF, e0 = 4 * qi % PF;     // slice, element inside its piece
+              const f32x4 fv = __builtin_bit_cast(f32x4, v[j]);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const int e = e0 + k;
+                if (e < FF) dcfa_s[ii * FF + e] = fv[k];
+                else if (e == FF) rpart_s[ii] = fv[k];
+              }
+            }
+        }
+        // alignments of step t-1 (what this step's location features were computed from; zeros for t = 0)
+        if (tid < TeP) alp_s[pbc + tid] = (tid < Te) ? p.align[((size_t)t * B + cbg) * Te + tid] : 0.f;
+      }
     }
+    SPB_STAMP(1);
     __syncthreads();
     if (flag[0]) return;
+    if constexpr (LOCB) {
+      // location features of my frames (as in the forward kernel) and, per filter, my frames' share of the carry
+      // d a_t[j] = sum_{f', c} d features_{t+1}[f', c] ck[j - f' + pb][c]
+      for (int i = tid; i < FF; i += NT) {
+        const int f = i / Fc, c = i % Fc;
+        const float *a = alp_s + f0 + f;
+        const f32x4 *c4 = reinterpret_cast<const f32x4 *>(ck_s + (size_t)c * K4);
+        f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+        for (int d = 0; d < K4; d += 4) {
+          const f32x4 cc = c4[d / 4];
+          acc4.x = fmaf(a[d], cc.x, acc4.x);
+          acc4.y = fmaf(a[d + 1], cc.y, acc4.y);
+          acc4.z = fmaf(a[d + 2], cc.z, acc4.z);
+          acc4.w = fmaf(a[d + 3], cc.w, acc4.w);
+        }
+        const float feat = (acc4.x + acc4.y) + (acc4.z + acc4.w);
+        cf_s[i] = feat;
+        if (f0 + f < Te) p.cf_all[(((size_t)t * B + cbg) * Te + f0 + f) * Fc + c] = feat;
+        float cp = 0.f;
+        if (n > 0) {
+          const int j = f0 + f + pbc;                    // f' = j - d
+          const int dlo = max(0, j - (TeP - 1)), dhi = min(Kc - 1, j);
+          const float *cw = ck_s + (size_t)c * K4;
+          for (int d = dlo; d <= dhi; ++d) cp = fmaf(dcfa_s[(j - d) * Fc + c], cw[d], cp);
+        }
+        cpart_s[i] = cp;
+      }
+      SPB_STAMP(2);
+      __syncthreads();
+      {
+        float r = (redw[0] + redw[1]) + (redw[2] + redw[3]);
+        if (n > 0)
+#pragma unroll
+          for (int i = 0; i < S; ++i) r += rpart_s[i];
+        // d alignment of my frames: wave w takes frames w, w + NW, ...
+        for (int f = w; f < FS; f += NW) {
+          f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+          const bool live = f0 + f < cn && !frozen;
+          if (live) {
+            const float *vr = svals ? p.values + ((size_t)cbg * Te + f0 + f) * E : vals_s + (size_t)f * E;
+            for (int e4 = lane; e4 < E / 4; e4 += 64)
+              a4 += *reinterpret_cast<const f32x4 *>(dcx + 4 * e4) * *reinterpret_cast<const f32x4 *>(vr + 4 * e4);
+          }
+          float da = wsum((a4.x + a4.y) + (a4.z + a4.w));
+          if (lane == 0) {
+            for (int c = 0; c < Fc; ++c) da += cpart_s[f * Fc + c];
+            const float a = live ? p.align[((size_t)(t + 1) * B + cbg) * Te + f0 + f] : 0.f;
+            const float g = a * (da - r);          // d score
+            redw[64 + f] = g;
+            if (f0 + f < Te) p.ds_all[((size_t)t * B + cbg) * Te + f0 + f] = g;
+          }
+        }
+      }
+      SPB_STAMP(3);
+      __syncthreads();
+      {
+        // through v . tanh(keys + q + features . conv_proj): waves over frames, lanes over 16-byte unit groups
+        constexpr int MJ = 2, MF = 12;             // U / 4 <= 128 groups; filters (host check)
+        f32x4 dq_l[MJ], qq[MJ], vv[MJ];
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+          const int u4 = lane + 64 * j;
+          dq_l[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          qq[j] = u4 < U4 ? *reinterpret_cast<const f32x4 *>(p.q + ((size_t)t * B + cbg) * U + 4 * u4) : dq_l[j];
+          vv[j] = u4 < U4 ? *reinterpret_cast<const f32x4 *>(v_s + 4 * u4) : dq_l[j];
+        }
+        for (int f = w; f < FS; f += NW) {
+          const float g = redw[64 + f];
+          float dcf_l[MF];
+#pragma unroll
+          for (int c = 0; c < MF; ++c) dcf_l[c] = 0.f;
+#pragma unroll
+          for (int j = 0; j < MJ; ++j) {
+            const int u4 = lane + 64 * j;
+            if (u4 < U4) {
+              f32x4 x = *reinterpret_cast<const f32x4 *>(keys_s + (size_t)f * U + 4 * u4) + qq[j];
+              for (int c = 0; c < Fc; ++c) x += cf_s[f * Fc + c] * *reinterpret_cast<const f32x4 *>(wf_s + (size_t)c * U + 4 * u4);
+              f32x4 th, dd;
+              th.x = ftanh(x.x); th.y = ftanh(x.y); th.z = ftanh(x.z); th.w = ftanh(x.w);
+              dd.x = g * vv[j].x * (1.f - th.x * th.x); dd.y = g * vv[j].y * (1.f - th.y * th.y);
+              dd.z = g * vv[j].z * (1.f - th.z * th.z); dd.w = g * vv[j].w * (1.f - th.w * th.w);
+              dq_l[j] += dd;
+#pragma unroll
+              for (int c = 0; c < MF; ++c)
+                if (c < Fc) {
+                  const f32x4 wc = *reinterpret_cast<const f32x4 *>(wf_s + (size_t)c * U + 4 * u4);
+                  dcf_l[c] = fmaf(dd.x, wc.x, fmaf(dd.y, wc.y, fmaf(dd.z, wc.z, fmaf(dd.w, wc.w, dcf_l[c]))));
+                }
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < MF; ++c)
+            if (c < Fc) {
+              const float tot = wsum(dcf_l[c]);
+              if (lane == 0) dcf_s[f * Fc + c] = tot;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+          const int u4 = lane + 64 * j;
+          if (u4 < U4) *reinterpret_cast<f32x4 *>(dqh + (size_t)w * U + 4 * u4) = dq_l[j];
+        }
+      }
+      SPB_STAMP(4);
+      __syncthreads();
+      if (w == 0) {
+        // my ring piece: d features of my frames + my part of sum_{f,c} d features . features
+        float rp = 0.f;
+        for (int i = lane; i < FF; i += 64) rp = fmaf(dcf_s[i], cf_s[i], rp);
+        rp = wsum(rp);
+        for (int q4 = lane; q4 < PF / 4; q4 += 64) {
+          f32x4 o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int e = 4 * q4 + k;
+            o[k] = e < FF ? dcf_s[e] : (e == FF ? rp : 0.f);
+          }
+          xst4(__builtin_bit_cast(u32x4, o), rf, so * fbz + (unsigned)(((ci * S + cs) * PF + 4 * q4) * 4), coloc);
+          xst4(sent4, rf, n >= 2 ? sr * fbz + (unsigned)(((ci * S + cs) * PF + 4 * q4) * 4) : OOB, coloc);
+        }
+      }
+      // conv kernel's gradient of my frames: d ck[d][c] += sum_f d features[f][c] a_{t-1}[f0 + f + d - pb]
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int i = tid + NT * m;
+        if (i < Kc * Fc) {
+          const int d = i / Fc, c = i % Fc;
+          float acc = dck_acc[m];
+          for (int f = 0; f < FS; ++f) acc = fmaf(dcf_s[f * Fc + c], alp_s[f0 + f + d], acc);
+          dck_acc[m] = acc;
+        }
+      }
+    } else {
     {
       const float r = (redw[0] + redw[1]) + (redw[2] + redw[3]);
       // d alignment of my frames: wave w takes frames w, w + NW, ...
@@ -1033,12 +1252,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
       }
     }
     __syncthreads();
+    }
     if (tid < U4) {
+      const int NH = LOCB ? NW : NFH;
       f32x4 s4 = *reinterpret_cast<const f32x4 *>(dqh + 4 * tid);
-      for (int h = 1; h < NFH; ++h) s4 += *reinterpret_cast<const f32x4 *>(dqh + (size_t)h * U + 4 * tid);
+      for (int h = 1; h < NH; ++h) s4 += *reinterpret_cast<const f32x4 *>(dqh + (size_t)h * U + 4 * tid);
       xst4(__builtin_bit_cast(u32x4, s4), ra, so * ab + (unsigned)(((ci * S + cs) * U + 4 * tid) * 4), coloc);
       xst4(sent4, ra, n >= 2 ? sr * ab + (unsigned)(((ci * S + cs) * U + 4 * tid) * 4) : OOB, coloc);
     }
+    SPB_STAMP(5);
     // =========================== D1b: my block of dq ===========================
     {
       const int PC = UB / 4, NPC = S * PC;            // <= NT (host check)
@@ -1066,6 +1288,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
       xst1(SENT, rq, (tid < UB && n >= 2) ? sr * qb + (unsigned)((ci * U + cs * UB + tid) * 4) : OOB, coloc);
     }
     __syncthreads();          // blk read: the scratch is free for dq / carry
+    SPB_STAMP(6);
     // =========================== D2: dq . Wq^T, cell backward ===================
     {
       const int NPC = R * U / 4;                       // <= 2 * NT
@@ -1098,6 +1321,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
         d[0] = fc.x; d[1] = fc.y; d[2] = fc.z; d[3] = fc.w;
       }
     }
+    SPB_STAMP(7);
     __syncthreads();
     if (flag[0]) return;
     {
@@ -1156,6 +1380,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
       xst1(SENT, rz, (gate_thr && n >= 2) ? sr * zb + (unsigned)((grow * 4 * U + gg * U + gunit) * 4) : OOB, coloc);
     }
     __syncthreads();          // dqs / qred read: the scratch is free for the staged dz
+    SPB_STAMP(8);
     // =========================== D3: dz . [Kx^T | Kh^T] ==========================
     f32x4 acc[NSETC];
 #pragma unroll
@@ -1226,6 +1451,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
         }
       }
     }
+    SPB_STAMP(9);
     __syncthreads();
     if (flag[0]) return;
     if (t > 0) {
@@ -1238,9 +1464,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
       xst1(fbits(s), rk, pub ? so * kb + (unsigned)((row * (E + U) + NC * slot + col) * 4) : OOB, coloc);
       xst1(SENT, rk, (pub && n >= 2) ? sr * kb + (unsigned)((row * (E + U) + NC * slot + col) * 4) : OOB, coloc);
     }
+    SPB_STAMP(10);
     __syncthreads();
   }
   save_step(0);
+  if constexpr (LOCB) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int i = tid + NT * m;
+      if (i < Kc * Fc) p.dck_part[((size_t)cbg * S + cs) * Kc * Fc + i] = dck_acc[m];
+    }
+    return;
+  }
   // d keys of my frames, d v partial row of (utterance, slice)
   if (fh < NFH) {
 #pragma unroll
@@ -1346,20 +1581,32 @@ static int bwd_frames_per_thread(const SpPersistDesc &d) {
   if (nfh < 1) nfh = 1;
   return (FS + nfh - 1) / nfh;
 }
-static size_t bwd_lds_floats(const SpPersistDesc &d) {
+static size_t bwd_loc_floats(const SpPersistDesc &d, int FS) {      // (LOCB) the arrays between v_s and the scratch
+  if (d.kind != 1) return 0;
+  const size_t pb = (d.K - 1) / 2, TeP = (size_t)S * FS, FF = (size_t)FS * d.F, FFp = (FF + 3) & ~(size_t)3;
+  return (size_t)d.F * d.U + (size_t)((d.K + 3) & ~3) * d.F + ((pb + TeP + d.K + 8) & ~(size_t)3) + 3 * FFp + TeP * d.F + 2 * S;
+}
+static size_t bwd_lds_floats(const SpPersistDesc &d, bool stream) {
   const int FS = frames_per_slice(d), UW = d.U / P, NC = (d.E + d.U) / P, KBW = 4 * d.U / NW;
   int nfh = NT / (d.U / 4);
   if (nfh > FS) nfh = FS;
   if (nfh < 1) nfh = 1;
+  if (d.kind == 1) nfh = NW;                       // the score backward's partial dq rows: one per wave
   size_t scr = (size_t)NW * R * (KBW / 2) + (size_t)NW * NC * 4;
   const size_t d1 = (size_t)d.E + 192 + (size_t)nfh * d.U, d1b = d.U, d2 = (size_t)R * (d.U + 4) + 64 + NW * 64;
   if (scr < d1) scr = d1;
   if (scr < d1b) scr = d1b;
   if (scr < d2) scr = d2;
-  return (size_t)FS * d.U + (size_t)FS * d.E + (size_t)UW * (d.U + 4) + d.U + scr + 64;
+  return (size_t)FS * d.U + (stream ? 0 : (size_t)FS * d.E) + (size_t)UW * (d.U + 4) + d.U + bwd_loc_floats(d, FS) + scr + 64;
+}
+// location-aware attention: the values slice is read from L2 in every step when it does not fit next to the keys
+static bool bwd_stream_values(const SpPersistDesc &d) {
+  if (d.kind != 1) return false;
+  if (const char *e = getenv("NABU_SPELLER_STREAM_VALUES")) return atoi(e) != 0;     // (tests: force the streamed path)
+  return bwd_lds_floats(d, false) * 4 > 160 * 1024 - 512;
 }
 static bool bwd_shape_ok(const SpPersistDesc &d) {
-  if (!shape_ok(d) || d.kind != 0 || d.B != NU * R) return false;
+  if (!shape_ok(d)) return false;
   const int NC = (d.E + d.U) / P, KBW = 4 * d.U / NW;
   if ((d.E + d.U) % P || NC % 4 || R * NC > NT) return false;
   if (bwd_ks4(d)) {
@@ -1368,16 +1615,31 @@ static bool bwd_shape_ok(const SpPersistDesc &d) {
     if (NC / 4 > 3 || KBW % 32 || KBW / 16 > 8) return false;
   }
   if (d.E / 4 > NT || d.U / 4 > NT || (d.U / S) % 4) return false;
-  if (bwd_frames_per_thread(d) > 8) return false;
-  return bwd_lds_floats(d) * 4 <= 160 * 1024 - 512;
+  if (d.kind == 0 && bwd_frames_per_thread(d) > 8) return false;
+  if (d.kind == 1) {
+    const int FS = frames_per_slice(d), PF = (FS * d.F + 4) & ~3;
+    // unit groups of a lane, filters in registers, conv-kernel elements per thread, ring pieces per thread
+    if (d.U / 4 > 128 || d.F > 12 || d.K * d.F > 4 * NT || S * PF / 4 > 2 * NT || S * FS > NT) return false;
+  }
+  return bwd_lds_floats(d, bwd_stream_values(d)) * 4 <= 160 * 1024 - 512;
 }
 static size_t bwd_ring_bytes(const SpPersistDesc &d) {
   const size_t kb = (size_t)R * (d.E + d.U) * 4, ab = (size_t)R * S * d.U * 4, qb = (size_t)R * d.U * 4, zb = (size_t)R * 4 * d.U * 4;
-  return (size_t)NU * RING * (kb + ab + qb + zb);
+  const size_t fb = d.kind == 1 ? (size_t)R * S * ((frames_per_slice(d) * d.F + 4) & ~3) * 4 : 0;
+  return (size_t)NU * RING * (kb + ab + qb + zb + fb);
 }
 bool speller_persist_bwd_ok(const SpPersistDesc &d) {
   const char *env = getenv("NABU_SPELLER_PERSIST_BWD");
   if (env && !atoi(env)) return false;
+  if (d.kind == 1) {
+    // NABU_SPELLER_PERSIST_BWD_LOC: 0 = step chain, 1 (default) = persistent when the values slice is LDS-resident,
+    // 2 = also when it has to be read from L2 in every step.  Measured: cfg3's geometry with 10 filters of 101 taps
+    // 31.3 ms per training step against 32.3 on the chain; cfg5's geometry (25 frames per slice, values streamed)
+    // 71 us per decoder step and 32 rows = 72.0 ms per training step against 65.3 on the four-stream chain.
+    const char *e2 = getenv("NABU_SPELLER_PERSIST_BWD_LOC");
+    const int mode = e2 ? atoi(e2) : 1;
+    if (mode <= 0 || !bwd_shape_ok(d) || (mode == 1 && bwd_stream_values(d))) return false;
+  }
   return bwd_shape_ok(d) && device_fits();
 }
 size_t speller_persist_bwd_ws_bytes(const SpPersistDesc &d) { return bwd_shape_ok(d) ? TABLE_BYTES + bwd_ring_bytes(d) : 0; }
@@ -1386,11 +1648,17 @@ int speller_persist_bwd(const SpPersistDesc &d, const int32_t *dec_len, const in
                         const float *wq, const float *v, const float *keys, const float *values, const float *acts,
                         const float *Cs, const float *q, const float *ctx, const float *align, const float *dH, float *dCtx,
                         float *dq, float *dz, float *dkeys, float *dv_part, int *status, void *ws, size_t ws_bytes,
-                        hipStream_t stream) {
+                        hipStream_t stream, const float *conv_kernel, const float *conv_proj, float *ds_all, float *cf_all,
+                        float *dck_part) {
   if (!speller_persist_bwd_ok(d)) return fail(NABU_EUNSUP, "persistent decoder (backward): unsupported shape");
   if (ws_bytes < speller_persist_bwd_ws_bytes(d)) return fail(NABU_EWS, "persistent decoder (backward): workspace too small");
+  const bool loc = d.kind == 1;
+  if (loc && !(conv_kernel && conv_proj && ds_all && cf_all && dck_part))
+    return fail(NABU_EINVAL, "persistent decoder (backward): location-aware attention needs its kernels and output arrays");
   BArgs a;
   a.L = d.L; a.U = d.U; a.E = d.E; a.Te = d.Te; a.FS = frames_per_slice(d);
+  a.Bt = d.B; a.b0 = 0; a.K = d.K; a.F = d.F; a.stream_vals = bwd_stream_values(d) ? 1 : 0;
+  a.ck = conv_kernel; a.wf = conv_proj; a.ds_all = ds_all; a.cf_all = cf_all; a.dck_part = dck_part;
   a.dec_len = dec_len; a.enc_len = enc_len; a.kxhT = kxhT; a.wq = wq; a.v = v; a.keys = keys; a.values = values;
   a.acts = acts; a.Cs = Cs; a.q = q; a.ctx = ctx; a.align = align; a.dH = dH; a.dCtx = dCtx; a.dq = dq; a.dz = dz;
   a.dkeys = dkeys; a.dv_part = dv_part;
@@ -1401,14 +1669,23 @@ int speller_persist_bwd(const SpPersistDesc &d, const int32_t *dec_len, const in
   a.timeout_ticks = lstm_persist_timeout_ticks();
   const char *e = getenv("NABU_PERSIST_DEBUG");
   a.dbg = e ? atoi(e) : 0;
-  NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + bwd_ring_bytes(d), stream));
-  const size_t lds = bwd_lds_floats(d) * 4;
-  auto kern = bwd_ks4(d) ? speller_persist_bwd_kernel<3, 128, 4, 8, false> : speller_persist_bwd_kernel<3, 8, 16, 8, false>;
-  if (d.keep_prob < 1.f) kern = bwd_ks4(d) ? speller_persist_bwd_kernel<3, 128, 4, 8, true> : speller_persist_bwd_kernel<3, 8, 16, 8, true>;
+  const size_t lds = bwd_lds_floats(d, a.stream_vals != 0) * 4;
+  const bool ks4 = bwd_ks4(d), drop = d.keep_prob < 1.f;
+  auto kern = ks4 ? speller_persist_bwd_kernel<3, 128, 4, 8, false, false> : speller_persist_bwd_kernel<3, 8, 16, 8, false, false>;
+  if (drop && !loc) kern = ks4 ? speller_persist_bwd_kernel<3, 128, 4, 8, true, false> : speller_persist_bwd_kernel<3, 8, 16, 8, true, false>;
+  if (loc) {
+    kern = ks4 ? speller_persist_bwd_kernel<3, 128, 4, 1, false, true> : speller_persist_bwd_kernel<3, 8, 16, 1, false, true>;
+    if (drop) kern = ks4 ? speller_persist_bwd_kernel<3, 128, 4, 1, true, true> : speller_persist_bwd_kernel<3, 8, 16, 1, true, true>;
+  }
   // per call: the attribute is per device, a cache keyed by the function alone would miss a second device
   NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-  hipLaunchKernelGGL(kern, dim3(NU * P), dim3(NT), lds, stream, a);
-  NABU_LAUNCH_CHECK();
+  // 32 utterances per launch (4 per XCD): a batch of 64 runs as two launches on the stream
+  for (int b0 = 0; b0 < d.B; b0 += NU * R) {
+    a.b0 = b0;
+    NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + bwd_ring_bytes(d), stream));
+    hipLaunchKernelGGL(kern, dim3(NU * P), dim3(NT), lds, stream, a);
+    NABU_LAUNCH_CHECK();
+  }
   return 0;
 }
 

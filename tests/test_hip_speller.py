@@ -111,11 +111,15 @@ def test_speller_step_on_the_fused_and_multi_stream_paths(attention, nl, K, F):
 
 @pytest.mark.parametrize('B', [32, 64])
 @pytest.mark.parametrize('stream', [0, 1])
-def test_persistent_decoder_location_aware_forward(B, stream):
-    """the location-aware variant of the persistent forward kernel (fifth ring with the alignments, conv features,
-    feature projection in the score duty), a batch of 64 as two launches of 32, and the values slice read from L2
-    instead of LDS (what cfg5's geometry needs; forced here) — against the oracle (inside check_speller) and the chain"""
+def test_persistent_decoder_location_aware(B, stream):
+    """the location-aware variants of the persistent kernels — forward: fifth ring with the alignments, conv features,
+    feature projection in the score duty; backward: features recomputed, d features handed to the other slices through a
+    ring, the carry into the previous step's alignments and the conv kernel's gradient in the kernel, d keys / d v /
+    d conv_proj left to attn_param_grads_kernel — a batch of 64 as two launches of 32, and the values slice read from L2
+    instead of LDS (what cfg5's geometry needs; forced here): logits and every gradient against the oracle (inside
+    check_speller), the logits against the chain"""
     import os
+    from nabu_amd.neuralnetworks.models.ed_decoders import rnn_decoder
     rng = np.random.default_rng(21 + B)
     Te = 37
     enc_len = rng.integers(Te // 2, Te + 1, B).astype(np.int32)
@@ -123,13 +127,17 @@ def test_persistent_decoder_location_aware_forward(B, stream):
     tlen = rng.integers(1, 7, B).astype(np.int32)
     tlen[2] = 6
     os.environ['NABU_SPELLER_STREAM_VALUES'] = str(stream)
+    os.environ['NABU_SPELLER_PERSIST_BWD_LOC'] = '2'                   # (by default only with LDS-resident values)
     try:
         got = check_speller('location_aware', 1, 64, 7, 3, enc_len, tlen, E=64)
+        assert rnn_decoder.dynamic_decode.last_paths == (1, 1)         # both passes took the persistent launch
         os.environ['NABU_SPELLER_PERSIST'] = '0'
         ref = check_speller('location_aware', 1, 64, 7, 3, enc_len, tlen, E=64)
+        assert rnn_decoder.dynamic_decode.last_paths[0] == 0
     finally:
         os.environ.pop('NABU_SPELLER_PERSIST', None)
         del os.environ['NABU_SPELLER_STREAM_VALUES']
+        del os.environ['NABU_SPELLER_PERSIST_BWD_LOC']
     assert np.abs(got - ref).max() < 2e-5
     from nabu_amd import ops as hip
     hip.check_persist_status()
@@ -155,6 +163,22 @@ def test_persistent_decoder_forward(U, E, Te):
     finally:
         del os.environ['NABU_SPELLER_PERSIST']
     assert np.abs(got - ref).max() < 2e-5
+    from nabu_amd import ops as hip
+    hip.check_persist_status()
+
+
+def test_persistent_decoder_batch_of_64_runs_as_two_launches():
+    """vanilla attention, 64 utterances: forward AND backward as two persistent launches of 32 rows each (row offset,
+    whole-batch strides of the time-major tensors) — logits and every gradient against the oracle"""
+    from nabu_amd.neuralnetworks.models.ed_decoders import rnn_decoder
+    rng = np.random.default_rng(77)
+    Te = 40
+    enc_len = rng.integers(Te // 2, Te + 1, 64).astype(np.int32)
+    enc_len[40] = Te
+    tlen = rng.integers(1, 9, 64).astype(np.int32)
+    tlen[50] = 8
+    check_speller('vanilla', 1, 64, 0, 0, enc_len, tlen, E=64)
+    assert rnn_decoder.dynamic_decode.last_paths == (1, 1)
     from nabu_amd import ops as hip
     hip.check_persist_status()
 
@@ -216,7 +240,7 @@ def test_persistent_decoder_with_output_dropout(attention):
     if attention == 'location_aware':
         over.update({'decoder.numfilt': 3, 'decoder.filtersize': 7})
     got = _decoder_run(over, enc, enc_len, tg, tlen, C, seed=123)
-    assert got[4] == (1, 1 if attention == 'vanilla' else 0)           # the persistent kernels really ran
+    assert got[4] == (1, 1)           # the persistent kernels really ran
     os.environ['NABU_SPELLER_PERSIST'] = os.environ['NABU_SPELLER_PERSIST_BWD'] = '0'
     try:
         ref = _decoder_run(over, enc, enc_len, tg, tlen, C, seed=123)
