@@ -434,6 +434,9 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const in
   const float *kern[2] = {kernel_fw, kernel_bw};
   const float *bias[2] = {bias_fw, bias_bw};
 
+  // narrow input (first layer): the persistent kernel projects its input itself (lstm_persist.hip, XK) — no product here
+  const bool fuse_in = use_persistent(d) && lstm_persist_fuses_input(B, T, D, H);
+  auto input_projection = [&]() -> int {
   // time-batched input projections (MFMA): gates_d = x·Wx_d + b_d
   if (L.pk_in) {
     // packed bf16-plane operands: X once, Wx^T of both cells as the rows of ONE operand; one product fills the
@@ -481,6 +484,10 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const in
                           4 * H, bias[dir], 0, 0, 0, w + L.gemm_off, L.gemm_bytes, stream);
     if (e) return e;
   }
+  return 0;
+  };
+  if (!fuse_in)
+    if (int e = input_projection()) return e;
   // frames t in [max_len, T) are never visited by the recurrence
   if (max_len < T)
     NABU_HIP(hipMemset2DAsync(out + (size_t)max_len * 2 * H, (size_t)T * 2 * H * sizeof(float), 0,
@@ -489,13 +496,15 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const in
   if (use_persistent(d)) {
     NABU_PROFILE_MARK(g_ev_begin, s);
     int e = lstm_persist_fwd(B, T, D, H, max_len, len, kern, gates, cs, out, reinterpret_cast<int *>(w), w + L.persist_off,
-                             L.persist_bytes, s);
+                             L.persist_bytes, s, fuse_in ? x : nullptr, fuse_in ? bias : nullptr);
     // the grid cannot be co-resident on this device (occupancy check before the launch): LSTM_AUTO steps instead
     if (!(e == NABU_EUNSUP && d->mode == NABU_LSTM_AUTO)) {
       if (e) return e;
       NABU_PROFILE_MARK(g_ev_end, s);
       return 0;
     }
+    if (fuse_in)      // the step kernels read the projection from the gate buffers
+      if (int e2 = input_projection()) return e2;
   }
   StepArgs p;
   p.B = B; p.T = T; p.D = D; p.H = H; p.max_len = max_len; p.len = len;

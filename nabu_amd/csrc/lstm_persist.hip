@@ -84,6 +84,8 @@ struct PersistArgs {
   float *gates[2];
   float *cs[2];
   float *out;         // forward
+  const float *x;     // forward, narrow input (XK > 0): the layer input [B, T, D], projected inside the kernel
+  const float *bias[2];   // ... and the cells' biases [4H]
   const float *dout;  // backward
   float *db_part;     // backward: [shards][2 directions][4H] bias-gradient partial sums (one row per unit)
   int shard_base;     // first shard of this launch (batches split over several launches)
@@ -247,8 +249,8 @@ struct FwdLds {
   static constexpr int ROW = KW + 4;             // padded row of the staged h: [RG][4 rows][KW] per wave
   static constexpr int HS = 0;
   static constexpr int PART = HS + NW * RG * 4 * ROW;   // [2][NW][RG][64 lanes][4 rows]
-  static constexpr int XST = PART + 2 * NW * RG * 256;  // [2][64*BS] prefetched x-projection
-  static constexpr int FLAG = XST + 2 * 64 * BS;
+  static constexpr int XST = PART + 2 * NW * RG * 256;  // [2][64*BS] prefetched x-projection ([3][64*BS]: the input rows, XK > 0)
+  static constexpr int FLAG = XST + 3 * 64 * BS;
   static constexpr int TOTAL = FLAG + 4;
 };
 
@@ -265,8 +267,14 @@ __device__ __forceinline__ float row_shl_f(float v, const int n) {   // lane i <
   return __builtin_bit_cast(float, r);
 }
 
-template <int KPL, int BS>
+// XK > 0 (narrow input, D = 4 XK <= 80; BS = 4): the input projection x_t . Wx + b is part of the step — XK more
+// instructions per wave on top of the recurrent product's KW, Wx's slice in XK more registers — instead of a GEMM that
+// writes [B T, 4H] per direction (524 MB at cfg2's first layer) for this kernel to read back.  x_t of the four rows
+// (4 D floats) is fetched two steps ahead into a ring of three LDS buffers: the wave that issued a piece waits for it
+// at the end of the step, the step's barrier orders it before the product two steps later.
+template <int KPL, int BS, int XK = 0>
 __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8 ? 4 : 2))) void lstm_persist_fwd_kernel(PersistArgs p) {
+  static_assert(XK == 0 || BS == 4, "in-kernel input projection: 4 rows per unit");
   using L = FwdLds<KPL, BS>;
   constexpr int PT = 64 * BS, NW = BS;   // threads, waves
   constexpr int H = L::H;
@@ -308,6 +316,14 @@ __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8
 #pragma unroll
     for (int j = 0; j < KW; ++j) Wr[j] = Wh[(size_t)j * 4 * H];
   }
+  float Wxr[XK > 0 ? XK : 1];      // (XK > 0) rows w*XK .. of Wx, my column
+  float bias_r = 0.f;              // ... bias of my gate-phase column
+  if (XK > 0) {
+    const float *Wx = p.kernel[dir] + (size_t)w * XK * 4 * H + (size_t)mg * H + U0 + mu;
+#pragma unroll
+    for (int j = 0; j < XK; ++j) Wxr[j] = Wx[(size_t)j * 4 * H];
+    bias_r = p.bias[dir][(size_t)gg * H + U0 + gu];
+  }
   float c_state = 0.f, h_state = 0.f;
   if (!unit_handshake(p, unit, slot, NU, P, flag)) return;
   const bool coloc = flag[1] != 0;
@@ -338,11 +354,28 @@ __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8
     const unsigned off = (s < n_g && !(p.dbg & 64)) ? goff + (unsigned)t * (unsigned)(16 * H) : OOB;
     prefetch_lds_b32(rg, off, smem, xst + (s & 1) * PT + 64 * w);
   };
-  fetch_x(0);
+  // (XK > 0) input rows of step s: lane L = 64 w + lane < 4 D is element (row L / D, k L % D); buffer s % 3
+  constexpr int XD = 4 * XK;
+  const i32x4 rx = raw_rsrc(p.x, XK > 0 ? (unsigned)((size_t)p.B * T * XD * 4) : 0u);
+  const int xr_row = XK > 0 ? tid / (XK > 0 ? XD : 1) : 0, xr_k = XK > 0 ? tid % (XK > 0 ? XD : 1) : 0;
+  const int xr_b = b0 + xr_row;
+  const int n_x = (XK > 0 && tid < 4 * XD && xr_b < p.B) ? p.len[xr_b] : 0;
+  auto fetch_xt = [&](int s) {
+    const int t = dir ? n_x - 1 - s : s;
+    const unsigned off = s < n_x ? (unsigned)((((size_t)xr_b * T + t) * XD + xr_k) * 4) : OOB;
+    prefetch_lds_b32(rx, off, smem, xst + (s % 3) * PT + 64 * w);
+  };
+  if (XK > 0) {
+    fetch_xt(0);
+    fetch_xt(1);
+  } else {
+    fetch_x(0);
+  }
   // all prologue loads (W_h, the first prefetch) are complete before the loop
   wait_vm<0>();
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), visible to the compiler's bookkeeping
-  float xnext = xst[tid];
+  if (XK > 0) __syncthreads();          // the input rows were fetched by other waves than their readers
+  float xnext = XK > 0 ? 0.f : xst[tid];
 
   if (hi_prio) __builtin_amdgcn_s_setprio(2);   // for the whole sequence (a change inside the loop body
                                                 // split its basic blocks and cost the FMA loop its registers)
@@ -388,8 +421,9 @@ __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8
     NABU_STAMP(0, 1);
     if ((p.dbg & 4096) && (unit == 0 || unit == NU / 2) && tid == 0 && s == p.max_len / 2 + 1)
       p.status[384 + 64 * (unit != 0) + 2 * slot + 1] = (int)wall_clock64();   // poll done (wave 0)
-    const float xg = xnext;
-    fetch_x(s + 1);
+    const float xg = XK > 0 ? bias_r : xnext;
+    if (XK > 0) fetch_xt(s + 2);
+    else fetch_x(s + 1);
 
     // (b) recurrent product on the matrix pipe, exact fp32: v_mfma_f32_4x4x1_16b_f32 multiplies, for
     // each of 16 hidden units, [4 rows x 1] (h) by [1 x 4 gates] (W): no padding waste at 4 batch
@@ -423,6 +457,12 @@ __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8
           acc[g][3 % NACC] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.w, Wr[4 * ch + 3], acc[g][3 % NACC], 0, 0, 0);
         }
       }
+    }
+    if (XK > 0) {
+      // + x_s . Wx: my XK input indices, row lane & 3 (the staged rows are [row][D])
+      const float *xrow = xst + (s % 3) * PT + (lane & 3) * XD + w * XK;
+#pragma unroll
+      for (int j = 0; j < XK; ++j) acc[0][j % NACC] = __builtin_amdgcn_mfma_f32_4x4x1f32(xrow[j], Wxr[j], acc[0][j % NACC], 0, 0, 0);
     }
     NABU_STAMP(0, 2);
     // hand the wave's partial sums to the gate phase: [wave][row group][lane][4 rows]
@@ -471,7 +511,7 @@ __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8
     // claim the prefetched x-projection: 2 = the publish and the reset store above.  (Here, in
     // front of the result stores: a later wait would also wait for those.)
     wait_vm<2>();
-    xnext = xst[((s + 1) & 1) * PT + tid];
+    if (XK == 0) xnext = xst[((s + 1) & 1) * PT + tid];
     NABU_STAMP(0, 4);
     if ((p.dbg & 4096) && (unit == 0 || unit == NU / 2) && tid == 0 && s == p.max_len / 2)
       p.status[384 + 64 * (unit != 0) + 2 * slot] = (int)wall_clock64();
@@ -809,6 +849,7 @@ static int cu_count() {
 }
 
 // geometry: BS = 4 (two 256-thread workgroups per CU) when the batch fits, else BS = 8
+bool lstm_persist_fuses_input(int B, int T, int D, int H);
 static int pick_bs(int B, int H, bool fwd) {
   const int P = H / UC, ncu = cu_count();
   if (2 * ((B + 3) / 4) * P <= 2 * ncu) return 4;
@@ -894,12 +935,12 @@ static int launch(K kernel, const PersistArgs &a, int grid, int threads, size_t 
 static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
                      const float *dout, int *status, void *ws, size_t ws_bytes, float *db_part, int *shard_base,
-                     hipStream_t stream);
+                     hipStream_t stream, const float *x, const float *const bias[2]);
 
 static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
                const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
                const float *dout, int *status, void *ws, size_t ws_bytes, float **db_part_out, int *db_rows_out,
-               hipStream_t stream) {
+               hipStream_t stream, const float *x = nullptr, const float *const bias[2] = nullptr) {
   if (!lstm_persist_supported(B, T, H)) return fail(NABU_EUNSUP, "persistent LSTM: unsupported B=%d H=%d", B, H);
   const size_t need = lstm_persist_ws_bytes(B, T, H);
   if (ws_bytes < need) return fail(NABU_EWS, "persistent LSTM: workspace %zu < %zu", ws_bytes, need);
@@ -913,7 +954,7 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
     const int e = run_chunk(fwd, nb, T, D, H, max_len, len + b0, kernel, g2, c2,
                             out ? out + (size_t)b0 * T * 2 * H : nullptr,
                             dout ? dout + (size_t)b0 * T * 2 * H : nullptr, status, ws, ws_bytes, db_part, &shards,
-                            stream);
+                            stream, x ? x + (size_t)b0 * T * D : nullptr, bias);
     if (e) return e;
   }
   if (db_part_out) *db_part_out = db_part;
@@ -924,7 +965,7 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
 static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
                      const float *dout, int *status, void *ws, size_t ws_bytes, float *db_part, int *shard_base,
-                     hipStream_t stream) {
+                     hipStream_t stream, const float *x, const float *const bias[2]) {
   PersistArgs a;
   { const char *e = getenv("NABU_PERSIST_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   int BS = pick_bs(B, H, fwd);
@@ -933,6 +974,9 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
   a.len = len;
   for (int i = 0; i < 2; ++i) { a.kernel[i] = kernel[i]; a.gates[i] = gates[i]; a.cs[i] = cs[i]; }
   a.out = out; a.dout = dout;
+  a.x = x; a.bias[0] = bias ? bias[0] : nullptr; a.bias[1] = bias ? bias[1] : nullptr;
+  const int XK = (fwd && x && bias && BS == 4 && lstm_persist_fuses_input(B, T, D, H)) ? D / 4 : 0;
+  if (fwd && x && !XK) return fail(NABU_EINVAL, "persistent LSTM: the in-kernel input projection does not take this shape");
   a.db_part = db_part; a.shard_base = *shard_base;
   *shard_base += a.nshard;
   a.status = status;
@@ -949,6 +993,8 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
   const size_t lds = BS == 4 ? 64 * 1024 : (grid > cu_count() ? 72 * 1024 : 96 * 1024);
 #define NABU_PERSIST_CASE(h)                                                                         \
   case h:                                                                                            \
+    if (XK == 10) return launch(lstm_persist_fwd_kernel<h / 16, 4, 10>, a, grid, 256, lds, stream);    \
+    if (XK == 20) return launch(lstm_persist_fwd_kernel<h / 16, 4, 20>, a, grid, 256, lds, stream);    \
     if (BS == 4)                                                                                     \
       return fwd ? launch(lstm_persist_fwd_kernel<h / 16, 4>, a, grid, 256, lds, stream)             \
                  : launch(lstm_persist_bwd_kernel<h, 4>, a, grid, 256, lds, stream);                 \
@@ -965,9 +1011,23 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
 
 int lstm_persist_fwd(int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2],
-                     float *out, int *status, void *ws, size_t ws_bytes, hipStream_t stream) {
+                     float *out, int *status, void *ws, size_t ws_bytes, hipStream_t stream, const float *x,
+                     const float *const bias[2]) {
   return run(true, B, T, D, H, max_len, len, kernel, gates, cs, out, nullptr, status, ws, ws_bytes, nullptr, nullptr,
-             stream);
+             stream, x, bias);
+}
+
+// narrow input (D = 40 or 80), every launch of the forward pass on the 4-row geometry: the kernel projects the input
+// itself (no x . Wx GEMM in front of it)
+bool lstm_persist_fuses_input(int B, int T, int D, int H) {
+  static int env = -1;
+  if (env < 0) { const char *e = getenv("NABU_PERSIST_FUSE_INPUT"); env = e ? atoi(e) : 1; }
+  if (!env || !(D == 40 || D == 80) || !lstm_persist_supported(B, T, H)) return false;
+  if ((size_t)B * T * D * 4 >= 0x80000000ull) return false;
+  const int Bc = chunk_rows(B, H, true);
+  for (int b0 = 0; b0 < B; b0 += Bc)
+    if (pick_bs(B - b0 < Bc ? B - b0 : Bc, H, true) != 4) return false;
+  return true;
 }
 
 int lstm_persist_bwd(int B, int T, int D, int H, int max_len, const int32_t *len,
