@@ -104,6 +104,8 @@ int cvt_bf16_t(int R, int C, const float *src, int ld, unsigned short *dst, int 
 
 // packed bf16-plane operands (gemm_pk.hip): does the current device offer the tile loop's 144 KiB of LDS?
 bool gemm_pk_device_ok();
+// f16x3 row maxima from per-unit partial maxima [rows][ld] (lstm_persist.hip): amax[n] = bits of max_r |part[r][n]|
+int pk_amax_from_partials(int rows, int N, const float *part, int ld, uint32_t *amax, hipStream_t s);
 // natural AND transposed pack of one source in one pass
 int pk_pack_both(int planes, const float *src, long long ld, int R, int C, void *dst_n, int rows_pad_n, int kb_off_n,
                  int fill_rows_n, int fill_kb_n, void *dst_t, int rows_pad_t, int row_off_t, int fill_rows_t,

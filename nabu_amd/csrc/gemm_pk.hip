@@ -658,6 +658,16 @@ __global__ __launch_bounds__(256) void pk_amax_kernel(const float *src, long lon
   }
 }
 
+// row maxima from per-unit partial maxima (the backward recurrence keeps the largest |dz| of every gate column per
+// unit): dst[n] = bits of max_r src[r][n]
+__global__ void pk_colmax_kernel(int rows, int N, const float *src, int ld, unsigned *dst) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float m = 0.f;
+  for (int r = 0; r < rows; ++r) m = fmaxf(m, fabsf(src[(size_t)r * ld + n]));
+  dst[n] = __builtin_bit_cast(unsigned, m);
+}
+
 __global__ void pk_fill_u32_kernel(unsigned *dst, int n, unsigned v) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) dst[i] = v;
@@ -809,6 +819,12 @@ extern "C" int nabu_pk_amax_fill(uint32_t *dst, int n, float value, nabu_stream_
 // (dst_t: rows_pad_t, row_off_t, fill_rows_t) of the same [R x C] source in one pass.  The natural pack fills rows
 // [0, fill_rows_n), the transposed pack k-blocks [0, fill_kb_t).
 namespace nabu {
+int pk_amax_from_partials(int rows, int N, const float *part, int ld, uint32_t *amax, hipStream_t s) {
+  if (rows <= 0 || N <= 0) return 0;
+  hipLaunchKernelGGL(pk_colmax_kernel, dim3((N + 255) / 256), dim3(256), 0, s, rows, N, part, ld, amax);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
 int pk_pack_both(int planes, const float *src, long long ld, int R, int C, void *dst_n, int rows_pad_n, int kb_off_n,
                  int fill_rows_n, int fill_kb_n, void *dst_t, int rows_pad_t, int row_off_t, int fill_rows_t,
                  int fill_kb_t, hipStream_t s, const unsigned *amax_n, const unsigned *amax_t) {

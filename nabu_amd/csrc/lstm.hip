@@ -610,10 +610,16 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
       const bool both = d_x && L.pk_in;    // dz is also needed row-major (dx): both packs from one read of dz
       if (P == 2) {
         // one read of dz per cell: its rows' maxima over BOTH cells (the row scale of dZ as [BT, 8H]) and its columns'
-        if (both) NABU_HIP(hipMemsetAsync(adz, 0, 4 * (size_t)rpBT, s));
-        NABU_HIP(hipMemsetAsync(adzT, 0, 4 * (size_t)rpG, s));
-        for (int dir = 0; dir < 2; ++dir)
-          if ((e = nabu_pk_amax(gates[dir], G, M, G, both ? adz : nullptr, adzT + dir * G, stream))) return e;
+        if (!both && db_part) {
+          // no input gradient (the first layer): only dZ^T is packed, and its row maxima — the gate columns' — were
+          // kept by the persistent kernel next to the bias-gradient partials: no extra read of dz
+          if ((e = pk_amax_from_partials(db_rows, 2 * G, db_part + lstm_persist_db_floats(B, H), 2 * G, adzT, s))) return e;
+        } else {
+          if (both) NABU_HIP(hipMemsetAsync(adz, 0, 4 * (size_t)rpBT, s));
+          NABU_HIP(hipMemsetAsync(adzT, 0, 4 * (size_t)rpG, s));
+          for (int dir = 0; dir < 2; ++dir)
+            if ((e = nabu_pk_amax(gates[dir], G, M, G, both ? adz : nullptr, adzT + dir * G, stream))) return e;
+        }
       }
       for (int dir = 0; dir < 2; ++dir) {
         if (both)

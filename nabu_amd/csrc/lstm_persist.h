@@ -19,5 +19,8 @@ int lstm_persist_bwd(int B, int T, int D, int H, int max_len, const int32_t *len
                      const float *dout, int *status, void *ws, size_t ws_bytes, float **db_part, int *db_rows,
                      hipStream_t stream);
 // db_part: [db_rows][2 directions][4H] bias-gradient partial sums written by the backward kernels
-// (inside ws); bias gradient of direction d = column sums of db_part[:, d, :]
+// (inside ws); bias gradient of direction d = column sums of db_part[:, d, :].  In the same layout, at
+// db_part + lstm_persist_db_floats(B, H): the largest |dz| of every gate column per unit (column maxima of dz = the
+// maximum over the rows; the row scales of the f16x3 weight-gradient products' dZ^T operand)
+size_t lstm_persist_db_floats(int B, int H);
 }  // namespace nabu

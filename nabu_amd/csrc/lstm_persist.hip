@@ -88,6 +88,7 @@ struct PersistArgs {
   const float *bias[2];   // ... and the cells' biases [4H]
   const float *dout;  // backward
   float *db_part;     // backward: [shards][2 directions][4H] bias-gradient partial sums (one row per unit)
+  float *amax_part;   // backward: same shape, the largest |dz| of every gate column over the unit's rows and steps
   int shard_base;     // first shard of this launch (batches split over several launches)
   unsigned *table;    // [grid] XCC ids, pre-set to SENT
   char *xbuf;         // exchange ring
@@ -443,6 +444,7 @@ __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8
       for (int g = 0; g < RG; ++g) hq[0][g] = *reinterpret_cast<const float4 *>(hrow + (size_t)g * 4 * L::ROW);
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
+        if ((p.dbg & 256) && ch >= NCH * 3 / 4) break;      // timing experiment: three quarters of the product
         if (ch + 1 < NCH) {
 #pragma unroll
           for (int g = 0; g < RG; ++g)
@@ -594,6 +596,7 @@ __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8
   }
   float dc_state = 0.f;
   float db_acc = 0.f;   // bias gradient: my (gate, row, unit) dz summed over the sequence
+  float am_acc = 0.f;   // ... and its largest magnitude (the column scales of the f16x3 weight-gradient products)
   if (!unit_handshake(p, unit, slot, NU, P, flag)) return;
   const bool coloc = flag[1] != 0;
   if (BS == 4 && unit >= NU / 2 && (p.dbg & 8192) && !(p.dbg & 32)) {   // see the forward kernel
@@ -719,6 +722,7 @@ __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8
       dc_state = dct * gf;
     }
     db_acc += dz;
+    am_acc = fmaxf(am_acc, fabsf(dz));
     float *const dzb = dzs + (s & 1) * (RG * 4 * L::DROW);
     dzb[(size_t)gb * L::DROW + gg * 16 + gu] = dz;      // [row group][row][gate*16 + unit] = [gb][c]
     NABU_STAMP(1, 2);
@@ -819,6 +823,15 @@ __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8
     for (int r = 0; r < BS; ++r) sum += red[gg + 4 * r + 4 * BS * gu];
     p.db_part[((size_t)(p.shard_base + shard) * 2 + dir) * 4 * H + (size_t)gg * H + U0 + gu] = sum;
   }
+  __syncthreads();
+  red[tid] = am_acc;
+  __syncthreads();
+  if (gb == 0) {
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < BS; ++r) m = fmaxf(m, red[gg + 4 * r + 4 * BS * gu]);
+    p.amax_part[((size_t)(p.shard_base + shard) * 2 + dir) * 4 * H + (size_t)gg * H + U0 + gu] = m;
+  }
 }
 
 // ===========================================================================
@@ -850,6 +863,7 @@ static int cu_count() {
 
 // geometry: BS = 4 (two 256-thread workgroups per CU) when the batch fits, else BS = 8
 bool lstm_persist_fuses_input(int B, int T, int D, int H);
+size_t lstm_persist_db_floats(int B, int H) { return (size_t)((B + 3) / 4) * 2 * 4 * H; }
 static int pick_bs(int B, int H, bool fwd) {
   const int P = H / UC, ncu = cu_count();
   if (2 * ((B + 3) / 4) * P <= 2 * ncu) return 4;
@@ -880,7 +894,7 @@ bool lstm_persist_supported(int B, int T, int H) {
 }
 
 // bias-gradient partials of the backward kernel: one row of 2 x 4H per shard (BS = 4 gives the most)
-static size_t db_part_bytes(int B, int H) { return (size_t)((B + 3) / 4) * 2 * 4 * H * sizeof(float); }
+static size_t db_part_bytes(int B, int H) { return 2 * (size_t)((B + 3) / 4) * 2 * 4 * H * sizeof(float); }   // sums, maxima
 
 static size_t ring_bytes(bool fwd, int BS, int nshard, int H) {
   const size_t NU = 2 * (size_t)nshard, P = H / UC;
@@ -934,8 +948,8 @@ static int launch(K kernel, const PersistArgs &a, int grid, int threads, size_t 
 
 static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
-                     const float *dout, int *status, void *ws, size_t ws_bytes, float *db_part, int *shard_base,
-                     hipStream_t stream, const float *x, const float *const bias[2]);
+                     const float *dout, int *status, void *ws, size_t ws_bytes, float *db_part, float *amax_part,
+                     int *shard_base, hipStream_t stream, const float *x, const float *const bias[2]);
 
 static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
                const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
@@ -945,6 +959,7 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
   const size_t need = lstm_persist_ws_bytes(B, T, H);
   if (ws_bytes < need) return fail(NABU_EWS, "persistent LSTM: workspace %zu < %zu", ws_bytes, need);
   float *db_part = reinterpret_cast<float *>(static_cast<char *>(ws) + need - db_part_bytes(B, H));
+  float *amax_part = db_part + db_part_bytes(B, H) / (2 * sizeof(float));
   int shards = 0;
   const int Bc = chunk_rows(B, H, fwd);
   for (int b0 = 0; b0 < B; b0 += Bc) {
@@ -953,19 +968,19 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
     float *c2[2] = {cs[0] + (size_t)b0 * T * H, cs[1] + (size_t)b0 * T * H};
     const int e = run_chunk(fwd, nb, T, D, H, max_len, len + b0, kernel, g2, c2,
                             out ? out + (size_t)b0 * T * 2 * H : nullptr,
-                            dout ? dout + (size_t)b0 * T * 2 * H : nullptr, status, ws, ws_bytes, db_part, &shards,
+                            dout ? dout + (size_t)b0 * T * 2 * H : nullptr, status, ws, ws_bytes, db_part, amax_part, &shards,
                             stream, x ? x + (size_t)b0 * T * D : nullptr, bias);
     if (e) return e;
   }
-  if (db_part_out) *db_part_out = db_part;
+  if (db_part_out) *db_part_out = db_part;      // (the maxima follow at db_part + lstm_persist_db_floats(B, H))
   if (db_rows_out) *db_rows_out = shards;
   return 0;
 }
 
 static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
-                     const float *dout, int *status, void *ws, size_t ws_bytes, float *db_part, int *shard_base,
-                     hipStream_t stream, const float *x, const float *const bias[2]) {
+                     const float *dout, int *status, void *ws, size_t ws_bytes, float *db_part, float *amax_part,
+                     int *shard_base, hipStream_t stream, const float *x, const float *const bias[2]) {
   PersistArgs a;
   { const char *e = getenv("NABU_PERSIST_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   int BS = pick_bs(B, H, fwd);
@@ -978,6 +993,7 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
   const int XK = (fwd && x && bias && BS == 4 && lstm_persist_fuses_input(B, T, D, H)) ? D / 4 : 0;
   if (fwd && x && !XK) return fail(NABU_EINVAL, "persistent LSTM: the in-kernel input projection does not take this shape");
   a.db_part = db_part; a.shard_base = *shard_base;
+  a.amax_part = amax_part;
   *shard_base += a.nshard;
   a.status = status;
   a.table = static_cast<unsigned *>(ws);
