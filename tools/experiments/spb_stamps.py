@@ -1,5 +1,6 @@
 import sys, os; sys.path.insert(0, '.')
 os.environ.setdefault('NABU_PERSIST_DEBUG', '4')
+os.environ.setdefault('NABU_SPELLER_PERSIST_BWD_LOC', '2')     # cfg5: the location-aware backward kernel (not its default there)
 import torch, numpy as np
 import bench
 from nabu_amd import _hip
