@@ -11,7 +11,7 @@ int lstm_persist_fwd(int B, int T, int D, int H, int max_len, const int32_t *len
                      const float *const kernel[2], float *const gates[2], float *const cs[2],
                      float *out, int *status, void *ws, size_t ws_bytes, hipStream_t stream, const float *x = nullptr,
                      const float *const bias[2] = nullptr);
-// x, bias given (only when lstm_persist_fuses_input says so: D = 40 or 80, the 4-row geometry): gates[] need NOT hold
+// x, bias given (only when lstm_persist_fuses_input says so: D = 40, the 4-row geometry): gates[] need NOT hold
 // the input projection, the kernel computes x_t . Wx + b itself; it still leaves the activations there
 bool lstm_persist_fuses_input(int B, int T, int D, int H);
 int lstm_persist_bwd(int B, int T, int D, int H, int max_len, const int32_t *len,

@@ -268,14 +268,14 @@ __device__ __forceinline__ float row_shl_f(float v, const int n) {   // lane i <
   return __builtin_bit_cast(float, r);
 }
 
-// XK > 0 (narrow input, D = 4 XK <= 80; BS = 4): the input projection x_t . Wx + b is part of the step — XK more
+// XK > 0 (narrow input, D = 4 XK = 40; BS = 4): the input projection x_t . Wx + b is part of the step — XK more
 // instructions per wave on top of the recurrent product's KW, Wx's slice in XK more registers — instead of a GEMM that
 // writes [B T, 4H] per direction (524 MB at cfg2's first layer) for this kernel to read back.  x_t of the four rows
 // (4 D floats) is fetched two steps ahead into a ring of three LDS buffers: the wave that issued a piece waits for it
 // at the end of the step, the step's barrier orders it before the product two steps later.
 template <int KPL, int BS, int XK = 0>
 __global__ __launch_bounds__(64 * BS) __attribute__((amdgpu_waves_per_eu(BS == 8 ? 4 : 2))) void lstm_persist_fwd_kernel(PersistArgs p) {
-  static_assert(XK == 0 || BS == 4, "in-kernel input projection: 4 rows per unit");
+  static_assert(XK == 0 || (BS == 4 && 16 * XK <= 64 * BS), "in-kernel input projection: 4 rows per unit, one prefetch lane per input element");
   using L = FwdLds<KPL, BS>;
   constexpr int PT = 64 * BS, NW = BS;   // threads, waves
   constexpr int H = L::H;
@@ -1010,7 +1010,6 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
 #define NABU_PERSIST_CASE(h)                                                                         \
   case h:                                                                                            \
     if (XK == 10) return launch(lstm_persist_fwd_kernel<h / 16, 4, 10>, a, grid, 256, lds, stream);    \
-    if (XK == 20) return launch(lstm_persist_fwd_kernel<h / 16, 4, 20>, a, grid, 256, lds, stream);    \
     if (BS == 4)                                                                                     \
       return fwd ? launch(lstm_persist_fwd_kernel<h / 16, 4>, a, grid, 256, lds, stream)             \
                  : launch(lstm_persist_bwd_kernel<h, 4>, a, grid, 256, lds, stream);                 \
@@ -1033,12 +1032,12 @@ int lstm_persist_fwd(int B, int T, int D, int H, int max_len, const int32_t *len
              stream, x, bias);
 }
 
-// narrow input (D = 40 or 80), every launch of the forward pass on the 4-row geometry: the kernel projects the input
-// itself (no x . Wx GEMM in front of it)
+// narrow input (D = 40: 4 rows x D elements fit the 256 lanes of one prefetch), every launch of the forward pass on the
+// 4-row geometry: the kernel projects the input itself (no x . Wx GEMM in front of it)
 bool lstm_persist_fuses_input(int B, int T, int D, int H) {
   static int env = -1;
   if (env < 0) { const char *e = getenv("NABU_PERSIST_FUSE_INPUT"); env = e ? atoi(e) : 1; }
-  if (!env || !(D == 40 || D == 80) || !lstm_persist_supported(B, T, H)) return false;
+  if (!env || D != 40 || !lstm_persist_supported(B, T, H)) return false;
   if ((size_t)B * T * D * 4 >= 0x80000000ull) return false;
   const int Bc = chunk_rows(B, H, true);
   for (int b0 = 0; b0 < B; b0 += Bc)

@@ -269,6 +269,11 @@ def test_pad_unpad_time():
     (4, 10, 8, 128, [6, 4, 6, 3]),              # max(len) < T
     (64, 12, 16, 512, 'ragged'),                # the cfg5 batch: two launches of 32 rows
     (40, 9, 8, 512, None),                      # chunk of 32 + chunk of 8
+    # narrow input (D = 40): the forward kernel projects x itself (lstm_persist.hip, XK); D = 80 keeps the GEMM
+    (6, 17, 40, 64, [17, 3, 9, 1, 12, 17]),     # B not a multiple of 4, ragged
+    (7, 11, 40, 128, [8, 5, 8, 2, 1, 7, 8]),    # max(len) < T
+    (7, 11, 80, 128, [8, 5, 8, 2, 1, 7, 8]),    # D = 80
+    (40, 9, 40, 512, 'ragged'),                 # chunk of 32 + chunk of 8
 ])
 def test_blstm_persistent_matches_oracle(B, T, D, H, lens):
     from nabu_amd import ops
