@@ -109,6 +109,22 @@ def test_speller_step_on_the_fused_and_multi_stream_paths(attention, nl, K, F):
     np.testing.assert_array_equal(got, one)
 
 
+def test_persistent_decoder_location_aware_even_filter_width_and_many_filters():
+    """'same' padding of an even filter width (left pad (K - 1) // 2), 12 filters (the kernel's register limit), 70
+    frames — both persistent passes against the oracle"""
+    from nabu_amd.neuralnetworks.models.ed_decoders import rnn_decoder
+    rng = np.random.default_rng(9)
+    Te = 70
+    enc_len = rng.integers(Te // 2, Te + 1, 32).astype(np.int32)
+    enc_len[0] = Te
+    tlen = rng.integers(1, 7, 32).astype(np.int32)
+    tlen[2] = 6
+    check_speller('location_aware', 1, 64, 6, 12, enc_len, tlen, E=64)
+    assert rnn_decoder.dynamic_decode.last_paths == (1, 1)
+    from nabu_amd import ops as hip
+    hip.check_persist_status()
+
+
 @pytest.mark.parametrize('B', [32, 64])
 @pytest.mark.parametrize('stream', [0, 1])
 def test_persistent_decoder_location_aware(B, stream):
