@@ -1113,23 +1113,40 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
         if (n > 0)
 #pragma unroll
           for (int i = 0; i < S; ++i) r += rpart_s[i];
-        // d alignment of my frames: wave w takes frames w, w + NW, ...
-        for (int f = w; f < FS; f += NW) {
-          f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
-          const bool live = f0 + f < cn && !frozen;
-          if (live) {
-            const float *vr = svals ? p.values + ((size_t)cbg * Te + f0 + f) * E : vals_s + (size_t)f * E;
-            for (int e4 = lane; e4 < E / 4; e4 += 64)
-              a4 += *reinterpret_cast<const f32x4 *>(dcx + 4 * e4) * *reinterpret_cast<const f32x4 *>(vr + 4 * e4);
+        // d alignment of my live frames (masked frames have a = 0): thread = 16 bytes of the encoder dimension, five
+        // frames' loads in flight (the values slice may come from L2), one wave reduction per frame
+        const int nf = frozen ? 0 : min(FS, max(cn - f0, 0));
+        float *wpart = dqh;                          // [NW][64]
+        {
+          constexpr int FB = 5;
+          const bool mine = tid < E / 4;
+          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+          const f32x4 dcv = mine ? *reinterpret_cast<const f32x4 *>(dcx + 4 * tid) : z4;
+          const float *vb = svals ? p.values + ((size_t)cbg * Te + f0) * E : vals_s;
+          for (int fb = 0; fb < nf; fb += FB) {
+            f32x4 vv[FB];
+#pragma unroll
+            for (int i = 0; i < FB; ++i) vv[i] = mine ? *reinterpret_cast<const f32x4 *>(vb + (size_t)min(fb + i, nf - 1) * E + 4 * tid) : z4;
+#pragma unroll
+            for (int i = 0; i < FB; ++i) {
+              const f32x4 m4 = dcv * vv[i];
+              const float tot = wsum((m4.x + m4.y) + (m4.z + m4.w));
+              if (lane == 0 && fb + i < nf) wpart[w * 64 + fb + i] = tot;
+            }
           }
-          float da = wsum((a4.x + a4.y) + (a4.z + a4.w));
-          if (lane == 0) {
-            for (int c = 0; c < Fc; ++c) da += cpart_s[f * Fc + c];
-            const float a = live ? p.align[((size_t)(t + 1) * B + cbg) * Te + f0 + f] : 0.f;
-            const float g = a * (da - r);          // d score
-            redw[64 + f] = g;
-            if (f0 + f < Te) p.ds_all[((size_t)t * B + cbg) * Te + f0 + f] = g;
-          }
+        }
+        __syncthreads();
+        if (tid < FS) {
+          const int f = tid;
+          const bool live = f < nf;
+          float da = 0.f;
+          if (live)
+            for (int ww = 0; ww < NW; ++ww) da += wpart[ww * 64 + f];
+          for (int c = 0; c < Fc; ++c) da += cpart_s[f * Fc + c];
+          const float a = live ? p.align[((size_t)(t + 1) * B + cbg) * Te + f0 + f] : 0.f;
+          const float g = a * (da - r);            // d score
+          redw[64 + f] = g;
+          if (f0 + f < Te) p.ds_all[((size_t)t * B + cbg) * Te + f0 + f] = g;
         }
       }
       SPB_STAMP(3);
@@ -1145,35 +1162,52 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
           qq[j] = u4 < U4 ? *reinterpret_cast<const f32x4 *>(p.q + ((size_t)t * B + cbg) * U + 4 * u4) : dq_l[j];
           vv[j] = u4 < U4 ? *reinterpret_cast<const f32x4 *>(v_s + 4 * u4) : dq_l[j];
         }
-        for (int f = w; f < FS; f += NW) {
-          const float g = redw[64 + f];
-          float dcf_l[MF];
+        // two frames of a wave at a time: every projection row read serves both
+        for (int f = w; f < FS; f += 2 * NW) {
+          const int fB = min(f + NW, FS - 1);
+          const bool hasB = f + NW < FS;
+          const float gA = redw[64 + f], gB = hasB ? redw[64 + fB] : 0.f;
+          float dcfA[MF], dcfB[MF];
 #pragma unroll
-          for (int c = 0; c < MF; ++c) dcf_l[c] = 0.f;
+          for (int c = 0; c < MF; ++c) dcfA[c] = dcfB[c] = 0.f;
 #pragma unroll
           for (int j = 0; j < MJ; ++j) {
             const int u4 = lane + 64 * j;
             if (u4 < U4) {
-              f32x4 x = *reinterpret_cast<const f32x4 *>(keys_s + (size_t)f * U + 4 * u4) + qq[j];
-              for (int c = 0; c < Fc; ++c) x += cf_s[f * Fc + c] * *reinterpret_cast<const f32x4 *>(wf_s + (size_t)c * U + 4 * u4);
-              f32x4 th, dd;
-              th.x = ftanh(x.x); th.y = ftanh(x.y); th.z = ftanh(x.z); th.w = ftanh(x.w);
-              dd.x = g * vv[j].x * (1.f - th.x * th.x); dd.y = g * vv[j].y * (1.f - th.y * th.y);
-              dd.z = g * vv[j].z * (1.f - th.z * th.z); dd.w = g * vv[j].w * (1.f - th.w * th.w);
-              dq_l[j] += dd;
+              f32x4 xA = *reinterpret_cast<const f32x4 *>(keys_s + (size_t)f * U + 4 * u4) + qq[j];
+              f32x4 xB = *reinterpret_cast<const f32x4 *>(keys_s + (size_t)fB * U + 4 * u4) + qq[j];
+#pragma unroll
+              for (int c = 0; c < MF; ++c)          // (unrolled: the LDS reads of all filters are in flight together)
+                if (c < Fc) {
+                  const f32x4 wc = *reinterpret_cast<const f32x4 *>(wf_s + (size_t)c * U + 4 * u4);
+                  xA += cf_s[f * Fc + c] * wc;
+                  xB += cf_s[fB * Fc + c] * wc;
+                }
+              f32x4 th, ddA, ddB;
+              th.x = ftanh(xA.x); th.y = ftanh(xA.y); th.z = ftanh(xA.z); th.w = ftanh(xA.w);
+              ddA.x = gA * vv[j].x * (1.f - th.x * th.x); ddA.y = gA * vv[j].y * (1.f - th.y * th.y);
+              ddA.z = gA * vv[j].z * (1.f - th.z * th.z); ddA.w = gA * vv[j].w * (1.f - th.w * th.w);
+              th.x = ftanh(xB.x); th.y = ftanh(xB.y); th.z = ftanh(xB.z); th.w = ftanh(xB.w);
+              ddB.x = gB * vv[j].x * (1.f - th.x * th.x); ddB.y = gB * vv[j].y * (1.f - th.y * th.y);
+              ddB.z = gB * vv[j].z * (1.f - th.z * th.z); ddB.w = gB * vv[j].w * (1.f - th.w * th.w);
+              dq_l[j] += ddA + ddB;
 #pragma unroll
               for (int c = 0; c < MF; ++c)
                 if (c < Fc) {
                   const f32x4 wc = *reinterpret_cast<const f32x4 *>(wf_s + (size_t)c * U + 4 * u4);
-                  dcf_l[c] = fmaf(dd.x, wc.x, fmaf(dd.y, wc.y, fmaf(dd.z, wc.z, fmaf(dd.w, wc.w, dcf_l[c]))));
+                  dcfA[c] = fmaf(ddA.x, wc.x, fmaf(ddA.y, wc.y, fmaf(ddA.z, wc.z, fmaf(ddA.w, wc.w, dcfA[c]))));
+                  dcfB[c] = fmaf(ddB.x, wc.x, fmaf(ddB.y, wc.y, fmaf(ddB.z, wc.z, fmaf(ddB.w, wc.w, dcfB[c]))));
                 }
             }
           }
 #pragma unroll
           for (int c = 0; c < MF; ++c)
             if (c < Fc) {
-              const float tot = wsum(dcf_l[c]);
-              if (lane == 0) dcf_s[f * Fc + c] = tot;
+              const float tA = wsum(dcfA[c]), tB = wsum(dcfB[c]);
+              if (lane == 0) {
+                dcf_s[f * Fc + c] = tA;
+                if (hasB) dcf_s[fB * Fc + c] = tB;
+              }
             }
         }
 #pragma unroll
@@ -1635,7 +1669,7 @@ bool speller_persist_bwd_ok(const SpPersistDesc &d) {
     // NABU_SPELLER_PERSIST_BWD_LOC: 0 = step chain, 1 (default) = persistent when the values slice is LDS-resident,
     // 2 = also when it has to be read from L2 in every step.  Measured: cfg3's geometry with 10 filters of 101 taps
     // 31.3 ms per training step against 32.3 on the chain; cfg5's geometry (25 frames per slice, values streamed)
-    // 71 us per decoder step and 32 rows = 72.0 ms per training step against 65.3 on the four-stream chain.
+    // 65 us per decoder step and 32 rows = 72.4 ms per training step against 67.4 on the four-stream chain.
     const char *e2 = getenv("NABU_SPELLER_PERSIST_BWD_LOC");
     const int mode = e2 ? atoi(e2) : 1;
     if (mode <= 0 || !bwd_shape_ok(d) || (mode == 1 && bwd_stream_values(d))) return false;
