@@ -218,10 +218,12 @@ def gemm_roofline_pk(B, T, D, H, planes):
 
     def run():
         for (a, b, M, N, nb), cs in zip(prods, outs):
+            direct = 2 if planes == 2 else 0           # what nabu_blstm_fwd/_bwd ask for (include/nabu_hip.h)
             if nb == 1:
-                ops.gemm_pk(a, b, cs[0], planes)
+                ops.gemm_pk(a, b, cs[0], planes, direct=direct)
             else:
-                ops.gemm_pk(a, b, None, planes, M=M, N=N, a_ptrs=[a.buf.data_ptr()] * 2, b_ptrs=[b.buf.data_ptr()] * 2, cs=cs)
+                ops.gemm_pk(a, b, None, planes, M=M, N=N, a_ptrs=[a.buf.data_ptr()] * 2, b_ptrs=[b.buf.data_ptr()] * 2, cs=cs,
+                            direct=direct)
 
     def timed(fn, reps):
         fn()
