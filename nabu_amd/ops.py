@@ -166,7 +166,7 @@ def gemm_pk(a, b, c, planes=None, alpha=1.0, beta=0.0, bias=None, c2=None, n_spl
 
 
 def set_gemm_precision(precision):
-    """process default of every GEMM that does not name a precision ('f32' | 'bf16' | 'bf16x3' | 'bf16x6')"""
+    """process default of every GEMM that does not name a precision ('f32' | 'bf16' | 'bf16x3' | 'bf16x6' | 'f16x3')"""
     check(_hip.lib().nabu_gemm_set_default_precision(_hip.GEMM_PRECISIONS[precision]), 'nabu_gemm_set_default_precision')
 
 
