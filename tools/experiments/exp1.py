@@ -3,7 +3,7 @@ import numpy as np, torch
 from nabu_amd import ops, _hip
 import os as _os
 if _os.environ.get('NABU_LIB'): _hip.LIB_PATH = _os.path.abspath(_os.environ['NABU_LIB'])
-B,T,D,H = int(_os.environ.get("EXP_B","32")),500,2048,512
+B,T,D,H = int(_os.environ.get("EXP_B","32")),int(_os.environ.get("EXP_T","500")),2048,512
 x = torch.randn(B,T,D, device='cuda')*0.1
 lens = torch.full((B,), T, dtype=torch.int32).cuda()
 p = [torch.randn(s, device='cuda')*0.03 for s in [(D+H,4*H),(4*H,),(D+H,4*H),(4*H,)]]
