@@ -54,189 +54,9 @@
 // (The first versions ran the product as 256 v_pk_fma_f32 per lane plus DPP reductions: at the
 // same FLOP rate, but ~3x the VALU instructions, fighting the other workgroup of the CU.)
 #include "lstm_persist.h"
-
-#include <stdlib.h>
+#include "lstm_persist_dev.h"
 
 namespace nabu {
-
-constexpr unsigned SENT = 0xFFFFFFFFu;
-constexpr unsigned OOB = 0xFFFFFFF0u;   // buffer offset beyond every exchange ring / tensor: access dropped
-constexpr int UC = 16;    // hidden units per workgroup
-#ifndef NABU_RING_BWD
-#define NABU_RING_BWD 2
-#endif
-#ifndef NABU_FWD_NACC
-#define NABU_FWD_NACC 2   // 4 chains measured: product phase 720 -> 680 ns, step time unchanged (2.35 -> 2.40 us)
-#endif
-constexpr int RING = 4;               // exchange ring depth, forward (all-gather of h)
-constexpr int RINGB = NABU_RING_BWD;  // ... backward (reduce-scatter of dh)
-constexpr int NCU = 256;  // MI355X
-constexpr size_t TABLE_BYTES = 4096;   // XCC-id table in front of the ring
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-struct PersistArgs {
-  int B, T, D, H, max_len, nshard;
-  const int32_t *len;
-  const float *kernel[2];
-  float *gates[2];
-  float *cs[2];
-  float *out;         // forward
-  const float *x;     // forward, narrow input (XK > 0): the layer input [B, T, D], projected inside the kernel
-  const float *bias[2];   // ... and the cells' biases [4H]
-  const float *dout;  // backward
-  float *db_part;     // backward: [shards][2 directions][4H] bias-gradient partial sums (one row per unit)
-  float *amax_part;   // backward: same shape, the largest |dz| of every gate column over the unit's rows and steps
-  int shard_base;     // first shard of this launch (batches split over several launches)
-  unsigned *table;    // [grid] XCC ids, pre-set to SENT
-  char *xbuf;         // exchange ring
-  int *status;
-  unsigned long long timeout_ticks;  // wall_clock64 ticks (100 MHz)
-  int dbg;  // NABU_PERSIST_DEBUG: 1 no exchange wait, 2 no matrix product, 4 phase stamps,
-            // 8 force write-through publishing, 16 force BS = 8 (timing experiments only)
-};
-
-__device__ __forceinline__ float dpp_f(float v, const int ctrl_sel) {
-  // quad permutes only (well defined on every wave64 target)
-  int r;
-  const int x = __builtin_bit_cast(int, v);
-  switch (ctrl_sel) {
-    case 0: r = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); break;   // [1,0,3,2]
-    case 1: r = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true); break;   // [2,3,0,1]
-    case 2: r = __builtin_amdgcn_update_dpp(0, x, 0x00, 0xF, 0xF, true); break;   // bcast lane 0
-    case 3: r = __builtin_amdgcn_update_dpp(0, x, 0x55, 0xF, 0xF, true); break;   // bcast lane 1
-    case 4: r = __builtin_amdgcn_update_dpp(0, x, 0xAA, 0xF, 0xF, true); break;   // bcast lane 2
-    default: r = __builtin_amdgcn_update_dpp(0, x, 0xFF, 0xF, 0xF, true); break;  // bcast lane 3
-  }
-  return __builtin_bit_cast(float, r);
-}
-#define QUAD_XOR1(v) dpp_f(v, 0)
-#define QUAD_XOR2(v) dpp_f(v, 1)
-#define QUAD_BCAST(v, i) dpp_f(v, 2 + (i))
-
-__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
-
-__device__ __forceinline__ bool has_sentinel(const u32x4 v) {
-  return v.x == SENT || v.y == SENT || v.z == SENT || v.w == SENT;
-}
-__device__ __forceinline__ bool all_sentinel(const u32x4 v) {
-  return v.x == SENT && v.y == SENT && v.z == SENT && v.w == SENT;
-}
-__device__ __forceinline__ float sel4(int q, float a, float b, float c, float d) {
-  return q == 0 ? a : q == 1 ? b : q == 2 ? c : d;
-}
-
-// PER-STEP PREFETCH.  hipcc's wait-count insertion drains the WHOLE vector memory queue
-// (s_waitcnt vmcnt(0)) at most control-flow joins; a compiler-visible prefetch of the next step's
-// saved tensors would put its HBM latency, or the acknowledgement of the exchange stores, on the
-// critical path.  The prefetch is therefore an LDS-DMA load (buffer_load ... lds: no destination
-// register, so no stale register copies are possible) issued from inline assembly, invisible to
-// the compiler, and claimed with an explicit counted wait before an ordinary LDS read:
-// wait_vm<N>, N = vector memory instructions certainly issued after the prefetch.  Vector memory
-// operations complete in issue order, so waits the compiler inserts for its own loads can only
-// become stricter by the extra operation, never weaker.  Lane l of wave w lands at
-// stage[64 w + l]; out-of-range offsets deliver 0.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ i32x4 raw_rsrc(const void *base, unsigned bytes) {
-  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
-  return (i32x4){(int)(unsigned)a, (int)(unsigned)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
-}
-__device__ __forceinline__ void prefetch_lds_b32(i32x4 rsrc, unsigned off, const float *smem, const float *stage_wave) {
-  const unsigned m0 = __builtin_amdgcn_readfirstlane((unsigned)((const char *)stage_wave - (const char *)smem));
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(m0), "v"(off), "s"(rsrc) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// publish 16 bytes: plain store when the whole unit shares one L2, else write-through
-__device__ __forceinline__ void xstore(const u32x4 v, __amdgpu_buffer_rsrc_t rs, unsigned off, bool coloc) {
-  if (coloc) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
-  else       __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
-}
-
-// Bounded spin bookkeeping: returns true when the caller must give up.
-struct SpinGuard {
-  unsigned long long t0;
-  unsigned spins;
-  __device__ __forceinline__ void start() { t0 = wall_clock64(); spins = 0; }
-  __device__ __forceinline__ bool expired(const PersistArgs &p) {
-    // back off between polls: 512 workgroups re-reading 8 KiB each as fast as the L2 answers
-    // (one way latency is ~50 ns, tools/experiments/ub/pingpong.hip) would saturate the L2 they wait on
-    switch ((p.dbg >> 8) & 7) {
-      case 1: __builtin_amdgcn_s_sleep(1); break;
-      case 2: __builtin_amdgcn_s_sleep(2); break;
-      case 3: __builtin_amdgcn_s_sleep(4); break;
-      case 4: __builtin_amdgcn_s_sleep(8); break;
-      case 5: __builtin_amdgcn_s_sleep(16); break;
-      default: break;
-    }
-    if ((++spins & 31u) != 0) return false;
-    __builtin_amdgcn_s_sleep(1);
-    if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
-    return wall_clock64() - t0 > p.timeout_ticks;
-  }
-};
-
-// NABU_PERSIST_DEBUG & 4: block 0 / thread 0 records the wall clock (10 ns units) at phase
-// boundaries of the middle timestep into status[320 + 32*pass + i] (pass 0 fwd, 1 bwd).
-#define NABU_STAMP(pass, i)                                                       \
-  do {                                                                            \
-    if ((p.dbg & 4) && blockIdx.x == 0 && tid == 0 && s == p.max_len / 2)         \
-      p.status[320 + 32 * (pass) + (i)] = (int)(wall_clock64());                  \
-  } while (0)
-
-// Kernel start: publish my XCC id, wait for the ids of my unit, decide whether the unit
-// is co-located on one XCD.  Returns false on timeout.  flag[0] = failure, flag[1] = coloc.
-// Logical identity of a block.  Blocks b and b+256 share a CU (measured: the dispatcher fills
-// every CU once before it places a second workgroup), so the second wave of blocks is rotated by
-// NU/2 units: the two workgroups of a CU then belong to DIFFERENT units of the same XCD and can
-// interleave (same-unit workgroups are in lockstep and would always collide on the VALU).
-__device__ __forceinline__ void block_identity(int NU, int *unit, int *slot, bool rotate) {
-  const int b = blockIdx.x;
-  int u = b % NU;
-  if (rotate && b >= NCU && NCU % NU == 0) u = (u + NU / 2) % NU;
-  *unit = u;
-  *slot = b / NU;
-}
-
-__device__ __forceinline__ bool unit_handshake(const PersistArgs &p, int unit, int slot, int NU, int P, int *flag) {
-  const int tid = threadIdx.x;
-  const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));  // HW_REG_XCC_ID
-  if (tid == 0) {
-    flag[0] = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    flag[1] = 0;
-    if (blockIdx.x < 256) p.status[16 + blockIdx.x] = (int)xcc;   // diagnostic
-    __hip_atomic_store(p.table + unit + NU * slot, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (flag[0]) return false;   // an earlier kernel of this workspace timed out
-  if (tid < 64) {
-    SpinGuard guard;
-    guard.start();
-    unsigned v = xcc;
-    bool failed = false;
-    for (;;) {
-      if (tid < P) v = __hip_atomic_load(p.table + unit + NU * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__all(v != SENT)) break;
-      if (guard.expired(p)) { failed = true; break; }
-    }
-    const bool same = __all(v == xcc) && !(p.dbg & 8);
-    if (tid == 0) {
-      if (failed) {
-        flag[0] = 1;
-        __hip_atomic_store(p.status, 3 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      flag[1] = same ? 1 : 0;
-    }
-  }
-  __syncthreads();
-  return flag[0] == 0;
-}
 
 // ===========================================================================
 // forward.  KPL = k values per lane, BS = batch rows per unit, threads = 64*BS.
@@ -861,6 +681,12 @@ static int cu_count() {
   return cached;
 }
 
+// lstm_persist_mx.hip: 8 rows per unit, bf16-plane product (the default wherever it applies; NABU_PERSIST_MX=0: off)
+bool lstm_mx_supported(int B, int H);
+int lstm_mx_chunk_rows();
+size_t lstm_mx_ring_bytes(bool fwd, int H);
+int lstm_mx_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream);
+
 // geometry: BS = 4 (two 256-thread workgroups per CU) when the batch fits, else BS = 8
 bool lstm_persist_fuses_input(int B, int T, int D, int H);
 size_t lstm_persist_db_floats(int B, int H) { return (size_t)((B + 3) / 4) * 2 * 4 * H; }
@@ -880,6 +706,7 @@ static int pick_bs(int B, int H, bool fwd) {
 // chunks of batch rows (the tensors are batch-major, a chunk is a contiguous slab): at H = 512 a
 // launch takes up to 64 rows (BS = 8, two workgroups per CU), B = 96 is a launch of 64 and one of 32.
 static int chunk_rows(int B, int H, bool fwd) {
+  if (lstm_mx_supported(B, H)) return B < lstm_mx_chunk_rows() ? B : lstm_mx_chunk_rows();
   if (pick_bs(B, H, fwd)) return B;
   int c = (fwd ? 8 : 4) * (2 * cu_count() / (2 * (H / UC)));   // largest batch of one launch
   return c < 4 ? 4 : c;
@@ -888,6 +715,7 @@ static int chunk_rows(int B, int H, bool fwd) {
 bool lstm_persist_supported(int B, int T, int H) {
   if (!(H == 64 || H == 128 || H == 256 || H == 512)) return false;
   if (B <= 0 || T <= 0) return false;
+  if (lstm_mx_supported(B, H)) return (size_t)chunk_rows(B, H, true) * T * 4 * H * 4 < 0x80000000ull;
   if ((size_t)B * T * 4 * H * 4 >= 0x80000000ull && (size_t)chunk_rows(B, H, true) * T * 4 * H * 4 >= 0x80000000ull)
     return false;   // 32-bit buffer offsets inside one launch
   return pick_bs(chunk_rows(B, H, true), H, true) != 0 && pick_bs(chunk_rows(B, H, false), H, false) != 0;
@@ -912,6 +740,9 @@ size_t lstm_persist_ws_bytes(int B, int T, int H) {
       if (r > m) m = r;
     }
   }
+  if (lstm_mx_supported(B, H))
+    for (int f = 0; f < 2; ++f)
+      if (lstm_mx_ring_bytes(f != 0, H) > m) m = lstm_mx_ring_bytes(f != 0, H);
   return TABLE_BYTES + m + db_part_bytes(B, H);
 }
 
@@ -983,6 +814,21 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
                      int *shard_base, hipStream_t stream, const float *x, const float *const bias[2]) {
   PersistArgs a;
   { const char *e = getenv("NABU_PERSIST_DEBUG"); a.dbg = e ? atoi(e) : 0; }
+  if (lstm_mx_supported(B, H)) {
+    if (fwd && x) return fail(NABU_EINVAL, "persistent LSTM (mx): no in-kernel input projection");
+    a.B = B; a.T = T; a.D = D; a.H = H; a.max_len = max_len; a.nshard = (B + 7) / 8;
+    a.len = len;
+    for (int i = 0; i < 2; ++i) { a.kernel[i] = kernel[i]; a.gates[i] = gates[i]; a.cs[i] = cs[i]; a.bias[i] = nullptr; }
+    a.out = out; a.dout = dout; a.x = nullptr;
+    a.db_part = db_part; a.amax_part = amax_part; a.shard_base = *shard_base;
+    *shard_base += a.nshard;
+    a.status = status;
+    a.table = static_cast<unsigned *>(ws);
+    a.xbuf = static_cast<char *>(ws) + TABLE_BYTES;
+    a.timeout_ticks = g_timeout_ticks;
+    NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + lstm_mx_ring_bytes(fwd, H), stream));
+    return lstm_mx_launch(fwd, H, a, stream);
+  }
   int BS = pick_bs(B, H, fwd);
   if ((a.dbg & 16) && 2 * ((B + 7) / 8) * (H / UC) <= cu_count()) BS = 8;
   a.B = B; a.T = T; a.D = D; a.H = H; a.max_len = max_len; a.nshard = (B + BS - 1) / BS;
@@ -1037,7 +883,7 @@ int lstm_persist_fwd(int B, int T, int D, int H, int max_len, const int32_t *len
 bool lstm_persist_fuses_input(int B, int T, int D, int H) {
   static int env = -1;
   if (env < 0) { const char *e = getenv("NABU_PERSIST_FUSE_INPUT"); env = e ? atoi(e) : 1; }
-  if (!env || D != 40 || !lstm_persist_supported(B, T, H)) return false;
+  if (!env || D != 40 || !lstm_persist_supported(B, T, H) || lstm_mx_supported(B, H)) return false;
   if ((size_t)B * T * D * 4 >= 0x80000000ull) return false;
   const int Bc = chunk_rows(B, H, true);
   for (int b0 = 0; b0 < B; b0 += Bc)

@@ -27,4 +27,7 @@ for pas, name in ((0,'fwd'),(1,'bwd')):
     wal = st[32*pas:32*pas+(6 if pas==0 else 7)]
     print(name, 'phase times (ns)', [int((wal[i+1]-wal[i]) & 0xffffffff)*10 for i in range(len(wal)-1)])
     if pas == 1: print('   bwd inner (ns): product end -> resets drained %d, -> barrier passed %d, -> publish issued %d, -> prefetch claimed %d' % tuple(int((st[32 + b] - st[32 + a]) & 0xffffffff) * 10 for a, b in ((4, 7), (7, 8), (8, 9), (9, 5))))
-    if pas == 0: print('   fwd inner: stamp1->6 (prefetch issue) %d, 6->7 (LDS reads + FMAs) %d, 7->2 (quad reduce) %d' % tuple(int((st[b]-st[a]) & 0xffffffff)*10 for a,b in ((1,6),(6,7),(7,2))))
+    if pas == 0: print('   fwd loads issued +%d, k-step 0 valid +%d, last k-step valid +%d, product done +%d (ns after step start)' % tuple(int((st[i]-st[0]) & 0xffffffff)*10 for i in (22,23,24,2)))
+    if pas == 0 and st[27] > 0: print('   fwd effective shader clock %.3f GHz' % (st[26] / (st[27] * 10.0)))
+    if pas == 0: print('   fwd poll rounds %d, first round took %d ns' % (st[20], int((st[21]-st[0]) & 0xffffffff)*10))
+    if pas == 0 and 0: print('   fwd inner: stamp1->6 (prefetch issue) %d, 6->7 (LDS reads + FMAs) %d, 7->2 (quad reduce) %d' % tuple(int((st[b]-st[a]) & 0xffffffff)*10 for a,b in ((1,6),(6,7),(7,2))))
