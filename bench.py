@@ -269,9 +269,13 @@ GEMM_ARITH = {'f32': 'f32 (v_mfma_f32_32x32x2_f32, exact fp32)',
                         'products (v_mfma_f32_32x32x16_bf16), 16-k partial sums promoted to fp32 accumulators; error vs '
                         'float64 <= the exact-fp32 MFMA kernel\'s (tests/test_hip_gemm_pk.py)',
               'f16x3': 'fp32-equivalent on the fp16 matrix pipe: every operand row scaled by a power of two (row maximum '
-                       'into [2^14, 2^15)) and held as two fp16 planes, 3 plane products (v_mfma_f32_32x32x16_f16), 16-k '
-                       'partial sums promoted to fp32 accumulators; error vs float64 <= the exact-fp32 MFMA kernel\'s on '
-                       'normal data, <= 1.25x on heavy-tailed data (tests/test_hip_gemm_pk.py)',
+                       'into [2^14, 2^15)) and held as two fp16 planes, 3 plane products (v_mfma_f32_32x32x16_f16) — chained '
+                       'directly into the fp32 accumulators where that rounds less often than the exact-fp32 kernel does '
+                       '(direct = 2: every product of this step), 16-k partial sums promoted otherwise; error vs float64 '
+                       '0.51-0.66 x rms / 0.27-0.76 x max of the exact-fp32 MFMA kernel\'s on EVERY dense product of a '
+                       'cfg2 step on the operands of a model trained for 50 updates, dz products included '
+                       '(tests/test_hip_real_operands.py); the recipe ships this arithmetic '
+                       '(config/recipes/cfg2_listener_ctc/model.cfg: gemm_precision)',
               'bf16x3': 'f32 operands split into 2 bf16 pieces, 3 bf16 MFMA products, f32 accumulate',
               'bf16': 'operands rounded to bf16, f32 accumulate'}
 
@@ -287,11 +291,13 @@ def parse_args(argv=None):
                     help='skip the measurements of the same step with the other fp32-class arithmetics of the dense products')
     ap.add_argument('--no-gemm-roofline', action='store_true',
                     help='skip the roofline_gemm measurement (keeps a kernel trace of this command to the training steps)')
-    ap.add_argument('--gemm-precision', default='f16x3', choices=['f32', 'bf16x6', 'f16x3', 'bf16x3', 'bf16'],
-                    help='arithmetic of the dense products (include/nabu_hip.h): f16x3 (default) = fp32-equivalent '
-                         'three-plane products of row-scaled fp16 operands, bf16x6 = fp32-equivalent six-plane products '
-                         'on the bf16 matrix pipe, f32 = exact fp32 MFMA; the line names it in config.gemm_arith and '
-                         'carries the other two as `exact_fp32` / `alt_bf16x6` / `alt_f16x3`')
+    ap.add_argument('--gemm-precision', default=None, choices=['f32', 'bf16x6', 'f16x3', 'bf16x3', 'bf16'],
+                    help='arithmetic of the BLSTM layers\' dense products (include/nabu_hip.h).  Default: what the '
+                         'workload\'s RECIPE ships (cfg2: f16x3 = fp32-equivalent three-plane products of row-scaled '
+                         'fp16 operands); given, it overrides the recipe\'s encoder.gemm_precision key for this run '
+                         '(bf16x6 = fp32-equivalent six-plane products on the bf16 matrix pipe, f32 = exact fp32 '
+                         'MFMA).  The line names the arithmetic in config.gemm_arith and carries the other two, timed '
+                         'with the same steps / warm-up, as `exact_fp32` / `alt_bf16x6` / `alt_f16x3`')
     ap.add_argument('--workload', default='cfg2', choices=['cfg1', 'cfg2', 'cfg3', 'cfg5'],
                     help='cfg2 (default) is the BASELINE.json metric; cfg3 = same encoder + Speller; cfg5 = '
                          'location-aware LAS, batch 64x1600x80, bf16 input GEMMs (BASELINE.json configs[2]/[4]), '
@@ -381,12 +387,13 @@ class HipWorkload(object):
         self.args, self.server = args, server
         rank = server.rank
         _hip.lib()
-        ops.set_gemm_precision(args.gemm_precision)
         layer.LSTM_MODE[0] = {'auto': ops.LSTM_AUTO, 'stepwise': ops.LSTM_STEPWISE,
                               'persistent': ops.LSTM_PERSISTENT}[args.mode]
         self.B, self.T, self.D, self.H = B, T, D, H
         self.layer_t = None
         over = {'trainer.allreduce_buckets': 'True' if args.allreduce == 'bucketed' else 'False'}
+        if args.gemm_precision:          # otherwise: the arithmetic the recipe ships
+            over['encoder.gemm_precision'] = args.gemm_precision
         if args.workload == 'cfg1':
             # BASELINE.json configs[0]: DBLSTM 2 x 256 + CTC, 8 x 200 x 40 (the reference's CPU-runnable case)
             self.B, self.T, self.D, self.H = 8, 200, 40, 256
@@ -411,6 +418,8 @@ class HipWorkload(object):
         self.tr = trainer_factory.factory('standard')(conf=tc, dataconf=data, modelconf=mc, evaluatorconf=ec,
                                                       expdir=None, server=server, task_index=rank)
         self.tr.time_allreduce = server.world_size > 1
+        # the arithmetic of the BLSTM layers' dense products this run computes in: the recipe's, unless overridden
+        self.precision = mc.get('encoder', 'gemm_precision') if mc.has_option('encoder', 'gemm_precision') else 'f32'
         self.batches = [self.tr.to_device(data.batch(i)) for i in range(2)]      # resident in HBM
         # the event profiler is armed during the warm-up as well: its first use (event pool creation
         # inside the HIP runtime) stalls the queue for tens of milliseconds once
@@ -461,10 +470,10 @@ class HipWorkload(object):
 
     def alt(self, steps):
         """the same step under the other fp32-class arithmetics of the dense products: [(precision, seconds, loss)]"""
-        if self.args.gemm_precision not in ALT_KEYS or self.args.workload != 'cfg2' or self.args.no_alt:
+        if self.precision not in ALT_KEYS or self.args.workload != 'cfg2' or self.args.no_alt:
             return []
-        return [(o,) + alt_gemm_arith(self.tr, self.batches, self.server, steps, o, self.args.gemm_precision)
-                for o in ALT_KEYS if o != self.args.gemm_precision]
+        return [(o,) + alt_gemm_arith(self.tr, self.batches, self.server, steps, max(self.args.warmup, 1), o)
+                for o in ALT_KEYS if o != self.precision]
 
     def describe(self, dt):
         """workload-specific part of the JSON line (rank 0)"""
@@ -512,15 +521,17 @@ class HipWorkload(object):
                             'per recurrent launch from the rocprofv3 PMC passes under profiles/'}
         return {
             'metric': METRICS[args.workload],
-            'dtype': 'f32' if args.gemm_precision in ALT_KEYS else 'f32 state / %s products' % args.gemm_precision,
+            'dtype': ('f32' if self.precision == 'f32' else 'f32 (%s products)' % self.precision if self.precision in ALT_KEYS
+                      else 'f32 state / %s products' % self.precision),
             'config': {'workload': WORKLOADS[args.workload], 'frames': T_,
                        'recurrent_path': 'persistent' if persistent else 'stepwise',
-                       'gemm_arith': GEMM_ARITH[args.gemm_precision]},
+                       'gemm_arith': GEMM_ARITH[self.precision],
+                       'gemm_precision_from': 'command line' if args.gemm_precision else 'recipe (encoder.gemm_precision)'},
             'roofline': roofline,
             'roofline_gemm': (None if args.workload != 'cfg2' or args.no_gemm_roofline
-                              else gemm_roofline(B_, T_, D_, H_, args.gemm_precision) if args.gemm_precision == 'f32'
-                              else gemm_roofline_pk(B_, T_, D_, H_, 3) if args.gemm_precision == 'bf16x6'
-                              else gemm_roofline_pk(B_, T_, D_, H_, 2) if args.gemm_precision == 'f16x3' else None),
+                              else gemm_roofline(B_, T_, D_, H_, self.precision) if self.precision == 'f32'
+                              else gemm_roofline_pk(B_, T_, D_, H_, 3) if self.precision == 'bf16x6'
+                              else gemm_roofline_pk(B_, T_, D_, H_, 2) if self.precision == 'f16x3' else None),
             'final_loss': round(self.final_loss, 4),
         }
 
@@ -551,7 +562,7 @@ def run(args, server, wl):
     dt_rank = time.perf_counter() - t0
     wl.end_timed_region()
     wl.check()
-    alt = wl.alt(min(args.steps, 5))
+    alt = wl.alt(args.steps)
     red = wl.reduce_max([dt_rank] + [a[1] for a in alt])
     per_rank = wl.gather(dt_rank)
     ar_ms = wl.allreduce_ms_per_step()
@@ -570,11 +581,12 @@ def run(args, server, wl):
                     'allreduce': getattr(args, 'allreduce', 'flat') if world > 1 else None,
                     'allreduce_ms_per_step': [round(v, 3) for v in ar_ranks] if world > 1 else None}
     for i, (other, _, alt_loss) in enumerate(alt):
-        n = min(args.steps, 5)
+        n = args.steps
         step_bytes_total = 2 * 2 * sum(wl.layer_t) * step_bytes(wl.B, wl.H)
         out[ALT_KEYS[other]] = {
-            'note': 'the identical step (same weights stream, batches, protocol: 1 warm-up, barrier + sync bracket, MAX '
-                    'over ranks) with the dense products in another arithmetic; not the headline value',
+            'note': 'the identical step (same weights stream, batches and protocol as the headline: %d warm-up steps, %d '
+                    'timed steps, barrier + sync bracket, MAX over ranks) with the dense products in another arithmetic; '
+                    'not the headline value' % (max(args.warmup, 1), n),
             'gemm_arith': GEMM_ARITH[other],
             'value': round(world * wl.units_per_step * n / red[1 + i], 2), 'ms_per_step': round(red[1 + i] / n * 1e3, 3),
             'steps': n, 'final_loss': round(alt_loss, 4),
@@ -604,14 +616,17 @@ def main(argv=None):
     server.shutdown()
 
 
-def alt_gemm_arith(tr, batches, server, steps, precision, restore):
-    """the same step with another arithmetic of the dense products (exact fp32 / bf16x6 / f16x3), timed with the
-    protocol of the headline; NOT the headline value"""
+def alt_gemm_arith(tr, batches, server, steps, warmup, precision):
+    """the same step with another arithmetic of the BLSTM layers' dense products (exact fp32 / bf16x6 / f16x3): the
+    encoder's gemm_precision key is switched for the duration (the layers read it at every call), timed with the
+    protocol, warm-up and step count of the headline; NOT the headline value"""
     import torch
-    from nabu_amd import ops
-    ops.set_gemm_precision(precision)
+    conf = tr.model.encoder.conf
+    restore = conf.get('gemm_precision', None)
+    conf['gemm_precision'] = precision
     try:
-        tr.step(batches[0])
+        for i in range(warmup):
+            tr.step(batches[i % 2])
         torch.cuda.synchronize()
         server.barrier()
         t0 = time.perf_counter()
@@ -621,7 +636,10 @@ def alt_gemm_arith(tr, batches, server, steps, precision, restore):
         server.barrier()
         dt = time.perf_counter() - t0
     finally:
-        ops.set_gemm_precision(restore)
+        if restore is None:
+            del conf['gemm_precision']
+        else:
+            conf['gemm_precision'] = restore
     return dt, float(loss.item())
 
 

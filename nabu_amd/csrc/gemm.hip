@@ -661,6 +661,16 @@ static bool fast_f32_ok(bool ta, bool tb, int M, int N, int K, const void *A, in
          b_seg % 4 == 0 && (!ta || M % 4 == 0) && (tb || N % 4 == 0);
 }
 
+// hipFuncSetAttribute is a per-device setting: remember, per calling thread, the devices a kernel family was
+// configured on (a process-wide flag would skip the second GPU of a multi-device process, and an unsynchronised one
+// races between threads)
+static bool configured_on_current_device(unsigned long long &mask, int *dev_out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  *dev_out = dev;
+  return dev < 64 && ((mask >> dev) & 1ull);
+}
+
 extern "C" int nabu_gemm_ex(int precision, int transA, int transB, int M, int N, int K, float alpha,
                             const float *A, int lda, const float *B, int ldb, float beta,
                             float *C, int ldc, const float *bias, int kseg,
@@ -737,12 +747,13 @@ static int gemm_run(int precision, int transA, int transB, int M, int N, int K, 
   if ((precision == NABU_GEMM_F32 || K % FBK != 0) && smallk_ok(transA != 0, transB != 0, M, N, K, A, lda, B, ldb, kseg, C, ldc, bias)) {
     a.nsplit = 1; a.partial = nullptr;
     const size_t lds = smallk_lds(K);
-    static bool configured = false;
-    if (!configured) {
+    static thread_local unsigned long long configured = 0;
+    int dev;
+    if (!configured_on_current_device(configured, &dev)) {
       NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_smallk_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)smallk_lds(SMALLK_MAX)));
-      configured = true;
+      if (dev < 64) configured |= 1ull << dev;
     }
     hipLaunchKernelGGL(gemm_smallk_kernel, dim3((N + BN - 1) / BN, (M + BM - 1) / BM), block, lds, s, a);
     NABU_LAUNCH_CHECK();
@@ -756,14 +767,15 @@ static int gemm_run(int precision, int transA, int transB, int M, int N, int K, 
   } else
   if (fast32) {
     const size_t lds = 4 * (size_t)(FKT * LDT > 128 * (FKT + 2) ? FKT * LDT : 128 * (FKT + 2)) * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
+    static thread_local unsigned long long configured = 0;
+    int dev;
+    if (!configured_on_current_device(configured, &dev)) {
       const void *fns[4] = {reinterpret_cast<const void *>(gemm_f32_fast_kernel<true, true>),
                             reinterpret_cast<const void *>(gemm_f32_fast_kernel<true, false>),
                             reinterpret_cast<const void *>(gemm_f32_fast_kernel<false, true>),
                             reinterpret_cast<const void *>(gemm_f32_fast_kernel<false, false>)};
       for (const void *f : fns) NABU_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      configured = true;
+      if (dev < 64) configured |= 1ull << dev;
     }
     if (transA && transB) hipLaunchKernelGGL((gemm_f32_fast_kernel<true, true>), grid, block, lds, s, a);
     else if (transA) hipLaunchKernelGGL((gemm_f32_fast_kernel<true, false>), grid, block, lds, s, a);

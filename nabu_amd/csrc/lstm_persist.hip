@@ -685,7 +685,7 @@ static int cu_count() {
 bool lstm_mx_supported(int B, int H);
 int lstm_mx_chunk_rows();
 size_t lstm_mx_ring_bytes(bool fwd, int H);
-int lstm_mx_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream);
+int lstm_mx_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry);
 
 // geometry: BS = 4 (two 256-thread workgroups per CU) when the batch fits, else BS = 8
 bool lstm_persist_fuses_input(int B, int T, int D, int H);
@@ -753,8 +753,11 @@ size_t lstm_persist_ws_bytes(int B, int T, int H) {
 // 256-thread blocks (same guide); the grids here need at most 2 per CU where the register file admits 2 and the
 // LDS request is sized for exactly that, and every spin is bounded, so an optimistic answer costs a time-out,
 // never a hang.  NABU_EUNSUP makes LSTM_AUTO take the step-wise kernels.
+// dry: validate only (every chunk of a call is validated BEFORE the first one is enqueued: a later chunk that cannot be
+// co-resident must not leave the earlier chunks' in-place updates of the gate buffers behind — the step-wise fallback
+// of LSTM_AUTO restarts from the untouched buffers)
 template <typename K>
-static int launch(K kernel, const PersistArgs &a, int grid, int threads, size_t lds, hipStream_t stream) {
+static int launch(K kernel, const PersistArgs &a, int grid, int threads, size_t lds, hipStream_t stream, bool dry) {
   const void *fn = reinterpret_cast<const void *>(kernel);
   struct Seen { const void *fn; int dev, threads, blocks; size_t lds; };
   static thread_local Seen seen[32] = {};
@@ -772,6 +775,7 @@ static int launch(K kernel, const PersistArgs &a, int grid, int threads, size_t 
   if ((long long)blocks * cu_count() < grid)
     return fail(NABU_EUNSUP, "persistent LSTM: %d workgroups cannot be co-resident (%d per CU x %d CUs on this device)",
                 grid, blocks, cu_count());
+  if (dry) return 0;
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, stream, a);
   NABU_LAUNCH_CHECK();
   return 0;
@@ -780,7 +784,7 @@ static int launch(K kernel, const PersistArgs &a, int grid, int threads, size_t 
 static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
                      const float *dout, int *status, void *ws, size_t ws_bytes, float *db_part, float *amax_part,
-                     int *shard_base, hipStream_t stream, const float *x, const float *const bias[2]);
+                     int *shard_base, hipStream_t stream, const float *x, const float *const bias[2], bool dry);
 
 static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
                const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
@@ -793,15 +797,18 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
   float *amax_part = db_part + db_part_bytes(B, H) / (2 * sizeof(float));
   int shards = 0;
   const int Bc = chunk_rows(B, H, fwd);
-  for (int b0 = 0; b0 < B; b0 += Bc) {
-    const int nb = B - b0 < Bc ? B - b0 : Bc;
-    float *g2[2] = {gates[0] + (size_t)b0 * T * 4 * H, gates[1] + (size_t)b0 * T * 4 * H};
-    float *c2[2] = {cs[0] + (size_t)b0 * T * H, cs[1] + (size_t)b0 * T * H};
-    const int e = run_chunk(fwd, nb, T, D, H, max_len, len + b0, kernel, g2, c2,
-                            out ? out + (size_t)b0 * T * 2 * H : nullptr,
-                            dout ? dout + (size_t)b0 * T * 2 * H : nullptr, status, ws, ws_bytes, db_part, amax_part, &shards,
-                            stream, x ? x + (size_t)b0 * T * D : nullptr, bias);
-    if (e) return e;
+  for (int pass = 0; pass < 2; ++pass) {     // pass 0 validates every chunk, pass 1 enqueues them
+    shards = 0;
+    for (int b0 = 0; b0 < B; b0 += Bc) {
+      const int nb = B - b0 < Bc ? B - b0 : Bc;
+      float *g2[2] = {gates[0] + (size_t)b0 * T * 4 * H, gates[1] + (size_t)b0 * T * 4 * H};
+      float *c2[2] = {cs[0] + (size_t)b0 * T * H, cs[1] + (size_t)b0 * T * H};
+      const int e = run_chunk(fwd, nb, T, D, H, max_len, len + b0, kernel, g2, c2,
+                              out ? out + (size_t)b0 * T * 2 * H : nullptr,
+                              dout ? dout + (size_t)b0 * T * 2 * H : nullptr, status, ws, ws_bytes, db_part, amax_part, &shards,
+                              stream, x ? x + (size_t)b0 * T * D : nullptr, bias, pass == 0);
+      if (e) return e;
+    }
   }
   if (db_part_out) *db_part_out = db_part;      // (the maxima follow at db_part + lstm_persist_db_floats(B, H))
   if (db_rows_out) *db_rows_out = shards;
@@ -811,7 +818,7 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
 static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
                      const float *dout, int *status, void *ws, size_t ws_bytes, float *db_part, float *amax_part,
-                     int *shard_base, hipStream_t stream, const float *x, const float *const bias[2]) {
+                     int *shard_base, hipStream_t stream, const float *x, const float *const bias[2], bool dry) {
   PersistArgs a;
   { const char *e = getenv("NABU_PERSIST_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   if (lstm_mx_supported(B, H)) {
@@ -826,8 +833,8 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
     a.table = static_cast<unsigned *>(ws);
     a.xbuf = static_cast<char *>(ws) + TABLE_BYTES;
     a.timeout_ticks = g_timeout_ticks;
-    NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + lstm_mx_ring_bytes(fwd, H), stream));
-    return lstm_mx_launch(fwd, H, a, stream);
+    if (!dry) NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + lstm_mx_ring_bytes(fwd, H), stream));
+    return lstm_mx_launch(fwd, H, a, stream, dry);
   }
   int BS = pick_bs(B, H, fwd);
   if ((a.dbg & 16) && 2 * ((B + 7) / 8) * (H / UC) <= cu_count()) BS = 8;
@@ -850,17 +857,17 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
   const int per_cu = (BS == 4 || grid > cu_count()) ? 2 : 1;
   if (grid > per_cu * cu_count())
     return fail(NABU_EUNSUP, "persistent LSTM: %d workgroups > %d x %d CUs", grid, per_cu, cu_count());
-  NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + ring_bytes(fwd, BS, a.nshard, H), stream));
+  if (!dry) NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + ring_bytes(fwd, BS, a.nshard, H), stream));
   // dynamic LDS chosen so that exactly `per_cu` workgroups fit on a CU (160 KiB)
   const size_t lds = BS == 4 ? 64 * 1024 : (grid > cu_count() ? 72 * 1024 : 96 * 1024);
 #define NABU_PERSIST_CASE(h)                                                                         \
   case h:                                                                                            \
-    if (XK == 10) return launch(lstm_persist_fwd_kernel<h / 16, 4, 10>, a, grid, 256, lds, stream);    \
+    if (XK == 10) return launch(lstm_persist_fwd_kernel<h / 16, 4, 10>, a, grid, 256, lds, stream, dry);    \
     if (BS == 4)                                                                                     \
-      return fwd ? launch(lstm_persist_fwd_kernel<h / 16, 4>, a, grid, 256, lds, stream)             \
-                 : launch(lstm_persist_bwd_kernel<h, 4>, a, grid, 256, lds, stream);                 \
-    return fwd ? launch(lstm_persist_fwd_kernel<h / 32, 8>, a, grid, 512, lds, stream)               \
-               : launch(lstm_persist_bwd_kernel<h, 8>, a, grid, 512, lds, stream);
+      return fwd ? launch(lstm_persist_fwd_kernel<h / 16, 4>, a, grid, 256, lds, stream, dry)        \
+                 : launch(lstm_persist_bwd_kernel<h, 4>, a, grid, 256, lds, stream, dry);            \
+    return fwd ? launch(lstm_persist_fwd_kernel<h / 32, 8>, a, grid, 512, lds, stream, dry)          \
+               : launch(lstm_persist_bwd_kernel<h, 8>, a, grid, 512, lds, stream, dry);
   switch (H) {
     NABU_PERSIST_CASE(64)
     NABU_PERSIST_CASE(128)

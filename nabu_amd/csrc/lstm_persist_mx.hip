@@ -680,7 +680,7 @@ size_t lstm_mx_ring_bytes(bool fwd, int H) {
 }
 
 template <typename K>
-static int mx_launch(K kernel, const PersistArgs &a, int grid, size_t lds, hipStream_t stream) {
+static int mx_launch(K kernel, const PersistArgs &a, int grid, size_t lds, hipStream_t stream, bool dry) {
   const void *fn = reinterpret_cast<const void *>(kernel);
   struct Seen { const void *fn; int dev, blocks; };
   static thread_local Seen seen[8] = {};
@@ -696,18 +696,19 @@ static int mx_launch(K kernel, const PersistArgs &a, int grid, size_t lds, hipSt
   }
   if (blocks < 1 || grid > NCU)
     return fail(NABU_EUNSUP, "persistent LSTM (mx): %d workgroups cannot be co-resident (%d per CU)", grid, blocks);
+  if (dry) return 0;          // validation pass (lstm_persist.hip, run)
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, stream, a);
   NABU_LAUNCH_CHECK();
   return 0;
 }
 
 // one launch over B <= 32 rows; `a` comes filled from run_chunk (nshard = ceil(B / 8))
-int lstm_mx_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream) {
+int lstm_mx_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry) {
   const int grid = MXNU * (H / UC);
 #define NABU_MX_CASE(h)                                                                                          \
   case h:                                                                                                        \
-    return fwd ? mx_launch(lstm_mx_fwd_kernel<h>, a, grid, MxFwdLds<h>::TOTAL * sizeof(float), stream)           \
-               : mx_launch(lstm_mx_bwd_kernel<h>, a, grid, MxBwdLds<h>::TOTAL * sizeof(float), stream);
+    return fwd ? mx_launch(lstm_mx_fwd_kernel<h>, a, grid, MxFwdLds<h>::TOTAL * sizeof(float), stream, dry)      \
+               : mx_launch(lstm_mx_bwd_kernel<h>, a, grid, MxBwdLds<h>::TOTAL * sizeof(float), stream, dry);
   switch (H) {
     NABU_MX_CASE(128)
     NABU_MX_CASE(256)

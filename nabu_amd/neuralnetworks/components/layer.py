@@ -20,6 +20,9 @@ GEMM_PRECISION = ['default']
 # nabu_blstm_bwd_data).  NABU_DEFER_WGRAD=0: one fused nabu_blstm_bwd per layer as before.
 import os as _os
 DEFER_WEIGHT_GRADS = [_os.environ.get('NABU_DEFER_WGRAD', '1') != '0']
+# tests: a list here receives, per layer and backward pass, the operands of the layer's dense products (x, out, the
+# kernels and a copy of dz as the data part of the backward pass left it in the reserve) — tests/test_hip_real_operands.py
+CAPTURE = [None]
 
 
 def blstm(inputs, sequence_length, num_units, layer_norm=False, scope=None):
@@ -55,6 +58,10 @@ def blstm(inputs, sequence_length, num_units, layer_norm=False, scope=None):
         tape = Tape.current_backward
         if DEFER_WEIGHT_GRADS[0] and tape is not None:
             hip.blstm_bwd_data(plan, x, lens.dev, kf.data, kb.data, out, dout.contiguous(), reserve, dx, bf.grad, bb.grad)
+            if CAPTURE[0] is not None:
+                n = B * T * 4 * H
+                dz = reserve[:2 * n * 4].view(torch.float32).view(2, B * T, 4 * H).clone()
+                CAPTURE[0].append({'x': x, 'out': out, 'kf': kf.data, 'kb': kb.data, 'dz': dz, 'B': B, 'T': T, 'D': D, 'H': H})
             tape.defer(lambda: hip.blstm_bwd_weights(plan, x, lens.dev, out, reserve, kf.grad, kb.grad), params=(kf, kb))
         else:
             hip.blstm_bwd(plan, x, lens.dev, kf.data, kb.data, out, dout.contiguous(), reserve, dx,

@@ -41,6 +41,7 @@ class Evaluator(object, metaclass=ABCMeta):
             batch_size=int(self.conf['batch_size']), numbuckets=1, shuffle=False)
         nb = len(self.data.elements) // int(self.conf['batch_size'])
         self.data.num_steps = nb
+        self.data.bounded = True          # no look-ahead batch past the last validation batch
 
     def evaluate(self):
         '''Returns:

@@ -121,6 +121,8 @@ def pk_pack(dst, src, transposed=False, row_off=0, kb_off=0, fill_rows=None, fil
         if bound is not None:
             check(L.nabu_pk_amax_fill(ptr(am), rows, float(bound), stream()), 'nabu_pk_amax_fill')
         elif measure:
+            if kb_off == 0:        # a fresh measurement of these rows (the maxima accumulate only along k: kb_off > 0)
+                am[:rows].zero_()
             check(L.nabu_pk_amax(src.data_ptr(), ld, R, C, None if transposed else ptr(am), ptr(am) if transposed else None,
                                  stream()), 'nabu_pk_amax')
         check(L.nabu_pk_pack_f16(int(transposed), src.data_ptr(), ld, R, C, ptr(dst.buf), dst.rows_pad, row_off, kb_off,

@@ -111,7 +111,8 @@ class RecordData(object):
         self._pool = ThreadPoolExecutor(max_workers=1)
         self._lock = threading.Lock()
         self._ahead = {}           # step -> Future of its batch
-        self.lookahead = True      # bounded consumers (validation) switch it off: no batch past the last one
+        self.lookahead = True
+        self.bounded = False       # bounded consumers (validation) set it: no look-ahead past the last batch
         self._last_step = None
         self._epochs = []          # per epoch: list of batches (lists of utterance indices)
         self._carry = [[] for _ in self.batch_sizes]
@@ -176,7 +177,7 @@ class RecordData(object):
         stride = step - self._last_step if self._last_step is not None and step > self._last_step else 1
         self._last_step = step
         nxt = step + stride
-        if self.lookahead and self._pool is not None:
+        if self.lookahead and self._pool is not None and not (self.bounded and nxt >= self.num_steps):
             self._ahead[nxt] = self._pool.submit(self._assemble, nxt)
         return out
 
