@@ -171,12 +171,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // lane (u16, r2, gp) fetches gates 2 gp and 2 gp + 1 of (row frow, unit u16); the finishing lane reads all four
   const i32x4 rg = raw_rsrc(p.gates[dir], (unsigned)((size_t)p.B * T * 4 * H * 4));
   const unsigned goff = (unsigned)(((size_t)fb * T * 4 * H + (size_t)(2 * gp) * H + U0 + u16) * 4);
-  auto fetch_x = [&](int s) {
+  auto fetch_x_part = [&](int s, int part) {
     const int t = dir ? n_f - 1 - s : s;
     const bool act = s < n_f && !(p.dbg & 64);
     float *st = xst + (s & 1) * 512 + 64 * w;
-    prefetch_lds_b32(rg, act ? goff + (unsigned)t * (unsigned)(16 * H) : OOB, smem, st);
-    prefetch_lds_b32(rg, act ? goff + (unsigned)t * (unsigned)(16 * H) + (unsigned)(4 * H) : OOB, smem, st + 256);
+    if (part == 0) prefetch_lds_b32(rg, act ? goff + (unsigned)t * (unsigned)(16 * H) : OOB, smem, st);
+    if (part == 1) prefetch_lds_b32(rg, act ? goff + (unsigned)t * (unsigned)(16 * H) + (unsigned)(4 * H) : OOB, smem, st + 256);
+  };
+  auto fetch_x = [&](int s) {
+    fetch_x_part(s, 0);
+    fetch_x_part(s, 1);
   };
   fetch_x(0);
   wait_vm<0>();
@@ -257,9 +261,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       wait_vm<0>();        // (no exchange loads to order the prefetch: s = 0, or the no-waiting experiment)
     }
     NABU_STAMP(0, 1);
-    fetch_x(s + 1);
     // (b) product: 4 column tiles (gate c) x NKS k-steps x {Wl.B1, Wm.B1, Wh.B2, Wh.B1}; the l planes of k-steps
-    // 2 jp (lanes n < 8) and 2 jp + 1 (the others) arrived in one register set
+    // 2 jp (lanes n < 8) and 2 jp + 1 (the others) arrived in one register set.  Next step's x-projection (HBM
+    // latency: as early as possible) is requested from inside the matrix stream, one instruction behind each of the
+    // first two groups of matrix instructions.
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = (mxf32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0 && !(p.dbg & 2)) {
@@ -275,13 +280,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = MX_MFMA(Wp[2][c][j], b1[j], acc[c]);
+        if (j == 0) { fetch_x_part(s + 1, 0); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = MX_MFMA(Wp[1][c][j], b1[j], acc[c]);
+        if (j == 0) { fetch_x_part(s + 1, 1); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = MX_MFMA(Wp[0][c][j], b2, acc[c]);
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = MX_MFMA(Wp[0][c][j], b1[j], acc[c]);
       }
+    } else {
+      fetch_x(s + 1);
     }
     NABU_STAMP(0, 2);
     if ((p.dbg & 4096) && (unit == 0 || unit == 4) && lane == 0 && s == p.max_len / 2 + 1)
