@@ -307,6 +307,10 @@ def parse_args(argv=None):
                          'would (self-launch or the given environment, rendezvous over 127.0.0.1, device assignment), '
                          'run one collective, print one JSON line and stop before the workload.  With fewer visible '
                          'GPUs than ranks the process group is gloo and the ranks share the devices round-robin.')
+    ap.add_argument('--shrink', action='store_true',
+                    help='NOT a measurement: cfg2\'s recipe at 4 utterances x 64 frames, 64 units — lets the tests run the '
+                         'whole multi-rank line (ranks, exchange, carried cpu_baseline, roofline object) in seconds; the '
+                         'line says config.shrunk = true')
     ap.add_argument('--allreduce', default='flat', choices=['flat', 'bucketed'],
                     help='gradient exchange of the data-parallel mode (trainer cfg key allreduce_buckets)')
     return ap.parse_args(argv)
@@ -387,6 +391,11 @@ class HipWorkload(object):
         self.args, self.server = args, server
         rank = server.rank
         _hip.lib()
+        self.shared = bool(getattr(server, 'shared_devices', False))
+        if self.shared:
+            # more ranks than GPUs (first-contact runs, tests): the ranks' launches interleave on one device, and the
+            # persistent recurrent kernels need a whole device to themselves -> one launch per frame
+            args.mode = 'stepwise'
         layer.LSTM_MODE[0] = {'auto': ops.LSTM_AUTO, 'stepwise': ops.LSTM_STEPWISE,
                               'persistent': ops.LSTM_PERSISTENT}[args.mode]
         self.B, self.T, self.D, self.H = B, T, D, H
@@ -409,6 +418,11 @@ class HipWorkload(object):
             mc, tc, ec = recipes.load_recipe('cfg3_las_vanilla', **over)
             data = SyntheticData(B, T, D, min_frames=T, min_labels=20, max_labels=79, eos=True, time_reduction=8,
                                  seed=3234 + rank)
+        elif args.shrink:
+            self.B, self.T, self.H = 4, 64, 64
+            over.update({'encoder.num_units': '64', 'trainer.batch_size': '4'})
+            mc, tc, ec = recipes.load_recipe('cfg2_listener_ctc', **over)
+            data = SyntheticData(4, 64, D, min_frames=64, min_labels=2, max_labels=5, time_reduction=8, seed=4234 + rank)
         else:
             mc, tc, ec = recipes.load_recipe('cfg2_listener_ctc', **over)
             data = SyntheticData(B, T, D, min_frames=T, min_labels=20, max_labels=60, time_reduction=8,
@@ -418,6 +432,8 @@ class HipWorkload(object):
         self.tr = trainer_factory.factory('standard')(conf=tc, dataconf=data, modelconf=mc, evaluatorconf=ec,
                                                       expdir=None, server=server, task_index=rank)
         self.tr.time_allreduce = server.world_size > 1
+        if server.world_size > 1 and args.allreduce == 'bucketed':
+            self.tr.schedule_log = []
         # the arithmetic of the BLSTM layers' dense products this run computes in: the recipe's, unless overridden
         self.precision = mc.get('encoder', 'gemm_precision') if mc.has_option('encoder', 'gemm_precision') else 'f32'
         self.batches = [self.tr.to_device(data.batch(i)) for i in range(2)]      # resident in HBM
@@ -468,6 +484,15 @@ class HipWorkload(object):
             return None
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
+    def bucket_schedule(self):
+        """bucketed exchange: (bucket, 'hook' = between a recurrence and the products behind it / after the deferred
+        weight gradients, 'final' = at the optimiser) of the last step, in launch order"""
+        log = getattr(self.tr, 'schedule_log', None)
+        if not log:
+            return None
+        n = len(self.tr.buckets)
+        return [list(e) for e in log[-n:]]
+
     def alt(self, steps):
         """the same step under the other fp32-class arithmetics of the dense products: [(precision, seconds, loss)]"""
         if self.precision not in ALT_KEYS or self.args.workload != 'cfg2' or self.args.no_alt:
@@ -495,7 +520,7 @@ class HipWorkload(object):
         # WRITE_SIZE, separate runs of this command; summarised by tools/pmc_summary.py with the
         # gfx950 corrections of MI355X_MICROARCH.md).  null when this workload was not profiled.
         traffic = None
-        for name in ('r03_cfg2_pmc_traffic.json', 'r02_cfg2_pmc_traffic.json', 'r01_cfg2_pmc_traffic.json'):
+        for name in ('r04_cfg2_pmc_traffic.json', 'r03_cfg2_pmc_traffic.json', 'r02_cfg2_pmc_traffic.json'):
             pmc = os.path.join(ROOT, 'profiles', name)
             if persistent and args.workload == 'cfg2' and os.path.exists(pmc):
                 with open(pmc) as fid:
@@ -504,7 +529,7 @@ class HipWorkload(object):
         step_bytes_total = 2 * 2 * sum(self.layer_t) * step_bytes(B_, H_)
         step_s = dt / args.steps
         frac_step = step_bytes_total / step_s / (HBM_PEAK_GBS * 1e9)
-        kname = 'lstm_persist_{fwd,bwd}' if persistent else 'lstm_step_{fwd,bwd}_kernel'
+        kname = 'lstm_mx_{fwd,bwd}_kernel (lstm_persist_* where the bf16-plane kernels do not apply)' if persistent else 'lstm_step_{fwd,bwd}_kernel'
         roofline = {'bound': 'hbm', 'achieved': round(step_bytes_total / step_s / 1e9, 1), 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': round(frac_step, 4), 'traffic': traffic, 'kernel': kname,
                     'bytes_per_step': int(step_bytes_total), 'launches_per_step': launches // max(args.steps, 1),
@@ -526,7 +551,8 @@ class HipWorkload(object):
             'config': {'workload': WORKLOADS[args.workload], 'frames': T_,
                        'recurrent_path': 'persistent' if persistent else 'stepwise',
                        'gemm_arith': GEMM_ARITH[self.precision],
-                       'gemm_precision_from': 'command line' if args.gemm_precision else 'recipe (encoder.gemm_precision)'},
+                       'gemm_precision_from': 'command line' if args.gemm_precision else 'recipe (encoder.gemm_precision)',
+                       'shrunk': bool(getattr(args, 'shrink', False))},
             'roofline': roofline,
             'roofline_gemm': (None if args.workload != 'cfg2' or args.no_gemm_roofline
                               else gemm_roofline(B_, T_, D_, H_, self.precision) if self.precision == 'f32'
@@ -579,7 +605,9 @@ def run(args, server, wl):
     out['ranks'] = {'world_size_seen': world, 'backend': server.backend,
                     'ms_per_step_per_rank': [round(t / args.steps * 1e3, 3) for t in per_rank],
                     'allreduce': getattr(args, 'allreduce', 'flat') if world > 1 else None,
-                    'allreduce_ms_per_step': [round(v, 3) for v in ar_ranks] if world > 1 else None}
+                    'allreduce_ms_per_step': [round(v, 3) for v in ar_ranks] if world > 1 else None,
+                    'ranks_share_devices': bool(getattr(server, 'shared_devices', False)),
+                    'bucket_schedule_last_step': wl.bucket_schedule()}
     for i, (other, _, alt_loss) in enumerate(alt):
         n = args.steps
         step_bytes_total = 2 * 2 * sum(wl.layer_t) * step_bytes(wl.B, wl.H)

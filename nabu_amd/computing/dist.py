@@ -16,22 +16,40 @@ class ProcessGroup(object):
 
     def __init__(self, rank, world_size, backend):
         self.rank, self.world_size, self.backend = rank, world_size, backend
+        self.shared_devices = False
+
+    def _staged(self, tensor):
+        """gloo with device tensors (ranks sharing a GPU: bench.py's first-contact mode, tests): through the host"""
+        return self.backend == 'gloo' and tensor.is_cuda
 
     def all_reduce_sum_(self, tensor):
         if self.world_size > 1:
-            dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+            if self._staged(tensor):
+                host = tensor.detach().cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                tensor.copy_(host)
+            else:
+                dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
         return tensor
 
     def all_reduce_sum_async(self, tensor):
         """start the all-reduce and return a handle whose wait() joins the caller's stream with
         the collective's (RCCL: stream-ordered, the host does not block; gloo: blocks)"""
         if self.world_size > 1:
+            if self._staged(tensor):
+                self.all_reduce_sum_(tensor)
+                return None
             return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, async_op=True)
         return None
 
     def broadcast_(self, tensor, src=0):
         if self.world_size > 1:
-            dist.broadcast(tensor, src)
+            if self._staged(tensor):
+                host = tensor.detach().cpu()
+                dist.broadcast(host, src)
+                tensor.copy_(host)
+            else:
+                dist.broadcast(tensor, src)
         return tensor
 
     def barrier(self):
@@ -51,11 +69,15 @@ def create_server(backend=None):
     rank = int(os.environ.get('RANK', '0'))
     if world == 1:
         return ProcessGroup(0, 1, None)
+    ngpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    shared = ngpu > 0 and world > ngpu          # more ranks than GPUs on this node: they share the devices
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-    if torch.cuda.is_available():
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        backend = 'gloo' if (shared or not ngpu) else 'nccl'
+    if ngpu:
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % ngpu)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    return ProcessGroup(rank, world, backend)
+    pg = ProcessGroup(rank, world, backend)
+    pg.shared_devices = shared
+    return pg

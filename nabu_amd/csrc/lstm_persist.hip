@@ -686,6 +686,14 @@ bool lstm_mx_supported(int B, int H);
 int lstm_mx_chunk_rows();
 size_t lstm_mx_ring_bytes(bool fwd, int H);
 int lstm_mx_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry);
+// lstm_persist_mx16.hip: 16 rows per unit, 33 .. 64 batch rows in one launch (NABU_PERSIST_MX16=0: chunks of 32 rows)
+size_t lstm_mx16_ring_bytes(bool fwd, int H);
+int lstm_mx16_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry);
+static bool mx16_on() {
+  static int env = -1;
+  if (env < 0) { const char *e = getenv("NABU_PERSIST_MX16"); env = e ? atoi(e) : 1; }
+  return env != 0;
+}
 
 // geometry: BS = 4 (two 256-thread workgroups per CU) when the batch fits, else BS = 8
 bool lstm_persist_fuses_input(int B, int T, int D, int H);
@@ -706,7 +714,11 @@ static int pick_bs(int B, int H, bool fwd) {
 // chunks of batch rows (the tensors are batch-major, a chunk is a contiguous slab): at H = 512 a
 // launch takes up to 64 rows (BS = 8, two workgroups per CU), B = 96 is a launch of 64 and one of 32.
 static int chunk_rows(int B, int H, bool fwd) {
-  if (lstm_mx_supported(B, H)) return B < lstm_mx_chunk_rows() ? B : lstm_mx_chunk_rows();
+  if (lstm_mx_supported(B, H)) {
+    // up to 32 rows: 8 per unit; 33 .. 64: 16 per unit; more: launches of 64 rows (and a remainder)
+    const int c = lstm_mx_chunk_rows() * (mx16_on() && B > lstm_mx_chunk_rows() ? 2 : 1);
+    return B < c ? B : c;
+  }
   if (pick_bs(B, H, fwd)) return B;
   int c = (fwd ? 8 : 4) * (2 * cu_count() / (2 * (H / UC)));   // largest batch of one launch
   return c < 4 ? 4 : c;
@@ -741,8 +753,10 @@ size_t lstm_persist_ws_bytes(int B, int T, int H) {
     }
   }
   if (lstm_mx_supported(B, H))
-    for (int f = 0; f < 2; ++f)
+    for (int f = 0; f < 2; ++f) {
       if (lstm_mx_ring_bytes(f != 0, H) > m) m = lstm_mx_ring_bytes(f != 0, H);
+      if (mx16_on() && B > lstm_mx_chunk_rows() && lstm_mx16_ring_bytes(f != 0, H) > m) m = lstm_mx16_ring_bytes(f != 0, H);
+    }
   return TABLE_BYTES + m + db_part_bytes(B, H);
 }
 
@@ -823,7 +837,8 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
   { const char *e = getenv("NABU_PERSIST_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   if (lstm_mx_supported(B, H)) {
     if (fwd && x) return fail(NABU_EINVAL, "persistent LSTM (mx): no in-kernel input projection");
-    a.B = B; a.T = T; a.D = D; a.H = H; a.max_len = max_len; a.nshard = (B + 7) / 8;
+    const bool r16 = B > lstm_mx_chunk_rows();        // 33 .. 64 rows: 16 per unit
+    a.B = B; a.T = T; a.D = D; a.H = H; a.max_len = max_len; a.nshard = r16 ? (B + 15) / 16 : (B + 7) / 8;
     a.len = len;
     for (int i = 0; i < 2; ++i) { a.kernel[i] = kernel[i]; a.gates[i] = gates[i]; a.cs[i] = cs[i]; a.bias[i] = nullptr; }
     a.out = out; a.dout = dout; a.x = nullptr;
@@ -833,8 +848,9 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
     a.table = static_cast<unsigned *>(ws);
     a.xbuf = static_cast<char *>(ws) + TABLE_BYTES;
     a.timeout_ticks = g_timeout_ticks;
-    if (!dry) NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + lstm_mx_ring_bytes(fwd, H), stream));
-    return lstm_mx_launch(fwd, H, a, stream, dry);
+    if (!dry)
+      NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + (r16 ? lstm_mx16_ring_bytes(fwd, H) : lstm_mx_ring_bytes(fwd, H)), stream));
+    return r16 ? lstm_mx16_launch(fwd, H, a, stream, dry) : lstm_mx_launch(fwd, H, a, stream, dry);
   }
   int BS = pick_bs(B, H, fwd);
   if ((a.dbg & 16) && 2 * ((B + 7) / 8) * (H / UC) <= cu_count()) BS = 8;

@@ -102,6 +102,7 @@ class Trainer(object, metaclass=ABCMeta):
                             'lengths and fails at graph construction in the reference, DESIGN.md section 8)')
         self.model = Model(conf=modelconf, trainlabels=int(self.conf['trainlabels']), constraint=None)
         self._graph = None
+        self.schedule_log = None       # a list here records the bucketed exchange: (bucket key, 'hook' | 'final')
 
     # ------------------------------------------------------------------ graph
     def _create_graph(self):
@@ -297,6 +298,8 @@ class Trainer(object, metaclass=ABCMeta):
             hip.clip_(view, CLIP)
             self._works.append(self.server.all_reduce_sum_async(view))
             self._sent.add(i)
+            if self.schedule_log is not None:       # (bench.py / tests: which bucket went on the wire at which call)
+                self.schedule_log.append((b['key'], 'final' if everything else 'hook'))
 
     def _join_comm(self):
         '''the launch stream waits for every exchange in flight (before a recurrent launch and

@@ -136,6 +136,9 @@ class StandIn(object):
     def allreduce_ms_per_step(self):
         return None
 
+    def bucket_schedule(self):
+        return None
+
     def alt(self, steps):
         return []
 

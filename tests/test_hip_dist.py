@@ -38,3 +38,53 @@ def test_bench_two_rank_dry_run_on_one_gpu():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert out['ok'] and out['world_size_seen'] == 2 and out['all_reduce_sum'] == 3.0
+
+
+def _two_rank_line(extra):
+    """python bench.py --gpus 2 --shrink ...: two REAL ranks on the one-GPU test box (they share the device, so the
+    group is gloo and the recurrence runs step-wise), 2 timed training steps, the whole JSON line"""
+    import json
+    import socket
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cache = os.path.join(root, 'gpurun_out', 'cpu_baseline_cache.json')
+    os.makedirs(os.path.dirname(cache), exist_ok=True)
+    keep = open(cache).read() if os.path.exists(cache) else None
+    with open(cache, 'w') as fid:      # what an N = 1 run on this host leaves behind; the N > 1 line carries it
+        json.dump({'host': socket.gethostname(), 'time': time.time(),
+                   'cpu_baseline': {'value': 0.5, 'unit': 'utterances/sec', 'cores': 8, 'kind': 'port', 'sample': 'test'}}, fid)
+    try:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--shrink', '--steps', '2',
+                            '--warmup', '1', '--no-alt', '--no-gemm-roofline'] + extra, env=env, capture_output=True,
+                           text=True, timeout=900)
+    finally:
+        if keep is None:
+            os.remove(cache)
+        else:
+            with open(cache, 'w') as fid:
+                fid.write(keep)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+
+
+def test_bench_two_rank_line_end_to_end_on_one_gpu():
+    """the N > 1 JSON line, every object of it, from two real ranks and two real training steps (flat exchange), then
+    the bucketed exchange: same loss to the bit, buckets on the wire in backward order from the phase hooks"""
+    flat = _two_rank_line([])
+    assert flat['n_gpus'] == 2 and flat['ranks']['world_size_seen'] == 2 and flat['ranks']['backend'] == 'gloo'
+    assert flat['ranks']['ranks_share_devices'] and flat['config']['shrunk'] and flat['config']['recurrent_path'] == 'stepwise'
+    assert flat['config']['global_batch'] == 8 and flat['config']['parallelism'] == 'dp2'
+    assert len(flat['ranks']['ms_per_step_per_rank']) == 2 and all(v > 0 for v in flat['ranks']['ms_per_step_per_rank'])
+    assert flat['ranks']['allreduce'] == 'flat' and all(v > 0 for v in flat['ranks']['allreduce_ms_per_step'])
+    assert flat['cpu_baseline']['value'] == 0.5 and 'carried_from' in flat['cpu_baseline']
+    assert flat['roofline']['bound'] == 'hbm' and flat['roofline']['frac'] > 0 and flat['value'] > 0
+    assert flat['scaling'] == 'weak' and flat['higher_is_better'] is True
+    buck = _two_rank_line(['--allreduce', 'bucketed'])
+    assert buck['ranks']['allreduce'] == 'bucketed'
+    assert buck['final_loss'] == flat['final_loss']
+    sched = buck['ranks']['bucket_schedule_last_step']
+    assert [k for k, _ in sched] == ['decoder', 'Listener/features/layer3', 'Listener/features/layer2',
+                                     'Listener/features/layer1', 'Listener/features/layer0'], sched
+    # every bucket but the last one to become final leaves from a hook between kernels, not at the optimiser
+    assert [w for _, w in sched][:4] == ['hook'] * 4, sched

@@ -32,7 +32,7 @@ def main():
         w = write.get(k, [0.0])
         out['kernels'][k] = {'launches': len(f), 'fetch_bytes': sum(f) / len(f), 'write_bytes': sum(w) / len(w),
                              'traffic_bytes': sum(f) / len(f) + sum(w) / len(w)}
-    rec = [v for k, v in out['kernels'].items() if 'lstm_persist' in k]
+    rec = [v for k, v in out['kernels'].items() if 'lstm_persist' in k or 'lstm_mx' in k]     # the recurrent kernels
     n = sum(v['launches'] for v in rec)
     out['lstm_persist_traffic_bytes_per_launch'] = sum(v['traffic_bytes'] * v['launches'] for v in rec) / max(n, 1)
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
