@@ -380,6 +380,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       unsigned long long t_fail = 0;
       int fails = 0;
       bool first = true;
+      __builtin_amdgcn_s_sleep(4);      // (lstm_persist_mx.hip: a first round issued at once fails)
       for (;;) {
         unsigned mx = 0u;
 #pragma unroll
