@@ -307,6 +307,10 @@ def parse_args(argv=None):
                          'would (self-launch or the given environment, rendezvous over 127.0.0.1, device assignment), '
                          'run one collective, print one JSON line and stop before the workload.  With fewer visible '
                          'GPUs than ranks the process group is gloo and the ranks share the devices round-robin.')
+    ap.add_argument('--cpu-all-cores', action='store_true',
+                    help='ONLY measure one cfg2 training step of the CPU port at ALL physical cores of this host (SURVEY.md '
+                         '8(d) names that setting; it takes ~10 minutes on a 128-core host, which is why the default run '
+                         'reports it as a labelled prediction) and print it as one JSON line; no GPU work')
     ap.add_argument('--shrink', action='store_true',
                     help='NOT a measurement: cfg2\'s recipe at 4 utterances x 64 frames, 64 units — lets the tests run the '
                          'whole multi-rank line (ranks, exchange, carried cpu_baseline, roofline object) in seconds; the '
@@ -631,6 +635,15 @@ def main(argv=None):
     if args.gpus > 1 and env_world == 1:
         # no ranks in the environment: start them ourselves
         sys.exit(self_launch(argv, args.gpus))
+    if args.cpu_all_cores:
+        from oracle import cpu_baseline as cb
+        phys = cb.physical_cores()
+        r = cb.time_config('cfg2', 0, 1, threads=phys)
+        print(json.dumps({'cpu_all_physical_cores': {'workload': 'cfg2', 'cores': phys, 'logical': os.cpu_count(),
+                                                     'seconds_per_step': r['seconds_per_step'], 'value': r['utt_per_s'],
+                                                     'unit': 'utterances/sec', 'kind': 'port', 'warmup': 0,
+                                                     'steps': r['steps_timed'], 'host': socket.gethostname()}}), flush=True)
+        sys.exit(0)
     if args.dry_run:
         sys.exit(dry_run(args))
     server = make_server()

@@ -13,6 +13,15 @@
 namespace nabu {
 
 constexpr int MXR16 = 16;
+// backward exchange ring of the 16-row kernel: a slot is P x P KiB (1 MiB per unit at H = 512).  Three slots do not
+// stay in the 4 MiB L2 next to the step's streamed tensors (WRITE_SIZE of a cfg5-shaped launch, 64 x 400: 4.2 GB against
+// 0.4 GB of dz); two (-DNABU_RING_BWD16=2: lstm_persist.hip's drain + execution barrier in front of the first publish)
+// spill less (2.8 GB) and are SLOWER (4.76 against 4.40 us per step), so three it is: the write-backs are asynchronous,
+// and the total stays near the algorithmic bytes of SURVEY.md 8(d) (9.8 against 8.65 GB per cfg5 launch)
+#ifndef NABU_RING_BWD16
+#define NABU_RING_BWD16 3
+#endif
+constexpr int MXRINGB16 = NABU_RING_BWD16;
 
 // ===========================================================================
 // forward
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const size_t block_bytes = (size_t)P * piece_bytes;
   const size_t slot_bytes = (size_t)P * block_bytes;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-      p.xbuf + (size_t)unit * MXRINGB * slot_bytes, 0, (int)(MXRINGB * slot_bytes), 0x00020000);
+      p.xbuf + (size_t)unit * MXRINGB16 * slot_bytes, 0, (int)(MXRINGB16 * slot_bytes), 0x00020000);
   const u32x4 sent4 = {SENT, SENT, SENT, SENT};
   unsigned in_off[2];
 #pragma unroll
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int ps = 0; ps < 2; ++ps)
 #pragma unroll
       for (int i = 0; i < NQ; ++i) v[ps][i] = zero4;
-    const unsigned sbase = (unsigned)(((s + 1) % MXRINGB) * slot_bytes);
+    const unsigned sbase = (unsigned)(((s + 1) % MXRINGB16) * slot_bytes);
     const bool have_in = s + 1 < p.max_len && !(p.dbg & 1);
     if (have_in) {
       unsigned long long t_fail = 0;
@@ -484,17 +493,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int t = 0; t < HT; ++t) acc[t] = MX_MFMA(Wp[WPL[g]][hf * HT + t][j], bp[BPL[g]][j], acc[t]);
             const int slot_i = hf * 12 + 6 * j + g;     // one memory instruction behind every group
-            if (slot_i < 8) fetch_part(s - 1, slot_i);
-            if (slot_i >= 8 && slot_i - 8 < 2 * NQ) {
-              const int ri = slot_i - 8;
-              xstore(sent4, rs, have_in ? sbase + in_off[ri / NQ] + (unsigned)(ri % NQ) * SRC8 : OOB, coloc);
+            if (MXRINGB16 >= 3) {
+              if (slot_i < 8) fetch_part(s - 1, slot_i);
+              if (slot_i >= 8 && slot_i - 8 < 2 * NQ) {
+                const int ri = slot_i - 8;
+                xstore(sent4, rs, have_in ? sbase + in_off[ri / NQ] + (unsigned)(ri % NQ) * SRC8 : OOB, coloc);
+              }
+            } else {
+              // ring of 2: every hand-back in front of the first publish (drained below), then the prefetches
+              if (slot_i < 2 * NQ)
+                xstore(sent4, rs, have_in ? sbase + in_off[slot_i / NQ] + (unsigned)(slot_i % NQ) * SRC8 : OOB, coloc);
+              if (slot_i >= 2 * NQ && slot_i - 2 * NQ < 8) fetch_part(s - 1, slot_i - 2 * NQ);
             }
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-        if (hf == 0) NABU_STAMP(1, 4);
+        if (hf == 0) {
+          NABU_STAMP(1, 4);
+          if (MXRINGB16 == 2) {
+            // the pieces I publish into were handed back by their readers in the step I have just polled: every wave
+            // drains its hand-back stores (all but the prefetches issued behind them in this half) and the workgroup
+            // meets at an execution barrier before anybody publishes (lstm_persist.hip, backward (c))
+            constexpr int behind = 12 - 2 * NQ < 8 ? 12 - 2 * NQ : 8;
+            wait_vm<behind>();
+            __builtin_amdgcn_s_barrier();
+          }
+        }
         // piece (dest, me)[row n][quad q]: every lane stores its tile rows
-        const unsigned pbase = (unsigned)((s % MXRINGB) * slot_bytes + (size_t)(NT * w + hf * HT) * block_bytes +
+        const unsigned pbase = (unsigned)((s % MXRINGB16) * slot_bytes + (size_t)(NT * w + hf * HT) * block_bytes +
                                           (size_t)slot * piece_bytes + (size_t)n * 64 + q * 16);
 #pragma unroll
         for (int t = 0; t < HT; ++t)
@@ -543,7 +569,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // host side (called from lstm_persist.hip's run_chunk through lstm_mx_launch)
 size_t lstm_mx16_ring_bytes(bool fwd, int H) {
   const size_t P = H / UC;
-  return fwd ? (size_t)MXNU * RING * 3 * MXR16 * H * 2 : (size_t)MXNU * MXRINGB * P * P * MXR16 * UC * 4;
+  return fwd ? (size_t)MXNU * RING * 3 * MXR16 * H * 2 : (size_t)MXNU * MXRINGB16 * P * P * MXR16 * UC * 4;
 }
 
 template <typename K>
