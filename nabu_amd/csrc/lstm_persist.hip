@@ -713,10 +713,12 @@ static int pick_bs(int B, int H, bool fwd) {
 // Batches that need more workgroups than the chip holds run as consecutive launches over
 // chunks of batch rows (the tensors are batch-major, a chunk is a contiguous slab): at H = 512 a
 // launch takes up to 64 rows (BS = 8, two workgroups per CU), B = 96 is a launch of 64 and one of 32.
-static int chunk_rows(int B, int H, bool fwd) {
+static int chunk_rows(int B, int H, bool fwd, int T = 0) {
   if (lstm_mx_supported(B, H)) {
-    // up to 32 rows: 8 per unit; 33 .. 64: 16 per unit; more: launches of 64 rows (and a remainder)
-    const int c = lstm_mx_chunk_rows() * (mx16_on() && B > lstm_mx_chunk_rows() ? 2 : 1);
+    // up to 32 rows: 8 per unit; 33 .. 64: 16 per unit; more: launches of 64 rows (and a remainder) — unless a slab of
+    // 64 rows x T frames of gates is beyond the 32-bit buffer offsets of one launch: then launches of 32 rows
+    int c = lstm_mx_chunk_rows() * (mx16_on() && B > lstm_mx_chunk_rows() ? 2 : 1);
+    if (T > 0 && c > lstm_mx_chunk_rows() && (size_t)c * T * 4 * H * 4 >= 0x80000000ull) c = lstm_mx_chunk_rows();
     return B < c ? B : c;
   }
   if (pick_bs(B, H, fwd)) return B;
@@ -727,7 +729,7 @@ static int chunk_rows(int B, int H, bool fwd) {
 bool lstm_persist_supported(int B, int T, int H) {
   if (!(H == 64 || H == 128 || H == 256 || H == 512)) return false;
   if (B <= 0 || T <= 0) return false;
-  if (lstm_mx_supported(B, H)) return (size_t)chunk_rows(B, H, true) * T * 4 * H * 4 < 0x80000000ull;
+  if (lstm_mx_supported(B, H)) return (size_t)chunk_rows(B, H, true, T) * T * 4 * H * 4 < 0x80000000ull;
   if ((size_t)B * T * 4 * H * 4 >= 0x80000000ull && (size_t)chunk_rows(B, H, true) * T * 4 * H * 4 >= 0x80000000ull)
     return false;   // 32-bit buffer offsets inside one launch
   return pick_bs(chunk_rows(B, H, true), H, true) != 0 && pick_bs(chunk_rows(B, H, false), H, false) != 0;
@@ -746,7 +748,7 @@ size_t lstm_persist_ws_bytes(int B, int T, int H) {
   size_t m = 0;
   for (int BS = 4; BS <= 8; BS += 4) {   // either geometry may be selected at run time
     for (int f = 0; f < 2; ++f) {
-      const int Bc = chunk_rows(B, H, f != 0);
+      const int Bc = chunk_rows(B, H, f != 0, T);
       const int ns = (Bc + BS - 1) / BS;
       const size_t r = ring_bytes(f != 0, BS, ns, H);
       if (r > m) m = r;
@@ -810,7 +812,7 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
   float *db_part = reinterpret_cast<float *>(static_cast<char *>(ws) + need - db_part_bytes(B, H));
   float *amax_part = db_part + db_part_bytes(B, H) / (2 * sizeof(float));
   int shards = 0;
-  const int Bc = chunk_rows(B, H, fwd);
+  const int Bc = chunk_rows(B, H, fwd, T);
   for (int pass = 0; pass < 2; ++pass) {     // pass 0 validates every chunk, pass 1 enqueues them
     shards = 0;
     for (int b0 = 0; b0 < B; b0 += Bc) {
@@ -908,7 +910,7 @@ bool lstm_persist_fuses_input(int B, int T, int D, int H) {
   if (env < 0) { const char *e = getenv("NABU_PERSIST_FUSE_INPUT"); env = e ? atoi(e) : 1; }
   if (!env || D != 40 || !lstm_persist_supported(B, T, H) || lstm_mx_supported(B, H)) return false;
   if ((size_t)B * T * D * 4 >= 0x80000000ull) return false;
-  const int Bc = chunk_rows(B, H, true);
+  const int Bc = chunk_rows(B, H, true, T);
   for (int b0 = 0; b0 < B; b0 += Bc)
     if (pick_bs(B - b0 < Bc ? B - b0 : Bc, H, true) != 4) return false;
   return true;
