@@ -17,14 +17,18 @@
 // seven products; the two N halves of the result are added with one DPP row rotation.  64 instructions per wave
 // and step at ~17 cycles instead of 2 x 128 at 12.
 //
-// FORWARD step: the exchange slot of a unit is X[24 = plane*8 + row][H] bf16 — a lane's B operand (8 consecutive k
-// of one (plane, row)) is ONE 16-byte load straight into the instruction's register layout: the poll loop IS the
-// operand fetch, no LDS staging.  Wave w multiplies its quarter of k; partial sums meet in LDS behind the step's
-// only barrier; wave w then finishes rows 2w, 2w+1 (lane = (row, unit), all four gates), splits h into planes,
-// assembles 16-byte pieces with DPP and publishes.
-// BACKWARD step: reduce-scatter of the partial dh as before (fp32 pieces [src][row][4 k]); lane = (row, unit,
-// gate pair) after an 8-lane DPP butterfly over the sources; dz planes go to LDS in the B-operand layout;
-// product dz[8 rows x 64 columns] . W^T against this workgroup's [64 x H] slice, tile t = destination workgroup t.
+// FORWARD step: the exchange slot of a unit is an array of 16-byte CELLS = 8 consecutive k of one (plane, row),
+// [k / 8][24 = plane * 8 + row]: a lane's B operand is ONE cell — the poll loop IS the operand fetch, straight into the
+// instruction's register layout, full 128-byte lines, no LDS staging.  Wave w multiplies its quarter of k; partial sums
+// meet in LDS behind the step's only barrier; wave w then finishes rows 2w, 2w+1 (lane = (row, unit), all four gates),
+// splits h into planes, assembles one cell per plane with DPP and publishes with ONE store instruction.
+// BACKWARD step: reduce-scatter of the partial dh (fp32 pieces [dest][src][row][4 k], ring of 3: header of
+// lstm_persist_mx.h); lane = (row, unit, gate pair) after an 8-lane DPP butterfly over the sources; dz planes go to LDS
+// in the B-operand layout; product dz[8 rows x 64 columns] . W^T against this workgroup's [64 x H] slice in two halves,
+// tile t = destination workgroup t; hand-back and next step's prefetch ride in the first half's matrix stream.
+// BOTH: the results of a step (activations, c, h; dz) go to HBM at the top of the NEXT step, behind its exchange loads,
+// with always-issued stores — between a publish and the next poll a wave's memory queue holds exchange traffic only
+// (DESIGN.md section 5.1 for the measurements behind every one of these choices).
 #include "lstm_persist_mx.h"
 
 namespace nabu {
