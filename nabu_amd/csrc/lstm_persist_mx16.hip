@@ -566,9 +566,347 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 // ===========================================================================
+// backward, the product split in TWO dimensions (the default at H = 512; NABU_PERSIST_MX16_BWD2=0 and smaller H: the
+// kernel above).  With 16 rows the reduce-scatter above moves 96 KiB per workgroup and step (32 published, 32 summed, 32
+// handed back).  Here workgroup (cg, kg) of a unit owns W_h[64 k of group kg] x [H columns of group cg] (4 column
+// groups x P/4 k groups: the same registers); per step
+//   A  the dh of the 16 units it does the gate math for = FOUR pieces (one per column group) of 1 KiB;
+//   its dz as bf16-plane cells [c'/8][48 = plane*16 + row] (c' = 4 unit + gate), 6 KiB;
+//   B  the dz cells of ITS column group, 48 KiB, fetched straight into the operand layout (the forward pattern), the four
+//      waves split the columns, partial sums meet in LDS behind the step's only barrier;
+//   four 1-KiB pieces out.  63 KiB per workgroup and step, almost all reads of full lines.
+// Rings: B 4 slots handed back by the producer two steps later, A 3 slots handed back by the reader — safe by causality:
+// nobody can publish dz(s) before EVERYBODY has published dz(s+1) (its four A sources multiplied step s+1 against the
+// cells of all four column groups), which in turn means everybody's sources finished step s+2, i.e. read slot s+2; a
+// reader's hand-back of step s is performed before any of its waves publishes dz(s-1) (each wave publishes its own
+// rows' cells behind its own poll of step s-1, issued behind its reset stores), and an A piece is written again only by
+// a workgroup multiplying dz(s-2).  (The 8-row version of this split was measured and NOT adopted:
+// tools/experiments/variants/lstm_persist_mx2.hip)
+template <int H>
+struct Mx16Bwd2Lds {
+  static constexpr int KROW = 64 + 4;                            // floats per (wave, row): 64 k + pad
+  static constexpr int PART = 0;                                 // [2][4 waves][16 rows][KROW]
+  static constexpr int XST = PART + 2 * 4 * MXR16 * KROW;        // [2 parities][2 passes][4][256] saved values
+  static constexpr int RED = XST + 2 * 2 * 4 * 256;              // [16 rows][64]
+  static constexpr int FLAG = RED + 16 * 64;
+  static constexpr int TOTAL = FLAG + 4;
+};
+constexpr int MX16RA = 3, MX16RB = 4;
+
+template <int H>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_mx16_bwd2_kernel(PersistArgs p) {
+  using L = Mx16Bwd2Lds<H>;
+  constexpr int P = H / UC;
+  constexpr int KW = H / 4;          // columns c' of my column group multiplied by one wave
+  constexpr int NKS = KW / 32;
+  static_assert(NKS >= 1 && P % 4 == 0, "mx16 backward (2-D): H >= 128");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *part = smem + L::PART, *xst = smem + L::XST, *red = smem + L::RED;
+  int *flag = reinterpret_cast<int *>(smem + L::FLAG);
+
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const int NU = 2 * p.nshard;
+  int unit, slot;
+  mx_identity(&unit, &slot);
+  if (unit >= NU) return;
+  const int dir = unit & 1, shard = unit >> 1;
+  const int b0 = shard * MXR16;
+  const int T = p.T;
+  const int cg = slot & 3, kg = slot >> 2;
+  const int Gb = 64 * kg + 16 * cg;                         // first of the 16 units whose gate math is mine
+  const int n = lane & 15, q = lane >> 4;                   // matrix phase: n = batch row
+  // gate identity: lane & 7 = 2 s4 + dup; kq = k quad of the A piece; rows 2 w + r2 (pass 0) and 8 + 2 w + r2 (pass 1)
+  const int dup = lane & 1, s4 = (lane >> 1) & 3, kq = (lane >> 3) & 3, r2 = lane >> 5;
+  const int gu = 4 * kq + s4;
+  int grow[2], gb[2], n_g[2];
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    grow[ps] = 8 * ps + 2 * w + r2;
+    gb[ps] = b0 + grow[ps];
+    n_g[ps] = gb[ps] < p.B ? p.len[gb[ps]] : 0;
+  }
+
+  // A operands: W^T planes of my block.  Row m = output k = 64 kg + 16 t + n; c' = cg H + w KW + 32 j + 8 q + e
+  u32x4 Wp[3][4][NKS];
+  {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float *Wh = p.kernel[dir] + ((size_t)p.D + 64 * kg + 16 * t + n) * 4 * H;
+#pragma unroll
+      for (int j = 0; j < NKS; ++j) {
+        float x[8];
+        const int u0 = (cg * H + w * KW + 32 * j + 8 * q) >> 2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = Wh[(size_t)(e & 3) * H + u0 + (e >> 2)];
+        mx_split8(x, Wp[0][t][j], Wp[1][t][j], Wp[2][t][j]);
+      }
+    }
+  }
+  float dc_state[2] = {0.f, 0.f};
+  float db0[2] = {0.f, 0.f}, db1[2] = {0.f, 0.f}, am0[2] = {0.f, 0.f}, am1[2] = {0.f, 0.f};
+  if (!unit_handshake(p, unit, slot, MXNU, P, flag)) return;
+  const bool coloc = flag[1] != 0;
+
+  // ring A: slot = [dest P][src 4][16 rows][4 k quads] x 16 bytes; ring B: slot = [c'/8][48 cells] x 16 bytes
+  constexpr int NSL = 3 * MXR16;
+  constexpr size_t A_SLOT = (size_t)P * 4 * MXR16 * 64, B_SLOT = (size_t)(4 * H / 8) * NSL * 16;
+  char *const ubase = p.xbuf + (size_t)unit * (MX16RA * A_SLOT + MX16RB * B_SLOT);
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(ubase, 0, (int)(MX16RA * A_SLOT), 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(ubase + MX16RA * A_SLOT, 0, (int)(MX16RB * B_SLOT), 0x00020000);
+  const u32x4 sent4 = {SENT, SENT, SENT, SENT};
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  unsigned a_in[2], b_out[2];
+  const int bpl = lane & 3;
+  const bool b_pub = bpl < 3;
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    a_in[ps] = (unsigned)((((size_t)slot * 4 + s4) * MXR16 + grow[ps]) * 64 + kq * 16);
+    b_out[ps] = (unsigned)((((size_t)(Gb >> 1) + 2 * kq + (s4 >> 1)) * NSL + bpl * MXR16 + grow[ps]) * 16);
+  }
+  // A output piece (after the cross-wave sum: wave w = tile w, lane = (row, quad)): dest (cg = w, my kg)
+  const int orow = lane >> 2, okq = lane & 3;
+  const unsigned a_out = (unsigned)((((size_t)(4 * kg + w) * 4 + cg) * MXR16 + orow) * 64 + okq * 16);
+  constexpr int KGW = KW / 8;
+  constexpr unsigned KSTEP_BYTES = 4 * NSL * 16;
+  const unsigned off0 = (unsigned)((((size_t)cg * (H / 8) + (size_t)w * KGW + q) * NSL + n) * 16);      // plane: + 256
+
+  const i32x4 rg = raw_rsrc(p.gates[dir], (unsigned)((size_t)p.B * T * 4 * H * 4));
+  const i32x4 rc = raw_rsrc(p.cs[dir], (unsigned)((size_t)p.B * T * H * 4));
+  const i32x4 rd = raw_rsrc(p.dout, (unsigned)((size_t)p.B * T * 2 * H * 4));
+  unsigned goff[2], coff[2], doff[2];
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    goff[ps] = (unsigned)(((size_t)gb[ps] * T * 4 * H + (size_t)(2 * dup) * H + Gb + gu) * 4);
+    coff[ps] = (unsigned)(((size_t)gb[ps] * T * H + Gb + gu) * 4);
+    doff[ps] = (unsigned)(((size_t)gb[ps] * T * 2 * H + (size_t)dir * H + Gb + gu) * 4);
+  }
+  auto fetch_part = [&](int s, int idx) {
+    const int ps = idx >> 2, part_i = idx & 3;
+    const bool act = s >= 0 && s < n_g[ps];
+    const int t = dir ? n_g[ps] - 1 - s : s;
+    const int tc = dup == 0 ? t : (dir ? t + 1 : t - 1);
+    const bool want_c = act && (dup == 0 || s > 0);
+    float *st = xst + ((s & 1) * 2 + ps) * 1024 + 64 * w;
+    if (part_i == 0) prefetch_lds_b32(rg, act ? goff[ps] + (unsigned)t * (unsigned)(16 * H) : OOB, smem, st);
+    if (part_i == 1) prefetch_lds_b32(rg, act ? goff[ps] + (unsigned)t * (unsigned)(16 * H) + (unsigned)(4 * H) : OOB, smem, st + 256);
+    if (part_i == 2) prefetch_lds_b32(rc, want_c ? coff[ps] + (unsigned)tc * (unsigned)(4 * H) : OOB, smem, st + 512);
+    if (part_i == 3) prefetch_lds_b32(rd, (act && dup == 0) ? doff[ps] + (unsigned)t * (unsigned)(8 * H) : OOB, smem, st + 768);
+  };
+  for (int i = 0; i < 8; ++i) fetch_part(p.max_len - 1, i);
+  wait_vm<0>();
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(p.gates[dir], 0, (int)((size_t)p.B * T * 4 * H * 4), 0x00020000);
+  float d_0[2] = {0.f, 0.f}, d_1[2] = {0.f, 0.f};
+  int d_t[2] = {0, 0};
+  bool d_any = false;
+  auto dz_stores = [&]() {
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const bool ok = d_any && gb[ps] < p.B && !(p.dbg & 128);
+      const unsigned o = ok ? goff[ps] + (unsigned)d_t[ps] * (unsigned)(16 * H) : OOB;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d_0[ps]), rsg, o, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d_1[ps]), rsg, o == OOB ? OOB : o + (unsigned)(4 * H), 0, 0);
+    }
+  };
+  auto timed_out = [&](unsigned long long &t_fail, int &fails, int code) -> bool {
+    if (fails == 0) t_fail = wall_clock64();
+    if ((++fails & 7) != 0) return false;
+    __builtin_amdgcn_s_sleep(1);
+    if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t_fail > p.timeout_ticks) {
+      if (lane == 0) {
+        flag[0] = 1;
+        __hip_atomic_store(p.status, code + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return true;
+    }
+    return false;
+  };
+
+  for (int s = p.max_len - 1; s >= 0; --s) {
+    NABU_STAMP(1, 0);
+    // (a) the four pieces of dh for my units, both passes
+    u32x4 v[2] = {zero4, zero4};
+    const unsigned abase = (unsigned)(((s + 1) % MX16RA) * A_SLOT);
+    const bool have_in = s + 1 < p.max_len && !(p.dbg & 1);
+    if (have_in) {
+      unsigned long long t_fail = 0;
+      int fails = 0;
+      bool first = true;
+      for (;;) {
+        v[0] = __builtin_amdgcn_raw_buffer_load_b128(ra, abase + a_in[0], 0, 16);
+        v[1] = __builtin_amdgcn_raw_buffer_load_b128(ra, abase + a_in[1], 0, 16);
+        if (first) { dz_stores(); first = false; }
+        const bool ok = __all(mx_max4(mx_max4(0u, v[0]), v[1]) != SENT);
+        if (ok) break;
+        if (timed_out(t_fail, fails, 2)) break;
+      }
+    } else {
+      dz_stores();
+      wait_vm<0>();
+    }
+    NABU_STAMP(1, 1);
+    unsigned cell[2][3];      // my packed pair words (gates 2 dup, 2 dup + 1) of both passes, per plane
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      mxf32x4 sum = __builtin_bit_cast(mxf32x4, v[ps]);
+      // sum over the four sources (lanes 2 s4 + dup; both lanes of a pair hold the same piece): fixed order
+      sum.x += mx_dpp<DPP_XOR2>(sum.x); sum.y += mx_dpp<DPP_XOR2>(sum.y);
+      sum.z += mx_dpp<DPP_XOR2>(sum.z); sum.w += mx_dpp<DPP_XOR2>(sum.w);
+      sum.x += mx_dpp<DPP_HALF_MIRROR>(sum.x); sum.y += mx_dpp<DPP_HALF_MIRROR>(sum.y);
+      sum.z += mx_dpp<DPP_HALF_MIRROR>(sum.z); sum.w += mx_dpp<DPP_HALF_MIRROR>(sum.w);
+      const float dh = sel4(s4, sum.x, sum.y, sum.z, sum.w);
+      const float *st = xst + ((s & 1) * 2 + ps) * 1024 + tid;
+      const float sA = st[0], sB = st[256], sC = st[512], sD = st[768];
+      const float pA = mx_dpp<DPP_XOR1>(sA), pB = mx_dpp<DPP_XOR1>(sB), pC = mx_dpp<DPP_XOR1>(sC), pD = mx_dpp<DPP_XOR1>(sD);
+      const float gi = dup ? pA : sA, gj = dup ? pB : sB, gf = dup ? sA : pA, go = dup ? sB : pB;
+      const float c = dup ? pC : sC, cprev = dup ? sC : pC, dout = dup ? pD : sD;
+      const bool act_g = s < n_g[ps];
+      const float tc = fast_tanh(c);
+      const float dht = dout + dh;
+      const float dct = dc_state[ps] + dht * go * (1.f - tc * tc);
+      float d0 = 0.f, d1 = 0.f;
+      if (act_g) {
+        d0 = dup ? dct * cprev * gf * (1.f - gf) : dct * gj * gi * (1.f - gi);
+        d1 = dup ? dht * tc * go * (1.f - go) : dct * gi * (1.f - gj * gj);
+        dc_state[ps] = dct * gf;
+      }
+      db0[ps] += d0; db1[ps] += d1;
+      am0[ps] = fmaxf(am0[ps], fabsf(d0)); am1[ps] = fmaxf(am1[ps], fabsf(d1));
+      mx_split3x2(d0, d1, cell[ps][0], cell[ps][1], cell[ps][2]);
+      const int t_g = dir ? n_g[ps] - 1 - s : s;
+      d_0[ps] = d0; d_1[ps] = d1; d_t[ps] = act_g ? t_g : s;
+    }
+    d_any = true;
+    // I am the only reader of my A pieces: hand them back
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) xstore(sent4, ra, have_in ? abase + a_in[ps] : OOB, coloc);
+    if (s == 0) break;      // no step in front of the first: nothing to multiply
+
+    // (c) publish dz(s) as plane cells: a quad holds the 8 values c' = 4 u .. 4 u + 7 of two units in lane order; quad lane
+    // = plane collects the plane's four pair words; hand back my cells of two steps ago (header)
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const unsigned ph = cell[ps][0], pm = cell[ps][1], pl = cell[ps][2];
+      const u32x4 v0 = {mx_dppu<0x00>(ph), mx_dppu<0x55>(ph), mx_dppu<0xAA>(ph), mx_dppu<0xFF>(ph)};
+      const u32x4 v1 = {mx_dppu<0x00>(pm), mx_dppu<0x55>(pm), mx_dppu<0xAA>(pm), mx_dppu<0xFF>(pm)};
+      const u32x4 v2 = {mx_dppu<0x00>(pl), mx_dppu<0x55>(pl), mx_dppu<0xAA>(pl), mx_dppu<0xFF>(pl)};
+      const u32x4 pv = bpl == 0 ? v0 : bpl == 1 ? v1 : v2;
+      xstore(pv, rb, b_pub ? (unsigned)((s % MX16RB) * B_SLOT) + b_out[ps] : OOB, coloc);
+    }
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps)
+      xstore(sent4, rb, (b_pub && s + 2 < p.max_len) ? (unsigned)(((s + 2) % MX16RB) * B_SLOT) + b_out[ps] : OOB, coloc);
+    NABU_STAMP(1, 2);
+
+    // (d) the dz planes of my column group: the poll loop is the operand fetch
+    u32x4 bp[3][NKS];
+    {
+      const unsigned bbase = (unsigned)((s % MX16RB) * B_SLOT);
+      unsigned long long t_fail = 0;
+      int fails = 0;
+      for (;;) {
+        unsigned mx = 0u;
+#pragma unroll
+        for (int j = 0; j < NKS; ++j)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            bp[pl][j] = __builtin_amdgcn_raw_buffer_load_b128(rb, bbase + off0 + pl * 256u + j * KSTEP_BYTES, 0, 16);
+#pragma unroll
+        for (int j = 0; j < NKS; ++j)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) mx = mx_max4(mx, bp[pl][j]);
+        const bool ok = __all(mx != SENT);       // (examined on every path out of the loop: lstm_persist_mx2.hip)
+        if (ok || (p.dbg & 1)) break;
+        if (timed_out(t_fail, fails, 1)) break;
+      }
+    }
+    NABU_STAMP(1, 3);
+    // (e) product: 4 k tiles x NKS k-steps x {Wl.h, Wm.m, Wh.l, Wm.h, Wh.m, Wh.h}; next step's saved values are
+    // requested from inside the matrix stream
+    mxf32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (mxf32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NKS; ++j) {
+#pragma unroll
+      for (int g = 0; g < 6; ++g) {
+        constexpr int WPL[6] = {2, 1, 0, 1, 0, 0}, BPL[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = MX_MFMA(Wp[WPL[g]][t][j], bp[BPL[g]][j], acc[t]);
+        const int slot_i = 6 * j + g;
+        if (slot_i < 8) { fetch_part(s - 1, slot_i); __builtin_amdgcn_sched_barrier(0); }
+      }
+    }
+    if (6 * NKS < 8)
+      for (int i = 6 * NKS; i < 8; ++i) fetch_part(s - 1, i);
+    NABU_STAMP(1, 4);
+    // partial sums of my column quarter -> LDS [wave][row n][k = 16 t + 4 q + i]
+    float *const pbuf = part + (s & 1) * (4 * MXR16 * L::KROW);
+    {
+      float *d = pbuf + ((size_t)(w * MXR16 + n)) * L::KROW + 4 * q;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) *reinterpret_cast<mxf32x4 *>(d + 16 * t) = acc[t];
+    }
+    __syncthreads();                                            // the step's only barrier
+    if (flag[0]) return;
+    // (f) the four 16-k pieces: wave w sums tile w over the waves and sends it to workgroup (cg = w, my kg)
+    {
+      const float *pr = pbuf + (size_t)orow * L::KROW + 16 * w + 4 * okq;
+      mxf32x4 o = *reinterpret_cast<const mxf32x4 *>(pr);
+#pragma unroll
+      for (int ww = 1; ww < 4; ++ww) o += *reinterpret_cast<const mxf32x4 *>(pr + (size_t)ww * MXR16 * L::KROW);
+      xstore(__builtin_bit_cast(u32x4, o), ra, (unsigned)((s % MX16RA) * A_SLOT) + a_out, coloc);
+    }
+    NABU_STAMP(1, 9);
+    NABU_STAMP(1, 5);
+    NABU_STAMP(1, 6);
+  }
+  dz_stores();
+  __syncthreads();
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    red[grow[ps] * 64 + (2 * dup) * 16 + gu] = db0[ps];
+    red[grow[ps] * 64 + (2 * dup + 1) * 16 + gu] = db1[ps];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < MXR16; ++r) sum += red[r * 64 + tid];
+    p.db_part[((size_t)(p.shard_base + shard) * 2 + dir) * 4 * H + (size_t)(tid >> 4) * H + Gb + (tid & 15)] = sum;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    red[grow[ps] * 64 + (2 * dup) * 16 + gu] = am0[ps];
+    red[grow[ps] * 64 + (2 * dup + 1) * 16 + gu] = am1[ps];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < MXR16; ++r) m = fmaxf(m, red[r * 64 + tid]);
+    p.amax_part[((size_t)(p.shard_base + shard) * 2 + dir) * 4 * H + (size_t)(tid >> 4) * H + Gb + (tid & 15)] = m;
+  }
+}
+
+// measured (64 rows, us per sequential step, 2-D against 1-D): H = 512 3.29 against 4.22; H = 256 2.71 against 2.47;
+// H = 128 2.53 against 2.17 — the two hand-offs of the 2-D split only pay where the 1-D reduce-scatter is large
+static bool mx16_bwd2_on(int H) {
+  static int env = -1;
+  if (env < 0) { const char *e = getenv("NABU_PERSIST_MX16_BWD2"); env = e ? atoi(e) : 1; }
+  return env != 0 && H >= 512;
+}
+static size_t mx16_bwd2_ring_bytes(int H) {
+  const size_t P = H / UC;
+  return (size_t)MXNU * ((size_t)MX16RA * P * 4 * MXR16 * 64 + (size_t)MX16RB * (4 * H / 8) * 3 * MXR16 * 16);
+}
+
+// ===========================================================================
 // host side (called from lstm_persist.hip's run_chunk through lstm_mx_launch)
 size_t lstm_mx16_ring_bytes(bool fwd, int H) {
   const size_t P = H / UC;
+  if (!fwd && mx16_bwd2_on(H)) return mx16_bwd2_ring_bytes(H);
   return fwd ? (size_t)MXNU * RING * 3 * MXR16 * H * 2 : (size_t)MXNU * MXRINGB16 * P * P * MXR16 * UC * 4;
 }
 
@@ -601,8 +939,9 @@ int lstm_mx16_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, 
   const int grid = MXNU * (H / UC);
 #define NABU_MX16_CASE(h)                                                                                          \
   case h:                                                                                                          \
-    return fwd ? mx16_launch(lstm_mx16_fwd_kernel<h>, a, grid, Mx16FwdLds<h>::TOTAL * sizeof(float), stream, dry)  \
-               : mx16_launch(lstm_mx16_bwd_kernel<h>, a, grid, Mx16BwdLds<h>::TOTAL * sizeof(float), stream, dry);
+    if (fwd) return mx16_launch(lstm_mx16_fwd_kernel<h>, a, grid, Mx16FwdLds<h>::TOTAL * sizeof(float), stream, dry);          \
+    return mx16_bwd2_on(h) ? mx16_launch(lstm_mx16_bwd2_kernel<h>, a, grid, Mx16Bwd2Lds<h>::TOTAL * sizeof(float), stream, dry) \
+                          : mx16_launch(lstm_mx16_bwd_kernel<h>, a, grid, Mx16BwdLds<h>::TOTAL * sizeof(float), stream, dry);
   switch (H) {
     NABU_MX16_CASE(128)
     NABU_MX16_CASE(256)
