@@ -273,3 +273,48 @@ def test_bf16_plane_recurrence_is_as_close_to_float64_as_the_fp32_kernels():
         e = rms(g_p[k], gref[k]), rms(g_s[k], gref[k])
         print('%s gradient rms error vs float64: plane kernels %.3e, fp32 step kernels %.3e (ratio %.2f)' % ((k,) + e + (e[0] / e[1],)))
         assert e[0] <= 1.25 * e[1], k
+
+
+@pytest.mark.parametrize('B,T,D,H,lens', [
+    (1, 1, 40, 128, [1]),                               # one frame: no exchange step at all
+    (3, 2, 40, 128, [2, 1, 2]),
+    (9, 17, 40, 128, [17, 1, 5, 9, 0, 16, 3, 17, 2]),   # a row of length 0, two units with 8 + 1 rows
+    (8, 12, 256, 256, [7, 5, 7, 3, 6, 7, 1, 2]),        # max(len) < T: frames never visited
+    (33, 6, 40, 128, None),                             # 16 rows per unit: 16 + 16 + 1
+    (40, 5, 256, 512, None),                            # 16 rows per unit at H = 512: the two-dimensional backward split
+    (64, 3, 40, 256, [3] * 32 + [1] * 32),
+])
+def test_bf16_plane_recurrence_edge_shapes(B, T, D, H, lens):
+    """the kernels of lstm_persist_mx.hip / lstm_persist_mx16.hip (H in {128, 256, 512}) on the shapes the small-H parity
+    tests of tests/test_hip_ops.py cover for the other kernels: single frames, single rows, empty rows, partial units,
+    max(len) < T — against the step-wise kernels"""
+    from nabu_amd import ops
+    rng = np.random.default_rng(B * 100 + T)
+    if lens is None:
+        lens = rng.integers(1, T + 1, B)
+        lens[0] = T
+    lens = np.asarray(lens)
+    gen = torch.Generator(device=DEV).manual_seed(B + T)
+    x = torch.randn((B, T, D), generator=gen, device=DEV)
+    mask = (torch.arange(T, device=DEV)[None, :] < torch.tensor(lens, device=DEV)[:, None])
+    x = x * mask[:, :, None]
+    s = 1.0 / np.sqrt(D + H)
+    p = {k: torch.randn(shape, generator=gen, device=DEV) * s
+         for k, shape in (('fw_kernel', (D + H, 4 * H)), ('fw_bias', (4 * H,)),
+                          ('bw_kernel', (D + H, 4 * H)), ('bw_bias', (4 * H,)))}
+    dout = torch.randn((B, T, 2 * H), generator=gen, device=DEV) * mask[:, :, None]
+    assert ops.blstm_uses_persistent(B, T, D, H) if hasattr(ops, 'blstm_uses_persistent') else True
+    old = ops.get_gemm_precision()
+    ops.set_gemm_precision('f32')
+    try:
+        out_p, dx_p, g_p = _layer(B, T, D, H, lens, ops.LSTM_PERSISTENT, x, p, dout, True)
+        out_s, dx_s, g_s = _layer(B, T, D, H, lens, ops.LSTM_STEPWISE, x, p, dout, True)
+    finally:
+        ops.set_gemm_precision(old)
+    assert torch.isfinite(out_p).all()
+    assert float((out_p - out_s).abs().max()) < 1e-5
+    for b in range(B):
+        assert torch.all(out_p[b, lens[b]:] == 0)
+    assert float((dx_p - dx_s).abs().max()) < 1e-4 * (float(dx_s.abs().max()) + 1e-6) + 1e-6
+    for k in g_p:
+        assert float((g_p[k] - g_s[k]).abs().max()) < 2e-4 * (float(g_s[k].abs().max()) + 1e-6) + 1e-6, k
