@@ -33,6 +33,14 @@
 
 namespace nabu {
 
+#define MX_STAMP(pass, i)                                                          \
+  do {                                                                             \
+    if constexpr (DBG) {                                                           \
+      if ((dbg & 4) && blockIdx.x == 0 && tid == 0 && s == p.max_len / 2)          \
+        p.status[320 + 32 * (pass) + (i)] = (int)(wall_clock64());                 \
+    }                                                                              \
+  } while (0)
+
 // ===========================================================================
 // forward
 template <int H>
@@ -44,8 +52,11 @@ struct MxFwdLds {
   static constexpr int TOTAL = FLAG + 4;
 };
 
-template <int H>
+// DBG: the instantiation that honours NABU_PERSIST_DEBUG (phase stamps, ablations); the production one carries none of
+// those tests — a dozen scalar branches per step of a wave that has nothing to hide them behind
+template <int H, bool DBG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_mx_fwd_kernel(PersistArgs p) {
+  const int dbg = DBG ? p.dbg : 0;
   using L = MxFwdLds<H>;
   constexpr int P = H / UC;
   constexpr int KW = H / 4;          // k values multiplied by one wave
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const unsigned goff = (unsigned)(((size_t)fb * T * 4 * H + (size_t)(2 * gp) * H + U0 + u16) * 4);
   auto fetch_x_part = [&](int s, int part) {
     const int t = dir ? n_f - 1 - s : s;
-    const bool act = s < n_f && !(p.dbg & 64);
+    const bool act = s < n_f && !(dbg & 64);
     float *st = xst + (s & 1) * 512 + 64 * w;
     if (part == 0) prefetch_lds_b32(rg, act ? goff + (unsigned)t * (unsigned)(16 * H) : OOB, smem, st);
     if (part == 1) prefetch_lds_b32(rg, act ? goff + (unsigned)t * (unsigned)(16 * H) + (unsigned)(4 * H) : OOB, smem, st + 256);
@@ -141,7 +152,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)p.B * T * 2 * H * 4), 0x00020000);
   const unsigned coff = (unsigned)(((size_t)fb * T * H + U0 + u16) * 4);
   const unsigned ooff = (unsigned)(((size_t)fb * T * 2 * H + (size_t)dir * H + U0 + u16) * 4);
-  const bool st_ok = fb < p.B && !(p.dbg & 128);
+  const bool st_ok = fb < p.B && !(dbg & 128);
   auto result_stores = [&]() {
     const bool on = d_any && st_ok;
     const unsigned go_ = (on && d_act) ? goff + (unsigned)d_t * (unsigned)(16 * H) : OOB;
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
 
   for (int s = 0; s < p.max_len; ++s) {
-    NABU_STAMP(0, 0);
+    MX_STAMP(0, 0);
     mxf32x4 acc[4];
     unsigned long long t_fail = 0;
     int fails = 0;
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int j = 0; j < NKS; ++j) b1[j] = zero4;
 #pragma unroll
     for (int j = 0; j < NPR; ++j) bl[j] = zero4;
-    if (s > 0 && !(p.dbg & 1)) {
+    if (s > 0 && !(dbg & 1)) {
       const unsigned base = (unsigned)(((s - 1) % RING) * slot_bytes);
       bool first = true;
       for (;;) {
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int j = 0; j < NPR; ++j) mx = mx_max4(mx, bl[j]);
         if (__all(mx != SENT)) break;
-        if ((p.dbg & 4) && blockIdx.x == 0 && tid == 0 && s == p.max_len / 2) p.status[320 + 20] += 1;
+        if ((dbg & 4) && blockIdx.x == 0 && tid == 0 && s == p.max_len / 2) p.status[320 + 20] += 1;
         // a failed round: bounded-spin bookkeeping (the clock is first read here)
         if (fails == 0) t_fail = wall_clock64();
         if ((++fails & 7) == 0) {
@@ -200,14 +211,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       result_stores();
       wait_vm<0>();        // (no exchange loads to order the prefetch: s = 0, or the no-waiting experiment)
     }
-    NABU_STAMP(0, 1);
+    MX_STAMP(0, 1);
     // (b) product: 4 column tiles (gate c) x NKS k-steps x {Wl.B1, Wm.B1, Wh.B2, Wh.B1}; the l planes of k-steps
     // 2 jp (lanes n < 8) and 2 jp + 1 (the others) arrived in one register set.  Next step's x-projection (HBM
     // latency: as early as possible) is requested from inside the matrix stream, one instruction behind each of the
     // first two groups of matrix instructions.
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = (mxf32x4){0.f, 0.f, 0.f, 0.f};
-    if (s > 0 && !(p.dbg & 2)) {
+    if (s > 0 && !(dbg & 2)) {
 #pragma unroll
       for (int j = 0; j < NKS; ++j) {
         u32x4 b2;
@@ -232,8 +243,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     } else {
       fetch_x(s + 1);
     }
-    NABU_STAMP(0, 2);
-    if ((p.dbg & 4096) && (unit == 0 || unit == 4) && lane == 0 && s == p.max_len / 2 + 1)
+    MX_STAMP(0, 2);
+    if ((dbg & 4096) && (unit == 0 || unit == 4) && lane == 0 && s == p.max_len / 2 + 1)
       p.status[384 + 64 * (unit != 0) + 2 * slot + 1] = (int)wall_clock64() + (w << 28);   // product done (last wave wins)
     // the two plane halves of N: lanes n and n ^ 8 end with the same sums (row n & 7; units 4 q + i, gate c)
 #pragma unroll
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __syncthreads();                                            // the step's only barrier
     if (flag[0]) return;
-    NABU_STAMP(0, 3);
+    MX_STAMP(0, 3);
 
     // (c) gates of (row frow, unit u16): both lane halves compute the same
     mxf32x4 z;
@@ -287,9 +298,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // hand back my pieces of h_{s-2} (ordering: lstm_persist.hip, forward (d))
       xstore(sent4, rs, (pub_lane && s >= 2) ? (unsigned)(((s - 2) % RING) * slot_bytes) + pub_off : OOB, coloc);
     }
-    if ((p.dbg & 4096) && (unit == 0 || unit == 4) && tid == 0 && s == p.max_len / 2)
+    if ((dbg & 4096) && (unit == 0 || unit == 4) && tid == 0 && s == p.max_len / 2)
       p.status[384 + 64 * (unit != 0) + 2 * slot] = (int)wall_clock64();
-    NABU_STAMP(0, 4);
+    MX_STAMP(0, 4);
     // (e) results of this step: stored at the top of the next one (see result_stores)
     {
       const int t_g = dir ? n_f - 1 - s : s;
@@ -298,10 +309,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       d_g1 = gp ? go : gj;
       d_v = gp ? (act ? h_new : 0.f) : c_new;
     }
-    NABU_STAMP(0, 5);
+    MX_STAMP(0, 5);
   }
   result_stores();
-  if ((p.dbg & 4) && blockIdx.x == 0 && tid == 0) {   // effective shader clock over the sequence
+  if ((dbg & 4) && blockIdx.x == 0 && tid == 0) {   // effective shader clock over the sequence
     p.status[320 + 26] = (int)(__builtin_readcyclecounter() - clk0);
     p.status[320 + 27] = (int)(wall_clock64() - wall0);
   }
@@ -319,8 +330,9 @@ struct MxBwdLds {
   static constexpr int TOTAL = FLAG + 4;
 };
 
-template <int H>
+template <int H, bool DBG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_mx_bwd_kernel(PersistArgs p) {
+  const int dbg = DBG ? p.dbg : 0;
   using L = MxBwdLds<H>;
   constexpr int P = H / UC;
   constexpr int NT = P / 4;          // 16-k output tiles (= destination workgroups) per wave
@@ -406,7 +418,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // dz of step s goes to HBM at the top of step s - 1, behind that step's exchange loads (see the forward kernel:
   // between a publish and the next poll the wave's memory queue holds exchange traffic only); always issued
   __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(p.gates[dir], 0, (int)((size_t)p.B * T * 4 * H * 4), 0x00020000);
-  const bool st_ok = gb < p.B && !(p.dbg & 128);
+  const bool st_ok = gb < p.B && !(dbg & 128);
   float d_0 = 0.f, d_1 = 0.f;
   int d_t = 0;
   bool d_any = false;
@@ -418,13 +430,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
   for (int s = p.max_len - 1; s >= 0; --s) {
-    NABU_STAMP(1, 0);
+    MX_STAMP(1, 0);
     // (a) reduce-scatter input: the partial products of step s + 1 addressed to my units
     u32x4 v[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) v[i] = zero4;
     const unsigned base = (unsigned)(((s + 1) % MXRINGB) * slot_bytes) + in_off;
-    const bool have_in = s + 1 < p.max_len && !(p.dbg & 1);
+    const bool have_in = s + 1 < p.max_len && !(dbg & 1);
     if (have_in) {
       unsigned long long t_fail = 0;
       int fails = 0;
@@ -458,8 +470,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       dz_stores();
       wait_vm<0>();     // (no exchange loads to order the prefetched values: first step, or the no-waiting experiment)
     }
-    NABU_STAMP(1, 1);
-    if ((p.dbg & 4096) && (unit == 0 || unit == 4) && lane == 0 && s == p.max_len / 2 - 1)
+    MX_STAMP(1, 1);
+    if ((dbg & 4096) && (unit == 0 || unit == 4) && lane == 0 && s == p.max_len / 2 - 1)
       p.status[384 + 64 * (unit != 0) + 2 * slot + 1] = (int)wall_clock64() + (w << 28);   // poll done (last wave wins)
     mxf32x4 ps = __builtin_bit_cast(mxf32x4, v[0]);
 #pragma unroll
@@ -505,10 +517,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const int t_g = dir ? n_g - 1 - s : s;
       d_any = true; d_0 = d0; d_1 = d1; d_t = act_g ? t_g : s;
     }
-    NABU_STAMP(1, 2);
+    MX_STAMP(1, 2);
     __syncthreads();                                            // the step's only barrier
     if (flag[0]) return;
-    NABU_STAMP(1, 3);
+    MX_STAMP(1, 3);
     if (s > 0) {
       // (c) partial dh of step s - 1: dz planes [16 slots x 64 columns] against W^T, tile t -> destination NT w + t,
       // in two halves of NT / 2 tiles; lanes n < 8 publish the first tiles of a half, the others (same sums) the
@@ -549,7 +561,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           acc[t].z += mx_dpp<DPP_ROR8>(acc[t].z);
           acc[t].w += mx_dpp<DPP_ROR8>(acc[t].w);
         }
-        if (hf == 0) NABU_STAMP(1, 4);
+        if (hf == 0) MX_STAMP(1, 4);
         constexpr int QT = HT / 2 > 0 ? HT / 2 : 1;      // tiles per lane half and product half
         const int t0 = NT * w + hf * HT + (n < 8 ? 0 : HT / 2);
         const unsigned pbase = (unsigned)((s % MXRINGB) * slot_bytes + (size_t)t0 * block_bytes + (size_t)slot * piece_bytes +
@@ -562,16 +574,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           xstore(__builtin_bit_cast(u32x4, o), rs, (HT >= 2 || n < 8) ? pbase + (unsigned)t * (unsigned)block_bytes : OOB, coloc);
         }
       }
-      NABU_STAMP(1, 9);
-      if ((p.dbg & 4096) && (unit == 0 || unit == 4) && tid == 0 && s == p.max_len / 2)
+      MX_STAMP(1, 9);
+      if ((dbg & 4096) && (unit == 0 || unit == 4) && tid == 0 && s == p.max_len / 2)
         p.status[384 + 64 * (unit != 0) + 2 * slot] = (int)wall_clock64();     // last publish issued (wave 0)
     } else {
 #pragma unroll
       for (int i = 0; i < NQ; ++i)
         xstore(sent4, rs, have_in ? base + (unsigned)(8 * i) * (unsigned)(MXR * 64) : OOB, coloc);
     }
-    NABU_STAMP(1, 5);
-    NABU_STAMP(1, 6);
+    MX_STAMP(1, 5);
+    MX_STAMP(1, 6);
   }
   dz_stores();
   // bias gradient / column maxima of my 64 gate columns over the unit's 8 rows
@@ -635,7 +647,7 @@ template <typename K>
 static int mx_launch(K kernel, const PersistArgs &a, int grid, size_t lds, hipStream_t stream, bool dry) {
   const void *fn = reinterpret_cast<const void *>(kernel);
   struct Seen { const void *fn; int dev, blocks; };
-  static thread_local Seen seen[8] = {};
+  static thread_local Seen seen[16] = {};
   int dev = 0;
   NABU_HIP(hipGetDevice(&dev));
   int blocks = -1;
@@ -659,8 +671,11 @@ int lstm_mx_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bo
   const int grid = MXNU * (H / UC);
 #define NABU_MX_CASE(h)                                                                                          \
   case h:                                                                                                        \
-    return fwd ? mx_launch(lstm_mx_fwd_kernel<h>, a, grid, MxFwdLds<h>::TOTAL * sizeof(float), stream, dry)      \
-               : mx_launch(lstm_mx_bwd_kernel<h>, a, grid, MxBwdLds<h>::TOTAL * sizeof(float), stream, dry);
+    if (a.dbg)                                                                                                   \
+      return fwd ? mx_launch(lstm_mx_fwd_kernel<h, true>, a, grid, MxFwdLds<h>::TOTAL * sizeof(float), stream, dry) \
+                 : mx_launch(lstm_mx_bwd_kernel<h, true>, a, grid, MxBwdLds<h>::TOTAL * sizeof(float), stream, dry); \
+    return fwd ? mx_launch(lstm_mx_fwd_kernel<h, false>, a, grid, MxFwdLds<h>::TOTAL * sizeof(float), stream, dry) \
+               : mx_launch(lstm_mx_bwd_kernel<h, false>, a, grid, MxBwdLds<h>::TOTAL * sizeof(float), stream, dry);
   switch (H) {
     NABU_MX_CASE(128)
     NABU_MX_CASE(256)
