@@ -1,6 +1,13 @@
 // lstm_persist.hip — whole-sequence persistent recurrent kernels for one BLSTM
 // layer (both directions in one launch), MI355X / gfx950.
 //
+// THIS FILE: the host side of every persistent recurrent kernel (geometry, workspace, validation, chunking: run /
+// run_chunk at the end) and the exact-fp32 kernels of rounds 1-3 (v_mfma_f32_4x4x1, 4 or 8 rows per unit) — since
+// round 4 the fallback for H = 64, partitioned devices and NABU_PERSIST_MX=0.  The kernels that run by default for
+// H in {128, 256, 512} multiply on the bf16 matrix pipe over exactly split operands: lstm_persist_mx.hip (launches of up
+// to 32 rows, 8 per unit) and lstm_persist_mx16.hip (33 .. 64 rows, 16 per unit); they share the exchange protocol
+// described below (lstm_persist_dev.h).
+//
 // WHY: the recurrence is 2 x sum(T_l) strictly sequential steps per pass; one
 // launch per timestep pays a kernel boundary (>=1.5 us) plus a cold re-read of
 // W_h every step.  Here one launch covers the whole sequence and W_h never
