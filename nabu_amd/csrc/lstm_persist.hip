@@ -693,6 +693,11 @@ bool lstm_mx_supported(int B, int H);
 int lstm_mx_chunk_rows();
 size_t lstm_mx_ring_bytes(bool fwd, int H);
 int lstm_mx_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry);
+// lstm_persist_mxh.hip: the same kernels with three fp16 plane products of row-scaled operands instead of seven bf16 plane
+// products (NABU_PERSIST_MXH=0: the bf16-plane kernels); rings never larger than lstm_mx_ring_bytes
+bool lstm_mxh_on(bool fwd);
+size_t lstm_mxh_ring_bytes(bool fwd, int H);
+int lstm_mxh_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry);
 // lstm_persist_mx16.hip: 16 rows per unit, 33 .. 64 batch rows in one launch (NABU_PERSIST_MX16=0: chunks of 32 rows)
 size_t lstm_mx16_ring_bytes(bool fwd, int H);
 int lstm_mx16_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry);
@@ -857,9 +862,12 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
     a.table = static_cast<unsigned *>(ws);
     a.xbuf = static_cast<char *>(ws) + TABLE_BYTES;
     a.timeout_ticks = g_timeout_ticks;
+    const bool f16 = !r16 && lstm_mxh_on(fwd);
     if (!dry)
-      NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + (r16 ? lstm_mx16_ring_bytes(fwd, H) : lstm_mx_ring_bytes(fwd, H)), stream));
-    return r16 ? lstm_mx16_launch(fwd, H, a, stream, dry) : lstm_mx_launch(fwd, H, a, stream, dry);
+      NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + (r16 ? lstm_mx16_ring_bytes(fwd, H) : f16 ? lstm_mxh_ring_bytes(fwd, H)
+                                                                                                  : lstm_mx_ring_bytes(fwd, H)), stream));
+    return r16 ? lstm_mx16_launch(fwd, H, a, stream, dry) : f16 ? lstm_mxh_launch(fwd, H, a, stream, dry)
+                                                                  : lstm_mx_launch(fwd, H, a, stream, dry);
   }
   int BS = pick_bs(B, H, fwd);
   if ((a.dbg & 16) && 2 * ((B + 7) / 8) * (H / UC) <= cu_count()) BS = 8;

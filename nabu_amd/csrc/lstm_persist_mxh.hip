@@ -1,0 +1,730 @@
+// lstm_persist_mxh.hip — the persistent recurrence of lstm_persist_mx.hip with its product as THREE fp16 plane
+// products of row-scaled operands (the arithmetic of the step's dense products, gemm_pk.hip NP = 2 / DESIGN.md
+// section 4.4) instead of seven bf16 plane products: half the matrix instructions per step.  Round 4.
+//
+// ARITHMETIC.  A factor that is constant along the reduction index factors out of a dot product, so every row of an
+// operand carries its own power-of-two scale s = 2^(14 - floor(log2 amax)) (amax = the row's largest magnitude: the
+// scaled row lies in (-2^15, 2^15), fp16 overflows at 65504) and x s = h + l with h = rne16(x s), l = rne16(x s - h):
+// 22 significant bits for every element within 2^13 of its row's maximum, an absolute error <= 2^-40 of that maximum
+// below.  Products kept: h.h, h.l, l.h (l.l rides along for free); accumulation in fp32 inside the matrix pipe, one
+// rounding per 32-k instruction; the result is multiplied by 1 / (s_a s_b), exact.
+//   forward:  W_h's gate columns are scaled once per launch (amax over all H rows of the column); h_(t-1) needs no
+//             measurement: |h| = |o tanh c| < 1 + 2^-22 by construction, s = 2^14.
+//   backward: W_h^T per output k over this workgroup's 64 gate columns, once per launch; dz per batch row over the same
+//             64 columns EVERY STEP (a 32-lane maximum: four DPP steps and one swizzle) — the scale only has to be
+//             constant inside one workgroup's reduction, the partial dh it publishes are plain fp32.
+// Against float64 the recurrence with this product is as close as with the exact-fp32 kernels
+// (tests/test_hip_fullsize.py::test_plane_recurrence_is_as_close_to_float64_as_the_fp32_kernels).
+//
+// GEOMETRY, PROTOCOL, DEFERRED STORES: lstm_persist_mx.hip (same units, rings, in-order arguments).  What changes: the
+// forward exchange cell array is [k / 8][16 = plane * 8 + row] (4 loads per lane instead of 6, 4 KiB per wave), the N
+// side of every instruction is B = [h | l] of 8 rows, 32 instructions per wave and step: W_l.B, W_h.B per (16 columns x
+// 32 k).
+#include "lstm_persist_mx.h"
+
+namespace nabu {
+
+#define MXH_STAMP(pass, i)                                                         \
+  do {                                                                             \
+    if constexpr (DBG) {                                                           \
+      if ((dbg & 4) && blockIdx.x == 0 && tid == 0 && s == p.max_len / 2)          \
+        p.status[320 + 32 * (pass) + (i)] = (int)(wall_clock64());                 \
+    }                                                                              \
+  } while (0)
+
+// timing experiments (never defined in the library build): exchange volume cut to a quarter / no backward product
+#ifdef MXH_EXP_QVOL
+#define MXH_QVOL(x) ((x) != 0)
+#else
+#define MXH_QVOL(x) false
+#endif
+
+typedef _Float16 mxh16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 mxh16x2 __attribute__((ext_vector_type(2)));
+#define MXH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mxh16x8, a), __builtin_bit_cast(mxh16x8, b), c, 0, 0, 0)
+
+constexpr int DPP_ROW_MIRROR = 0x140;
+// backward exchange ring: 2 slots, NO hand-back.  The backward step is bound by the volume of its exchange (16 KB
+// written, 16 KB read and — with sentinels — 16 KB handed back per workgroup and step, at ~2.5 TB/s per XCD: cutting the
+// volume to a quarter takes 0.45 us off a 2.2 us step, removing the whole product nothing).  So
+// the flag is ONE BIT of the data: the least significant bit of every published fp32 partial sum carries the
+// generation of its slot (iteration it = max_len - 1 - s: slot it & 1, generation it >> 1, tag = generation & 1; the ring
+// starts as 0xFF bytes, tag 1, and generation 0 has tag 0), the reader repeats its loads until every word carries the
+// tag it waits for.  A published partial sum thus has 23 significant bits and is off by at most one unit of its last
+// place — the size of the rounding it went through anyway — low in even generations, high in odd ones: no bias over
+// time.  Ring of 2 is safe without hand-back: a slot written in iteration it is overwritten in it + 2 by a writer that
+// has polled the reader's own publish of it + 1, issued behind the barrier that follows the reader's poll of the slot.
+constexpr int MXHRINGB = 2;
+constexpr float MXH_HSCALE = 16384.f, MXH_HINV = 1.f / 16384.f;     // forward h: |h| < 1 + 2^-22
+
+// row scales from the bit pattern of the row's largest magnitude (the convention of gemm_pk.hip, pk_scale_of): exponent
+// field clamped so that scale and inverse are normal numbers; an all-zero row takes amax = 1; inf / NaN rows keep a
+// finite scale and propagate through the planes
+__device__ __forceinline__ unsigned mxh_amax_exp(unsigned bits) {
+  unsigned e = (bits >> 23) & 0xFFu;
+  if ((bits & 0x7FFFFFFFu) == 0) e = 127;
+  return e < 15 ? 15 : (e > 253 ? 253 : e);
+}
+__device__ __forceinline__ float mxh_scale_of(float amax) {
+  return __builtin_bit_cast(float, (268u - mxh_amax_exp(__builtin_bit_cast(unsigned, amax))) << 23);
+}
+__device__ __forceinline__ float mxh_inv_scale_of(float amax) {
+  return __builtin_bit_cast(float, (mxh_amax_exp(__builtin_bit_cast(unsigned, amax)) - 14u) << 23);
+}
+__device__ __forceinline__ unsigned mxh_cvt2(float a, float b) {   // (fp16(a), fp16(b)), round to nearest even
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, mxh16x2));
+}
+// two scaled values -> one word per plane (a | b << 16)
+__device__ __forceinline__ void mxh_split2x2(float a, float b, unsigned &h, unsigned &l) {
+  h = mxh_cvt2(a, b);
+  const mxh16x2 hv = __builtin_bit_cast(mxh16x2, h);
+  l = mxh_cvt2(a - (float)hv.x, b - (float)hv.y);
+}
+// 8 consecutive-k scaled values -> the two plane operands
+__device__ __forceinline__ void mxh_split8(const float *x, u32x4 &h, u32x4 &l) {
+  unsigned hh[4], ll[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) mxh_split2x2(x[2 * i], x[2 * i + 1], hh[i], ll[i]);
+  h = (u32x4){hh[0], hh[1], hh[2], hh[3]};
+  l = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+}
+__device__ __forceinline__ float mxh_xor16(float v) {      // lane ^ 16 inside every group of 32 (bit-mask swizzle)
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
+
+// ===========================================================================
+// forward
+template <int H>
+struct MxhFwdLds {
+  static constexpr int ROWF = 17 * 4;                        // floats per (wave, row): 16 units x 4 gates + pad
+  static constexpr int PART = 0;                             // [2][4 waves][8 rows][ROWF]
+  static constexpr int XST = PART + 2 * 4 * MXR * ROWF;      // [2][2][256] prefetched x-projection
+  static constexpr int FLAG = XST + 2 * 2 * 256;
+  static constexpr int TOTAL = FLAG + 4;
+};
+
+template <int H, bool DBG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_mxh_fwd_kernel(PersistArgs p) {
+  const int dbg = DBG ? p.dbg : 0;
+  using L = MxhFwdLds<H>;
+  constexpr int P = H / UC;
+  constexpr int KW = H / 4;          // k values multiplied by one wave
+  constexpr int NKS = KW / 32;       // k-steps of 32 per wave
+  static_assert(NKS >= 1, "mxh forward: H >= 128");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *part = smem + L::PART, *xst = smem + L::XST;
+  int *flag = reinterpret_cast<int *>(smem + L::FLAG);
+
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const int NU = 2 * p.nshard;
+  int unit, slot;
+  mx_identity(&unit, &slot);
+  if (unit >= NU) return;
+  const int dir = unit & 1, shard = unit >> 1;
+  const int U0 = slot * UC, b0 = shard * MXR;
+  const int T = p.T;
+  // matrix-phase identity: n = N index (plane half, row), q = k group (B) / column group (D)
+  const int n = lane & 15, q = lane >> 4;
+  // finishing identity (lanes 0..31 of every wave): row 2w + r2, unit u16 — and, for the prefetch, gate pair gp
+  const int u16 = lane & 15, r2 = (lane >> 4) & 1, gp = lane >> 5;
+  const int frow = 2 * w + r2, fb = b0 + frow;
+  const int n_f = fb < p.B ? p.len[fb] : 0;
+  const bool fin = lane < 32;
+
+  // this lane's slice of W_h as two scaled fp16 planes, A operands: column (gate c, unit U0 + n), k = w KW + 32 j + 8 q + e.
+  // The column's scale needs its largest magnitude over ALL k: lanes q (shuffles), then the four waves (LDS).
+  // inv[c]: what the finished sum of column (c, U0 + n) is multiplied with — n = u16: the lane that multiplies column
+  // n is the lane that finishes unit n.
+  u32x4 Wp[2][4][NKS];
+  float inv[4];
+  {
+    const float *Wh = p.kernel[dir] + ((size_t)p.D + (size_t)w * KW + 8 * q) * 4 * H + U0 + n;
+    float mx[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      mx[c] = 0.f;
+#pragma unroll
+      for (int j = 0; j < NKS; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx[c] = fmaxf(mx[c], fabsf(Wh[((size_t)32 * j + e) * 4 * H + (size_t)c * H]));
+      mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], 16));
+      mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], 32));
+      if (q == 0) part[w * 64 + c * 16 + n] = mx[c];
+    }
+    __syncthreads();
+    float sc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float m = fmaxf(fmaxf(part[c * 16 + n], part[64 + c * 16 + n]), fmaxf(part[128 + c * 16 + n], part[192 + c * 16 + n]));
+      sc[c] = mxh_scale_of(m);
+      inv[c] = mxh_inv_scale_of(m) * MXH_HINV;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < NKS; ++j) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = Wh[((size_t)32 * j + e) * 4 * H + (size_t)c * H] * sc[c];
+        mxh_split8(x, Wp[0][c][j], Wp[1][c][j]);
+      }
+  }
+  float c_state = 0.f, h_state = 0.f;
+  if (!unit_handshake(p, unit, slot, MXNU, P, flag)) return;
+  const bool coloc = flag[1] != 0;
+
+  // exchange slot of a unit: cells of 16 bytes = 8 consecutive k of one (plane, row): [k / 8][16 = plane * 8 + row]
+  // — a k group's 16 cells are 256 contiguous bytes, a wave's k range 4 KiB of full 128-byte lines
+  const size_t slot_bytes = (size_t)16 * H * 2;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      p.xbuf + (size_t)unit * RING * slot_bytes, 0, (int)(RING * slot_bytes), 0x00020000);
+  constexpr int KGW = KW / 8;                      // k groups per wave
+  constexpr unsigned KSTEP_BYTES = 4 * 16 * 16;    // 4 k groups
+  const unsigned off1 = (unsigned)((((size_t)w * KGW + q) * 16 + n) * 16);
+  // my published piece (finishing half, lanes u16 & 7 = plane 0, 1): units U0 + (u16 & 8) .. + 7 of row frow
+  const int ppl = u16 & 7;
+  const bool pub_lane = fin && ppl < 2;
+  const unsigned pub_off = (unsigned)((((size_t)(U0 >> 3) + (u16 >> 3)) * 16 + ppl * 8 + frow) * 16);
+  const u32x4 sent4 = {SENT, SENT, SENT, SENT};
+
+  // x-projection of step s (bias included), one step ahead, by LDS-DMA (lstm_persist.hip: PER-STEP PREFETCH):
+  // lane (u16, r2, gp) fetches gates 2 gp and 2 gp + 1 of (row frow, unit u16); the finishing lane reads all four
+  const i32x4 rg = raw_rsrc(p.gates[dir], (unsigned)((size_t)p.B * T * 4 * H * 4));
+  const unsigned goff = (unsigned)(((size_t)fb * T * 4 * H + (size_t)(2 * gp) * H + U0 + u16) * 4);
+  auto fetch_x_part = [&](int s, int part_i) {
+    const int t = dir ? n_f - 1 - s : s;
+    const bool act = s < n_f && !(dbg & 64);
+    float *st = xst + (s & 1) * 512 + 64 * w;
+    if (part_i == 0) prefetch_lds_b32(rg, act ? goff + (unsigned)t * (unsigned)(16 * H) : OOB, smem, st);
+    if (part_i == 1) prefetch_lds_b32(rg, act ? goff + (unsigned)t * (unsigned)(16 * H) + (unsigned)(4 * H) : OOB, smem, st + 256);
+  };
+  auto fetch_x = [&](int s) {
+    fetch_x_part(s, 0);
+    fetch_x_part(s, 1);
+  };
+  fetch_x(0);
+  wait_vm<0>();
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  // RESULT STORES ARE DEFERRED to the top of the next step, behind its exchange loads (lstm_persist_mx.hip); always
+  // issued, inactive lanes out of range: the wait counts of the loads in front stay exact
+  float d_g0 = 0.f, d_g1 = 0.f, d_v = 0.f;
+  int d_t = 0, d_to = 0;
+  bool d_act = false, d_any = false;
+  __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(p.gates[dir], 0, (int)((size_t)p.B * T * 4 * H * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(p.cs[dir], 0, (int)((size_t)p.B * T * H * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)p.B * T * 2 * H * 4), 0x00020000);
+  const unsigned coff = (unsigned)(((size_t)fb * T * H + U0 + u16) * 4);
+  const unsigned ooff = (unsigned)(((size_t)fb * T * 2 * H + (size_t)dir * H + U0 + u16) * 4);
+  const bool st_ok = fb < p.B && !(dbg & 128);
+  auto result_stores = [&]() {
+    const bool on = d_any && st_ok;
+    const unsigned go_ = (on && d_act) ? goff + (unsigned)d_t * (unsigned)(16 * H) : OOB;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d_g0), rsg, go_, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d_g1), rsg, go_ == OOB ? OOB : go_ + (unsigned)(4 * H), 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d_v), rsc, (on && d_act && !gp) ? coff + (unsigned)d_t * (unsigned)(4 * H) : OOB, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d_v), rso, (on && gp) ? ooff + (unsigned)d_to * (unsigned)(8 * H) : OOB, 0, 0);
+  };
+
+  for (int s = 0; s < p.max_len; ++s) {
+    MXH_STAMP(0, 0);
+    mxf32x4 acc[4];
+    unsigned long long t_fail = 0;
+    int fails = 0;
+    // (a) h_{s-1} as planes: the poll loop IS the operand fetch — the loads of the wave's k range (4 KiB of full lines)
+    // are repeated until no word holds the sentinel
+    u32x4 b1[NKS];
+#pragma unroll
+    for (int j = 0; j < NKS; ++j) b1[j] = zero4;
+    if (s > 0 && !(dbg & 1)) {
+      const unsigned base = (unsigned)(((s - 1) % RING) * slot_bytes);
+      bool first = true;
+      for (;;) {
+        unsigned mx = 0u;
+#pragma unroll
+        for (int j = 0; j < NKS; ++j) b1[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + off1 + j * KSTEP_BYTES, 0, 16);
+        if (first) { result_stores(); first = false; }     // step s - 1's results, behind the loads
+#pragma unroll
+        for (int j = 0; j < NKS; ++j) mx = mx_max4(mx, b1[j]);
+        if (__all(mx != SENT)) break;
+        // a failed round: bounded-spin bookkeeping (the clock is first read here)
+        if (fails == 0) t_fail = wall_clock64();
+        if ((++fails & 7) == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+              wall_clock64() - t_fail > p.timeout_ticks) {
+            if (lane == 0) {
+              flag[0] = 1;
+              __hip_atomic_store(p.status, 1 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            break;
+          }
+        }
+      }
+    } else {
+      result_stores();
+      wait_vm<0>();        // (no exchange loads to order the prefetch: s = 0, or the no-waiting experiment)
+    }
+    MXH_STAMP(0, 1);
+    // (b) product: 4 column tiles (gate c) x NKS k-steps x {W_l.B, W_h.B}, small terms first.  Next step's
+    // x-projection (HBM latency: as early as possible) is requested from inside the matrix stream.
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = (mxf32x4){0.f, 0.f, 0.f, 0.f};
+    if (s > 0 && !(dbg & 2)) {
+#pragma unroll
+      for (int j = 0; j < NKS; ++j) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = MXH_MFMA(Wp[1][c][j], b1[j], acc[c]);
+        if (j == 0) { fetch_x_part(s + 1, 0); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = MXH_MFMA(Wp[0][c][j], b1[j], acc[c]);
+        if (j == 0) { fetch_x_part(s + 1, 1); __builtin_amdgcn_sched_barrier(0); }
+      }
+    } else {
+      fetch_x(s + 1);
+    }
+    MXH_STAMP(0, 2);
+    // the two plane halves of N: lanes n and n ^ 8 end with the same sums (row n & 7; units 4 q + i, gate c)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc[c].x += mx_dpp<DPP_ROR8>(acc[c].x);
+      acc[c].y += mx_dpp<DPP_ROR8>(acc[c].y);
+      acc[c].z += mx_dpp<DPP_ROR8>(acc[c].z);
+      acc[c].w += mx_dpp<DPP_ROR8>(acc[c].w);
+    }
+    // partial sums -> LDS [wave][row][unit][4 gates]: lanes n < 8 write units 4 q + {0, 1}, the others 4 q + {2, 3}
+    float *const pbuf = part + (s & 1) * (4 * MXR * L::ROWF);
+    {
+      const bool lo = n < 8;
+      float *d = pbuf + ((size_t)(w * MXR + (n & 7))) * L::ROWF + (4 * q + (lo ? 0 : 2)) * 4;
+      const mxf32x4 v0 = {lo ? acc[0].x : acc[0].z, lo ? acc[1].x : acc[1].z, lo ? acc[2].x : acc[2].z, lo ? acc[3].x : acc[3].z};
+      const mxf32x4 v1 = {lo ? acc[0].y : acc[0].w, lo ? acc[1].y : acc[1].w, lo ? acc[2].y : acc[2].w, lo ? acc[3].y : acc[3].w};
+      *reinterpret_cast<mxf32x4 *>(d) = v0;
+      *reinterpret_cast<mxf32x4 *>(d + 4) = v1;
+    }
+    __syncthreads();                                            // the step's only barrier
+    if (flag[0]) return;
+    MXH_STAMP(0, 3);
+
+    // (c) gates of (row frow, unit u16): both lane halves compute the same; the four waves' partial sums are added
+    // first, then descaled (exact: powers of two), then the x-projection
+    mxf32x4 z;
+    {
+      const float *xs = xst + (s & 1) * 512 + 64 * w + (lane & 31);
+      const float *pr = pbuf + (size_t)frow * L::ROWF + u16 * 4;
+      mxf32x4 sum = *reinterpret_cast<const mxf32x4 *>(pr);
+#pragma unroll
+      for (int ww = 1; ww < 4; ++ww) sum += *reinterpret_cast<const mxf32x4 *>(pr + (size_t)ww * MXR * L::ROWF);
+      z = (mxf32x4){xs[0] + sum.x * inv[0], xs[256] + sum.y * inv[1], xs[32] + sum.z * inv[2], xs[256 + 32] + sum.w * inv[3]};
+    }
+    const float gi = fast_sigmoid(z.x), gj = fast_tanh(z.y), gf = fast_sigmoid(z.z + 1.0f), go = fast_sigmoid(z.w);
+    const bool act = s < n_f;
+    const float c_new = c_state * gf + gi * gj;
+    const float h_new = fast_tanh(c_new) * go;
+    if (act) { c_state = c_new; h_state = h_new; }
+
+    // (d) publish h_s as two planes (frozen rows republish): the pair words of a plane sit in the even lanes of an
+    // 8-lane group; lane 8 g + pl collects the four words of plane pl -> ONE 16-byte store instruction per wave
+    {
+      const float hs = h_state * MXH_HSCALE;
+      const unsigned w0 = mxh_cvt2(hs, 0.f) & 0xFFFFu;
+      const float r = hs - (float)__builtin_bit_cast(mxh16x2, w0).x;
+      const unsigned w1 = mxh_cvt2(r, 0.f) & 0xFFFFu;
+      const unsigned pr0 = w0 | (mx_dppu<DPP_XOR1>(w0) << 16), pr1 = w1 | (mx_dppu<DPP_XOR1>(w1) << 16);   // even lanes: units u, u + 1
+      const u32x4 v0 = {pr0, mx_dppu<0x102>(pr0), mx_dppu<0x104>(pr0), mx_dppu<0x106>(pr0)};   // lane 8 g
+      const u32x4 v1 = {mx_dppu<0x111>(pr1), mx_dppu<0x101>(pr1), mx_dppu<0x103>(pr1), mx_dppu<0x105>(pr1)};   // 8 g + 1
+      const u32x4 pv = ppl == 0 ? v0 : v1;
+      xstore(pv, rs, (pub_lane && s + 1 < p.max_len) ? (unsigned)((s % RING) * slot_bytes) + pub_off : OOB, coloc);
+      // hand back my pieces of h_{s-2} (ordering: lstm_persist.hip, forward (d))
+      xstore(sent4, rs, (pub_lane && s >= 2) ? (unsigned)(((s - 2) % RING) * slot_bytes) + pub_off : OOB, coloc);
+    }
+    MXH_STAMP(0, 4);
+    // (e) results of this step: stored at the top of the next one (see result_stores)
+    {
+      const int t_g = dir ? n_f - 1 - s : s;
+      d_any = true; d_act = act; d_t = t_g; d_to = act ? t_g : s;
+      d_g0 = gp ? gf : gi;
+      d_g1 = gp ? go : gj;
+      d_v = gp ? (act ? h_new : 0.f) : c_new;
+    }
+    MXH_STAMP(0, 5);
+  }
+  result_stores();
+}
+
+// ===========================================================================
+// backward
+template <int H>
+struct MxhBwdLds {
+  static constexpr int DROWB = 64 * 2 + 16;                  // bytes per slot row of dz planes: 64 columns fp16 + pad
+  static constexpr int DZ = 0;                               // [2][16][DROWB] bytes
+  static constexpr int INVD = (2 * 16 * DROWB + 15) / 16 * 4;   // floats: [2][8] inverse row scales of dz
+  static constexpr int XST = INVD + 16;                      // [2][4][256] prefetched saved values
+  static constexpr int RED = XST + 2 * 4 * 256;              // [8 rows][64] floats, final reductions
+  static constexpr int FLAG = RED + 8 * 64;
+  static constexpr int TOTAL = FLAG + 4;
+};
+
+template <int H, bool DBG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_mxh_bwd_kernel(PersistArgs p) {
+  const int dbg = DBG ? p.dbg : 0;
+  using L = MxhBwdLds<H>;
+  constexpr int P = H / UC;
+  constexpr int NT = P / 4;          // 16-k output tiles (= destination workgroups) per wave
+  constexpr int NQ = P / 8;          // source pieces per lane
+  static_assert(NT >= 2 && NQ >= 1 && NQ <= 4, "mxh backward: 128 <= H <= 512");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char *dzs = reinterpret_cast<char *>(smem) + L::DZ;
+  float *invd = smem + L::INVD, *xst = smem + L::XST, *red = smem + L::RED;
+  int *flag = reinterpret_cast<int *>(smem + L::FLAG);
+
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const int NU = 2 * p.nshard;
+  int unit, slot;
+  mx_identity(&unit, &slot);
+  if (unit >= NU) return;
+  const int dir = unit & 1, shard = unit >> 1;
+  const int U0 = slot * UC, b0 = shard * MXR;
+  const int T = p.T;
+  const int n = lane & 15, q = lane >> 4;                 // matrix-phase identity
+  // exchange / gate identity: source group s8, k quad kq, row 2 w + r2; after the butterfly: unit 4 kq + (s8 >> 1),
+  // gate pair dup (0: i, j; 1: f, o).  The 32 lanes of a row are one half of the wave.
+  const int s8 = lane & 7, kq = (lane >> 3) & 3, r2 = lane >> 5;
+  const int grow = 2 * w + r2, gb = b0 + grow;
+  const int gu = 4 * kq + (s8 >> 1), dup = s8 & 1;
+  const int n_g = gb < p.B ? p.len[gb] : 0;
+  constexpr int HT = NT / 2;                              // tiles per product half
+  constexpr int QT = HT / 2 > 0 ? HT / 2 : 1;             // tiles per lane half and product half
+
+  // A operands: W^T as two scaled fp16 planes.  Row m = output k = 16 (NT w + t) + n; reduction index c' = 32 j + 8 q + e
+  // = 4 unit + gate.  Row scale: the largest magnitude over this workgroup's 64 gate columns (lanes q: shuffles).
+  // inv_sel[hf][t][i]: the inverse scale of the output k this lane PUBLISHES in register i of piece t of half hf
+  // (D layout: k = 16 tile + 4 q + i; lanes n < 8 publish the first QT tiles of a half, the others the rest).
+  u32x4 Wp[2][NT][2];
+  float inv_sel[2][QT][4];
+  {
+    float inv_lane[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float *Wh = p.kernel[dir] + ((size_t)p.D + 16 * (NT * w + t) + n) * 4 * H + U0;
+      float x[2][8], m = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          x[j][e] = Wh[(size_t)(e & 3) * H + 8 * j + 2 * q + (e >> 2)];
+          m = fmaxf(m, fabsf(x[j][e]));
+        }
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      const float sc = mxh_scale_of(m);
+      inv_lane[t] = mxh_inv_scale_of(m);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[j][e] *= sc;
+        mxh_split8(x[j], Wp[0][t][j], Wp[1][t][j]);
+      }
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float lo = __shfl(inv_lane[hf * HT + t], 4 * q + i);
+          const float hi = __shfl(inv_lane[hf * HT + (HT / 2 + t < HT ? HT / 2 + t : t)], 4 * q + i);
+          inv_sel[hf][t][i] = n < 8 ? lo : hi;
+        }
+  }
+  float dc_state = 0.f;
+  float db0 = 0.f, db1 = 0.f, am0 = 0.f, am1 = 0.f;   // bias gradient / largest |dz| of my two gate columns, my row
+  if (!unit_handshake(p, unit, slot, MXNU, P, flag)) return;
+  const bool coloc = flag[1] != 0;
+
+  // ring slot = [dest P][src P][8 rows][4 k quads] x 16 bytes
+  const size_t piece_bytes = (size_t)MXR * UC * 4;
+  const size_t block_bytes = (size_t)P * piece_bytes;
+  const size_t slot_bytes = (size_t)P * block_bytes;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      p.xbuf + (size_t)unit * MXHRINGB * slot_bytes, 0, (int)(MXHRINGB * slot_bytes), 0x00020000);
+  const unsigned in_off = (unsigned)((size_t)slot * block_bytes + ((size_t)s8 * MXR + grow) * 64 + kq * 16);
+
+  // saved forward values of step s, one step ahead: A, B = the activations of my two gates, C = c (dup 0) / c_prev
+  // (dup 1), D = dout (dup 0); the pair exchanges what the other needs
+  const i32x4 rg = raw_rsrc(p.gates[dir], (unsigned)((size_t)p.B * T * 4 * H * 4));
+  const i32x4 rc = raw_rsrc(p.cs[dir], (unsigned)((size_t)p.B * T * H * 4));
+  const i32x4 rd = raw_rsrc(p.dout, (unsigned)((size_t)p.B * T * 2 * H * 4));
+  const unsigned goff = (unsigned)(((size_t)gb * T * 4 * H + (size_t)(2 * dup) * H + U0 + gu) * 4);
+  const unsigned coff = (unsigned)(((size_t)gb * T * H + U0 + gu) * 4);
+  const unsigned doff = (unsigned)(((size_t)gb * T * 2 * H + (size_t)dir * H + U0 + gu) * 4);
+  auto fetch_part = [&](int s, int part_i) {
+    const bool act = s >= 0 && s < n_g && !(dbg & 64);
+    const int t = dir ? n_g - 1 - s : s;
+    const int tc = dup == 0 ? t : (dir ? t + 1 : t - 1);
+    const bool want_c = act && (dup == 0 || s > 0);
+    float *st = xst + (s & 1) * 1024 + 64 * w;
+    if (part_i == 0) prefetch_lds_b32(rg, act ? goff + (unsigned)t * (unsigned)(16 * H) : OOB, smem, st);
+    if (part_i == 1) prefetch_lds_b32(rg, act ? goff + (unsigned)t * (unsigned)(16 * H) + (unsigned)(4 * H) : OOB, smem, st + 256);
+    if (part_i == 2) prefetch_lds_b32(rc, want_c ? coff + (unsigned)tc * (unsigned)(4 * H) : OOB, smem, st + 512);
+    if (part_i == 3) prefetch_lds_b32(rd, (act && dup == 0) ? doff + (unsigned)t * (unsigned)(8 * H) : OOB, smem, st + 768);
+  };
+  auto fetch = [&](int s) {
+    for (int i = 0; i < 4; ++i) fetch_part(s, i);
+  };
+  fetch(p.max_len - 1);
+  wait_vm<0>();
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  // dz of step s goes to HBM at the top of step s - 1, behind that step's exchange loads; always issued
+  __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(p.gates[dir], 0, (int)((size_t)p.B * T * 4 * H * 4), 0x00020000);
+  const bool st_ok = gb < p.B && !(dbg & 128);
+  float d_0 = 0.f, d_1 = 0.f;
+  int d_t = 0;
+  bool d_any = false;
+  auto dz_stores = [&]() {
+    const unsigned o = (d_any && st_ok) ? goff + (unsigned)d_t * (unsigned)(16 * H) : OOB;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d_0), rsg, o, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d_1), rsg, o == OOB ? OOB : o + (unsigned)(4 * H), 0, 0);
+  };
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  for (int s = p.max_len - 1; s >= 0; --s) {
+    MXH_STAMP(1, 0);
+    // (a) reduce-scatter input: the partial products of step s + 1 addressed to my units
+    u32x4 v[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) v[i] = zero4;
+    const int it = p.max_len - 1 - s;                       // iteration count: slot it & 1, generation it >> 1
+    const unsigned base = (unsigned)(((it - 1) & 1) * slot_bytes) + in_off;
+    const bool have_in = it > 0 && !(dbg & 1);
+    if (have_in) {
+      unsigned long long t_fail = 0;
+      int fails = 0;
+      const bool want1 = (((it - 1) >> 1) & 1) != 0;        // the tag of the pieces published in iteration it - 1
+      // (a first round issued at once fails and costs the memory queue a round trip: lstm_persist_mx.hip)
+      __builtin_amdgcn_s_sleep(4);
+      // (re-loading only the cells that failed, the others out of range, was measured: 2.11 against 2.02 us per step)
+      bool first = true;
+      for (;;) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+          v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, MXH_QVOL(kq) ? OOB : base + (unsigned)(8 * i) * (unsigned)(MXR * 64), 0, 16);
+        if (first) { dz_stores(); first = false; }
+        // every word must carry the tag: AND of the last bits (tag 1) / OR of the last bits (tag 0)
+        unsigned a = v[0].x & v[0].y & v[0].z & v[0].w, o = v[0].x | v[0].y | v[0].z | v[0].w;
+#pragma unroll
+        for (int i = 1; i < NQ; ++i) {
+          a &= v[i].x & v[i].y & v[i].z & v[i].w;
+          o |= v[i].x | v[i].y | v[i].z | v[i].w;
+        }
+        if (__all(MXH_QVOL(kq) || (want1 ? (a & 1u) != 0 : (o & 1u) == 0))) break;
+        if (fails == 0) t_fail = wall_clock64();
+        if ((++fails & 7) == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+              wall_clock64() - t_fail > p.timeout_ticks) {
+            if (lane == 0) {
+              flag[0] = 1;
+              __hip_atomic_store(p.status, 2 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            break;
+          }
+        }
+      }
+    } else {
+      dz_stores();
+      wait_vm<0>();     // (no exchange loads to order the prefetched values: first step, or the no-waiting experiment)
+    }
+    MXH_STAMP(1, 1);
+    mxf32x4 ps = __builtin_bit_cast(mxf32x4, v[0]);
+#pragma unroll
+    for (int i = 1; i < NQ; ++i) ps += __builtin_bit_cast(mxf32x4, v[i]);
+    // sum over the 8 source groups, every lane of the group ends with the total (fixed order, bitwise equal)
+    ps.x += mx_dpp<DPP_HALF_MIRROR>(ps.x); ps.y += mx_dpp<DPP_HALF_MIRROR>(ps.y);
+    ps.z += mx_dpp<DPP_HALF_MIRROR>(ps.z); ps.w += mx_dpp<DPP_HALF_MIRROR>(ps.w);
+    ps.x += mx_dpp<DPP_XOR1>(ps.x); ps.y += mx_dpp<DPP_XOR1>(ps.y);
+    ps.z += mx_dpp<DPP_XOR1>(ps.z); ps.w += mx_dpp<DPP_XOR1>(ps.w);
+    ps.x += mx_dpp<DPP_XOR2>(ps.x); ps.y += mx_dpp<DPP_XOR2>(ps.y);
+    ps.z += mx_dpp<DPP_XOR2>(ps.z); ps.w += mx_dpp<DPP_XOR2>(ps.w);
+    const float dh = sel4(s8 >> 1, ps.x, ps.y, ps.z, ps.w);
+
+    // (b) gate gradients of (row, unit): the pair shares its saved values (prefetched a step ahead: older than the
+    // exchange loads above, and vector-memory operations complete in issue order)
+    const float *st = xst + (s & 1) * 1024 + tid;
+    const float sA = st[0], sB = st[256], sC = st[512], sD = st[768];
+    const float pA = mx_dpp<DPP_XOR1>(sA), pB = mx_dpp<DPP_XOR1>(sB), pC = mx_dpp<DPP_XOR1>(sC), pD = mx_dpp<DPP_XOR1>(sD);
+    const float gi = dup ? pA : sA, gj = dup ? pB : sB, gf = dup ? sA : pA, go = dup ? sB : pB;
+    const float c = dup ? pC : sC, cprev = dup ? sC : pC, dout = dup ? pD : sD;
+    const bool act_g = s < n_g;
+    const float tc = fast_tanh(c);
+    const float dht = dout + dh;
+    const float dct = dc_state + dht * go * (1.f - tc * tc);
+    float d0 = 0.f, d1 = 0.f;
+    if (act_g) {
+      d0 = dup ? dct * cprev * gf * (1.f - gf) : dct * gj * gi * (1.f - gi);
+      d1 = dup ? dht * tc * go * (1.f - go) : dct * gi * (1.f - gj * gj);
+      dc_state = dct * gf;
+    }
+    db0 += d0; db1 += d1;
+    am0 = fmaxf(am0, fabsf(d0)); am1 = fmaxf(am1, fabsf(d1));
+    char *const dzb = dzs + (s & 1) * (16 * L::DROWB);
+    {
+      // this row's largest |dz| over the workgroup's 64 columns = over the 32 lanes of the row: 16 by DPP, the two
+      // halves by one swizzle; every lane of the row ends with the same value
+      float m = fmaxf(fabsf(d0), fabsf(d1));
+      m = fmaxf(m, mx_dpp<DPP_XOR1>(m));
+      m = fmaxf(m, mx_dpp<DPP_XOR2>(m));
+      m = fmaxf(m, mx_dpp<DPP_HALF_MIRROR>(m));
+      m = fmaxf(m, mx_dpp<DPP_ROW_MIRROR>(m));
+      m = fmaxf(m, mxh_xor16(m));
+      const float sc = mxh_scale_of(m);
+      unsigned ph, pl;
+      mxh_split2x2(d0 * sc, d1 * sc, ph, pl);
+      const unsigned o = (unsigned)grow * L::DROWB + (unsigned)(4 * gu + 2 * dup) * 2;
+      *reinterpret_cast<unsigned *>(dzb + o) = ph;
+      *reinterpret_cast<unsigned *>(dzb + o + 8 * L::DROWB) = pl;
+      if ((lane & 31) == 0) invd[(s & 1) * 8 + grow] = mxh_inv_scale_of(m);
+    }
+    {   // dz of this step: stored at the top of the next one; padded frames get 0
+      const int t_g = dir ? n_g - 1 - s : s;
+      d_any = true; d_0 = d0; d_1 = d1; d_t = act_g ? t_g : s;
+    }
+    MXH_STAMP(1, 2);
+    __syncthreads();                                            // the step's only barrier
+    if (flag[0]) return;
+    MXH_STAMP(1, 3);
+    if (s > 0) {
+      // (c) partial dh of step s - 1: dz planes [16 slots x 64 columns] against W^T, tile t -> destination NT w + t,
+      // in two halves of NT / 2 tiles; lanes n < 8 publish the first tiles of a half, the others (same sums) the
+      // rest: piece (dest, me)[row n & 7][quad q], the last bit of every word = the slot's generation tag.  Next
+      // step's saved values (HBM latency: as early as possible) are requested from inside the first half's matrix stream.
+      u32x4 b1[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b1[j] = *reinterpret_cast<const u32x4 *>(dzb + (unsigned)n * L::DROWB + 64 * j + 16 * q);
+      const float idz = invd[(s & 1) * 8 + (n & 7)];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        mxf32x4 acc[HT];
+#pragma unroll
+        for (int t = 0; t < HT; ++t) acc[t] = (mxf32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+#ifndef MXH_EXP_NOPROD
+#pragma unroll
+            for (int t = 0; t < HT; ++t) acc[t] = MXH_MFMA(Wp[1 - g][hf * HT + t][j], b1[j], acc[t]);
+#endif
+            if (hf == 0) fetch_part(s - 1, 2 * j + g);     // one memory instruction behind every group of matrix instructions
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          acc[t].x += mx_dpp<DPP_ROR8>(acc[t].x);
+          acc[t].y += mx_dpp<DPP_ROR8>(acc[t].y);
+          acc[t].z += mx_dpp<DPP_ROR8>(acc[t].z);
+          acc[t].w += mx_dpp<DPP_ROR8>(acc[t].w);
+        }
+        if (hf == 0) MXH_STAMP(1, 4);
+        const int t0 = NT * w + hf * HT + (n < 8 ? 0 : HT / 2);
+        const unsigned pbase = (unsigned)((it & 1) * slot_bytes + (size_t)t0 * block_bytes + (size_t)slot * piece_bytes +
+                                          (size_t)(n & 7) * 64 + q * 16);
+        const unsigned tag = (unsigned)(it >> 1) & 1u;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          const mxf32x4 lo = acc[t], hi = acc[HT / 2 + t < HT ? HT / 2 + t : t];
+          // descaled: 1 / (scale of output k) x 1 / (scale of the dz row), both powers of two
+          const mxf32x4 o = {(n < 8 ? lo.x : hi.x) * inv_sel[hf][t][0] * idz, (n < 8 ? lo.y : hi.y) * inv_sel[hf][t][1] * idz,
+                             (n < 8 ? lo.z : hi.z) * inv_sel[hf][t][2] * idz, (n < 8 ? lo.w : hi.w) * inv_sel[hf][t][3] * idz};
+          const u32x4 ob = __builtin_bit_cast(u32x4, o);
+          const u32x4 ot = {(ob.x & ~1u) | tag, (ob.y & ~1u) | tag, (ob.z & ~1u) | tag, (ob.w & ~1u) | tag};
+          // (HT = 1, H = 128: one tile per half, published by the lanes n < 8 only)
+          xstore(ot, rs, ((HT >= 2 || n < 8) && !MXH_QVOL(q)) ? pbase + (unsigned)t * (unsigned)block_bytes : OOB, coloc);
+        }
+      }
+      MXH_STAMP(1, 9);
+    }
+    MXH_STAMP(1, 5);
+  }
+  dz_stores();
+  // bias gradient / column maxima of my 64 gate columns over the unit's 8 rows
+  __syncthreads();
+  red[grow * 64 + (2 * dup) * 16 + gu] = db0;
+  red[grow * 64 + (2 * dup + 1) * 16 + gu] = db1;
+  __syncthreads();
+  if (tid < 64) {
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < MXR; ++r) sum += red[r * 64 + tid];
+    p.db_part[((size_t)(p.shard_base + shard) * 2 + dir) * 4 * H + (size_t)(tid >> 4) * H + U0 + (tid & 15)] = sum;
+  }
+  __syncthreads();
+  red[grow * 64 + (2 * dup) * 16 + gu] = am0;
+  red[grow * 64 + (2 * dup + 1) * 16 + gu] = am1;
+  __syncthreads();
+  if (tid < 64) {
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < MXR; ++r) m = fmaxf(m, red[r * 64 + tid]);
+    p.amax_part[((size_t)(p.shard_base + shard) * 2 + dir) * 4 * H + (size_t)(tid >> 4) * H + U0 + (tid & 15)] = m;
+  }
+}
+
+// ===========================================================================
+// host side (called from lstm_persist.hip's run_chunk)
+// NABU_PERSIST_MXH: bit 0 = forward, bit 1 = backward
+bool lstm_mxh_on(bool fwd) {
+  static int env = -1;
+  if (env < 0) { const char *e = getenv("NABU_PERSIST_MXH"); env = e ? atoi(e) : 3; }
+  return (env & (fwd ? 1 : 2)) != 0;
+}
+
+size_t lstm_mxh_ring_bytes(bool fwd, int H) {
+  const size_t P = H / UC;
+  return fwd ? (size_t)MXNU * RING * 16 * H * 2 : (size_t)MXNU * MXHRINGB * P * P * MXR * UC * 4;
+}
+
+template <typename K>
+static int mxh_launch(K kernel, const PersistArgs &a, int grid, size_t lds, hipStream_t stream, bool dry) {
+  const void *fn = reinterpret_cast<const void *>(kernel);
+  struct Seen { const void *fn; int dev, blocks; };
+  static thread_local Seen seen[16] = {};
+  int dev = 0;
+  NABU_HIP(hipGetDevice(&dev));
+  int blocks = -1;
+  for (const Seen &c : seen)
+    if (c.fn == fn && c.dev == dev) blocks = c.blocks;
+  if (blocks < 0) {
+    NABU_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 256, lds));
+    for (Seen &c : seen)
+      if (!c.fn) { c = Seen{fn, dev, blocks}; break; }
+  }
+  if (blocks < 1 || grid > NCU)
+    return fail(NABU_EUNSUP, "persistent LSTM (mxh): %d workgroups cannot be co-resident (%d per CU)", grid, blocks);
+  if (dry) return 0;          // validation pass (lstm_persist.hip, run)
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, stream, a);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+// one launch over B <= 32 rows; `a` comes filled from run_chunk (nshard = ceil(B / 8))
+int lstm_mxh_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry) {
+  const int grid = MXNU * (H / UC);
+#define NABU_MXH_CASE(h)                                                                                            \
+  case h:                                                                                                           \
+    if (a.dbg)                                                                                                      \
+      return fwd ? mxh_launch(lstm_mxh_fwd_kernel<h, true>, a, grid, MxhFwdLds<h>::TOTAL * sizeof(float), stream, dry) \
+                 : mxh_launch(lstm_mxh_bwd_kernel<h, true>, a, grid, MxhBwdLds<h>::TOTAL * sizeof(float), stream, dry); \
+    return fwd ? mxh_launch(lstm_mxh_fwd_kernel<h, false>, a, grid, MxhFwdLds<h>::TOTAL * sizeof(float), stream, dry) \
+               : mxh_launch(lstm_mxh_bwd_kernel<h, false>, a, grid, MxhBwdLds<h>::TOTAL * sizeof(float), stream, dry);
+  switch (H) {
+    NABU_MXH_CASE(128)
+    NABU_MXH_CASE(256)
+    NABU_MXH_CASE(512)
+  }
+  return fail(NABU_EUNSUP, "persistent LSTM (mxh): unsupported H=%d", H);
+}
+
+}  // namespace nabu
