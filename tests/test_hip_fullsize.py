@@ -14,6 +14,8 @@ the properties below need no reference numbers at all.)
     gradient of the batch is the mean of the gradients of its halves (the loss is a mean over
     utterances, loss_functions.py:206-212) — which also exercises another shard geometry;
   * clip + Adam at cfg2's parameter count against the closed form in NumPy."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -318,3 +320,23 @@ def test_bf16_plane_recurrence_edge_shapes(B, T, D, H, lens):
     assert float((dx_p - dx_s).abs().max()) < 1e-4 * (float(dx_s.abs().max()) + 1e-6) + 1e-6
     for k in g_p:
         assert float((g_p[k] - g_s[k]).abs().max()) < 2e-4 * (float(g_s[k].abs().max()) + 1e-6) + 1e-6, k
+
+
+@pytest.mark.parametrize('env,shape', [
+    ({'NABU_PERSIST_MXH': '0'}, (32, 60, 1024, 512)),     # bf16-plane kernels, sentinel rings (lstm_persist_mx.hip)
+    ({'NABU_PERSIST_MXH': '1'}, (20, 40, 256, 256)),      # fp16-plane forward, bf16-plane backward
+    ({'NABU_PERSIST_MXH': '2'}, (9, 33, 40, 128)),        # bf16-plane forward, fp16-plane backward with tag bits
+    ({'NABU_PERSIST_MX': '0'}, (32, 60, 1024, 512)),      # exact-fp32 4x4x1 kernels (lstm_persist.hip)
+    ({'NABU_PERSIST_MX16': '0'}, (48, 30, 256, 512)),     # 33 .. 64 rows as two launches of <= 32 rows
+])
+def test_alternative_persistent_kernel_families(env, shape):
+    """the kernel families the defaults do not select (environment switches of INTEGRATION.md) stay parity-green:
+    one layer per family in its own process (the switches are read once per process) against the step-wise kernels"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(here, 'persist_family_check.py')] + [str(v) for v in shape], env=e,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'FAMILY OK' in r.stdout, (env, r.stdout[-2000:], r.stderr[-2000:])
