@@ -698,6 +698,8 @@ int lstm_mx_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bo
 bool lstm_mxh_on(bool fwd);
 size_t lstm_mxh_ring_bytes(bool fwd, int H);
 int lstm_mxh_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry);
+size_t lstm_mxh16_ring_bytes(int H);
+int lstm_mxh16_fwd_launch(int H, const PersistArgs &a, hipStream_t stream, bool dry);
 // lstm_persist_mx16.hip: 16 rows per unit, 33 .. 64 batch rows in one launch (NABU_PERSIST_MX16=0: chunks of 32 rows)
 size_t lstm_mx16_ring_bytes(bool fwd, int H);
 int lstm_mx16_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry);
@@ -769,7 +771,11 @@ size_t lstm_persist_ws_bytes(int B, int T, int H) {
   if (lstm_mx_supported(B, H))
     for (int f = 0; f < 2; ++f) {
       if (lstm_mx_ring_bytes(f != 0, H) > m) m = lstm_mx_ring_bytes(f != 0, H);
-      if (mx16_on() && B > lstm_mx_chunk_rows() && lstm_mx16_ring_bytes(f != 0, H) > m) m = lstm_mx16_ring_bytes(f != 0, H);
+      if (lstm_mxh_ring_bytes(f != 0, H) > m) m = lstm_mxh_ring_bytes(f != 0, H);
+      if (mx16_on() && B > lstm_mx_chunk_rows()) {
+        if (lstm_mx16_ring_bytes(f != 0, H) > m) m = lstm_mx16_ring_bytes(f != 0, H);
+        if (f && lstm_mxh16_ring_bytes(H) > m) m = lstm_mxh16_ring_bytes(H);
+      }
     }
   return TABLE_BYTES + m + db_part_bytes(B, H);
 }
@@ -862,12 +868,12 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
     a.table = static_cast<unsigned *>(ws);
     a.xbuf = static_cast<char *>(ws) + TABLE_BYTES;
     a.timeout_ticks = g_timeout_ticks;
-    const bool f16 = !r16 && lstm_mxh_on(fwd);
-    if (!dry)
-      NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + (r16 ? lstm_mx16_ring_bytes(fwd, H) : f16 ? lstm_mxh_ring_bytes(fwd, H)
-                                                                                                  : lstm_mx_ring_bytes(fwd, H)), stream));
-    return r16 ? lstm_mx16_launch(fwd, H, a, stream, dry) : f16 ? lstm_mxh_launch(fwd, H, a, stream, dry)
-                                                                  : lstm_mx_launch(fwd, H, a, stream, dry);
+    const bool f16 = lstm_mxh_on(fwd) && (!r16 || fwd);     // 16 rows per unit: the forward kernel only
+    const size_t ring = r16 ? (f16 ? lstm_mxh16_ring_bytes(H) : lstm_mx16_ring_bytes(fwd, H))
+                            : (f16 ? lstm_mxh_ring_bytes(fwd, H) : lstm_mx_ring_bytes(fwd, H));
+    if (!dry) NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + ring, stream));
+    if (r16) return f16 ? lstm_mxh16_fwd_launch(H, a, stream, dry) : lstm_mx16_launch(fwd, H, a, stream, dry);
+    return f16 ? lstm_mxh_launch(fwd, H, a, stream, dry) : lstm_mx_launch(fwd, H, a, stream, dry);
   }
   int BS = pick_bs(B, H, fwd);
   if ((a.dbg & 16) && 2 * ((B + 7) / 8) * (H / UC) <= cu_count()) BS = 8;

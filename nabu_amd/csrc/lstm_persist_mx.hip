@@ -397,7 +397,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const unsigned goff = (unsigned)(((size_t)gb * T * 4 * H + (size_t)(2 * dup) * H + U0 + gu) * 4);
   const unsigned coff = (unsigned)(((size_t)gb * T * H + U0 + gu) * 4);
   const unsigned doff = (unsigned)(((size_t)gb * T * 2 * H + (size_t)dir * H + U0 + gu) * 4);
-  float *const gbase = p.gates[dir] + (size_t)gb * T * 4 * H + (size_t)(2 * dup) * H + U0 + gu;
   auto fetch_part = [&](int s, int part) {
     const bool act = s >= 0 && s < n_g;
     const int t = dir ? n_g - 1 - s : s;
