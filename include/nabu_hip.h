@@ -203,10 +203,12 @@ int nabu_colsum_f32(int M, int N, const float *A, int lda, float beta, float *ou
  * mode: NABU_LSTM_AUTO picks the persistent whole-sequence kernel when the
  * shape is supported, else one launch per timestep.
  * Persistent kernels, by shape (nabu_amd/csrc/): H in {128, 256, 512} on a whole MI355X (256 CUs): the recurrent
- * product on the bf16 matrix pipe over operands split EXACTLY into three bf16 planes (fp32-equivalent: outputs and
- * gradients agree with the exact-fp32 kernels to rounding, tests/test_hip_fullsize.py) — lstm_persist_mx.hip for
- * launches of up to 32 batch rows (8 per unit), lstm_persist_mx16.hip for 33..64 rows (16 per unit), larger batches
- * as consecutive launches; otherwise (H = 64, fewer CUs, NABU_PERSIST_MX=0) the exact-fp32 v_mfma_f32_4x4x1 kernels of
+ * product on the 16-bit matrix pipe — by default three fp16 plane products of row-scaled operands (lstm_persist_mxh.hip:
+ * launches of up to 32 batch rows, 8 per unit; forward of 33..64 rows, 16 per unit), with NABU_PERSIST_MXH=0 and for the
+ * backward pass of 33..64 rows seven bf16 plane products of exactly split operands (lstm_persist_mx.hip,
+ * lstm_persist_mx16.hip); both fp32-equivalent: outputs and gradients agree with the exact-fp32 kernels to rounding and
+ * are as close to a float64 layer (tests/test_hip_fullsize.py); larger batches as consecutive launches; otherwise
+ * (H = 64, fewer CUs, NABU_PERSIST_MX=0) the exact-fp32 v_mfma_f32_4x4x1 kernels of
  * lstm_persist.hip.  All need their whole grid co-resident: every launch is validated against the occupancy query
  * first (all chunks of a call before the first is enqueued) and NABU_LSTM_AUTO steps instead where it does not fit. */
 #define NABU_LSTM_AUTO       0

@@ -249,11 +249,14 @@ def _blstm_float64(x, lens, p, dout):
     return out.detach(), {k: v.grad for k, v in q.items()}
 
 
-def test_bf16_plane_recurrence_is_as_close_to_float64_as_the_fp32_kernels():
-    """the persistent recurrence multiplies on the bf16 matrix pipe over exactly split operands (lstm_persist_mx.hip);
-    the step-wise kernels multiply in fp32.  Both against a float64 layer on the device, cfg2's last-layer shape with
-    ragged lengths, exact-fp32 input products for both: the plane kernels' error must not exceed the fp32 kernels'
-    (observed: outputs 0.9-1.0 x, recurrent weight gradients 0.9-1.0 x; asserted with a margin for run-to-run layout)."""
+def test_plane_recurrence_is_as_close_to_float64_as_the_fp32_kernels():
+    """the persistent recurrence multiplies on the 16-bit matrix pipe — three fp16 plane products of row-scaled operands
+    (lstm_persist_mxh.hip, the default; the backward exchange carries a tag in the last bit of every partial sum) or,
+    with NABU_PERSIST_MXH=0, seven bf16 plane products of exactly split operands (lstm_persist_mx.hip); the step-wise
+    kernels multiply in fp32.  Both against a float64 layer on the device, cfg2's last-layer shape with ragged lengths,
+    exact-fp32 input products for both: the plane kernels' error must not exceed the fp32 kernels' (observed with either
+    family: outputs 1.00 x, recurrent weight gradients 0.99 x, bias gradients 1.11-1.13 x; asserted with a margin for
+    run-to-run layout)."""
     from nabu_amd import ops
     B, T, D, H = 32, 125, 2048, 512
     lens, x, p, dout = _layer_case(B, T, D, H, seed=77)
