@@ -61,7 +61,8 @@ def blstm(inputs, sequence_length, num_units, layer_norm=False, scope=None):
             if CAPTURE[0] is not None:
                 n = B * T * 4 * H
                 dz = reserve[:2 * n * 4].view(torch.float32).view(2, B * T, 4 * H).clone()
-                CAPTURE[0].append({'x': x, 'out': out, 'kf': kf.data, 'kb': kb.data, 'dz': dz, 'B': B, 'T': T, 'D': D, 'H': H})
+                CAPTURE[0].append({'x': x, 'out': out, 'kf': kf.data, 'kb': kb.data, 'dz': dz, 'B': B, 'T': T, 'D': D, 'H': H,
+                                   'bf': bf.data, 'bb': bb.data, 'lens': lens.dev.cpu().numpy(), 'dout': dout.contiguous().clone()})
             tape.defer(lambda: hip.blstm_bwd_weights(plan, x, lens.dev, out, reserve, kf.grad, kb.grad), params=(kf, kb))
         else:
             hip.blstm_bwd(plan, x, lens.dev, kf.data, kb.data, out, dout.contiguous(), reserve, dx,
