@@ -819,19 +819,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     {
       // this row's largest |dz| over the workgroup's 64 columns = over the 32 lanes of the row: 16 by DPP, the two
       // halves by one swizzle; every lane of the row ends with the same value
-      float m = fmaxf(fabsf(d0), fabsf(d1));
-      m = fmaxf(m, mx_dpp<DPP_XOR1>(m));
-      m = fmaxf(m, mx_dpp<DPP_XOR2>(m));
-      m = fmaxf(m, mx_dpp<DPP_HALF_MIRROR>(m));
-      m = fmaxf(m, mx_dpp<DPP_ROW_MIRROR>(m));
-      m = fmaxf(m, mxh_xor16(m));
-      const float sc = mxh_scale_of(m);
+      // (on the BIT PATTERNS of |dz|, which compare like the magnitudes: one integer maximum per stage where fmaxf costs
+      // a canonicalising move besides; NaN patterns compare largest and keep a finite scale)
+      unsigned mb = max(__builtin_bit_cast(unsigned, d0) & 0x7FFFFFFFu, __builtin_bit_cast(unsigned, d1) & 0x7FFFFFFFu);
+      mb = max(mb, mx_dppu<DPP_XOR1>(mb));
+      mb = max(mb, mx_dppu<DPP_XOR2>(mb));
+      mb = max(mb, mx_dppu<DPP_HALF_MIRROR>(mb));
+      mb = max(mb, mx_dppu<DPP_ROW_MIRROR>(mb));
+      mb = max(mb, (unsigned)__builtin_amdgcn_ds_swizzle((int)mb, 0x401F));
+      // scale / inverse straight from the exponent field (clamped to [15, 253]: both normal; an all-zero row takes the
+      // smallest exponent, 0 * scale = 0)
+      const unsigned ex = min(max(mb >> 23, 15u), 253u);
+      const float sc = __builtin_bit_cast(float, (268u - ex) << 23);
       unsigned ph, pl;
       mxh_split2x2(d0 * sc, d1 * sc, ph, pl);
       const unsigned o = (unsigned)grow * L::DROWB + (unsigned)(4 * gu + 2 * dup) * 2;
       *reinterpret_cast<unsigned *>(dzb + o) = ph;
       *reinterpret_cast<unsigned *>(dzb + o + 8 * L::DROWB) = pl;
-      if ((lane & 31) == 0) invd[(s & 1) * 8 + grow] = mxh_inv_scale_of(m);
+      if ((lane & 31) == 0) invd[(s & 1) * 8 + grow] = __builtin_bit_cast(float, (ex - 14u) << 23);
     }
     {   // dz of this step: stored at the top of the next one; padded frames get 0
       const int t_g = dir ? n_g - 1 - s : s;
