@@ -700,6 +700,11 @@ size_t lstm_mxh_ring_bytes(bool fwd, int H);
 int lstm_mxh_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry);
 size_t lstm_mxh16_ring_bytes(int H);
 int lstm_mxh16_fwd_launch(int H, const PersistArgs &a, hipStream_t stream, bool dry);
+// lstm_persist_mxf.hip: fp16 planes, 32 hidden units per workgroup, two units of 8 rows per XCD: 33 .. 64 batch rows at
+// H = 512 in one launch (NABU_PERSIST_MXF=0: the 16-rows-per-unit kernels below)
+bool lstm_mxf_supported(int B, int H);
+size_t lstm_mxf_ring_bytes(bool fwd, int H);
+int lstm_mxf_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry);
 // lstm_persist_mx16.hip: 16 rows per unit, 33 .. 64 batch rows in one launch (NABU_PERSIST_MX16=0: chunks of 32 rows)
 size_t lstm_mx16_ring_bytes(bool fwd, int H);
 int lstm_mx16_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry);
@@ -775,6 +780,7 @@ size_t lstm_persist_ws_bytes(int B, int T, int H) {
       if (mx16_on() && B > lstm_mx_chunk_rows()) {
         if (lstm_mx16_ring_bytes(f != 0, H) > m) m = lstm_mx16_ring_bytes(f != 0, H);
         if (f && lstm_mxh16_ring_bytes(H) > m) m = lstm_mxh16_ring_bytes(H);
+        if (lstm_mxf_supported(B, H) && lstm_mxf_ring_bytes(f != 0, H) > m) m = lstm_mxf_ring_bytes(f != 0, H);
       }
     }
   return TABLE_BYTES + m + db_part_bytes(B, H);
@@ -868,6 +874,12 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
     a.table = static_cast<unsigned *>(ws);
     a.xbuf = static_cast<char *>(ws) + TABLE_BYTES;
     a.timeout_ticks = g_timeout_ticks;
+    if (r16 && lstm_mxh_on(fwd) && lstm_mxf_supported(B, H)) {     // 8 rows per unit, 16 units, 128 columns per workgroup
+      *shard_base += (B + 7) / 8 - a.nshard;
+      a.nshard = (B + 7) / 8;
+      if (!dry) NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + lstm_mxf_ring_bytes(fwd, H), stream));
+      return lstm_mxf_launch(fwd, H, a, stream, dry);
+    }
     const bool f16 = lstm_mxh_on(fwd) && (!r16 || fwd);     // 16 rows per unit: the forward kernel only
     const size_t ring = r16 ? (f16 ? lstm_mxh16_ring_bytes(H) : lstm_mx16_ring_bytes(fwd, H))
                             : (f16 ? lstm_mxh_ring_bytes(fwd, H) : lstm_mx_ring_bytes(fwd, H));

@@ -20,7 +20,7 @@
 // forward exchange cell array is [k / 8][16 = plane * 8 + row] (4 loads per lane instead of 6, 4 KiB per wave), the N
 // side of every instruction is B = [h | l] of 8 rows, 32 instructions per wave and step: W_l.B, W_h.B per (16 columns x
 // 32 k).
-#include "lstm_persist_mx.h"
+#include "lstm_persist_mxh.h"
 
 namespace nabu {
 
@@ -31,66 +31,6 @@ namespace nabu {
         p.status[320 + 32 * (pass) + (i)] = (int)(wall_clock64());                 \
     }                                                                              \
   } while (0)
-
-// timing experiments (never defined in the library build): exchange volume cut to a quarter / no backward product
-#ifdef MXH_EXP_QVOL
-#define MXH_QVOL(x) ((x) != 0)
-#else
-#define MXH_QVOL(x) false
-#endif
-
-typedef _Float16 mxh16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 mxh16x2 __attribute__((ext_vector_type(2)));
-#define MXH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mxh16x8, a), __builtin_bit_cast(mxh16x8, b), c, 0, 0, 0)
-
-constexpr int DPP_ROW_MIRROR = 0x140;
-// backward exchange ring: 2 slots, NO hand-back.  The backward step is bound by the volume of its exchange (16 KB
-// written, 16 KB read and — with sentinels — 16 KB handed back per workgroup and step, at ~2.5 TB/s per XCD: cutting the
-// volume to a quarter takes 0.45 us off a 2.2 us step, removing the whole product nothing).  So
-// the flag is ONE BIT of the data: the least significant bit of every published fp32 partial sum carries the
-// generation of its slot (iteration it = max_len - 1 - s: slot it & 1, generation it >> 1, tag = generation & 1; the ring
-// starts as 0xFF bytes, tag 1, and generation 0 has tag 0), the reader repeats its loads until every word carries the
-// tag it waits for.  A published partial sum thus has 23 significant bits and is off by at most one unit of its last
-// place — the size of the rounding it went through anyway — low in even generations, high in odd ones: no bias over
-// time.  Ring of 2 is safe without hand-back: a slot written in iteration it is overwritten in it + 2 by a writer that
-// has polled the reader's own publish of it + 1, issued behind the barrier that follows the reader's poll of the slot.
-constexpr int MXHRINGB = 2;
-constexpr float MXH_HSCALE = 16384.f, MXH_HINV = 1.f / 16384.f;     // forward h: |h| < 1 + 2^-22
-
-// row scales from the bit pattern of the row's largest magnitude (the convention of gemm_pk.hip, pk_scale_of): exponent
-// field clamped so that scale and inverse are normal numbers; an all-zero row takes amax = 1; inf / NaN rows keep a
-// finite scale and propagate through the planes
-__device__ __forceinline__ unsigned mxh_amax_exp(unsigned bits) {
-  unsigned e = (bits >> 23) & 0xFFu;
-  if ((bits & 0x7FFFFFFFu) == 0) e = 127;
-  return e < 15 ? 15 : (e > 253 ? 253 : e);
-}
-__device__ __forceinline__ float mxh_scale_of(float amax) {
-  return __builtin_bit_cast(float, (268u - mxh_amax_exp(__builtin_bit_cast(unsigned, amax))) << 23);
-}
-__device__ __forceinline__ float mxh_inv_scale_of(float amax) {
-  return __builtin_bit_cast(float, (mxh_amax_exp(__builtin_bit_cast(unsigned, amax)) - 14u) << 23);
-}
-__device__ __forceinline__ unsigned mxh_cvt2(float a, float b) {   // (fp16(a), fp16(b)), round to nearest even
-  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, mxh16x2));
-}
-// two scaled values -> one word per plane (a | b << 16)
-__device__ __forceinline__ void mxh_split2x2(float a, float b, unsigned &h, unsigned &l) {
-  h = mxh_cvt2(a, b);
-  const mxh16x2 hv = __builtin_bit_cast(mxh16x2, h);
-  l = mxh_cvt2(a - (float)hv.x, b - (float)hv.y);
-}
-// 8 consecutive-k scaled values -> the two plane operands
-__device__ __forceinline__ void mxh_split8(const float *x, u32x4 &h, u32x4 &l) {
-  unsigned hh[4], ll[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) mxh_split2x2(x[2 * i], x[2 * i + 1], hh[i], ll[i]);
-  h = (u32x4){hh[0], hh[1], hh[2], hh[3]};
-  l = (u32x4){ll[0], ll[1], ll[2], ll[3]};
-}
-__device__ __forceinline__ float mxh_xor16(float v) {      // lane ^ 16 inside every group of 32 (bit-mask swizzle)
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
-}
 
 // ===========================================================================
 // forward
