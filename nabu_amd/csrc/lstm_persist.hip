@@ -780,7 +780,8 @@ size_t lstm_persist_ws_bytes(int B, int T, int H) {
       if (mx16_on() && B > lstm_mx_chunk_rows()) {
         if (lstm_mx16_ring_bytes(f != 0, H) > m) m = lstm_mx16_ring_bytes(f != 0, H);
         if (f && lstm_mxh16_ring_bytes(H) > m) m = lstm_mxh16_ring_bytes(H);
-        if (lstm_mxf_supported(B, H) && lstm_mxf_ring_bytes(f != 0, H) > m) m = lstm_mxf_ring_bytes(f != 0, H);
+        // (a batch of more than 64 rows runs as launches of 64 rows and a remainder)
+        if (lstm_mxf_supported(B > 64 ? 64 : B, H) && lstm_mxf_ring_bytes(f != 0, H) > m) m = lstm_mxf_ring_bytes(f != 0, H);
       }
     }
   return TABLE_BYTES + m + db_part_bytes(B, H);
@@ -874,7 +875,7 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
     a.table = static_cast<unsigned *>(ws);
     a.xbuf = static_cast<char *>(ws) + TABLE_BYTES;
     a.timeout_ticks = g_timeout_ticks;
-    if (r16 && lstm_mxh_on(fwd) && lstm_mxf_supported(B, H)) {     // 8 rows per unit, 16 units, 128 columns per workgroup
+    if (lstm_mxh_on(fwd) && lstm_mxf_supported(B, H)) {     // 8 rows per unit, 16 units, 128 columns per workgroup
       *shard_base += (B + 7) / 8 - a.nshard;
       a.nshard = (B + 7) / 8;
       if (!dry) NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + lstm_mxf_ring_bytes(fwd, H), stream));

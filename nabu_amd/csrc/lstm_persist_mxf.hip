@@ -569,9 +569,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
           for (int g = 0; g < 2; ++g) {
+#ifndef MXF_EXP_NOPROD
 #pragma unroll
             for (int t = 0; t < HT; ++t)
               acc[t] = g == 0 ? mxf_mfma_acc(Wp[1][hf * HT + t][j], b1[j], acc[t]) : MXH_MFMA(Wp[0][hf * HT + t][j], b1[j], acc[t]);
+#endif
             if (hf == 0) fetch_part(s - 1, 2 * j + g);     // one memory instruction behind every group
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 bool lstm_mxf_supported(int B, int H) {
   static int env = -1;
   if (env < 0) { const char *e = getenv("NABU_PERSIST_MXF"); env = e ? atoi(e) : 1; }
-  return env != 0 && H == 512 && B > 32 && B <= 64;
+  return env != 0 && H == 512 && (B > 32 || env == 2) && B <= 64;     // 2: also batches of <= 32 rows (measurements)
 }
 
 size_t lstm_mxf_ring_bytes(bool fwd, int H) {

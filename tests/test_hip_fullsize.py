@@ -286,7 +286,8 @@ def test_plane_recurrence_is_as_close_to_float64_as_the_fp32_kernels():
     (9, 17, 40, 128, [17, 1, 5, 9, 0, 16, 3, 17, 2]),   # a row of length 0, two units with 8 + 1 rows
     (8, 12, 256, 256, [7, 5, 7, 3, 6, 7, 1, 2]),        # max(len) < T: frames never visited
     (33, 6, 40, 128, None),                             # 16 rows per unit: 16 + 16 + 1
-    (40, 5, 256, 512, None),                            # 16 rows per unit at H = 512: the two-dimensional backward split
+    (40, 5, 256, 512, None),                            # 33 .. 64 rows at H = 512: 32 hidden units per workgroup (lstm_persist_mxf.hip)
+    (72, 7, 256, 512, None),                            # a launch of 64 rows (nine units ... sixteen) and one of 8
     (64, 3, 40, 256, [3] * 32 + [1] * 32),
 ])
 def test_bf16_plane_recurrence_edge_shapes(B, T, D, H, lens):
@@ -331,6 +332,7 @@ def test_bf16_plane_recurrence_edge_shapes(B, T, D, H, lens):
     ({'NABU_PERSIST_MXH': '2'}, (9, 33, 40, 128)),        # bf16-plane forward, fp16-plane backward with tag bits
     ({'NABU_PERSIST_MX': '0'}, (32, 60, 1024, 512)),      # exact-fp32 4x4x1 kernels (lstm_persist.hip)
     ({'NABU_PERSIST_MX16': '0'}, (48, 30, 256, 512)),     # 33 .. 64 rows as two launches of <= 32 rows
+    ({'NABU_PERSIST_MXF': '0'}, (48, 30, 256, 512)),      # 33 .. 64 rows at 16 rows per unit (lstm_persist_mx16.hip, mxh16 forward)
 ])
 def test_alternative_persistent_kernel_families(env, shape):
     """the kernel families the defaults do not select (environment switches of INTEGRATION.md) stay parity-green:
