@@ -97,6 +97,11 @@ __device__ __forceinline__ void prefetch_lds_b32(i32x4 rsrc, unsigned off, const
   const unsigned m0 = __builtin_amdgcn_readfirstlane((unsigned)((const char *)stage_wave - (const char *)smem));
   asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(m0), "v"(off), "s"(rsrc) : "memory");
 }
+// the same with 16 bytes per lane (lane l of the wave lands at stage_wave + 16 l bytes: 1 KiB per wave)
+__device__ __forceinline__ void prefetch_lds_b128(i32x4 rsrc, unsigned off, const float *smem, const float *stage_wave) {
+  const unsigned m0 = __builtin_amdgcn_readfirstlane((unsigned)((const char *)stage_wave - (const char *)smem));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0), "v"(off), "s"(rsrc) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

@@ -38,8 +38,8 @@ template <int H>
 struct MxhFwdLds {
   static constexpr int ROWF = 17 * 4;                        // floats per (wave, row): 16 units x 4 gates + pad
   static constexpr int PART = 0;                             // [2][4 waves][8 rows][ROWF]
-  static constexpr int XST = PART + 2 * 4 * MXR * ROWF;      // [2][2][256] prefetched x-projection
-  static constexpr int FLAG = XST + 2 * 2 * 256;
+  static constexpr int XST = PART + 2 * 4 * MXR * ROWF;      // [2][4 waves][64 lanes x 4] prefetched x-projection
+  static constexpr int FLAG = XST + 2 * 4 * 256;
   static constexpr int TOTAL = FLAG + 4;
 };
 
@@ -132,16 +132,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // lane (u16, r2, gp) fetches gates 2 gp and 2 gp + 1 of (row frow, unit u16); the finishing lane reads all four
   const i32x4 rg = raw_rsrc(p.gates[dir], (unsigned)((size_t)p.B * T * 4 * H * 4));
   const unsigned goff = (unsigned)(((size_t)fb * T * 4 * H + (size_t)(2 * gp) * H + U0 + u16) * 4);
-  auto fetch_x_part = [&](int s, int part_i) {
-    const int t = dir ? n_f - 1 - s : s;
-    const bool act = s < n_f && !(dbg & 64);
-    float *st = xst + (s & 1) * 512 + 64 * w;
-    if (part_i == 0) prefetch_lds_b32(rg, act ? goff + (unsigned)t * (unsigned)(16 * H) : OOB, smem, st);
-    if (part_i == 1) prefetch_lds_b32(rg, act ? goff + (unsigned)t * (unsigned)(16 * H) + (unsigned)(4 * H) : OOB, smem, st + 256);
-  };
+  // ONE 16-byte LDS-DMA load per lane and step (two 4-byte loads per lane before: 1.35 -> 1.31 us per step): lane (r =
+  // lane >> 4, gate g, unit quad uq) of the lower half-wave fetches units 4 uq .. 4 uq + 3 of gate g of row 2 w + r — the
+  // row this lane also finishes, so its length is n_f.  (The same for the backward kernel's four loads — three tensors,
+  // hence global_load_lds_dwordx4 with 64-bit addresses — was built and measured slower: 2.06 against 2.03 us.)
+  const unsigned goff4 = (unsigned)(((size_t)fb * T * 4 * H + (size_t)((lane >> 2) & 3) * H + U0 + 4 * (lane & 3)) * 4);
   auto fetch_x = [&](int s) {
-    fetch_x_part(s, 0);
-    fetch_x_part(s, 1);
+    const int t = dir ? n_f - 1 - s : s;
+    const bool act = fin && s < n_f && !(dbg & 64);
+    prefetch_lds_b128(rg, act ? goff4 + (unsigned)t * (unsigned)(16 * H) : OOB, smem, xst + (s & 1) * 1024 + 256 * w);
   };
   fetch_x(0);
   wait_vm<0>();
@@ -216,10 +215,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int j = 0; j < NKS; ++j) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = MXH_MFMA(Wp[1][c][j], b1[j], acc[c]);
-        if (j == 0) { fetch_x_part(s + 1, 0); __builtin_amdgcn_sched_barrier(0); }
+        if (j == 0) { fetch_x(s + 1); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = MXH_MFMA(Wp[0][c][j], b1[j], acc[c]);
-        if (j == 0) { fetch_x_part(s + 1, 1); __builtin_amdgcn_sched_barrier(0); }
       }
     } else {
       fetch_x(s + 1);
@@ -251,12 +249,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // first, then descaled (exact: powers of two), then the x-projection
     mxf32x4 z;
     {
-      const float *xs = xst + (s & 1) * 512 + 64 * w + (lane & 31);
+      // staged as [row r2][gate][unit quad][4 units]
+      const float *xs = xst + (s & 1) * 1024 + 256 * w + r2 * 64 + (u16 >> 2) * 4 + (u16 & 3);
       const float *pr = pbuf + (size_t)frow * L::ROWF + u16 * 4;
       mxf32x4 sum = *reinterpret_cast<const mxf32x4 *>(pr);
 #pragma unroll
       for (int ww = 1; ww < 4; ++ww) sum += *reinterpret_cast<const mxf32x4 *>(pr + (size_t)ww * MXR * L::ROWF);
-      z = (mxf32x4){xs[0] + sum.x * inv[0], xs[256] + sum.y * inv[1], xs[32] + sum.z * inv[2], xs[256 + 32] + sum.w * inv[3]};
+      z = (mxf32x4){xs[0] + sum.x * inv[0], xs[16] + sum.y * inv[1], xs[32] + sum.z * inv[2], xs[48] + sum.w * inv[3]};
     }
     const float gi = fast_sigmoid(z.x), gj = fast_tanh(z.y), gf = fast_sigmoid(z.z + 1.0f), go = fast_sigmoid(z.w);
     const bool act = s < n_f;
