@@ -20,7 +20,7 @@ typedef _Float16 mxh16x2 __attribute__((ext_vector_type(2)));
 constexpr int DPP_ROW_MIRROR = 0x140;
 // backward exchange ring: 2 slots, NO hand-back.  The backward step is bound by the volume of its exchange (16 KB
 // written, 16 KB read and — with sentinels — 16 KB handed back per workgroup and step, at ~2.5 TB/s per XCD: cutting the
-// volume to a quarter takes 0.45 us off a 2.2 us step, removing the whole product nothing; DESIGN.md section 5.1).  So
+// volume to a quarter takes 0.45 us off a 2.2 us step, removing the whole product nothing; DESIGN.md section 5.2).  So
 // the flag is ONE BIT of the data: the least significant bit of every published fp32 partial sum carries the
 // generation of its slot (iteration it = max_len - 1 - s: slot it & 1, generation it >> 1, tag = generation & 1; the ring
 // starts as 0xFF bytes, tag 1, and generation 0 has tag 0), the reader repeats its loads until every word carries the
