@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NABU_ABI_VERSION 1
+#define NABU_ABI_VERSION 2
 
 #define NABU_EINVAL   (-1)  /* bad argument (shape, null pointer, alignment) */
 #define NABU_EUNSUP   (-2)  /* shape not supported by the requested kernel   */
@@ -216,14 +216,31 @@ int nabu_colsum_f32(int M, int N, const float *A, int lda, float beta, float *ou
 #define NABU_LSTM_STEPWISE   1
 #define NABU_LSTM_PERSISTENT 2
 
+/* nabu_blstm_desc.flags */
+#define NABU_BLSTM_FWD_ONLY   1   /* no backward pass will follow (validation, decoding): the reserve holds the
+                                     activations only — no room for the packed dZ^T / row maxima of the weight-gradient
+                                     products (0.2-0.8 GB per cfg2 layer); nabu_blstm_bwd* reject such a descriptor */
+/* nabu_blstm_desc.recurrent_precision */
+#define NABU_REC_DEFAULT      0   /* the recurrent product h.W_h on the 16-bit matrix pipe: three fp16 plane products of
+                                     row-scaled operands, fp32-equivalent (lstm_persist_mxh.hip / _mxf.hip) */
+#define NABU_REC_F32          1   /* exact fp32 (v_mfma_f32_4x4x1, lstm_persist.hip): with gemm_precision = NABU_GEMM_F32
+                                     the whole layer is float32 end to end, like layer.py:35-47 on TF's fp32 MatMul */
+
 typedef struct {
-  uint32_t size;      /* sizeof(nabu_blstm_desc), ABI versioning */
+  uint32_t size;      /* sizeof(nabu_blstm_desc), ABI versioning (the 32-byte layout of ABI version 1 — everything
+                         up to gemm_precision — is still accepted: the fields behind it read as 0) */
   int32_t B, T, D, H;
   int32_t max_len;    /* max(len) if known on the host, else T */
   int32_t mode;       /* NABU_LSTM_* */
   int32_t gemm_precision; /* NABU_GEMM_* of the input-to-hidden products X·Wx, dZ·Wx^T, X^T·dZ
                              (BASELINE.json configs[4]: "bf16 MFMA input-to-hidden GEMMs");
                              the recurrent weight gradient H^T·dZ follows the process default */
+  float x_bound;      /* > 0: the caller guarantees |x| <= x_bound for every element of the layer input — the previous
+                         layer's LSTM outputs (|o tanh c| <= 1), after dropout 1 / keep_prob: the f16x3 packs of x take
+                         their row scales from the bound and skip the measuring pass over x.  0: nothing is known, x is
+                         measured (the first layer's features) */
+  int32_t flags;      /* NABU_BLSTM_* */
+  int32_t recurrent_precision;   /* NABU_REC_* */
 } nabu_blstm_desc;
 
 size_t nabu_blstm_reserve_bytes(const nabu_blstm_desc *d);

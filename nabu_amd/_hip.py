@@ -18,7 +18,12 @@ _vp, _i, _f, _sz, _ll = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t, _c.c_lon
 class BlstmDesc(_c.Structure):
     _fields_ = [('size', _c.c_uint32), ('B', _c.c_int32), ('T', _c.c_int32), ('D', _c.c_int32),
                 ('H', _c.c_int32), ('max_len', _c.c_int32), ('mode', _c.c_int32),
-                ('gemm_precision', _c.c_int32)]
+                ('gemm_precision', _c.c_int32), ('x_bound', _c.c_float), ('flags', _c.c_int32),
+                ('recurrent_precision', _c.c_int32)]
+
+
+BLSTM_FWD_ONLY = 1
+REC_PRECISIONS = {'default': 0, 'f32': 1}
 
 
 class PkGemmDesc(_c.Structure):

@@ -44,6 +44,15 @@ int sample_ids_rows(int B, int C, const float *logits, float prob, unsigned long
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// elementwise.hip: up to 8 regions set to a 32-bit pattern each by ONE launch (ptr 16-byte aligned, a whole number of
+// 4-byte words).  Stands where a layer call needs several hipMemsetAsync in a row — exchange rings (0xFF), row-maximum
+// arrays (0 or an a-priori bound): every memset is its own dispatch and costs ~6 us of queue gap behind a kernel.
+// elementwise.hip: out0[c] = sum_r part[r * ld + c], out1[c] = sum_r part[r * ld + N + c] for a FEW rows (the per-unit
+// bias-gradient partials of the persistent backward kernel, both cells): one launch, fixed order
+int colsum_pair(int rows, int N, const float *part, int ld, float *out0, float *out1, hipStream_t stream);
+struct FillSeg { void *ptr; size_t words; unsigned value; };
+int multi_fill(const FillSeg *segs, int n, hipStream_t stream);
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 // tanh through one exp: 2*sigmoid(2x)-1 (abs error ~1e-7)
 __device__ __forceinline__ float tanhf_(float x) { return 2.0f / (1.0f + __expf(-2.0f * x)) - 1.0f; }

@@ -304,6 +304,40 @@ __global__ __launch_bounds__(256) void ceil_div_kernel(int n, const int32_t *__r
   if (i < n) out[i] = (in[i] + d - 1) / d;
 }
 
+__global__ __launch_bounds__(256) void colsum_pair_kernel(int rows, int N, const float *__restrict__ part, int ld,
+                                                         float *__restrict__ out0, float *__restrict__ out1) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= 2 * N) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += part[(size_t)r * ld + c];
+  if (c < N) out0[c] = s;
+  else out1[c - N] = s;
+}
+
+// several regions, one launch (common.h: multi_fill).  A block covers FILL_CHUNK words of one region.
+constexpr int FILL_MAX = 8;
+constexpr unsigned FILL_CHUNK = 4096;
+struct FillArgs {
+  unsigned *ptr[FILL_MAX];
+  unsigned long long words[FILL_MAX];
+  unsigned value[FILL_MAX];
+  unsigned first_block[FILL_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void multi_fill_kernel(FillArgs a) {
+  int i = 0;
+  while (i + 1 < a.n && blockIdx.x >= a.first_block[i + 1]) ++i;
+  const unsigned long long w0 = (unsigned long long)(blockIdx.x - a.first_block[i]) * FILL_CHUNK;
+  const unsigned long long w1 = w0 + FILL_CHUNK < a.words[i] ? w0 + FILL_CHUNK : a.words[i];
+  const unsigned v = a.value[i];
+  unsigned *p = a.ptr[i];
+  for (unsigned long long w = w0 + 4ull * threadIdx.x; w < w1; w += 1024) {
+    if (w + 3 < w1) *reinterpret_cast<uint4 *>(p + w) = make_uint4(v, v, v, v);
+    else
+      for (unsigned long long k = w; k < w1; ++k) p[k] = v;
+  }
+}
+
 static int grid_for(size_t work_items) {
   size_t b = (work_items + 255) / 256;
   if (b > 2048) b = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
@@ -391,6 +425,34 @@ extern "C" int nabu_dropout_f32(size_t n, const float *x, float *y, float keep_p
 }
 
 namespace nabu {
+int colsum_pair(int rows, int N, const float *part, int ld, float *out0, float *out1, hipStream_t stream) {
+  if (rows < 0 || N <= 0 || !part || !out0 || !out1) return fail(NABU_EINVAL, "colsum_pair: bad argument");
+  hipLaunchKernelGGL(colsum_pair_kernel, dim3((2 * N + 255) / 256), dim3(256), 0, stream, rows, N, part, ld, out0, out1);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+int multi_fill(const FillSeg *segs, int n, hipStream_t stream) {
+  FillArgs a = {};
+  unsigned blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!segs[i].words) continue;
+    if (a.n >= FILL_MAX) return fail(NABU_EINVAL, "multi_fill: more than %d regions", FILL_MAX);
+    if (!segs[i].ptr || (reinterpret_cast<uintptr_t>(segs[i].ptr) & 15)) return fail(NABU_EINVAL, "multi_fill: null or unaligned region");
+    a.ptr[a.n] = static_cast<unsigned *>(segs[i].ptr);
+    a.words[a.n] = segs[i].words;
+    a.value[a.n] = segs[i].value;
+    a.first_block[a.n] = blocks;
+    blocks += (unsigned)((segs[i].words + FILL_CHUNK - 1) / FILL_CHUNK);
+    ++a.n;
+  }
+  if (!a.n) return 0;
+  a.first_block[a.n] = blocks;
+  hipLaunchKernelGGL(multi_fill_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
 // rows [first_elem, first_elem + n) of a larger array (first_elem % 4 == 0): the same random numbers the
 // call on the whole array would use for them
 int dropout_rows(size_t n, const float *x, float *y, float keep_prob, unsigned long long seed, unsigned long long offset,

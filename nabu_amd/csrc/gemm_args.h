@@ -106,6 +106,21 @@ int cvt_bf16_t(int R, int C, const float *src, int ld, unsigned short *dst, int 
 bool gemm_pk_device_ok();
 // f16x3 row maxima from per-unit partial maxima [rows][ld] (lstm_persist.hip): amax[n] = bits of max_r |part[r][n]|
 int pk_amax_from_partials(int rows, int N, const float *part, int ld, uint32_t *amax, hipStream_t s);
+// the same maxima AND the row maxima of dz as [BT, ...] (adz, rows_pad entries) out of the persistent backward kernel's
+// per-workgroup row maxima rowpart[nparts][BT] (bit patterns): one launch, no read of dz (either output may be null)
+int pk_amax_from_persist(int BT, int rows_pad, int T, int max_len, int nparts, const uint32_t *rowpart, uint32_t *adz,
+                         int crow, int N, const float *colpart, int ld, uint32_t *adzT, hipStream_t s);
+// row / column maxima (nabu_pk_amax) of TWO sources of one shape in one launch: rows shared, columns per source;
+// cols_b (optional): a second array that receives the column maxima as well.  src1 = nullptr: one source.
+int pk_amax_pair(const float *src0, const float *src1, long long ld, int R, int C, uint32_t *rows, uint32_t *cols0,
+                 uint32_t *cols1, uint32_t *cols_b, hipStream_t s);
+// up to 4 packs of one kind (natural / transposed, the arguments of nabu_pk_pack / nabu_pk_pack_f16) in ONE launch
+struct PkPackReq {
+  const float *src; long long ld; int R, C;
+  void *dst; int rows_pad, row_off, kb_off, fill_rows, fill_kb, period, shift;
+  const uint32_t *amax;      // planes = 2 only
+};
+int pk_pack_multi(int planes, int transposed, const PkPackReq *req, int n, hipStream_t s);
 // natural AND transposed pack of one source in one pass
 int pk_pack_both(int planes, const float *src, long long ld, int R, int C, void *dst_n, int rows_pad_n, int kb_off_n,
                  int fill_rows_n, int fill_kb_n, void *dst_t, int rows_pad_t, int row_off_t, int fill_rows_t,

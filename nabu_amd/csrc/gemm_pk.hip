@@ -492,9 +492,9 @@ struct PackArgs {
 // reduction index contiguous in the source: packed row = source row, k = source column.
 // grid (ceil(fill_kb / 4), ceil(fill_rows / 64)), 256 threads: a 64 x 64 tile through LDS
 template <int NP>
-__global__ __launch_bounds__(256) void pk_pack_rows_kernel(PackArgs a) {
-  __shared__ __attribute__((aligned(16))) float tile[64][68];
+__device__ __forceinline__ void pk_pack_rows_body(const PackArgs &a, float (*tile)[68]) {
   const int tid = threadIdx.x, r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  if (r0 >= a.fill_rows || (int)blockIdx.x * 4 >= a.fill_kb) return;      // (uniform: a batched launch's spare blocks)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int i = tid + 256 * j, r = i >> 4, c4 = (i & 15) * 4;
@@ -523,13 +523,27 @@ __global__ __launch_bounds__(256) void pk_pack_rows_kernel(PackArgs a) {
   const int prow = a.row_off + row;
   pk_split_store<NP>(x, a.dst + (size_t)(a.kb_off + kb) * a.kb_stride + (size_t)prow * 32, a.plane_stride, prow, a.amax);
 }
+template <int NP>
+__global__ __launch_bounds__(256) void pk_pack_rows_kernel(PackArgs a) {
+  __shared__ __attribute__((aligned(16))) float tile[64][68];
+  pk_pack_rows_body<NP>(a, tile);
+}
+// up to PK_NREQ packs of one kind in ONE launch (blockIdx.z = request; the grid covers the largest): the two cells'
+// weights, the two directions' h^T — each a few microseconds of work behind its own dispatch otherwise
+constexpr int PK_NREQ = 4;
+struct PackArgsN { PackArgs r[PK_NREQ]; };
+template <int NP>
+__global__ __launch_bounds__(256) void pk_pack_rows_multi_kernel(PackArgsN a) {
+  __shared__ __attribute__((aligned(16))) float tile[64][68];
+  pk_pack_rows_body<NP>(a.r[blockIdx.z], tile);
+}
 
 // reduction index = source ROW: packed row = source column, k = source row (transposed copy).
 // grid (ceil(fill_rows / 64) over source columns, ceil(fill_kb / 4) over source rows)
 template <int NP>
-__global__ __launch_bounds__(256) void pk_pack_cols_kernel(PackArgs a) {
-  __shared__ float tile[64][65];
+__device__ __forceinline__ void pk_pack_cols_body(const PackArgs &a, float (*tile)[65]) {
   const int tid = threadIdx.x, c0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  if (c0 >= a.fill_rows || (int)blockIdx.y * 4 >= a.fill_kb) return;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int i = tid + 256 * j, kk = i >> 4, c4 = (i & 15) * 4;
@@ -561,6 +575,16 @@ __global__ __launch_bounds__(256) void pk_pack_cols_kernel(PackArgs a) {
   for (int i = 0; i < 16; ++i) x[i] = tile[kbl * 16 + i][c];
   const int prow = a.row_off + row;
   pk_split_store<NP>(x, a.dst + (size_t)(a.kb_off + kb) * a.kb_stride + (size_t)prow * 32, a.plane_stride, prow, a.amax);
+}
+template <int NP>
+__global__ __launch_bounds__(256) void pk_pack_cols_kernel(PackArgs a) {
+  __shared__ float tile[64][65];
+  pk_pack_cols_body<NP>(a, tile);
+}
+template <int NP>
+__global__ __launch_bounds__(256) void pk_pack_cols_multi_kernel(PackArgsN a) {
+  __shared__ float tile[64][65];
+  pk_pack_cols_body<NP>(a.r[blockIdx.z], tile);
 }
 
 // BOTH layouts of one source matrix from ONE read (the backward pass needs dz as [BT rows, k = gate column] for the
@@ -615,9 +639,13 @@ __global__ __launch_bounds__(256) void pk_pack_both_kernel(PackArgs a, PackArgs 
 // largest magnitudes of the rows and / or the columns of a source matrix, as bit patterns (|x| compares like its
 // bits; NaN compares largest, so a NaN row keeps its NaN): atomicMax into zero-initialised arrays.
 // grid (ceil(C / 64), ceil(R / 256)), 256 threads: 64 columns x 256 rows per workgroup
+// (blockIdx.z = 1: the second source / column array of nabu::pk_amax_pair — the two cells' kernels in one launch, the
+// row maxima shared; cols_b: a second array that receives the same column maxima)
 __global__ __launch_bounds__(256) void pk_amax_kernel(const float *src, long long ld, int R, int C, unsigned *rows,
-                                                      unsigned *cols) {
+                                                      unsigned *cols, const float *src1 = nullptr, unsigned *cols1 = nullptr,
+                                                      unsigned *cols_b = nullptr) {
   __shared__ unsigned cm[16][64];
+  if (blockIdx.z) { src = src1; cols = cols1; }
   const int tid = threadIdx.x, c0 = blockIdx.x * 64, r0 = blockIdx.y * 256;
   const int c4 = (tid & 15) * 4, rl = tid >> 4;
   unsigned cmax[4] = {0u, 0u, 0u, 0u};
@@ -655,6 +683,7 @@ __global__ __launch_bounds__(256) void pk_amax_kernel(const float *src, long lon
 #pragma unroll
     for (int q = 0; q < 16; ++q) m = max(m, cm[q][tid]);
     if (m) atomicMax(cols + c0 + tid, m);
+    if (m && cols_b) atomicMax(cols_b + c0 + tid, m);
   }
 }
 
@@ -666,6 +695,29 @@ __global__ void pk_colmax_kernel(int rows, int N, const float *src, int ld, unsi
   float m = 0.f;
   for (int r = 0; r < rows; ++r) m = fmaxf(m, fabsf(src[(size_t)r * ld + n]));
   dst[n] = __builtin_bit_cast(unsigned, m);
+}
+
+// f16x3 maxima of dz out of the persistent backward kernel's own bookkeeping, one launch, no read of dz:
+//   blocks [0, nb_rows): adz[r] = max over the nparts per-workgroup row maxima (bit patterns) of frame row r = b T + t
+//                        (frames t >= max_len were never visited: 0; rows >= BT up to rows_pad: 0)
+//   the others:          adzT[n] = bits of max_r |colpart[r][n]| (pk_colmax_kernel)
+__global__ __launch_bounds__(256) void pk_amax_persist_kernel(int nb_rows, int BT, int rows_pad, int T, int max_len, int nparts,
+                                                              const unsigned *rowpart, unsigned *adz, int crow, int N,
+                                                              const float *colpart, int ld, unsigned *adzT) {
+  if ((int)blockIdx.x < nb_rows) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows_pad) return;
+    unsigned m = 0;
+    if (r < BT && r % T < max_len)
+      for (int q = 0; q < nparts; ++q) m = max(m, rowpart[(size_t)q * BT + r]);
+    adz[r] = m;
+    return;
+  }
+  const int n = (blockIdx.x - nb_rows) * 256 + threadIdx.x;
+  if (n >= N) return;
+  float m = 0.f;
+  for (int r = 0; r < crow; ++r) m = fmaxf(m, fabsf(colpart[(size_t)r * ld + n]));
+  adzT[n] = __builtin_bit_cast(unsigned, m);
 }
 
 __global__ void pk_fill_u32_kernel(unsigned *dst, int n, unsigned v) {
@@ -819,6 +871,63 @@ extern "C" int nabu_pk_amax_fill(uint32_t *dst, int n, float value, nabu_stream_
 // (dst_t: rows_pad_t, row_off_t, fill_rows_t) of the same [R x C] source in one pass.  The natural pack fills rows
 // [0, fill_rows_n), the transposed pack k-blocks [0, fill_kb_t).
 namespace nabu {
+int pk_pack_multi(int planes, int transposed, const PkPackReq *req, int n, hipStream_t s) {
+  if (n < 1 || n > PK_NREQ) return fail(NABU_EINVAL, "pk_pack_multi: 1 .. %d requests", PK_NREQ);
+  if (planes < 1 || planes > 3) return fail(NABU_EINVAL, "pk_pack_multi: planes must be 1, 2 or 3");
+  PackArgsN a = {};
+  int gx = 0, gy = 0;
+  for (int i = 0; i < n; ++i) {
+    const PkPackReq &q = req[i];
+    if ((planes == 2) != (q.amax != nullptr)) return fail(NABU_EINVAL, "pk_pack_multi: the row maxima belong to planes = 2");
+    if (!q.src || !q.dst || q.R < 0 || q.C < 0 || q.ld < 0 || q.rows_pad <= 0 || q.rows_pad % PK_T || q.row_off < 0 ||
+        q.kb_off < 0 || q.fill_rows < 0 || q.fill_kb < 0 || q.row_off + q.fill_rows > q.rows_pad)
+      return fail(NABU_EINVAL, "pk_pack_multi: bad request %d", i);
+    if (q.ld % 4 || (reinterpret_cast<uintptr_t>(q.src) & 15) || (reinterpret_cast<uintptr_t>(q.dst) & 15))
+      return fail(NABU_EUNSUP, "pk_pack_multi: source rows and both buffers must be 16-byte aligned");
+    if (!transposed && q.period) return fail(NABU_EINVAL, "pk_pack_multi: shift only in the transposed form");
+    PackArgs &p = a.r[i];
+    p.src = q.src; p.ld = q.ld; p.R = q.R; p.C = q.C; p.fill_rows = q.fill_rows; p.fill_kb = q.fill_kb;
+    p.dst = static_cast<char *>(q.dst);
+    p.plane_stride = (unsigned)q.rows_pad * 32u;
+    p.kb_stride = (unsigned long long)planes * p.plane_stride;
+    p.row_off = q.row_off; p.kb_off = q.kb_off; p.period = q.period; p.shift = q.shift; p.amax = q.amax;
+    const int bx = transposed ? (q.fill_rows + 63) / 64 : (q.fill_kb + 3) / 4;
+    const int by = transposed ? (q.fill_kb + 3) / 4 : (q.fill_rows + 63) / 64;
+    gx = bx > gx ? bx : gx; gy = by > gy ? by : gy;
+  }
+  if (!gx || !gy) return 0;
+  const dim3 grid(gx, gy, n);
+#define PK_MULTI(NP_)                                                                              \
+  if (transposed) hipLaunchKernelGGL(pk_pack_cols_multi_kernel<NP_>, grid, dim3(256), 0, s, a);     \
+  else hipLaunchKernelGGL(pk_pack_rows_multi_kernel<NP_>, grid, dim3(256), 0, s, a);
+  if (planes == 3) { PK_MULTI(3) } else if (planes == 2) { PK_MULTI(2) } else { PK_MULTI(1) }
+#undef PK_MULTI
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+int pk_amax_pair(const float *src0, const float *src1, long long ld, int R, int C, uint32_t *rows, uint32_t *cols0,
+                 uint32_t *cols1, uint32_t *cols_b, hipStream_t s) {
+  if (!src0 || R < 0 || C < 0 || ld < 0 || !(rows || cols0)) return fail(NABU_EINVAL, "pk_amax_pair: bad arguments");
+  if (ld % 4 || (reinterpret_cast<uintptr_t>(src0) & 15) || (reinterpret_cast<uintptr_t>(src1) & 15))
+    return fail(NABU_EUNSUP, "pk_amax_pair: source rows must be 16-byte aligned");
+  if (R == 0 || C == 0) return 0;
+  hipLaunchKernelGGL(pk_amax_kernel, dim3((C + 63) / 64, (R + 255) / 256, src1 ? 2 : 1), dim3(256), 0, s, src0, ld, R, C, rows,
+                     cols0, src1, cols1, cols_b);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+int pk_amax_from_persist(int BT, int rows_pad, int T, int max_len, int nparts, const uint32_t *rowpart, uint32_t *adz,
+                         int crow, int N, const float *colpart, int ld, uint32_t *adzT, hipStream_t s) {
+  const int nb_rows = adz ? (rows_pad + 255) / 256 : 0, nb_cols = adzT ? (N + 255) / 256 : 0;
+  if (nb_rows + nb_cols == 0) return 0;
+  hipLaunchKernelGGL(pk_amax_persist_kernel, dim3(nb_rows + nb_cols), dim3(256), 0, s, nb_rows, BT, rows_pad, T, max_len, nparts,
+                     rowpart, adz, crow, N, colpart, ld, adzT);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
 int pk_amax_from_partials(int rows, int N, const float *part, int ld, uint32_t *amax, hipStream_t s) {
   if (rows <= 0 || N <= 0) return 0;
   hipLaunchKernelGGL(pk_colmax_kernel, dim3((N + 255) / 256), dim3(256), 0, s, rows, N, part, ld, amax);

@@ -14,6 +14,8 @@
 #include "lstm_persist.h"
 
 #include <stdlib.h>
+#include <string.h>
+#include <mutex>
 #include "gemm_args.h"
 
 namespace nabu {
@@ -202,9 +204,38 @@ struct Layout {
   // the column maxima of x and the row maxima of Wx (the backward pass's x^T and Wx operands) are measured by the
   // forward pass in the same reads as its own and kept in the reserve (res_axT_off, res_aw2_off)
   size_t pk_ax, pk_aw, pk_adz, pk_ahT[2], pk_abwd_bytes, res_adzT_off, res_axT_off, res_aw2_off;
+  // per-workgroup row maxima of dz written by the persistent backward kernel ([2 directions x H / 16][BT] bit patterns;
+  // 0 bytes where the layer has no input gradient): the row scales of dZ as [BT, 8H] without a pass over dz
+  size_t pk_rowmax, pk_rowmax_bytes;
+  bool fwd_only;    // NABU_BLSTM_FWD_ONLY: the reserve ends behind the activations
   // dZ^T packed [8H, BT] lives in the layer's RESERVE (behind the activations): it is written by the data part of
   // the backward pass and read by the weight-gradient part, which may run later (nabu_blstm_bwd_weights)
   size_t res_dzT_off, res_dzT_bytes;
+};
+
+// ABI version 1 callers pass the 32-byte descriptor (everything up to gemm_precision): the later fields read as 0
+static int load_desc(const nabu_blstm_desc *in, nabu_blstm_desc *out) {
+  constexpr uint32_t V1 = 8 * sizeof(int32_t);
+  if (!in || (in->size != sizeof(nabu_blstm_desc) && in->size != V1)) return fail(NABU_EINVAL, "blstm: bad descriptor size");
+  *out = nabu_blstm_desc{};
+  memcpy(out, in, in->size);
+  out->size = sizeof(nabu_blstm_desc);
+  if (!(out->x_bound >= 0.f) || out->x_bound > 3.0e38f) return fail(NABU_EINVAL, "blstm: x_bound must be finite and >= 0");
+  if (out->flags & ~NABU_BLSTM_FWD_ONLY) return fail(NABU_EINVAL, "blstm: unknown flag bits %d", out->flags);
+  if (out->recurrent_precision != NABU_REC_DEFAULT && out->recurrent_precision != NABU_REC_F32)
+    return fail(NABU_EINVAL, "blstm: recurrent_precision must be NABU_REC_DEFAULT or NABU_REC_F32");
+  return 0;
+}
+// every entry point works on the normalised copy and, for its duration, tells the persistent-kernel dispatch whether
+// this call asked for the exact-fp32 recurrence (workspace sizes depend on it as well)
+struct DescScope {
+  nabu_blstm_desc d;
+  int err;
+  bool prev;
+  explicit DescScope(const nabu_blstm_desc *in) : err(load_desc(in, &d)), prev(lstm_persist_exact()) {
+    if (!err) lstm_persist_set_exact(d.recurrent_precision == NABU_REC_F32);
+  }
+  ~DescScope() { lstm_persist_set_exact(prev); }
 };
 
 // the input-to-hidden products X·Wx, dZ·Wx^T, X^T·dZ run on bf16 copies of their operands (converted once per
@@ -241,6 +272,14 @@ static int pk_planes_of(const nabu_blstm_desc *d) {
   if (prec == NABU_GEMM_F16X3) return BT >= 2048 ? 2 : 3;
   return prec == NABU_GEMM_BF16X6 ? 3 : prec == NABU_GEMM_BF16 ? 1 : 0;
 }
+// the row "maximum" an a-priori bound stands for: the float just below it, so that a power-of-two bound (|h| <= 1) maps
+// [0, bound] into (-2^15, 2^15] — 2^15 itself is an fp16 number — instead of giving a bit of range away; 0: no bound
+static unsigned bound_bits(float bound) {
+  if (!(bound > 0.f)) return 0u;
+  unsigned b;
+  memcpy(&b, &bound, 4);
+  return b > 0x00800000u ? b - 1 : b;
+}
 // one entry point for the bf16-plane and the scaled-fp16-plane packs (amax: the row maxima of planes = 2)
 static int pk_pack_any(int planes, int transposed, const float *src, long long ld, int R, int C, void *dst, int rows_pad,
                        int row_off, int kb_off, int fill_rows, int fill_kb, int period, int shift, const uint32_t *amax,
@@ -270,6 +309,9 @@ static Layout make_layout(const nabu_blstm_desc *d) {
   L.cs_elems = B * T * H;
   L.reserve_bytes = (2 * L.gates_elems + 2 * L.cs_elems) * sizeof(float);
   L.res_dzT_off = L.res_dzT_bytes = 0;
+  L.res_adzT_off = L.res_axT_off = L.res_aw2_off = 0;
+  L.pk_rowmax = L.pk_rowmax_bytes = 0;
+  L.fwd_only = (d->flags & NABU_BLSTM_FWD_ONLY) != 0;
   size_t off = 2048;  // ws[0..4): persistent kernels' status word (0 = ok), zeroed by the caller once;
                       // ws[64..64+4*grid): XCC id of every block of the last forward launch (diagnostic)
   L.hstate_off = off; off += align_up(4 * B * H * sizeof(float), 256);
@@ -310,21 +352,29 @@ static Layout make_layout(const nabu_blstm_desc *d) {
     size_t fwd = 0, bwd = 0;
     auto take = [](size_t &o, size_t bytes) { const size_t at = o; o += align_up(bytes, 256); return at; };
     if (L.pk_in) { L.pk_x = take(fwd, nabu_pk_bytes(BT, (int)D, P)); L.pk_w = take(fwd, nabu_pk_bytes(2 * G, (int)D, P)); }
-    L.res_dzT_off = align_up(L.reserve_bytes, 256);
-    L.res_dzT_bytes = nabu_pk_bytes(2 * G, BT, P);
-    L.reserve_bytes = L.res_dzT_off + L.res_dzT_bytes;
+    if (!L.fwd_only) {
+      L.res_dzT_off = align_up(L.reserve_bytes, 256);
+      L.res_dzT_bytes = nabu_pk_bytes(2 * G, BT, P);
+      L.reserve_bytes = L.res_dzT_off + L.res_dzT_bytes;
+    }
     L.pk_abwd_bytes = 0;
     if (P == 2) {
       const size_t aBT = 4 * (size_t)nabu_pk_rows_pad(BT), aG = 4 * (size_t)nabu_pk_rows_pad(2 * G), aD = 4 * (size_t)nabu_pk_rows_pad((int)D);
       const size_t aW = 4 * (size_t)nabu_pk_rows_pad((int)(L.pk_whole ? D + H : H));
-      L.res_adzT_off = align_up(L.reserve_bytes, 256);
-      L.res_axT_off = L.res_adzT_off + aG;
-      L.res_aw2_off = L.res_axT_off + aD;
-      L.reserve_bytes = L.res_aw2_off + aD;
+      if (!L.fwd_only) {
+        L.res_adzT_off = align_up(L.reserve_bytes, 256);
+        L.res_axT_off = L.res_adzT_off + aG;
+        L.res_aw2_off = L.res_axT_off + aD;
+        L.reserve_bytes = L.res_aw2_off + aD;
+      }
       L.pk_ax = take(fwd, aBT); L.pk_aw = take(fwd, aG);
       L.pk_adz = take(bwd, aBT);
       L.pk_ahT[0] = take(bwd, aW); L.pk_ahT[1] = take(bwd, aW);
       L.pk_abwd_bytes = bwd;
+      if (L.pk_in && (size_t)2 * (H / 16) * BT * 4 < 0x80000000ull) {
+        L.pk_rowmax_bytes = (size_t)2 * (H / 16) * BT * 4;
+        L.pk_rowmax = take(bwd, L.pk_rowmax_bytes);
+      }
     }
     if (L.pk_in) L.pk_xT = take(bwd, nabu_pk_bytes((int)D, BT, P));
     for (int dir = 0; dir < 2; ++dir)
@@ -361,7 +411,6 @@ static Layout make_layout(const nabu_blstm_desc *d) {
 }
 
 static int check_desc(const nabu_blstm_desc *d) {
-  if (!d || d->size != sizeof(nabu_blstm_desc)) return fail(NABU_EINVAL, "blstm: bad descriptor size");
   if (d->B <= 0 || d->T <= 0 || d->D <= 0 || d->H <= 0) return fail(NABU_EINVAL, "blstm: non-positive dimension");
   if (d->H % 4 != 0) return fail(NABU_EUNSUP, "blstm: num_units must be a multiple of 4 (got %d)", d->H);
   if (d->max_len < 0 || d->max_len > d->T) return fail(NABU_EINVAL, "blstm: max_len out of range");
@@ -378,6 +427,58 @@ static thread_local void *g_phase_user = nullptr;
 static bool use_persistent(const nabu_blstm_desc *d) {
   if (d->mode == NABU_LSTM_STEPWISE) return false;
   return lstm_persist_supported(d->B, d->T, d->H);
+}
+
+// WHAT A RESERVE HOLDS is decided by make_layout from the descriptor AND from process state (the default GEMM
+// precision, NABU_PK, the device's LDS class): the forward call records a fingerprint of the layout it wrote, keyed by
+// the reserve's address, and the backward calls compare it with the layout THEY derive before they touch the buffer —
+// a reserve that no forward call produced, or one produced under another layout (precision switched in between, a
+// forward-only descriptor), is rejected with NABU_EINVAL instead of being read as something it is not.  Host memory
+// only: no device round trip, and the check works (and is tested) without a GPU.
+struct ReserveTag {
+  const void *reserve;
+  uint64_t serial;
+  int32_t B, T, D, H, planes, flags, rec;
+  uint8_t pk_in, pk_rec, pk_whole, bf16_pre;
+  size_t reserve_bytes, res_dzT_off;
+};
+static std::mutex g_tag_mutex;
+static ReserveTag g_tags[256];
+static uint64_t g_tag_serial = 0;
+static ReserveTag tag_of(const nabu_blstm_desc *d, const Layout &L, const void *reserve) {
+  ReserveTag t = {};
+  t.reserve = reserve; t.B = d->B; t.T = d->T; t.D = d->D; t.H = d->H; t.planes = L.pk_planes; t.flags = d->flags;
+  t.rec = d->recurrent_precision;
+  t.pk_in = L.pk_in; t.pk_rec = L.pk_rec; t.pk_whole = L.pk_whole; t.bf16_pre = L.bf16_pre;
+  t.reserve_bytes = L.reserve_bytes; t.res_dzT_off = L.res_dzT_off;
+  return t;
+}
+static void tag_store(const ReserveTag &t) {
+  std::lock_guard<std::mutex> lock(g_tag_mutex);
+  ReserveTag *slot = &g_tags[0];
+  for (ReserveTag &e : g_tags) {
+    if (e.reserve == t.reserve) { slot = &e; break; }
+    if (e.serial < slot->serial) slot = &e;          // least recently written
+  }
+  *slot = t;
+  slot->serial = ++g_tag_serial;
+}
+static int tag_check(const nabu_blstm_desc *d, const Layout &L, const void *reserve, const char *who) {
+  if (L.fwd_only) return fail(NABU_EINVAL, "%s: the descriptor says NABU_BLSTM_FWD_ONLY — its reserve has no room for a backward pass", who);
+  const ReserveTag want = tag_of(d, L, reserve);
+  std::lock_guard<std::mutex> lock(g_tag_mutex);
+  for (const ReserveTag &e : g_tags) {
+    if (e.reserve != reserve || !e.serial) continue;
+    if (e.B == want.B && e.T == want.T && e.D == want.D && e.H == want.H && e.planes == want.planes && e.flags == want.flags &&
+        e.pk_in == want.pk_in && e.pk_rec == want.pk_rec && e.pk_whole == want.pk_whole && e.bf16_pre == want.bf16_pre &&
+        e.reserve_bytes == want.reserve_bytes && e.res_dzT_off == want.res_dzT_off)
+      return 0;
+    return fail(NABU_EINVAL, "%s: the reserve was written by nabu_blstm_fwd under another layout (B %d T %d D %d H %d, %d planes, "
+                "%zu bytes, flags %d; this call: B %d T %d D %d H %d, %d planes, %zu bytes) — descriptor or process precision "
+                "changed between the passes", who, e.B, e.T, e.D, e.H, e.planes, e.reserve_bytes, e.flags, want.B, want.T, want.D,
+                want.H, want.planes, want.reserve_bytes);
+  }
+  return fail(NABU_EINVAL, "%s: no nabu_blstm_fwd call of this process wrote this reserve (%p)", who, reserve);
 }
 
 }  // namespace nabu
@@ -399,24 +500,33 @@ extern "C" int nabu_persist_set_timeout_us(long long us) {
   return 0;
 }
 
-extern "C" int nabu_blstm_uses_persistent(const nabu_blstm_desc *d) {
-  if (check_desc(d)) return 0;
+extern "C" int nabu_blstm_uses_persistent(const nabu_blstm_desc *d_in) {
+  DescScope scope(d_in);
+  const nabu_blstm_desc *d = &scope.d;
+  if (scope.err || check_desc(d)) return 0;
   return use_persistent(d) ? 1 : 0;
 }
 
-extern "C" size_t nabu_blstm_reserve_bytes(const nabu_blstm_desc *d) {
-  if (check_desc(d)) return 0;
+extern "C" size_t nabu_blstm_reserve_bytes(const nabu_blstm_desc *d_in) {
+  DescScope scope(d_in);
+  const nabu_blstm_desc *d = &scope.d;
+  if (scope.err || check_desc(d)) return 0;
   return make_layout(d).reserve_bytes;
 }
-extern "C" size_t nabu_blstm_ws_bytes(const nabu_blstm_desc *d) {
-  if (check_desc(d)) return 0;
+extern "C" size_t nabu_blstm_ws_bytes(const nabu_blstm_desc *d_in) {
+  DescScope scope(d_in);
+  const nabu_blstm_desc *d = &scope.d;
+  if (scope.err || check_desc(d)) return 0;
   return make_layout(d).total;
 }
 
-extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const int32_t *len,
+extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d_in, const float *x, const int32_t *len,
                               const float *kernel_fw, const float *bias_fw,
                               const float *kernel_bw, const float *bias_bw, float *out,
                               void *reserve, void *ws, size_t ws_bytes, nabu_stream_t stream) {
+  DescScope scope(d_in);
+  if (scope.err) return scope.err;
+  const nabu_blstm_desc *d = &scope.d;
   if (int e = check_desc(d)) return e;
   NABU_CHECK_ARG(x && len && kernel_fw && bias_fw && kernel_bw && bias_bw && out && reserve && ws,
                  "blstm_fwd: null pointer");
@@ -424,6 +534,7 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const in
   if (ws_bytes < L.total) return fail(NABU_EWS, "blstm_fwd: workspace %zu < %zu", ws_bytes, L.total);
   if (d->mode == NABU_LSTM_PERSISTENT && !lstm_persist_supported(d->B, d->T, d->H))
     return fail(NABU_EUNSUP, "blstm_fwd: persistent kernel does not support B=%d H=%d", d->B, d->H);
+  tag_store(tag_of(d, L, reserve));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int B = d->B, T = d->T, D = d->D, H = d->H;
   const int max_len = d->max_len > 0 ? d->max_len : T;
@@ -446,20 +557,27 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const in
     const int rpBT = nabu_pk_rows_pad(BT), rpG = nabu_pk_rows_pad(2 * G), nkb = nabu_pk_kblocks(D, P);
     uint32_t *ax = reinterpret_cast<uint32_t *>(pk + L.pk_ax), *aw = reinterpret_cast<uint32_t *>(pk + L.pk_aw);
     if (P == 2) {
-      // f16x3: the frames' and the gate columns' largest magnitudes first (one more read of x: nothing is assumed
-      // about the layer's input)
-      uint32_t *axT = reinterpret_cast<uint32_t *>(static_cast<char *>(reserve) + L.res_axT_off);
-      uint32_t *aw2 = reinterpret_cast<uint32_t *>(static_cast<char *>(reserve) + L.res_aw2_off);
-      NABU_HIP(hipMemsetAsync(ax, 0, L.pk_aw - L.pk_ax + 4 * (size_t)rpG, s));
-      NABU_HIP(hipMemsetAsync(axT, 0, 8 * (size_t)nabu_pk_rows_pad(D), s));     // axT and aw2 are adjacent
-      if (int e = nabu_pk_amax(x, D, BT, D, ax, axT, stream)) return e;
-      for (int dir = 0; dir < 2; ++dir)
-        if (int e = nabu_pk_amax(kern[dir], G, D, G, aw2, aw + dir * G, stream)) return e;
+      // f16x3: the frames' and the gate columns' largest magnitudes first.  The input: from the caller's bound where
+      // one is given (x_bound: the previous layer's LSTM outputs — no pass over x), measured otherwise (the features).
+      // The maxima the BACKWARD pass needs of the same tensors (columns of x, rows of Wx) come out of the same reads
+      // and wait in the reserve — unless no backward pass follows.
+      uint32_t *axT = L.fwd_only ? nullptr : reinterpret_cast<uint32_t *>(static_cast<char *>(reserve) + L.res_axT_off);
+      uint32_t *aw2 = L.fwd_only ? nullptr : reinterpret_cast<uint32_t *>(static_cast<char *>(reserve) + L.res_aw2_off);
+      const unsigned xb = bound_bits(d->x_bound);
+      const int rpD = nabu_pk_rows_pad(D);
+      const FillSeg fill[4] = {{ax, (size_t)rpBT, xb}, {aw, (size_t)rpG, 0u}, {axT, axT ? (size_t)rpD : 0, xb}, {aw2, aw2 ? (size_t)rpD : 0, 0u}};
+      if (int e = multi_fill(fill, 4, s)) return e;
+      if (!xb)
+        if (int e = nabu_pk_amax(x, D, BT, D, ax, axT, stream)) return e;
+      if (int e = pk_amax_pair(kern[0], kern[1], G, D, G, aw2, aw, aw + G, nullptr, s)) return e;
     }
     if (int e = pk_pack_any(P, 0, x, D, BT, D, pk + L.pk_x, rpBT, 0, 0, rpBT, nkb, 0, 0, ax, stream)) return e;
-    for (int dir = 0; dir < 2; ++dir)
-      if (int e = pk_pack_any(P, 1, kern[dir], G, D, G, pk + L.pk_w, rpG, dir * G, 0, dir ? rpG - G : G, nkb, 0, 0, aw, stream))
-        return e;
+    {   // Wx^T of both cells: one launch
+      PkPackReq rq[2];
+      for (int dir = 0; dir < 2; ++dir)
+        rq[dir] = PkPackReq{kern[dir], G, D, G, pk + L.pk_w, rpG, dir * G, 0, dir ? rpG - G : G, nkb, 0, 0, P == 2 ? aw : nullptr};
+      if (int e = pk_pack_multi(P, 1, rq, 2, s)) return e;
+    }
     nabu_pk_gemm_desc g = pk_desc(P, BT, 2 * G, nkb, pk + L.pk_x, rpBT, pk + L.pk_w, rpG, gates[0], G);
     g.C2[0] = gates[1]; g.n_split = G; g.bias = bias[0]; g.bias2 = bias[1];
     if (P == 2) { g.a_amax[0] = ax; g.b_amax[0] = aw; g.direct = 2; }
@@ -540,6 +658,7 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
   if (parts & 1) NABU_CHECK_ARG(kernel_fw && kernel_bw && d_out && dbias_fw && dbias_bw, "blstm_bwd: null pointer");
   if (parts & 2) NABU_CHECK_ARG(dkernel_fw && dkernel_bw, "blstm_bwd: null pointer");
   const Layout L = make_layout(d);
+  if (int e = tag_check(d, L, reserve, parts == 3 ? "blstm_bwd" : parts == 1 ? "blstm_bwd_data" : "blstm_bwd_weights")) return e;
   if (ws_bytes < L.total) return fail(NABU_EWS, "blstm_bwd: workspace %zu < %zu", ws_bytes, L.total);
   if (d->mode == NABU_LSTM_PERSISTENT && !lstm_persist_supported(d->B, d->T, d->H))
     return fail(NABU_EUNSUP, "blstm_bwd: persistent kernel does not support B=%d H=%d", d->B, d->H);
@@ -556,6 +675,10 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
 
   float *db_part = nullptr;   // persistent path: bias-gradient partials [db_rows][2][4H]
   int db_rows = 0;
+  // f16x3 with an input gradient: the persistent kernel leaves every workgroup's row maxima of dz in the workspace
+  uint32_t *rowmax = (L.pk_planes == 2 && L.pk_in && d_x && L.pk_rowmax_bytes)
+                         ? reinterpret_cast<uint32_t *>(w + L.pk_off + L.pk_rowmax) : nullptr;
+  bool rowmax_done = false;
   if (parts & 1) {
   // dz rows of frames never visited by the recurrence must be zero
   if (max_len < T)
@@ -567,8 +690,8 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
   bool stepwise = !use_persistent(d);
   if (!stepwise) {
     int e = lstm_persist_bwd(B, T, D, H, max_len, len, kern, gates, cs, d_out, reinterpret_cast<int *>(w), w + L.persist_off,
-                             L.persist_bytes, &db_part, &db_rows, s);
-    if (e == NABU_EUNSUP && d->mode == NABU_LSTM_AUTO) { stepwise = true; db_part = nullptr; db_rows = 0; }
+                             L.persist_bytes, &db_part, &db_rows, s, rowmax, &rowmax_done);
+    if (e == NABU_EUNSUP && d->mode == NABU_LSTM_AUTO) { stepwise = true; db_part = nullptr; db_rows = 0; rowmax_done = false; }
     else if (e) return e;
   }
   if (stepwise) {
@@ -609,16 +732,17 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
     if (parts & 1) {
       const bool both = d_x && L.pk_in;    // dz is also needed row-major (dx): both packs from one read of dz
       if (P == 2) {
-        // one read of dz per cell: its rows' maxima over BOTH cells (the row scale of dZ as [BT, 8H]) and its columns'
-        if (!both && db_part) {
-          // no input gradient (the first layer): only dZ^T is packed, and its row maxima — the gate columns' — were
-          // kept by the persistent kernel next to the bias-gradient partials: no extra read of dz
-          if ((e = pk_amax_from_partials(db_rows, 2 * G, db_part + lstm_persist_db_floats(B, H), 2 * G, adzT, s))) return e;
+        // the maxima of dz: its rows' over BOTH cells (the row scale of dZ as [BT, 8H]) and its columns'
+        if (db_part && (!both || rowmax_done)) {
+          // the persistent kernel kept them: the gate columns' maxima per unit next to its bias-gradient partials, the
+          // frames' per workgroup in the workspace (only asked for where an input gradient follows) — no read of dz
+          if ((e = pk_amax_from_persist(M, rpBT, T, max_len, 2 * (H / 16), rowmax, both ? adz : nullptr, db_rows, 2 * G,
+                                        db_part + lstm_persist_db_floats(B, H), 2 * G, adzT, s)))
+            return e;
         } else {
-          if (both) NABU_HIP(hipMemsetAsync(adz, 0, 4 * (size_t)rpBT, s));
-          NABU_HIP(hipMemsetAsync(adzT, 0, 4 * (size_t)rpG, s));
-          for (int dir = 0; dir < 2; ++dir)
-            if ((e = nabu_pk_amax(gates[dir], G, M, G, both ? adz : nullptr, adzT + dir * G, stream))) return e;
+          const FillSeg fill[2] = {{adz, both ? (size_t)rpBT : 0, 0u}, {adzT, (size_t)rpG, 0u}};
+          if ((e = multi_fill(fill, 2, s))) return e;
+          if ((e = pk_amax_pair(gates[0], gates[1], G, M, G, both ? adz : nullptr, adzT, adzT + G, nullptr, s))) return e;
         }
       }
       for (int dir = 0; dir < 2; ++dir) {
@@ -631,16 +755,16 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
       }
       if (d_x && L.pk_in) {
         // dx = [dZ_fw | dZ_bw] · [Wx_fw | Wx_bw]^T: the two cells are two ranges of ONE reduction
+        PkPackReq rq[2];
         for (int dir = 0; dir < 2; ++dir)
-          if ((e = pk_pack_any(P, 0, kern[dir], G, D, G, pk + L.pk_w2, rpD, 0, dir * kbG, rpD, dir ? nkb2 - kbG : kbG, 0, 0,
-                               aw2, stream)))
-            return e;
+          rq[dir] = PkPackReq{kern[dir], G, D, G, pk + L.pk_w2, rpD, 0, dir * kbG, rpD, dir ? nkb2 - kbG : kbG, 0, 0,
+                              P == 2 ? aw2 : nullptr};
+        if ((e = pk_pack_multi(P, 0, rq, 2, s))) return e;
         nabu_pk_gemm_desc g = pk_desc(P, M, D, nkb2, pk + L.pk_dz, rpBT, pk + L.pk_w2, rpD, d_x, D);
         if (P == 2) { g.a_amax[0] = adz; g.b_amax[0] = aw2; g.direct = 2; }
         if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
       }
     }
-    if ((parts & 2) && P == 2 && L.pk_whole) NABU_HIP(hipMemsetAsync(ahT[0], 0, L.pk_abwd_bytes - L.pk_ahT[0], s));
     if ((parts & 2) && L.pk_in) {
       if ((e = pk_pack_any(P, 1, x, D, M, D, pk + L.pk_xT, rpD, 0, 0, rpD, nkbT, 0, 0, axT, stream))) return e;
       nabu_pk_gemm_desc g = pk_desc(P, D, 2 * G, nkbT, pk + L.pk_xT, rpD, dzTp, rpG, dkern[0], G);
@@ -655,15 +779,23 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
       // Narrow input (the first layer, D = 40): x^T sits in front of h^T in the same operand and the whole kernel
       // gradient [(D+H), 4H] of a cell is ONE product (its dWx alone cost more on the in-kernel-split kernel)
       const int r0 = L.pk_whole ? D : 0, Mw = r0 + H, rpW = nabu_pk_rows_pad(Mw);
-      for (int dir = 0; dir < 2; ++dir) {
-        if (P == 2) {   // |h| < 1 by construction (o · tanh c); the input features are measured
-          if (L.pk_whole && (e = nabu_pk_amax(x, D, M, D, nullptr, ahT[dir], stream))) return e;
-          if ((e = nabu_pk_amax_fill(ahT[dir] + r0, H, 1.0f, stream))) return e;
+      if (P == 2) {   // |h| <= 1 by construction (o · tanh c): one fill for both cells; the input features are measured
+        const unsigned hb = bound_bits(1.0f);
+        const FillSeg fill[4] = {{ahT[0], (size_t)r0, 0u}, {ahT[0] + r0, (size_t)(rpW - r0), hb},
+                                 {ahT[1], (size_t)r0, 0u}, {ahT[1] + r0, (size_t)(rpW - r0), hb}};
+        // (r0 = D is a multiple of 4: every region starts 16-byte aligned)
+        if ((e = multi_fill(fill, 4, s))) return e;
+        if (L.pk_whole && (e = pk_amax_pair(x, nullptr, D, M, D, nullptr, ahT[0], nullptr, ahT[1], s))) return e;
+      }
+      {   // [x^T ;] h^T of both cells: one launch
+        PkPackReq rq[4];
+        int n = 0;
+        for (int dir = 0; dir < 2; ++dir) {
+          const uint32_t *am = P == 2 ? ahT[dir] : nullptr;
+          if (L.pk_whole) rq[n++] = PkPackReq{x, D, M, D, pk + L.pk_hT[dir], rpW, 0, 0, D, nkbT, 0, 0, am};
+          rq[n++] = PkPackReq{out + (size_t)dir * H, 2 * H, M, H, pk + L.pk_hT[dir], rpW, r0, 0, rpW - r0, nkbT, T, dir ? 1 : -1, am};
         }
-        if (L.pk_whole && (e = pk_pack_any(P, 1, x, D, M, D, pk + L.pk_hT[dir], rpW, 0, 0, D, nkbT, 0, 0, ahT[dir], stream))) return e;
-        if ((e = pk_pack_any(P, 1, out + (size_t)dir * H, 2 * H, M, H, pk + L.pk_hT[dir], rpW, r0, 0, rpW - r0, nkbT, T,
-                             dir ? 1 : -1, ahT[dir], stream)))
-          return e;
+        if ((e = pk_pack_multi(P, 1, rq, n, s))) return e;
       }
       nabu_pk_gemm_desc g = pk_desc(P, Mw, G, nkbT, pk + L.pk_hT[0], rpW, dzTp, rpG, dkern[0] + (size_t)(D - r0) * G, G);
       g.nbatch = 2; g.A[1] = pk + L.pk_hT[1]; g.B[1] = dzTp + (size_t)G * 32; g.C[1] = dkern[1] + (size_t)(D - r0) * G;
@@ -706,10 +838,10 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
     if (e) return e;
     }
     if (!(parts & 1)) continue;
-    // db = column sums of dz: the persistent kernel already summed them per shard
+    // db = column sums of dz: the persistent kernel already summed them per unit (one launch adds the few partial
+    // rows of both cells)
     if (db_part)
-      e = nabu_colsum_f32(db_rows, 4 * H, db_part + (size_t)dir * 4 * H, 2 * 4 * H, 0.f, dbias[dir], w + L.gemm_off,
-                          L.gemm_bytes, stream);
+      e = dir ? 0 : colsum_pair(db_rows, 4 * H, db_part, 2 * 4 * H, dbias[0], dbias[1], s);
     else
       e = nabu_colsum_f32(M, 4 * H, gates[dir], 4 * H, 0.f, dbias[dir], w + L.gemm_off, L.gemm_bytes, stream);
     if (e) return e;
@@ -730,24 +862,33 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
   return 0;
 }
 
-extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d, const float *x, const int32_t *len,
+extern "C" int nabu_blstm_bwd(const nabu_blstm_desc *d_in, const float *x, const int32_t *len,
                               const float *kernel_fw, const float *kernel_bw, const float *out,
                               const float *d_out, void *reserve, float *d_x, float *dkernel_fw,
                               float *dbias_fw, float *dkernel_bw, float *dbias_bw, void *ws,
                               size_t ws_bytes, nabu_stream_t stream) {
+  DescScope scope(d_in);
+  if (scope.err) return scope.err;
+  const nabu_blstm_desc *d = &scope.d;
   return blstm_bwd_parts(3, d, x, len, kernel_fw, kernel_bw, out, d_out, reserve, d_x, dkernel_fw, dbias_fw, dkernel_bw,
                          dbias_bw, ws, ws_bytes, stream);
 }
-extern "C" int nabu_blstm_bwd_data(const nabu_blstm_desc *d, const float *x, const int32_t *len,
+extern "C" int nabu_blstm_bwd_data(const nabu_blstm_desc *d_in, const float *x, const int32_t *len,
                                    const float *kernel_fw, const float *kernel_bw, const float *out,
                                    const float *d_out, void *reserve, float *d_x, float *dbias_fw, float *dbias_bw,
                                    void *ws, size_t ws_bytes, nabu_stream_t stream) {
+  DescScope scope(d_in);
+  if (scope.err) return scope.err;
+  const nabu_blstm_desc *d = &scope.d;
   return blstm_bwd_parts(1, d, x, len, kernel_fw, kernel_bw, out, d_out, reserve, d_x, nullptr, dbias_fw, nullptr, dbias_bw,
                          ws, ws_bytes, stream);
 }
-extern "C" int nabu_blstm_bwd_weights(const nabu_blstm_desc *d, const float *x, const int32_t *len, const float *out,
+extern "C" int nabu_blstm_bwd_weights(const nabu_blstm_desc *d_in, const float *x, const int32_t *len, const float *out,
                                       void *reserve, float *dkernel_fw, float *dkernel_bw, void *ws, size_t ws_bytes,
                                       nabu_stream_t stream) {
+  DescScope scope(d_in);
+  if (scope.err) return scope.err;
+  const nabu_blstm_desc *d = &scope.d;
   return blstm_bwd_parts(2, d, x, len, nullptr, nullptr, out, nullptr, reserve, nullptr, dkernel_fw, nullptr, dkernel_bw,
                          nullptr, ws, ws_bytes, stream);
 }

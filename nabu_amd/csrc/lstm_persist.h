@@ -17,7 +17,14 @@ bool lstm_persist_fuses_input(int B, int T, int D, int H);
 int lstm_persist_bwd(int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2],
                      const float *dout, int *status, void *ws, size_t ws_bytes, float **db_part, int *db_rows,
-                     hipStream_t stream);
+                     hipStream_t stream, uint32_t *rowmax = nullptr, bool *rowmax_done = nullptr);
+// rowmax (optional, [2 directions x H / 16][B T] uint32): every workgroup's largest |dz| (bit pattern) of every frame
+// row over its 64 gate columns, written step by step next to dz; *rowmax_done says whether the kernels that ran keep
+// it (the fp16-plane kernels of lstm_persist_mxh.hip do) — the row scales of dZ as an f16x3 operand without a pass over dz
+// Per-thread switch (set by the blstm entry points from nabu_blstm_desc.recurrent_precision for the duration of a
+// call): true = only the exact-fp32 kernels of lstm_persist.hip, whatever the shape
+void lstm_persist_set_exact(bool exact);
+bool lstm_persist_exact();
 // db_part: [db_rows][2 directions][4H] bias-gradient partial sums written by the backward kernels
 // (inside ws); bias gradient of direction d = column sums of db_part[:, d, :].  In the same layout, at
 // db_part + lstm_persist_db_floats(B, H): the largest |dz| of every gate column per unit (column maxima of dz = the

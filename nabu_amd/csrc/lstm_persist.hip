@@ -822,15 +822,28 @@ static int launch(K kernel, const PersistArgs &a, int grid, int threads, size_t 
   return 0;
 }
 
+struct RowMax { unsigned *part; unsigned stride; bool kept; };   // (lstm_persist.h: rowmax) of the chunk at hand
 static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
                      const float *dout, int *status, void *ws, size_t ws_bytes, float *db_part, float *amax_part,
-                     int *shard_base, hipStream_t stream, const float *x, const float *const bias[2], bool dry);
+                     int *shard_base, hipStream_t stream, const float *x, const float *const bias[2], bool dry, RowMax *rm);
+
+// exchange ring + XCC table back to 0xFF bytes: one small kernel (a hipMemsetAsync is its own kind of dispatch and
+// costs ~6 us of queue gap in front of every recurrent launch)
+static int ring_reset(void *ws, size_t bytes, hipStream_t stream) {
+  const FillSeg seg = {ws, (bytes + 3) / 4, 0xFFFFFFFFu};
+  return multi_fill(&seg, 1, stream);
+}
+
+static thread_local bool g_exact = false;
+void lstm_persist_set_exact(bool exact) { g_exact = exact; }
+bool lstm_persist_exact() { return g_exact; }
 
 static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
                const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
                const float *dout, int *status, void *ws, size_t ws_bytes, float **db_part_out, int *db_rows_out,
-               hipStream_t stream, const float *x = nullptr, const float *const bias[2] = nullptr) {
+               hipStream_t stream, const float *x = nullptr, const float *const bias[2] = nullptr, uint32_t *rowmax = nullptr,
+               bool *rowmax_done = nullptr) {
   if (!lstm_persist_supported(B, T, H)) return fail(NABU_EUNSUP, "persistent LSTM: unsupported B=%d H=%d", B, H);
   const size_t need = lstm_persist_ws_bytes(B, T, H);
   if (ws_bytes < need) return fail(NABU_EWS, "persistent LSTM: workspace %zu < %zu", ws_bytes, need);
@@ -838,19 +851,23 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
   float *amax_part = db_part + db_part_bytes(B, H) / (2 * sizeof(float));
   int shards = 0;
   const int Bc = chunk_rows(B, H, fwd, T);
+  bool kept = rowmax != nullptr;
   for (int pass = 0; pass < 2; ++pass) {     // pass 0 validates every chunk, pass 1 enqueues them
     shards = 0;
     for (int b0 = 0; b0 < B; b0 += Bc) {
+      RowMax rm = {rowmax ? rowmax + (size_t)b0 * T : nullptr, (unsigned)((size_t)B * T), false};
       const int nb = B - b0 < Bc ? B - b0 : Bc;
       float *g2[2] = {gates[0] + (size_t)b0 * T * 4 * H, gates[1] + (size_t)b0 * T * 4 * H};
       float *c2[2] = {cs[0] + (size_t)b0 * T * H, cs[1] + (size_t)b0 * T * H};
       const int e = run_chunk(fwd, nb, T, D, H, max_len, len + b0, kernel, g2, c2,
                               out ? out + (size_t)b0 * T * 2 * H : nullptr,
                               dout ? dout + (size_t)b0 * T * 2 * H : nullptr, status, ws, ws_bytes, db_part, amax_part, &shards,
-                              stream, x ? x + (size_t)b0 * T * D : nullptr, bias, pass == 0);
+                              stream, x ? x + (size_t)b0 * T * D : nullptr, bias, pass == 0, &rm);
       if (e) return e;
+      kept = kept && rm.kept;
     }
   }
+  if (rowmax_done) *rowmax_done = kept;
   if (db_part_out) *db_part_out = db_part;      // (the maxima follow at db_part + lstm_persist_db_floats(B, H))
   if (db_rows_out) *db_rows_out = shards;
   return 0;
@@ -859,8 +876,9 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
 static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
                      const float *dout, int *status, void *ws, size_t ws_bytes, float *db_part, float *amax_part,
-                     int *shard_base, hipStream_t stream, const float *x, const float *const bias[2], bool dry) {
+                     int *shard_base, hipStream_t stream, const float *x, const float *const bias[2], bool dry, RowMax *rm) {
   PersistArgs a;
+  a.rowmax_part = nullptr; a.rowmax_stride = 0;
   { const char *e = getenv("NABU_PERSIST_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   if (lstm_mx_supported(B, H)) {
     if (fwd && x) return fail(NABU_EINVAL, "persistent LSTM (mx): no in-kernel input projection");
@@ -878,14 +896,20 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
     if (lstm_mxh_on(fwd) && lstm_mxf_supported(B, H)) {     // 8 rows per unit, 16 units, 128 columns per workgroup
       *shard_base += (B + 7) / 8 - a.nshard;
       a.nshard = (B + 7) / 8;
-      if (!dry) NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + lstm_mxf_ring_bytes(fwd, H), stream));
+      if (!dry)
+        if (int e = ring_reset(ws, TABLE_BYTES + lstm_mxf_ring_bytes(fwd, H), stream)) return e;
       return lstm_mxf_launch(fwd, H, a, stream, dry);
     }
     const bool f16 = lstm_mxh_on(fwd) && (!r16 || fwd);     // 16 rows per unit: the forward kernel only
     const size_t ring = r16 ? (f16 ? lstm_mxh16_ring_bytes(H) : lstm_mx16_ring_bytes(fwd, H))
                             : (f16 ? lstm_mxh_ring_bytes(fwd, H) : lstm_mx_ring_bytes(fwd, H));
-    if (!dry) NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + ring, stream));
+    if (!dry)
+      if (int e = ring_reset(ws, TABLE_BYTES + ring, stream)) return e;
     if (r16) return f16 ? lstm_mxh16_fwd_launch(H, a, stream, dry) : lstm_mx16_launch(fwd, H, a, stream, dry);
+    if (f16 && !fwd && rm->part) {     // the fp16-plane backward kernel keeps the frames' maxima of dz
+      a.rowmax_part = rm->part; a.rowmax_stride = rm->stride;
+      rm->kept = true;
+    }
     return f16 ? lstm_mxh_launch(fwd, H, a, stream, dry) : lstm_mx_launch(fwd, H, a, stream, dry);
   }
   int BS = pick_bs(B, H, fwd);
@@ -909,7 +933,8 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
   const int per_cu = (BS == 4 || grid > cu_count()) ? 2 : 1;
   if (grid > per_cu * cu_count())
     return fail(NABU_EUNSUP, "persistent LSTM: %d workgroups > %d x %d CUs", grid, per_cu, cu_count());
-  if (!dry) NABU_HIP(hipMemsetAsync(ws, 0xFF, TABLE_BYTES + ring_bytes(fwd, BS, a.nshard, H), stream));
+  if (!dry)
+    if (int e = ring_reset(ws, TABLE_BYTES + ring_bytes(fwd, BS, a.nshard, H), stream)) return e;
   // dynamic LDS chosen so that exactly `per_cu` workgroups fit on a CU (160 KiB)
   const size_t lds = BS == 4 ? 64 * 1024 : (grid > cu_count() ? 72 * 1024 : 96 * 1024);
 #define NABU_PERSIST_CASE(h)                                                                         \
@@ -953,9 +978,9 @@ bool lstm_persist_fuses_input(int B, int T, int D, int H) {
 int lstm_persist_bwd(int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2],
                      const float *dout, int *status, void *ws, size_t ws_bytes, float **db_part, int *db_rows,
-                     hipStream_t stream) {
+                     hipStream_t stream, uint32_t *rowmax, bool *rowmax_done) {
   return run(false, B, T, D, H, max_len, len, kernel, gates, cs, nullptr, dout, status, ws, ws_bytes, db_part, db_rows,
-             stream);
+             stream, nullptr, nullptr, rowmax, rowmax_done);
 }
 
 }  // namespace nabu

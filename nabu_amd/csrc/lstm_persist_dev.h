@@ -38,6 +38,8 @@ struct PersistArgs {
   const float *dout;  // backward
   float *db_part;     // backward: [shards][2 directions][4H] bias-gradient partial sums (one row per unit)
   float *amax_part;   // backward: same shape, the largest |dz| of every gate column over the unit's rows and steps
+  unsigned *rowmax_part;   // backward (fp16-plane kernels; may be null): [2 directions x P workgroups][rowmax_stride] bit
+  unsigned rowmax_stride;  // patterns of every frame row's largest |dz| over the workgroup's 64 gate columns
   int shard_base;     // first shard of this launch (batches split over several launches)
   unsigned *table;    // [grid] XCC ids, pre-set to SENT
   char *xbuf;         // exchange ring

@@ -632,7 +632,7 @@ static bool mx_device_ok() {
 }
 
 bool lstm_mx_supported(int B, int H) {
-  if (!mx_env() || !mx_device_ok()) return false;
+  if (!mx_env() || lstm_persist_exact() || !mx_device_ok()) return false;
   return (H == 128 || H == 256 || H == 512) && B >= 1;
 }
 int lstm_mx_chunk_rows() { return MXR * MXNU / 2; }   // 32 batch rows per launch

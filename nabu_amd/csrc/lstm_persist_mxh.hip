@@ -666,12 +666,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(p.gates[dir], 0, (int)((size_t)p.B * T * 4 * H * 4), 0x00020000);
   const bool st_ok = gb < p.B && !(dbg & 128);
   float d_0 = 0.f, d_1 = 0.f;
+  unsigned d_mb = 0u;
   int d_t = 0;
   bool d_any = false;
+  // ... and with it this workgroup's largest |dz| of the frame row (the bit pattern the plane scale is derived from
+  // anyway), one word per row: rowmax_part[(direction, workgroup)][b T + t] — what the f16x3 pack of dZ as [BT, 8H]
+  // needs as its row scale, reduced over the 2 P workgroups by pk_amax_persist_kernel (no pass over dz).  Always
+  // issued like the other result stores; no buffer (null base, 0 records): dropped.
+  __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc(
+      p.rowmax_part, 0, p.rowmax_part ? (int)((size_t)2 * P * p.rowmax_stride * 4) : 0, 0x00020000);
+  const unsigned moff = (unsigned)((((size_t)dir * P + slot) * p.rowmax_stride + (size_t)gb * T) * 4);
+  const bool m_ok = st_ok && (lane & 31) == 0;
   auto dz_stores = [&]() {
     const unsigned o = (d_any && st_ok) ? goff + (unsigned)d_t * (unsigned)(16 * H) : OOB;
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d_0), rsg, o, 0, 0);
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d_1), rsg, o == OOB ? OOB : o + (unsigned)(4 * H), 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(d_mb, rsm, (d_any && m_ok) ? moff + (unsigned)d_t * 4u : OOB, 0, 0);
   };
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
@@ -776,6 +786,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       *reinterpret_cast<unsigned *>(dzb + o) = ph;
       *reinterpret_cast<unsigned *>(dzb + o + 8 * L::DROWB) = pl;
       if ((lane & 31) == 0) invd[(s & 1) * 8 + grow] = __builtin_bit_cast(float, (ex - 14u) << 23);
+      d_mb = mb;
     }
     {   // dz of this step: stored at the top of the next one; padded frames get 0
       const int t_g = dir ? n_g - 1 - s : s;

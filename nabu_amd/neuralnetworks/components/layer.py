@@ -15,6 +15,9 @@ LSTM_MODE = [hip.LSTM_AUTO]      # tests flip this to compare the two recurrent 
 # arithmetic of the input-to-hidden GEMMs of the layers built next ('default' | 'f32' | 'bf16' |
 # 'bf16x3' | 'bf16x6'); set by the encoders from their `gemm_precision` cfg key
 GEMM_PRECISION = ['default']
+# arithmetic of the recurrent product h.W_h of the layers built next ('default' = three fp16 plane products of row-scaled
+# operands, fp32-equivalent | 'f32' = the exact-fp32 kernels); set by the encoders from their `recurrent_precision` key
+RECURRENT_PRECISION = ['default']
 # the weight-gradient products of a layer run after the LAST recurrence of the backward pass (Tape.defer): nothing
 # waits for them, and bf16 matrix bursts in front of a persistent recurrent kernel slow it down (include/nabu_hip.h,
 # nabu_blstm_bwd_data).  NABU_DEFER_WGRAD=0: one fused nabu_blstm_bwd per layer as before.
@@ -43,11 +46,17 @@ def blstm(inputs, sequence_length, num_units, layer_norm=False, scope=None):
         bf = vs.get_variable((_CELL % 'fw') + '/bias', [4 * H])
         kb = vs.get_variable((_CELL % 'bw') + '/kernel', [D + H, 4 * H])
         bb = vs.get_variable((_CELL % 'bw') + '/bias', [4 * H])
-    plan = hip.BlstmPlan(B, T, D, H, min(lens.max(), T), LSTM_MODE[0], GEMM_PRECISION[0])
+    # what is known about the input's magnitude (ops.value_bound: the previous layer's outputs, |o tanh c| <= 1, through
+    # pyramid stacking and dropout) spares the f16x3 packs of x their measuring pass; no tape = no backward pass: the
+    # reserve then holds the activations only
+    training = Tape.current is not None
+    plan = hip.BlstmPlan(B, T, D, H, min(lens.max(), T), LSTM_MODE[0], GEMM_PRECISION[0], x_bound=ops.value_bound(inputs),
+                         fwd_only=not training, recurrent_precision=RECURRENT_PRECISION[0])
     x = inputs if inputs.is_contiguous() else inputs.contiguous()
     out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
     reserve = torch.empty(plan.reserve_bytes, dtype=torch.uint8, device=x.device)
     hip.blstm_fwd(plan, x, lens.dev, kf.data, bf.data, kb.data, bb.data, out, reserve)
+    ops.set_value_bound(out, 1.0)
     need_dx = requires_grad(inputs)
 
     def backward(dout):

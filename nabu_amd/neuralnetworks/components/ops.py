@@ -1,8 +1,27 @@
 """Tensor plumbing ops of the hot path (reference: nabu/neuralnetworks/components/ops.py)."""
+import weakref
+
 import numpy as np
 
 from nabu_amd import ops as hip
 from nabu_amd.autodiff import record, SeqLen
+
+
+# A-priori magnitude bounds of tensors on the path: id(tensor) -> (weak reference, bound).  layer.blstm records
+# |out| <= 1 (o tanh c), the plumbing ops below carry the bound along, and the next layer hands it to the C ABI
+# (nabu_blstm_desc.x_bound), whose f16x3 operand packs then take their row scales from it instead of measuring x.
+_BOUNDS = {}
+
+
+def set_value_bound(tensor, bound):
+    key = id(tensor)
+    _BOUNDS[key] = (weakref.ref(tensor, lambda _r, k=key: _BOUNDS.pop(k, None)), float(bound))
+
+
+def value_bound(tensor):
+    """the recorded bound on |tensor|, 0.0 when nothing is known"""
+    e = _BOUNDS.get(id(tensor))
+    return e[1] if e is not None and e[0]() is tensor else 0.0
 
 
 def pyramid_stack(inputs, sequence_lengths, numsteps, axis=2, scope=None):
@@ -19,6 +38,8 @@ def pyramid_stack(inputs, sequence_lengths, numsteps, axis=2, scope=None):
     Tp = -(-T // numsteps) * numsteps
     src = inputs if Tp == T else hip.pad_time(inputs, Tp)
     outputs = src.view(B, Tp // numsteps, numsteps * F)
+    if value_bound(inputs):
+        set_value_bound(outputs, value_bound(inputs))
 
     def backward(dout):
         d = dout.reshape(B, Tp, F)
@@ -41,6 +62,8 @@ def seq_dropout(x, keep_prob, rng_state):
     """tf.nn.dropout(x, keep_prob) with a regenerable Philox mask."""
     seed, offset = rng_state.next()
     y = hip.dropout(x, keep_prob, seed, offset)
+    if value_bound(x):
+        set_value_bound(y, value_bound(x) / keep_prob)
 
     def backward(dy):
         return [hip.dropout(dy.contiguous(), keep_prob, seed, offset)]

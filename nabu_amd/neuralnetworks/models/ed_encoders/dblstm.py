@@ -9,7 +9,8 @@ class DBLSTM(ed_encoder.EDEncoder):
     """cfg keys: num_layers, num_units, input_noise, dropout (keep probability), gemm_precision"""
 
     def encode(self, inputs, input_seq_length, is_training):
-        layer.GEMM_PRECISION[0] = self.conf.get('gemm_precision', 'default')   # see listener.py
+        layer.GEMM_PRECISION[0] = self.conf.get('gemm_precision', 'default')
+        layer.RECURRENT_PRECISION[0] = self.conf.get('recurrent_precision', 'default')   # see listener.py
         keep, noise = float(self.conf['dropout']), float(self.conf['input_noise'])
         units = int(self.conf['num_units'])
         encoded = {}

@@ -31,6 +31,7 @@ class Listener(ed_encoder.EDEncoder):
         # arithmetic of the input-to-hidden GEMMs of the layers built below (BASELINE.json configs[4]
         # asks for bf16 MFMA there); 'default' = the process default = exact fp32
         layer.GEMM_PRECISION[0] = self.conf.get('gemm_precision', 'default')
+        layer.RECURRENT_PRECISION[0] = self.conf.get('recurrent_precision', 'default')
         encoded, encoded_seq_length = {}, {}
         for name, x in inputs.items():
             with vs.variable_scope(name):

@@ -191,9 +191,14 @@ def colsum(a, out, beta=0.0):
 class BlstmPlan(object):
     """Shape descriptor + buffers of one BLSTM layer call."""
 
-    def __init__(self, B, T, D, H, max_len, mode=LSTM_AUTO, gemm_precision='default'):
+    def __init__(self, B, T, D, H, max_len, mode=LSTM_AUTO, gemm_precision='default', x_bound=0.0, fwd_only=False,
+                 recurrent_precision='default'):
+        """x_bound > 0: |x| <= x_bound is guaranteed (the previous layer's LSTM outputs) — the f16x3 packs of x skip their
+        measuring pass; fwd_only: no backward pass follows (validation): the reserve holds the activations only;
+        recurrent_precision 'f32': the exact-fp32 recurrent kernels (include/nabu_hip.h, nabu_blstm_desc)"""
         self.desc = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), B, T, D, H, int(max_len), mode,
-                                   _hip.GEMM_PRECISIONS[gemm_precision])
+                                   _hip.GEMM_PRECISIONS[gemm_precision], float(x_bound),
+                                   _hip.BLSTM_FWD_ONLY if fwd_only else 0, _hip.REC_PRECISIONS[recurrent_precision])
         L = _hip.lib()
         self.reserve_bytes = L.nabu_blstm_reserve_bytes(ctypes.byref(self.desc))
         self.ws_bytes = L.nabu_blstm_ws_bytes(ctypes.byref(self.desc))

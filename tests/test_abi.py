@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert n in _hip.SIGNATURES, 'no ctypes signature for %s' % n
     for n in _hip.SIGNATURES:
         assert n in names, '%s bound in _hip.py but not declared in nabu_hip.h' % n
-    assert lib.nabu_version() == 1
+    assert lib.nabu_version() == 2
 
 
 def test_host_side_queries_and_argument_errors():
@@ -46,6 +46,55 @@ def test_host_side_queries_and_argument_errors():
     # null pointers are rejected before any launch
     assert lib.nabu_gemm_f32(0, 0, 4, 4, 4, 1.0, None, 4, None, 4, 0.0, None, 4, None, 0, 0, 0,
                              None, 0, None) == -1
+
+
+def test_blstm_descriptor_versions_and_forward_only_reserve():
+    """ABI version 2 of nabu_blstm_desc (x_bound, flags, recurrent_precision): the 32-byte version-1 layout is still
+    accepted; a forward-only descriptor's reserve ends behind the activations (no packed dZ^T region); bad values are
+    argument errors.  No GPU needed."""
+    import ctypes
+    from nabu_amd import _hip
+    lib = _hip.lib()
+    act = (2 * 32 * 500 * 2048 + 2 * 32 * 500 * 512) * 4
+    full = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), 32, 500, 2048, 512, 500, 0, _hip.GEMM_PRECISIONS['bf16x6'])
+    v1 = _hip.BlstmDesc(32, 32, 500, 2048, 512, 500, 0, _hip.GEMM_PRECISIONS['bf16x6'])
+    r_full, r_v1 = lib.nabu_blstm_reserve_bytes(ctypes.byref(full)), lib.nabu_blstm_reserve_bytes(ctypes.byref(v1))
+    assert r_full == r_v1 >= act
+    fwd = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), 32, 500, 2048, 512, 500, 0, _hip.GEMM_PRECISIONS['bf16x6'], 0.0,
+                         _hip.BLSTM_FWD_ONLY, 0)
+    assert lib.nabu_blstm_reserve_bytes(ctypes.byref(fwd)) == act
+    for field, value in (('x_bound', -1.0), ('x_bound', float('inf')), ('flags', 2), ('recurrent_precision', 7)):
+        bad = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), 32, 500, 2048, 512, 500, 0, 0)
+        setattr(bad, field, value)
+        assert lib.nabu_blstm_reserve_bytes(ctypes.byref(bad)) == 0, field
+    exact = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), 32, 500, 2048, 512, 500, 0, 0, 0.0, 0, _hip.REC_PRECISIONS['f32'])
+    assert lib.nabu_blstm_ws_bytes(ctypes.byref(exact)) > 0
+
+
+def test_backward_rejects_a_reserve_no_forward_call_wrote():
+    """nabu_blstm_bwd{,_data,_weights} compare the layout they derive with the fingerprint nabu_blstm_fwd recorded for
+    the reserve (host-side, before any device work): a reserve nobody wrote, or a forward-only descriptor, is
+    NABU_EINVAL.  (The matching case — forward then backward — is every GPU test; a layout that changed between the
+    passes is tests/test_hip_ops.py::test_backward_rejects_a_reserve_of_another_layout.)"""
+    import ctypes
+    from nabu_amd import _hip
+    lib = _hip.lib()
+    d = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), 4, 16, 8, 64, 16, 1, 0)
+    fake = ctypes.c_void_p(0x1000)           # never dereferenced: the check comes first
+    args = dict(x=fake, len=fake, k=fake, out=fake, dout=fake, reserve=ctypes.c_void_p(0x7000), ws=fake)
+    rc = lib.nabu_blstm_bwd(ctypes.byref(d), args['x'], args['len'], args['k'], args['k'], args['out'], args['dout'],
+                            args['reserve'], None, fake, fake, fake, fake, args['ws'], 1 << 40, None)
+    assert rc == -1 and b'no nabu_blstm_fwd call' in lib.nabu_last_error()
+    rc = lib.nabu_blstm_bwd_data(ctypes.byref(d), args['x'], args['len'], args['k'], args['k'], args['out'], args['dout'],
+                                 args['reserve'], None, fake, fake, args['ws'], 1 << 40, None)
+    assert rc == -1 and b'no nabu_blstm_fwd call' in lib.nabu_last_error()
+    rc = lib.nabu_blstm_bwd_weights(ctypes.byref(d), args['x'], args['len'], args['out'], args['reserve'], fake, fake,
+                                    args['ws'], 1 << 40, None)
+    assert rc == -1 and b'no nabu_blstm_fwd call' in lib.nabu_last_error()
+    fwd_only = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), 4, 16, 8, 64, 16, 1, 0, 0.0, _hip.BLSTM_FWD_ONLY, 0)
+    rc = lib.nabu_blstm_bwd(ctypes.byref(fwd_only), args['x'], args['len'], args['k'], args['k'], args['out'], args['dout'],
+                            args['reserve'], None, fake, fake, fake, fake, args['ws'], 1 << 40, None)
+    assert rc == -1 and b'NABU_BLSTM_FWD_ONLY' in lib.nabu_last_error()
 
 
 def test_product_path_has_no_cpu_fallback():
