@@ -24,7 +24,8 @@ error against float64 at or below the exact-fp32 MFMA kernel's (tests/test_hip_g
 loss within 5e-5 of the float64 oracle at the full size (tests/test_hip_golden.py) — everything else
 of the step is fp32.  The same step with the exact six-plane split on the bf16 pipe (bf16x6) and with
 exact-fp32 products (v_mfma_f32_32x32x2_f32) is timed in the same run and printed as the `alt_bf16x6`
-and `exact_fp32` objects of the line.
+and `f32_products` objects of the line, and once more as `fp32_end_to_end`: exact-fp32 products AND the exact-fp32
+recurrent kernels (the headline's recurrent product runs as three fp16 plane products of row-scaled operands).
 
 One JSON line is printed by rank 0.  Extra objects:
   roofline     — SURVEY.md 8(d): the recurrent LSTM step's ALGORITHMIC bytes (per timestep per
@@ -275,7 +276,17 @@ WORKLOADS = {'cfg1': 'cfg1: DBLSTM 2 x 256, DNNDecoder, CTC, Adam+clip; 8 utt x 
                      'average cross-entropy; 32 utt x 1000 frames x 40 fbank per GPU',
              'cfg5': 'cfg5: Listener-512 (bf16 input GEMMs) + Speller (location-aware attention); '
                      '64 utt x 1600 frames x 80 fbank per GPU'}
-ALT_KEYS = {'f32': 'exact_fp32', 'bf16x6': 'alt_bf16x6', 'f16x3': 'alt_f16x3'}
+ALT_KEYS = {'f32': 'f32_products', 'bf16x6': 'alt_bf16x6', 'f16x3': 'alt_f16x3'}
+# the other arithmetics the same step is timed under (object key of the line -> encoder cfg keys switched for the leg);
+# `fp32_end_to_end`: exact-fp32 dense products AND the exact-fp32 recurrent kernels — float32 from the features to the
+# update, as the reference's graph is (layer.py:35-47 on TF's fp32 MatMul)
+ALT_LEGS = [('alt_bf16x6', {'gemm_precision': 'bf16x6'}),
+            ('alt_f16x3', {'gemm_precision': 'f16x3'}),
+            ('f32_products', {'gemm_precision': 'f32'}),
+            ('fp32_end_to_end', {'gemm_precision': 'f32', 'recurrent_precision': 'f32'})]
+REC_ARITH = {'default': 'recurrent product h.W_h: three fp16 plane products of row-scaled operands (fp32-equivalent, '
+                        'lstm_persist_mxh.hip)',
+             'f32': 'recurrent product h.W_h: exact fp32 (v_mfma_f32_4x4x1, lstm_persist.hip)'}
 GEMM_ARITH = {'f32': 'f32 (v_mfma_f32_32x32x2_f32, exact fp32)',
               'bf16x6': 'fp32-equivalent on the bf16 matrix pipe: fp32 operands split exactly into 3 bf16 planes, 6 plane '
                         'products (v_mfma_f32_32x32x16_bf16), 16-k partial sums promoted to fp32 accumulators; error vs '
@@ -309,7 +320,7 @@ def parse_args(argv=None):
                          'fp16 operands); given, it overrides the recipe\'s encoder.gemm_precision key for this run '
                          '(bf16x6 = fp32-equivalent six-plane products on the bf16 matrix pipe, f32 = exact fp32 '
                          'MFMA).  The line names the arithmetic in config.gemm_arith and carries the other two, timed '
-                         'with the same steps / warm-up, as `exact_fp32` / `alt_bf16x6` / `alt_f16x3`')
+                         'with the same steps / warm-up, as `f32_products` / `alt_bf16x6` / `alt_f16x3`, plus `fp32_end_to_end` (exact-fp32 products AND recurrence)')
     ap.add_argument('--workload', default='cfg2', choices=['cfg1', 'cfg2', 'cfg3', 'cfg5'],
                     help='cfg2 (default) is the BASELINE.json metric; cfg3 = same encoder + Speller; cfg5 = '
                          'location-aware LAS, batch 64x1600x80, bf16 input GEMMs (BASELINE.json configs[2]/[4]), '
@@ -456,11 +467,18 @@ class HipWorkload(object):
         # the event profiler is armed during the warm-up as well: its first use (event pool creation
         # inside the HIP runtime) stalls the queue for tens of milliseconds once
         self.prof = ops.enable_profiler()
+        self.timing = False
         self.loss = None
 
     units_per_step = property(lambda self: self.B)
 
+    # HIP events around the recurrent launches cost the stream ~6 us each (a queue barrier per record: 16 per cfg2
+    # step): every PROFILE_EVERY-th step of the timed region carries them, the others run as a user's step does
+    PROFILE_EVERY = 4
+
     def step(self, i):
+        if self.timing:
+            self.prof.enabled = i % self.PROFILE_EVERY == 0
         self.loss = self.tr.step(self.batches[i % 2])
 
     def sync(self):
@@ -474,8 +492,10 @@ class HipWorkload(object):
     def start_timed_region(self):
         self.prof.collect()                                         # drop the warm-up records
         self.tr.allreduce_ms = []
+        self.timing = True
 
     def end_timed_region(self):
+        self.timing = False
         self.prof.enabled = False
         self.recs = self.prof.collect()
         self.final_loss = float(self.loss.item())
@@ -510,11 +530,11 @@ class HipWorkload(object):
         return [list(e) for e in log[-n:]]
 
     def alt(self, steps):
-        """the same step under the other fp32-class arithmetics of the dense products: [(precision, seconds, loss)]"""
+        """the same step under the other fp32-class arithmetics: [(line key, cfg keys, seconds, loss)]"""
         if self.precision not in ALT_KEYS or self.args.workload != 'cfg2' or self.args.no_alt:
             return []
-        return [(o,) + alt_gemm_arith(self.tr, self.batches, self.server, steps, max(self.args.warmup, 1), o)
-                for o in ALT_KEYS if o != self.precision]
+        return [(key, conf) + alt_gemm_arith(self.tr, self.batches, self.server, steps, max(self.args.warmup, 1), conf)
+                for key, conf in ALT_LEGS if conf != {'gemm_precision': self.precision}]
 
     def describe(self, dt):
         """workload-specific part of the JSON line (rank 0)"""
@@ -528,6 +548,7 @@ class HipWorkload(object):
         tot_ms = sum(r[4] for r in recs)
         tot_steps = sum(r[2] for r in recs)                   # timesteps covered (both directions each)
         tot_bytes = sum(2 * r[2] * step_bytes(r[1], r[3]) for r in recs)
+        prof_steps = max(len([i for i in range(args.steps) if i % self.PROFILE_EVERY == 0]), 1)
         launches = len(recs) if persistent else tot_steps
         per_launch_bytes = tot_bytes / max(launches, 1)
         per_launch_s = tot_ms * 1e-3 / max(launches, 1)
@@ -549,17 +570,19 @@ class HipWorkload(object):
                  if persistent else 'lstm_step_{fwd,bwd}_kernel')
         roofline = {'bound': 'hbm', 'achieved': round(step_bytes_total / step_s / 1e9, 1), 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': round(frac_step, 4), 'traffic': traffic, 'kernel': kname,
-                    'bytes_per_step': int(step_bytes_total), 'launches_per_step': launches // max(args.steps, 1),
+                    'bytes_per_step': int(step_bytes_total), 'launches_per_step': launches // prof_steps,
                     'recurrent_kernels': {
                         'achieved': round(achieved, 1), 'frac': round(achieved / HBM_PEAK_GBS, 4),
                         'bytes_per_launch': int(per_launch_bytes), 'us_per_launch': round(per_launch_s * 1e6, 3),
-                        'launches_timed': launches, 'ms_per_step': round(tot_ms / args.steps, 3),
+                        'launches_timed': launches, 'steps_with_events': prof_steps, 'ms_per_step': round(tot_ms / prof_steps, 3),
                         'us_per_sequential_step': round(tot_ms * 1e3 / max(tot_steps, 1), 3)},
                     'note': 'SURVEY.md 8(d): algorithmic bytes of the recurrent LSTM steps of ONE training step (W_h '
                             'streamed per timestep model) over the measured step time — the step also pays for its '
                             'MFMA-bound dense products, so this is the whole-step figure the 0.40 target is stated on; '
                             'recurrent_kernels = the same bytes per launch over the launch duration from HIP events the '
-                            'library records around the recurrent launches inside the timed region; traffic = HBM bytes '
+                            'library records around the recurrent launches of every 4th step of the timed region (an '
+                            'event record is a queue barrier, ~6 us: 16 of them per step would be paid by the metric); '
+                            'traffic = HBM bytes '
                             'per recurrent launch from the rocprofv3 PMC passes under profiles/'}
         return {
             'metric': METRICS[args.workload],
@@ -606,7 +629,7 @@ def run(args, server, wl):
     wl.end_timed_region()
     wl.check()
     alt = wl.alt(args.steps)
-    red = wl.reduce_max([dt_rank] + [a[1] for a in alt])
+    red = wl.reduce_max([dt_rank] + [a[2] for a in alt])
     per_rank = wl.gather(dt_rank)
     ar_ms = wl.allreduce_ms_per_step()
     ar_ranks = wl.gather(ar_ms if ar_ms is not None else 0.0)
@@ -625,14 +648,15 @@ def run(args, server, wl):
                     'allreduce_ms_per_step': [round(v, 3) for v in ar_ranks] if world > 1 else None,
                     'ranks_share_devices': bool(getattr(server, 'shared_devices', False)),
                     'bucket_schedule_last_step': wl.bucket_schedule()}
-    for i, (other, _, alt_loss) in enumerate(alt):
+    for i, (key, conf, _, alt_loss) in enumerate(alt):
         n = args.steps
         step_bytes_total = 2 * 2 * sum(wl.layer_t) * step_bytes(wl.B, wl.H)
-        out[ALT_KEYS[other]] = {
+        out[key] = {
             'note': 'the identical step (same weights stream, batches and protocol as the headline: %d warm-up steps, %d '
-                    'timed steps, barrier + sync bracket, MAX over ranks) with the dense products in another arithmetic; '
+                    'timed steps, barrier + sync bracket, MAX over ranks) in another arithmetic; '
                     'not the headline value' % (max(args.warmup, 1), n),
-            'gemm_arith': GEMM_ARITH[other],
+            'gemm_arith': GEMM_ARITH[conf['gemm_precision']],
+            'recurrent_arith': REC_ARITH[conf.get('recurrent_precision', 'default')],
             'value': round(world * wl.units_per_step * n / red[1 + i], 2), 'ms_per_step': round(red[1 + i] / n * 1e3, 3),
             'steps': n, 'final_loss': round(alt_loss, 4),
             'roofline_frac': round(step_bytes_total / (red[1 + i] / n) / (HBM_PEAK_GBS * 1e9), 4)}
@@ -670,14 +694,15 @@ def main(argv=None):
     server.shutdown()
 
 
-def alt_gemm_arith(tr, batches, server, steps, warmup, precision):
-    """the same step with another arithmetic of the BLSTM layers' dense products (exact fp32 / bf16x6 / f16x3): the
-    encoder's gemm_precision key is switched for the duration (the layers read it at every call), timed with the
-    protocol, warm-up and step count of the headline; NOT the headline value"""
+def alt_gemm_arith(tr, batches, server, steps, warmup, keys):
+    """the same step with another arithmetic of the BLSTM layers' dense products (exact fp32 / bf16x6 / f16x3) and / or of
+    their recurrent product: the encoder's cfg keys (gemm_precision, recurrent_precision) are switched for the duration
+    (the layers read them at every call), timed with the protocol, warm-up and step count of the headline; NOT the
+    headline value"""
     import torch
     conf = tr.model.encoder.conf
-    restore = conf.get('gemm_precision', None)
-    conf['gemm_precision'] = precision
+    restore = {k: conf.get(k, None) for k in keys}
+    conf.update(keys)
     try:
         for i in range(warmup):
             tr.step(batches[i % 2])
@@ -690,10 +715,11 @@ def alt_gemm_arith(tr, batches, server, steps, warmup, precision):
         server.barrier()
         dt = time.perf_counter() - t0
     finally:
-        if restore is None:
-            del conf['gemm_precision']
-        else:
-            conf['gemm_precision'] = restore
+        for k, v in restore.items():
+            if v is None:
+                del conf[k]
+            else:
+                conf[k] = v
     return dt, float(loss.item())
 
 

@@ -705,12 +705,18 @@ __global__ __launch_bounds__(256) void pk_amax_persist_kernel(int nb_rows, int B
                                                               const unsigned *rowpart, unsigned *adz, int crow, int N,
                                                               const float *colpart, int ld, unsigned *adzT) {
   if ((int)blockIdx.x < nb_rows) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows_pad) return;
+    // 64 frame rows per block, the partial rows in four groups (one per wave) that meet in LDS
+    __shared__ unsigned red[4][64];
+    const int r = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     unsigned m = 0;
-    if (r < BT && r % T < max_len)
-      for (int q = 0; q < nparts; ++q) m = max(m, rowpart[(size_t)q * BT + r]);
-    adz[r] = m;
+    if (r < BT && r % T < max_len) {
+      const int q0 = g * ((nparts + 3) / 4), q1 = min(nparts, q0 + (nparts + 3) / 4);
+#pragma unroll 8
+      for (int q = q0; q < q1; ++q) m = max(m, rowpart[(size_t)q * BT + r]);
+    }
+    red[g][threadIdx.x & 63] = m;
+    __syncthreads();
+    if (g == 0 && r < rows_pad) adz[r] = max(max(red[0][threadIdx.x], red[1][threadIdx.x]), max(red[2][threadIdx.x], red[3][threadIdx.x]));
     return;
   }
   const int n = (blockIdx.x - nb_rows) * 256 + threadIdx.x;
@@ -920,7 +926,7 @@ int pk_amax_pair(const float *src0, const float *src1, long long ld, int R, int 
 
 int pk_amax_from_persist(int BT, int rows_pad, int T, int max_len, int nparts, const uint32_t *rowpart, uint32_t *adz,
                          int crow, int N, const float *colpart, int ld, uint32_t *adzT, hipStream_t s) {
-  const int nb_rows = adz ? (rows_pad + 255) / 256 : 0, nb_cols = adzT ? (N + 255) / 256 : 0;
+  const int nb_rows = adz ? (rows_pad + 63) / 64 : 0, nb_cols = adzT ? (N + 255) / 256 : 0;
   if (nb_rows + nb_cols == 0) return 0;
   hipLaunchKernelGGL(pk_amax_persist_kernel, dim3(nb_rows + nb_cols), dim3(256), 0, s, nb_rows, BT, rows_pad, T, max_len, nparts,
                      rowpart, adz, crow, N, colpart, ld, adzT);

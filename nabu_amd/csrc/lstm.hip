@@ -186,7 +186,7 @@ struct Layout {
   size_t gates_elems, cs_elems;
   size_t reserve_bytes;
   // workspace carve
-  size_t hstate_off, cstate_off, gemm_off, gemm_bytes, persist_off, persist_bytes, total;
+  size_t hstate_off, cstate_off, gemm_off, gemm_bytes, persist_off, persist_bytes, xws_off, xws_bytes, total;
   // bf16-resident input products (gemm_precision = bf16): converted copies of the operands
   bool bf16_pre, bf16_fwd;
   size_t bf16_off, bf16_bytes;
@@ -332,6 +332,9 @@ static Layout make_layout(const nabu_blstm_desc *d) {
   L.gemm_off = off; L.gemm_bytes = align_up(g, 256); off += L.gemm_bytes;
   L.persist_bytes = align_up(lstm_persist_ws_bytes(d->B, d->T, d->H), 256);
   L.persist_off = off; off += L.persist_bytes;
+  // narrow input projected inside the forward kernel (lstm_persist.h): its plane copy of x
+  L.xws_bytes = align_up(lstm_persist_xws_bytes(d->B, d->T, d->D), 256);
+  L.xws_off = off; off += L.xws_bytes;
   L.bf16_pre = bf16_resident(d);
   L.bf16_fwd = bf16_resident_fwd(d);
   L.bf16_off = off;
@@ -403,7 +406,7 @@ static Layout make_layout(const nabu_blstm_desc *d) {
     }
     if (gws > L.gemm_bytes) {   // the gemm region precedes the persist region: grow it in place
       const size_t grow = align_up(gws, 256) - L.gemm_bytes;
-      L.gemm_bytes += grow; L.persist_off += grow; L.bf16_off += grow; L.pk_off += grow; off += grow;
+      L.gemm_bytes += grow; L.persist_off += grow; L.xws_off += grow; L.bf16_off += grow; L.pk_off += grow; off += grow;
     }
   }
   L.total = off;
@@ -614,7 +617,8 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d_in, const float *x, const
   if (use_persistent(d)) {
     NABU_PROFILE_MARK(g_ev_begin, s);
     int e = lstm_persist_fwd(B, T, D, H, max_len, len, kern, gates, cs, out, reinterpret_cast<int *>(w), w + L.persist_off,
-                             L.persist_bytes, s, fuse_in ? x : nullptr, fuse_in ? bias : nullptr);
+                             L.persist_bytes, s, fuse_in ? x : nullptr, fuse_in ? bias : nullptr,
+                             L.xws_bytes ? w + L.xws_off : nullptr);
     // the grid cannot be co-resident on this device (occupancy check before the launch): LSTM_AUTO steps instead
     if (!(e == NABU_EUNSUP && d->mode == NABU_LSTM_AUTO)) {
       if (e) return e;

@@ -700,6 +700,8 @@ size_t lstm_mxh_ring_bytes(bool fwd, int H);
 int lstm_mxh_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry);
 size_t lstm_mxh16_ring_bytes(int H);
 int lstm_mxh16_fwd_launch(int H, const PersistArgs &a, hipStream_t stream, bool dry);
+size_t lstm_mxh_xws_bytes(int B, int T);
+int lstm_mxh_prepare_x(int B, int T, int D, const float *x, void *ws, hipStream_t stream);
 // lstm_persist_mxf.hip: fp16 planes, 32 hidden units per workgroup, two units of 8 rows per XCD: 33 .. 64 batch rows at
 // H = 512 in one launch (NABU_PERSIST_MXF=0: the 16-rows-per-unit kernels below)
 bool lstm_mxf_supported(int B, int H);
@@ -826,7 +828,8 @@ struct RowMax { unsigned *part; unsigned stride; bool kept; };   // (lstm_persis
 static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
                      const float *dout, int *status, void *ws, size_t ws_bytes, float *db_part, float *amax_part,
-                     int *shard_base, hipStream_t stream, const float *x, const float *const bias[2], bool dry, RowMax *rm);
+                     int *shard_base, hipStream_t stream, const float *x, const float *const bias[2], bool dry, RowMax *rm,
+                     const void *xws, int xrow0);
 
 // exchange ring + XCC table back to 0xFF bytes: one small kernel (a hipMemsetAsync is its own kind of dispatch and
 // costs ~6 us of queue gap in front of every recurrent launch)
@@ -843,7 +846,7 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
                const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
                const float *dout, int *status, void *ws, size_t ws_bytes, float **db_part_out, int *db_rows_out,
                hipStream_t stream, const float *x = nullptr, const float *const bias[2] = nullptr, uint32_t *rowmax = nullptr,
-               bool *rowmax_done = nullptr) {
+               bool *rowmax_done = nullptr, void *xws = nullptr) {
   if (!lstm_persist_supported(B, T, H)) return fail(NABU_EUNSUP, "persistent LSTM: unsupported B=%d H=%d", B, H);
   const size_t need = lstm_persist_ws_bytes(B, T, H);
   if (ws_bytes < need) return fail(NABU_EWS, "persistent LSTM: workspace %zu < %zu", ws_bytes, need);
@@ -854,6 +857,8 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
   bool kept = rowmax != nullptr;
   for (int pass = 0; pass < 2; ++pass) {     // pass 0 validates every chunk, pass 1 enqueues them
     shards = 0;
+    if (pass == 1 && fwd && x && lstm_mx_supported(B, H))
+      if (int e = lstm_mxh_prepare_x(B, T, D, x, xws, stream)) return e;
     for (int b0 = 0; b0 < B; b0 += Bc) {
       RowMax rm = {rowmax ? rowmax + (size_t)b0 * T : nullptr, (unsigned)((size_t)B * T), false};
       const int nb = B - b0 < Bc ? B - b0 : Bc;
@@ -862,7 +867,7 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
       const int e = run_chunk(fwd, nb, T, D, H, max_len, len + b0, kernel, g2, c2,
                               out ? out + (size_t)b0 * T * 2 * H : nullptr,
                               dout ? dout + (size_t)b0 * T * 2 * H : nullptr, status, ws, ws_bytes, db_part, amax_part, &shards,
-                              stream, x ? x + (size_t)b0 * T * D : nullptr, bias, pass == 0, &rm);
+                              stream, x ? x + (size_t)b0 * T * D : nullptr, bias, pass == 0, &rm, xws, b0);
       if (e) return e;
       kept = kept && rm.kept;
     }
@@ -876,17 +881,26 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
 static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
                      const float *dout, int *status, void *ws, size_t ws_bytes, float *db_part, float *amax_part,
-                     int *shard_base, hipStream_t stream, const float *x, const float *const bias[2], bool dry, RowMax *rm) {
+                     int *shard_base, hipStream_t stream, const float *x, const float *const bias[2], bool dry, RowMax *rm,
+                     const void *xws, int xrow0) {
   PersistArgs a;
   a.rowmax_part = nullptr; a.rowmax_stride = 0;
   { const char *e = getenv("NABU_PERSIST_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   if (lstm_mx_supported(B, H)) {
-    if (fwd && x) return fail(NABU_EINVAL, "persistent LSTM (mx): no in-kernel input projection");
     const bool r16 = B > lstm_mx_chunk_rows();        // 33 .. 64 rows: 16 per unit
+    const bool xin = fwd && x != nullptr;
+    if (xin && (r16 || !lstm_mxh_on(true) || lstm_mxf_supported(B, H) || !bias || !xws || D > 64 || D % 8))
+      return fail(NABU_EINVAL, "persistent LSTM (mx): the in-kernel input projection does not take this shape");
     a.B = B; a.T = T; a.D = D; a.H = H; a.max_len = max_len; a.nshard = r16 ? (B + 15) / 16 : (B + 7) / 8;
     a.len = len;
     for (int i = 0; i < 2; ++i) { a.kernel[i] = kernel[i]; a.gates[i] = gates[i]; a.cs[i] = cs[i]; a.bias[i] = nullptr; }
     a.out = out; a.dout = dout; a.x = nullptr;
+    a.xplanes = nullptr; a.xscale = nullptr;
+    if (xin) {       // (the planes of the whole batch were written by lstm_persist_fwd; this chunk's rows)
+      a.xscale = static_cast<const float *>(xws);
+      a.xplanes = static_cast<const char *>(xws) + 1024 + (size_t)xrow0 * T * 256;
+      a.bias[0] = bias[0]; a.bias[1] = bias[1];
+    }
     a.db_part = db_part; a.amax_part = amax_part; a.shard_base = *shard_base;
     *shard_base += a.nshard;
     a.status = status;
@@ -919,6 +933,7 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
   for (int i = 0; i < 2; ++i) { a.kernel[i] = kernel[i]; a.gates[i] = gates[i]; a.cs[i] = cs[i]; }
   a.out = out; a.dout = dout;
   a.x = x; a.bias[0] = bias ? bias[0] : nullptr; a.bias[1] = bias ? bias[1] : nullptr;
+  a.xplanes = nullptr; a.xscale = nullptr;
   const int XK = (fwd && x && bias && BS == 4 && lstm_persist_fuses_input(B, T, D, H)) ? D / 4 : 0;
   if (fwd && x && !XK) return fail(NABU_EINVAL, "persistent LSTM: the in-kernel input projection does not take this shape");
   a.db_part = db_part; a.shard_base = *shard_base;
@@ -957,17 +972,21 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
 int lstm_persist_fwd(int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2],
                      float *out, int *status, void *ws, size_t ws_bytes, hipStream_t stream, const float *x,
-                     const float *const bias[2]) {
+                     const float *const bias[2], void *xws) {
   return run(true, B, T, D, H, max_len, len, kernel, gates, cs, out, nullptr, status, ws, ws_bytes, nullptr, nullptr,
-             stream, x, bias);
+             stream, x, bias, nullptr, nullptr, xws);
 }
+size_t lstm_persist_xws_bytes(int B, int T, int D) { return (D <= 64 && D % 8 == 0) ? lstm_mxh_xws_bytes(B, T) : 0; }
 
 // narrow input (D = 40: 4 rows x D elements fit the 256 lanes of one prefetch), every launch of the forward pass on the
 // 4-row geometry: the kernel projects the input itself (no x . Wx GEMM in front of it)
 bool lstm_persist_fuses_input(int B, int T, int D, int H) {
   static int env = -1;
   if (env < 0) { const char *e = getenv("NABU_PERSIST_FUSE_INPUT"); env = e ? atoi(e) : 1; }
-  if (!env || D != 40 || !lstm_persist_supported(B, T, H) || lstm_mx_supported(B, H)) return false;
+  if (!env || !lstm_persist_supported(B, T, H)) return false;
+  if (lstm_mx_supported(B, H))     // fp16-plane kernels: any narrow input of <= 64 features, one launch of <= 32 rows
+    return D <= 64 && D % 8 == 0 && B <= lstm_mx_chunk_rows() && lstm_mxh_on(true) && !lstm_mxf_supported(B, H);
+  if (D != 40) return false;
   if ((size_t)B * T * D * 4 >= 0x80000000ull) return false;
   const int Bc = chunk_rows(B, H, true, T);
   for (int b0 = 0; b0 < B; b0 += Bc)

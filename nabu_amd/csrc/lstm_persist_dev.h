@@ -34,6 +34,8 @@ struct PersistArgs {
   float *cs[2];
   float *out;         // forward
   const float *x;     // forward, narrow input (XK > 0): the layer input [B, T, D], projected inside the kernel
+  const void *xplanes;    // ... fp16-plane kernels (XIN): x as two fp16 planes [B][T][2][64 k], scaled by 2^14 / xscale[0]
+  const float *xscale;    // ... xscale[0] = g, a power of two with |x| <= g (lstm_mxh_prepare_x)
   const float *bias[2];   // ... and the cells' biases [4H]
   const float *dout;  // backward
   float *db_part;     // backward: [shards][2 directions][4H] bias-gradient partial sums (one row per unit)

@@ -39,11 +39,18 @@ struct MxhFwdLds {
   static constexpr int ROWF = 17 * 4;                        // floats per (wave, row): 16 units x 4 gates + pad
   static constexpr int PART = 0;                             // [2][4 waves][8 rows][ROWF]
   static constexpr int XST = PART + 2 * 4 * MXR * ROWF;      // [2][4 waves][64 lanes x 4] prefetched x-projection
-  static constexpr int FLAG = XST + 2 * 4 * 256;
+                                                             // XIN: [2][4 waves][2 k-steps][64 lanes x 4] planes of x_t
+  static constexpr int FLAG = XST + 2 * 4 * 512;
   static constexpr int TOTAL = FLAG + 4;
 };
 
-template <int H, bool DBG>
+// XIN = true — the first layer's narrow input (D <= 64 features) is projected INSIDE the kernel (z = [x_t,
+// h_(t-1)] . kernel + bias is ONE product in the reference's cell): x arrives as two fp16 planes per frame, scaled like h
+// (lstm_mxh_prepare_x below), as two more k-steps of the same matrix stream — wave w multiplies them against gate w's
+// columns of Wx into the accumulators its recurrent partial sums are in, so nothing downstream changes.  What this
+// replaces: a [B T, 4H] product per direction in front of the kernel (gemm_smallk_kernel: write-bound, 0.26 ms per cfg2
+// step for 8 % of the recurrent product's work) and its read-back, one float per thread and step.
+template <int H, bool DBG, bool XIN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_mxh_fwd_kernel(PersistArgs p) {
   const int dbg = DBG ? p.dbg : 0;
   using L = MxhFwdLds<H>;
@@ -76,9 +83,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // inv[c]: what the finished sum of column (c, U0 + n) is multiplied with — n = u16: the lane that multiplies column
   // n is the lane that finishes unit n.
   u32x4 Wp[2][4][NKS];
-  float inv[4];
+  u32x4 Wxp[2][2];        // XIN: gate w's columns of Wx, rows 32 j + 8 q + e, times the input's range g (a power of two)
+  float inv[4], bias_f[4] = {0.f, 0.f, 0.f, 0.f};
   {
     const float *Wh = p.kernel[dir] + ((size_t)p.D + (size_t)w * KW + 8 * q) * 4 * H + U0 + n;
+    // XIN: x is held as x 2^14 / g (|x| <= g: lstm_mxh_prepare_x), i.e. scaled like h, so that x . Wx and h . W_h share
+    // accumulators and descale; what remains of g goes into the weights: the column's scale covers g Wx as well
+    const float xg = XIN ? p.xscale[0] : 0.f;
+    const float *Wx = p.kernel[dir] + (size_t)(8 * q) * 4 * H + U0 + n;
     float mx[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -87,6 +99,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int j = 0; j < NKS; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) mx[c] = fmaxf(mx[c], fabsf(Wh[((size_t)32 * j + e) * 4 * H + (size_t)c * H]));
+      if constexpr (XIN) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int k = 32 * j + 8 * q + e;
+            if (k < p.D) mx[c] = fmaxf(mx[c], xg * fabsf(Wx[((size_t)32 * j + e) * 4 * H + (size_t)c * H]));
+          }
+      }
       mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], 16));
       mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], 32));
       if (q == 0) part[w * 64 + c * 16 + n] = mx[c];
@@ -109,6 +130,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int e = 0; e < 8; ++e) x[e] = Wh[((size_t)32 * j + e) * 4 * H + (size_t)c * H] * sc[c];
         mxh_split8(x, Wp[0][c][j], Wp[1][c][j]);
       }
+    if constexpr (XIN) {
+      const float scw = sel4(w, sc[0], sc[1], sc[2], sc[3]) * xg;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = 32 * j + 8 * q + e;
+          x[e] = k < p.D ? Wx[((size_t)32 * j + e) * 4 * H + (size_t)w * H] * scw : 0.f;
+        }
+        mxh_split8(x, Wxp[0][j], Wxp[1][j]);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bias_f[c] = p.bias[dir][(size_t)c * H + U0 + (lane & 15)];
+    }
   }
   float c_state = 0.f, h_state = 0.f;
   if (!unit_handshake(p, unit, slot, MXNU, P, flag)) return;
@@ -137,10 +173,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // row this lane also finishes, so its length is n_f.  (The same for the backward kernel's four loads — three tensors,
   // hence global_load_lds_dwordx4 with 64-bit addresses — was built and measured slower: 2.06 against 2.03 us.)
   const unsigned goff4 = (unsigned)(((size_t)fb * T * 4 * H + (size_t)((lane >> 2) & 3) * H + U0 + 4 * (lane & 3)) * 4);
+  // XIN: the planes of x_s, [b][t][plane][64 k] fp16 (lstm_mxh_prepare_x), one step ahead, EVERY wave its own copy (the
+  // claim stays what it is for the projection: older than the exchange loads the step waits for): lane (n, q) of k-step
+  // j fetches its B operand — 8 k of (plane n >> 3, row n & 7) — into [j][lane]: a lane reads back what it fetched
+  const i32x4 rxp = raw_rsrc(XIN ? p.xplanes : nullptr, XIN ? (unsigned)((size_t)p.B * T * 256) : 0u);
+  const int xrow = b0 + (n & 7);
+  const int n_x = (XIN && xrow < p.B) ? p.len[xrow] : 0;
+  const unsigned xoff = (unsigned)(((size_t)xrow * T * 2 + (n >> 3)) * 128 + 16 * q);
   auto fetch_x = [&](int s) {
-    const int t = dir ? n_f - 1 - s : s;
-    const bool act = fin && s < n_f && !(dbg & 64);
-    prefetch_lds_b128(rg, act ? goff4 + (unsigned)t * (unsigned)(16 * H) : OOB, smem, xst + (s & 1) * 1024 + 256 * w);
+    if constexpr (XIN) {
+      const int t = dir ? n_x - 1 - s : s;
+      const bool act = s < n_x && !(dbg & 64);
+      float *st = xst + (s & 1) * 2048 + 512 * w;
+      prefetch_lds_b128(rxp, act ? xoff + (unsigned)t * 256u : OOB, smem, st);
+      prefetch_lds_b128(rxp, act ? xoff + (unsigned)t * 256u + 64u : OOB, smem, st + 256);
+    } else {
+      const int t = dir ? n_f - 1 - s : s;
+      const bool act = fin && s < n_f && !(dbg & 64);
+      prefetch_lds_b128(rg, act ? goff4 + (unsigned)t * (unsigned)(16 * H) : OOB, smem, xst + (s & 1) * 1024 + 256 * w);
+    }
   };
   fetch_x(0);
   wait_vm<0>();
@@ -210,6 +261,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // x-projection (HBM latency: as early as possible) is requested from inside the matrix stream.
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = (mxf32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (XIN) {
+      // x_s . Wx for gate w's columns: the staged planes are this lane's own fetch of a step ago
+      asm volatile("" ::: "memory");       // (not above the poll loop: its returned loads are what claims the fetch)
+      const float *xs = xst + (s & 1) * 2048 + 512 * w + 4 * lane;
+      const u32x4 bx0 = *reinterpret_cast<const u32x4 *>(xs), bx1 = *reinterpret_cast<const u32x4 *>(xs + 256);
+      mxf32x4 ax = {0.f, 0.f, 0.f, 0.f};
+      if (!(dbg & 2)) {
+        ax = MXH_MFMA(Wxp[1][0], bx0, ax);
+        ax = MXH_MFMA(Wxp[1][1], bx1, ax);
+        ax = MXH_MFMA(Wxp[0][0], bx0, ax);
+        ax = MXH_MFMA(Wxp[0][1], bx1, ax);
+      }
+      if (w == 0) acc[0] = ax;
+      else if (w == 1) acc[1] = ax;
+      else if (w == 2) acc[2] = ax;
+      else acc[3] = ax;
+    }
     if (s > 0 && !(dbg & 2)) {
 #pragma unroll
       for (int j = 0; j < NKS; ++j) {
@@ -255,7 +323,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       mxf32x4 sum = *reinterpret_cast<const mxf32x4 *>(pr);
 #pragma unroll
       for (int ww = 1; ww < 4; ++ww) sum += *reinterpret_cast<const mxf32x4 *>(pr + (size_t)ww * MXR * L::ROWF);
-      z = (mxf32x4){xs[0] + sum.x * inv[0], xs[16] + sum.y * inv[1], xs[32] + sum.z * inv[2], xs[48] + sum.w * inv[3]};
+      if constexpr (XIN)
+        z = (mxf32x4){bias_f[0] + sum.x * inv[0], bias_f[1] + sum.y * inv[1], bias_f[2] + sum.z * inv[2], bias_f[3] + sum.w * inv[3]};
+      else
+        z = (mxf32x4){xs[0] + sum.x * inv[0], xs[16] + sum.y * inv[1], xs[32] + sum.z * inv[2], xs[48] + sum.w * inv[3]};
     }
     const float gi = fast_sigmoid(z.x), gj = fast_tanh(z.y), gf = fast_sigmoid(z.z + 1.0f), go = fast_sigmoid(z.w);
     const bool act = s < n_f;
@@ -875,6 +946,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 // ===========================================================================
+// XIN: the layer input as the forward kernel's operand.  Workspace: [0] g (float, a power of two >= max |x|), [16 .. 16 + D)
+// the columns' largest magnitudes (bit patterns, zeroed by the caller's fill), +1024 bytes: planes [B][T][2][64 k] fp16 of
+// x 2^14 / g, zero beyond D.  One scale for the whole tensor: a scale that differed between frames could not share the
+// recurrent product's accumulators; what it costs is range at the bottom only — an element below 2^-17 g keeps an absolute
+// error of 2^-40 g (the convention of every f16x3 operand), far below one rounding of the pre-activation it is added to.
+__device__ __forceinline__ float mxh_x_range(const unsigned *cols, int D) {
+  unsigned m = 0;
+  for (int i = 0; i < D; ++i) m = max(m, cols[i]);
+  unsigned e = (m >> 23) & 0xFFu;
+  if ((m & 0x7FFFFFFFu) == 0) e = 126;                 // all zero: g = 1
+  e = e < 15 ? 15 : (e > 252 ? 252 : e);
+  return __builtin_bit_cast(float, (e + 1u) << 23);   // 2^(floor(log2 max) + 1) > max
+}
+__global__ __launch_bounds__(256) void mxh_xplanes_kernel(int frames, int D, const float *__restrict__ x, char *ws) {
+  const unsigned *cols = reinterpret_cast<const unsigned *>(ws) + 16;
+  const float g = mxh_x_range(cols, D);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<float *>(ws) = g;
+  const float sc = MXH_HSCALE / g;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t f = i >> 3;
+  const int k0 = 8 * (int)(i & 7);
+  if (f >= (size_t)frames) return;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = k0 + e < D ? x[f * D + k0 + e] * sc : 0.f;
+  u32x4 h, l;
+  mxh_split8(v, h, l);
+  char *dst = ws + 1024 + f * 256 + 2 * k0;
+  *reinterpret_cast<u32x4 *>(dst) = h;
+  *reinterpret_cast<u32x4 *>(dst + 128) = l;
+}
+size_t lstm_mxh_xws_bytes(int B, int T) { return 1024 + (size_t)B * T * 256; }
+// x [B, T, D] -> ws (lstm_mxh_xws_bytes): three small launches (zero the maxima, measure, convert)
+int lstm_mxh_prepare_x(int B, int T, int D, const float *x, void *ws, hipStream_t stream) {
+  if (D > 64 || D % 4) return fail(NABU_EUNSUP, "persistent LSTM (mxh): in-kernel input projection takes D <= 64, D %% 4 == 0");
+  const FillSeg seg = {ws, 256, 0u};
+  if (int e = multi_fill(&seg, 1, stream)) return e;
+  if (int e = nabu_pk_amax(x, D, B * T, D, nullptr, static_cast<uint32_t *>(ws) + 16, stream)) return e;
+  const size_t n = (size_t)B * T * 8;
+  hipLaunchKernelGGL(mxh_xplanes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, B * T, D, x, static_cast<char *>(ws));
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+// ===========================================================================
 // host side (called from lstm_persist.hip's run_chunk)
 // NABU_PERSIST_MXH: bit 0 = forward, bit 1 = backward
 bool lstm_mxh_on(bool fwd) {
@@ -918,6 +1034,9 @@ int lstm_mxh_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, b
   const int grid = MXNU * (H / UC);
 #define NABU_MXH_CASE(h)                                                                                            \
   case h:                                                                                                           \
+    if (fwd && a.xplanes)                                                                                           \
+      return a.dbg ? mxh_launch(lstm_mxh_fwd_kernel<h, true, true>, a, grid, MxhFwdLds<h>::TOTAL * sizeof(float), stream, dry)  \
+                   : mxh_launch(lstm_mxh_fwd_kernel<h, false, true>, a, grid, MxhFwdLds<h>::TOTAL * sizeof(float), stream, dry); \
     if (a.dbg)                                                                                                      \
       return fwd ? mxh_launch(lstm_mxh_fwd_kernel<h, true>, a, grid, MxhFwdLds<h>::TOTAL * sizeof(float), stream, dry) \
                  : mxh_launch(lstm_mxh_bwd_kernel<h, true>, a, grid, MxhBwdLds<h>::TOTAL * sizeof(float), stream, dry); \
