@@ -25,11 +25,7 @@ constexpr int MXF_NU = 16;             // units per launch: two per XCD
 // otherwise copies four of them in front of every instruction (v_accvgpr_read: 0.2 us per step).  An l-plane instruction
 // is always followed, at least four matrix instructions later, by the compiler's own h-plane instruction on the same
 // accumulators, so every result the vector ALU reads comes out of an instruction whose hazards hipcc pads itself.
-__device__ __forceinline__ void mxf_pin_acc(u32x4 &w) { asm volatile("" : "+a"(w)); }
-__device__ __forceinline__ mxf32x4 mxf_mfma_acc(const u32x4 wa, const u32x4 b, mxf32x4 acc) {
-  asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "a"(wa), "v"(b));
-  return acc;
-}
+// (mxf_pin_acc / mxf_mfma_acc: lstm_persist_mxh.h)
 
 __device__ __forceinline__ void mxf_identity(int P, int *unit, int *slot) {
   const int xcd = blockIdx.x % 8, local = blockIdx.x / 8;

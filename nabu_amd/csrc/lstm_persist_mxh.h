@@ -17,6 +17,18 @@ typedef _Float16 mxh16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 mxh16x2 __attribute__((ext_vector_type(2)));
 #define MXH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mxh16x8, a), __builtin_bit_cast(mxh16x8, b), c, 0, 0, 0)
 
+// A plane of W_h held in the ACCUMULATION half of the unified register file and fed to the matrix instruction from there:
+// hipcc keeps matrix operands in ordinary registers, and once those run out (256 per lane) it parks values in accumulation
+// registers and copies them back in front of every use (v_accvgpr_read, one VALU slot each — dozens per step in these
+// kernels).  An instruction issued this way is invisible to hipcc's hazard padding, so it is ONLY used where the
+// compiler's own matrix instruction on the same accumulators follows before any vector-ALU read of them (the l plane in
+// front of the h plane of the same tile).
+__device__ __forceinline__ void mxf_pin_acc(u32x4 &w) { asm volatile("" : "+a"(w)); }
+__device__ __forceinline__ mxf32x4 mxf_mfma_acc(const u32x4 wa, const u32x4 b, mxf32x4 acc) {
+  asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "a"(wa), "v"(b));
+  return acc;
+}
+
 constexpr int DPP_ROW_MIRROR = 0x140;
 // backward exchange ring: 2 slots, NO hand-back.  The backward step is bound by the volume of its exchange (16 KB
 // written, 16 KB read and — with sentinels — 16 KB handed back per workgroup and step, at ~2.5 TB/s per XCD: cutting the

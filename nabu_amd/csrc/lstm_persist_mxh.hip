@@ -24,6 +24,18 @@
 
 namespace nabu {
 
+// experiment (off in the library build): the l plane of W_h in accumulation registers, fed to the matrix instruction
+// from there (lstm_persist_mxh.h) — measured SLOWER in this kernel (1.35 against 1.27 us per forward step): hipcc then
+// pairs the h-plane instruction of k-step j with the l-plane one of j + 1 on the SAME accumulators back to back
+#ifndef MXH_ACC_L
+#define MXH_ACC_L 0
+#endif
+#if MXH_ACC_L
+#define MXH_MFMA_L(a, b, c) mxf_mfma_acc(a, b, c)
+#else
+#define MXH_MFMA_L(a, b, c) MXH_MFMA(a, b, c)
+#endif
+
 #define MXH_STAMP(pass, i)                                                         \
   do {                                                                             \
     if constexpr (DBG) {                                                           \
@@ -129,6 +141,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = Wh[((size_t)32 * j + e) * 4 * H + (size_t)c * H] * sc[c];
         mxh_split8(x, Wp[0][c][j], Wp[1][c][j]);
+#if MXH_ACC_L
+        mxf_pin_acc(Wp[1][c][j]);        // the l plane: accumulation registers (lstm_persist_mxh.h)
+#endif
       }
     if constexpr (XIN) {
       const float scw = sel4(w, sc[0], sc[1], sc[2], sc[3]) * xg;
@@ -183,7 +198,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto fetch_x = [&](int s) {
     if constexpr (XIN) {
       const int t = dir ? n_x - 1 - s : s;
-      const bool act = s < n_x && !(dbg & 64);
+      const bool act = s < n_x && !(dbg & (64 | 1024));
       float *st = xst + (s & 1) * 2048 + 512 * w;
       prefetch_lds_b128(rxp, act ? xoff + (unsigned)t * 256u : OOB, smem, st);
       prefetch_lds_b128(rxp, act ? xoff + (unsigned)t * 256u + 64u : OOB, smem, st + 256);
@@ -217,6 +232,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d_v), rso, (on && gp) ? ooff + (unsigned)d_to * (unsigned)(8 * H) : OOB, 0, 0);
   };
 
+  // XIN: x_s . Wx for gate w's columns does not depend on the exchange: it is multiplied while the first poll round is in
+  // flight.  The staged planes (this lane's own fetch of a step ago) are claimed by a counted wait: everything but the
+  // XVM_AFTER vector-memory operations issued since — publish + hand-back, the round's loads, the four result stores.
+  constexpr int XVM_AFTER = NKS + 6;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  mxf32x4 ax = {0.f, 0.f, 0.f, 0.f};
+  auto x_product = [&](int s) {
+    if constexpr (XIN) {
+      asm volatile("" ::: "memory");
+      const float *xs = xst + (s & 1) * 2048 + 512 * w + 4 * lane;
+      const u32x4 bx0 = *reinterpret_cast<const u32x4 *>(xs), bx1 = *reinterpret_cast<const u32x4 *>(xs + 256);
+      mxf32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+      if (!(dbg & (2 | 512))) {
+        a0 = MXH_MFMA(Wxp[1][0], bx0, a0);
+        a1 = MXH_MFMA(Wxp[1][1], bx1, a1);
+        a0 = MXH_MFMA(Wxp[0][0], bx0, a0);
+        a1 = MXH_MFMA(Wxp[0][1], bx1, a1);
+      }
+      ax = a0 + a1;
+    }
+  };
+
   for (int s = 0; s < p.max_len; ++s) {
     MXH_STAMP(0, 0);
     mxf32x4 acc[4];
@@ -234,7 +271,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         unsigned mx = 0u;
 #pragma unroll
         for (int j = 0; j < NKS; ++j) b1[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + off1 + j * KSTEP_BYTES, 0, 16);
-        if (first) { result_stores(); first = false; }     // step s - 1's results, behind the loads
+        if (first) {     // step s - 1's results, behind the loads
+          result_stores();
+          if constexpr (XIN) { wait_vm<XVM_AFTER>(); x_product(s); }
+          first = false;
+        }
 #pragma unroll
         for (int j = 0; j < NKS; ++j) mx = mx_max4(mx, b1[j]);
         if (__all(mx != SENT)) break;
@@ -255,40 +296,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     } else {
       result_stores();
       wait_vm<0>();        // (no exchange loads to order the prefetch: s = 0, or the no-waiting experiment)
+      x_product(s);
     }
     MXH_STAMP(0, 1);
     // (b) product: 4 column tiles (gate c) x NKS k-steps x {W_l.B, W_h.B}, small terms first.  Next step's
     // x-projection (HBM latency: as early as possible) is requested from inside the matrix stream.
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = (mxf32x4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (XIN) {
-      // x_s . Wx for gate w's columns: the staged planes are this lane's own fetch of a step ago
-      asm volatile("" ::: "memory");       // (not above the poll loop: its returned loads are what claims the fetch)
-      const float *xs = xst + (s & 1) * 2048 + 512 * w + 4 * lane;
-      const u32x4 bx0 = *reinterpret_cast<const u32x4 *>(xs), bx1 = *reinterpret_cast<const u32x4 *>(xs + 256);
-      mxf32x4 ax = {0.f, 0.f, 0.f, 0.f};
-      if (!(dbg & 2)) {
-        ax = MXH_MFMA(Wxp[1][0], bx0, ax);
-        ax = MXH_MFMA(Wxp[1][1], bx1, ax);
-        ax = MXH_MFMA(Wxp[0][0], bx0, ax);
-        ax = MXH_MFMA(Wxp[0][1], bx1, ax);
-      }
-      if (w == 0) acc[0] = ax;
-      else if (w == 1) acc[1] = ax;
-      else if (w == 2) acc[2] = ax;
-      else acc[3] = ax;
-    }
     if (s > 0 && !(dbg & 2)) {
 #pragma unroll
       for (int j = 0; j < NKS; ++j) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = MXH_MFMA(Wp[1][c][j], b1[j], acc[c]);
+        for (int c = 0; c < 4; ++c) acc[c] = MXH_MFMA_L(Wp[1][c][j], b1[j], acc[c]);
         if (j == 0) { fetch_x(s + 1); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = MXH_MFMA(Wp[0][c][j], b1[j], acc[c]);
       }
     } else {
       fetch_x(s + 1);
+    }
+    if constexpr (XIN) {      // the input's part joins gate w's sums (same scales: see the weights above)
+      if (wu == 0) acc[0] += ax;
+      else if (wu == 1) acc[1] += ax;
+      else if (wu == 2) acc[2] += ax;
+      else acc[3] += ax;
     }
     MXH_STAMP(0, 2);
     // the two plane halves of N: lanes n and n ^ 8 end with the same sums (row n & 7; units 4 q + i, gate c)
@@ -696,7 +727,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
   }
   float dc_state = 0.f;
-  float db0 = 0.f, db1 = 0.f, am0 = 0.f, am1 = 0.f;   // bias gradient / largest |dz| of my two gate columns, my row
+  // bias gradient / largest |dz| of my two gate columns, my row.  The sums run over up to T steps: in float64 (a T-term
+  // fp32 chain was measurably worse than the step-wise path's tree over the stored dz: 1.1-1.3 x its error against a
+  // float64 layer), added at the END of a step, behind the publish, where the wave only waits for the next exchange
+  double db0 = 0.0, db1 = 0.0;
+  float am0 = 0.f, am1 = 0.f;
   if (!unit_handshake(p, unit, slot, MXNU, P, flag)) return;
   const bool coloc = flag[1] != 0;
 
@@ -755,6 +790,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __builtin_amdgcn_raw_buffer_store_b32(d_mb, rsm, (d_any && m_ok) ? moff + (unsigned)d_t * 4u : OOB, 0, 0);
   };
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  // GATE FACTORS AHEAD OF THE EXCHANGE.  dz is linear in what the exchange delivers (dh): with dht = dout + dh and
+  // dct = dc + dht A, the gate gradients are dct F0 and (dct | dht) F1, the carry dct G, where A, F0, F1, G depend on the
+  // saved forward values only.  Those were prefetched a step ahead, so they are claimed with a COUNTED wait right behind
+  // the first poll round's loads (everything but the VM_AFTER operations issued since the prefetch: the publishes of the
+  // previous step, this round's loads, the result stores) and turned into the factors while the exchange is in flight:
+  // the LDS round trip, the pair exchange, tanh c and a dozen multiplies leave the chain between "dh arrived" and
+  // "dz planes written".
+  constexpr int VM_AFTER = 2 * QT + NQ + 3;
+  float fA = 0.f, f0 = 0.f, f1 = 0.f, fG = 0.f, f_dout = 0.f;
+  bool act_g = false;
+  auto gate_factors = [&](int s) {
+    asm volatile("" ::: "memory");
+    const float *st = xst + (s & 1) * 1024 + tid;
+    const float sA = st[0], sB = st[256], sC = st[512], sD = st[768];
+    const float pA = mx_dpp<DPP_XOR1>(sA), pB = mx_dpp<DPP_XOR1>(sB), pC = mx_dpp<DPP_XOR1>(sC), pD = mx_dpp<DPP_XOR1>(sD);
+    const float gi = dup ? pA : sA, gj = dup ? pB : sB, gf = dup ? sA : pA, go = dup ? sB : pB;
+    const float c = dup ? pC : sC, cprev = dup ? sC : pC;
+    f_dout = dup ? pD : sD;
+    act_g = s < n_g;
+    const float tc = fast_tanh(c);
+    fA = go * (1.f - tc * tc);
+    const float a0 = dup ? cprev * gf * (1.f - gf) : gj * gi * (1.f - gi);
+    const float a1 = dup ? tc * go * (1.f - go) : gi * (1.f - gj * gj);
+    f0 = act_g ? a0 : 0.f;
+    f1 = act_g ? a1 : 0.f;
+    fG = gf;
+  };
 
   for (int s = p.max_len - 1; s >= 0; --s) {
     MXH_STAMP(1, 0);
@@ -777,7 +839,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int i = 0; i < NQ; ++i)
           v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, MXH_QVOL(kq) ? OOB : base + (unsigned)(8 * i) * (unsigned)(MXR * 64), 0, 16);
-        if (first) { dz_stores(); first = false; }
+        if (first) {
+          dz_stores();
+          wait_vm<VM_AFTER>();
+          gate_factors(s);
+          first = false;
+        }
         // every word must carry the tag: AND of the last bits (tag 1) / OR of the last bits (tag 0)
         unsigned a = v[0].x & v[0].y & v[0].z & v[0].w, o = v[0].x | v[0].y | v[0].z | v[0].w;
 #pragma unroll
@@ -802,6 +869,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     } else {
       dz_stores();
       wait_vm<0>();     // (no exchange loads to order the prefetched values: first step, or the no-waiting experiment)
+      gate_factors(s);
     }
     MXH_STAMP(1, 1);
     mxf32x4 ps = __builtin_bit_cast(mxf32x4, v[0]);
@@ -816,25 +884,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     ps.z += mx_dpp<DPP_XOR2>(ps.z); ps.w += mx_dpp<DPP_XOR2>(ps.w);
     const float dh = sel4(s8 >> 1, ps.x, ps.y, ps.z, ps.w);
 
-    // (b) gate gradients of (row, unit): the pair shares its saved values (prefetched a step ahead: older than the
-    // exchange loads above, and vector-memory operations complete in issue order)
-    const float *st = xst + (s & 1) * 1024 + tid;
-    const float sA = st[0], sB = st[256], sC = st[512], sD = st[768];
-    const float pA = mx_dpp<DPP_XOR1>(sA), pB = mx_dpp<DPP_XOR1>(sB), pC = mx_dpp<DPP_XOR1>(sC), pD = mx_dpp<DPP_XOR1>(sD);
-    const float gi = dup ? pA : sA, gj = dup ? pB : sB, gf = dup ? sA : pA, go = dup ? sB : pB;
-    const float c = dup ? pC : sC, cprev = dup ? sC : pC, dout = dup ? pD : sD;
-    const bool act_g = s < n_g;
-    const float tc = fast_tanh(c);
-    const float dht = dout + dh;
-    const float dct = dc_state + dht * go * (1.f - tc * tc);
-    float d0 = 0.f, d1 = 0.f;
-    if (act_g) {
-      d0 = dup ? dct * cprev * gf * (1.f - gf) : dct * gj * gi * (1.f - gi);
-      d1 = dup ? dht * tc * go * (1.f - go) : dct * gi * (1.f - gj * gj);
-      dc_state = dct * gf;
-    }
-    db0 += d0; db1 += d1;
-    am0 = fmaxf(am0, fabsf(d0)); am1 = fmaxf(am1, fabsf(d1));
+    // (b) gate gradients of (row, unit) from the factors computed above
+    const float dht = f_dout + dh;
+    const float dct = dc_state + dht * fA;
+    const float d0 = dct * f0, d1 = (dup ? dht : dct) * f1;
+    if (act_g) dc_state = dct * fG;
     char *const dzb = dzs + (s & 1) * (16 * L::DROWB);
     {
       // this row's largest |dz| over the workgroup's 64 columns = over the 32 lanes of the row: 16 by DPP, the two
@@ -919,19 +973,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       MXH_STAMP(1, 9);
     }
+    // (behind the publish: nothing waits for these)
+    db0 += (double)d0; db1 += (double)d1;
+    am0 = fmaxf(am0, fabsf(d0)); am1 = fmaxf(am1, fabsf(d1));
     MXH_STAMP(1, 5);
   }
   dz_stores();
   // bias gradient / column maxima of my 64 gate columns over the unit's 8 rows
   __syncthreads();
-  red[grow * 64 + (2 * dup) * 16 + gu] = db0;
-  red[grow * 64 + (2 * dup + 1) * 16 + gu] = db1;
+  // (the rows' sums meet in float64 as well: red as [8 rows][64] doubles fits the dz plane + staging area in front of it)
+  double *redd = reinterpret_cast<double *>(smem);
+  redd[grow * 64 + (2 * dup) * 16 + gu] = db0;
+  redd[grow * 64 + (2 * dup + 1) * 16 + gu] = db1;
   __syncthreads();
   if (tid < 64) {
-    float sum = 0.f;
+    double sum = 0.0;
 #pragma unroll
-    for (int r = 0; r < MXR; ++r) sum += red[r * 64 + tid];
-    p.db_part[((size_t)(p.shard_base + shard) * 2 + dir) * 4 * H + (size_t)(tid >> 4) * H + U0 + (tid & 15)] = sum;
+    for (int r = 0; r < MXR; ++r) sum += redd[r * 64 + tid];
+    p.db_part[((size_t)(p.shard_base + shard) * 2 + dir) * 4 * H + (size_t)(tid >> 4) * H + U0 + (tid & 15)] = (float)sum;
   }
   __syncthreads();
   red[grow * 64 + (2 * dup) * 16 + gu] = am0;
