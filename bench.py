@@ -138,8 +138,14 @@ def cpu_baseline():
     return out
 
 
-def cached_cpu_baseline():
-    """the N = 1 run's cpu_baseline of this host, if one was measured in the last day"""
+CPU_COMMITTED = os.path.join(ROOT, 'profiles', 'cpu_baseline_last.json')
+
+
+def cached_cpu_baseline(measure=True):
+    """the cpu_baseline object of an N > 1 line — never null: (1) the N = 1 run's object of this host, if one was
+    measured in the last day (the driver runs N = 1, 2, 4, 8 back to back); else (2) the last figure committed from an
+    N = 1 run (profiles/cpu_baseline_last.json), labelled with the host it came from; else (3) ONE bounded measurement
+    now on rank 0 (cfg2, 8 threads, one warm-up + one step: about a minute) — eight ranks never each run a baseline."""
     try:
         with open(CPU_CACHE) as fid:
             c = json.load(fid)
@@ -149,7 +155,25 @@ def cached_cpu_baseline():
             return out
     except (OSError, ValueError, KeyError):
         pass
-    return None
+    try:
+        with open(CPU_COMMITTED) as fid:
+            c = json.load(fid)
+        out = dict(c['cpu_baseline'])
+        out['carried_from'] = ('profiles/cpu_baseline_last.json: the N=1 run of %s on host %s (%s); no N=1 run of this '
+                               'host in the last day' % (c.get('commit', 'an earlier commit'), c.get('host', '?'),
+                                                         c.get('date', '?')))
+        return out
+    except (OSError, ValueError, KeyError):
+        pass
+    if not measure:
+        return None
+    from oracle import cpu_baseline as cb
+    c2 = cb.time_config('cfg2', 1, 1, threads=min(8, cb.physical_cores()))
+    return {'value': c2['utt_per_s'], 'unit': 'utterances/sec', 'cores': min(8, cb.physical_cores()), 'kind': 'port',
+            'sample': 'cfg2 (32 x 1000 x 40, 4x512 Listener + CTC), full T: 1 warm-up + 1 complete training step (%s s) of '
+                      'the reference graph restated at TF op granularity in PyTorch-CPU float32, measured by rank 0 after '
+                      'the timed region of this N > 1 run (no N=1 figure of this host or of the repository was found)'
+                      % c2['seconds_per_step']}
 
 
 def gemm_roofline(B, T, D, H, precision):
@@ -338,8 +362,10 @@ def parse_args(argv=None):
                     help='NOT a measurement: cfg2\'s recipe at 4 utterances x 64 frames, 64 units — lets the tests run the '
                          'whole multi-rank line (ranks, exchange, carried cpu_baseline, roofline object) in seconds; the '
                          'line says config.shrunk = true')
-    ap.add_argument('--allreduce', default='flat', choices=['flat', 'bucketed'],
-                    help='gradient exchange of the data-parallel mode (trainer cfg key allreduce_buckets)')
+    ap.add_argument('--allreduce', default='flat', choices=['flat', 'bucketed', 'both'],
+                    help='gradient exchange of the data-parallel mode (trainer cfg key allreduce_buckets).  both: the '
+                         'headline is timed with the flat exchange, then the same steps once more with the bucketed one '
+                         '(ranks.allreduce_both) — one run answers which of the two the scaling curve should use')
     return ap.parse_args(argv)
 
 
@@ -382,7 +408,7 @@ def dry_run(args):
     from nabu_amd.computing import dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     ngpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    shared = world > max(ngpu, 0)
+    shared = dist.ranks_share_devices(world, ngpu) or (world > 1 and ngpu == 0)
     if shared and ngpu:
         os.environ['LOCAL_RANK'] = str(int(os.environ.get('LOCAL_RANK', '0')) % ngpu)
     server = dist.create_server(backend='gloo' if shared else None)
@@ -427,7 +453,7 @@ class HipWorkload(object):
                               'persistent': ops.LSTM_PERSISTENT}[args.mode]
         self.B, self.T, self.D, self.H = B, T, D, H
         self.layer_t = None
-        over = {'trainer.allreduce_buckets': 'True' if args.allreduce == 'bucketed' else 'False'}
+        over = {'trainer.allreduce_buckets': 'True' if args.allreduce == 'bucketed' else 'False'}   # (both: flat first)
         if args.gemm_precision:          # otherwise: the arithmetic the recipe ships
             over['encoder.gemm_precision'] = args.gemm_precision
         if args.workload == 'cfg1':
@@ -519,6 +545,26 @@ class HipWorkload(object):
         if not ev:
             return None
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+    def set_allreduce(self, kind):
+        '''switch the trainer's gradient exchange between measurements (--allreduce both)'''
+        tr = self.tr
+        tr.buckets = tr._make_buckets() if (kind == 'bucketed' and self.server.world_size > 1) else None
+        tr.schedule_log = [] if tr.buckets is not None else None
+        tr.allreduce_ms = []
+
+    def rank_paths(self):
+        '''(recurrence persistent?, decoder persistent?) of THIS rank: 1 / 0, decoder -1 when the model has none'''
+        import ctypes
+        _hip, layer = self._hip, self.layer
+        desc = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), self.B, self.T, self.D, self.H, self.T, layer.LSTM_MODE[0], 0)
+        rec = int(bool(_hip.lib().nabu_blstm_uses_persistent(ctypes.byref(desc))))
+        dec = -1
+        from nabu_amd.neuralnetworks.models.ed_decoders import rnn_decoder
+        last = getattr(rnn_decoder.dynamic_decode, 'last_paths', None)      # (forward, backward) of the last decode call
+        if last is not None:
+            dec = int(bool(last[0])) + 2 * int(bool(last[1]))               # bit 0 forward, bit 1 backward persistent
+        return rec, dec
 
     def bucket_schedule(self):
         """bucketed exchange: (bucket, 'hook' = between a recurrence and the products behind it / after the deferred
@@ -628,11 +674,35 @@ def run(args, server, wl):
     dt_rank = time.perf_counter() - t0
     wl.end_timed_region()
     wl.check()
+    ar_ms = wl.allreduce_ms_per_step()
+    ar_ranks = wl.gather(ar_ms if ar_ms is not None else 0.0)
+    both = None
+    if getattr(args, 'allreduce', 'flat') == 'both' and world > 1:
+        # the same steps once more with the bucketed exchange: same protocol, not the headline
+        wl.set_allreduce('bucketed')
+        for i in range(max(args.warmup, 1)):
+            wl.step(i)
+        wl.sync()
+        server.barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            wl.step(i)
+        wl.sync()
+        server.barrier()
+        dt_b = wl.reduce_max([time.perf_counter() - t1])[0]
+        wl.check()
+        ar_b = wl.allreduce_ms_per_step()
+        ar_b_ranks = wl.gather(ar_b if ar_b is not None else 0.0)
+        both = {'flat': None, 'bucketed': {'ms_per_step': round(dt_b / args.steps * 1e3, 3),
+                                            'value': round(world * wl.units_per_step * args.steps / dt_b, 2),
+                                            'exposed_allreduce_ms_per_step': [round(v, 3) for v in ar_b_ranks],
+                                            'bucket_schedule_last_step': wl.bucket_schedule()}}
+        wl.set_allreduce('flat')
     alt = wl.alt(args.steps)
     red = wl.reduce_max([dt_rank] + [a[2] for a in alt])
     per_rank = wl.gather(dt_rank)
-    ar_ms = wl.allreduce_ms_per_step()
-    ar_ranks = wl.gather(ar_ms if ar_ms is not None else 0.0)
+    paths = wl.rank_paths() if hasattr(wl, 'rank_paths') else (-1, -1)
+    rec_ranks, dec_ranks = wl.gather(paths[0]), wl.gather(paths[1])
     dt = red[0]
     if rank != 0:
         return None
@@ -644,10 +714,19 @@ def run(args, server, wl):
     out['config'].update({'global_batch': world * wl.units_per_step, 'parallelism': 'dp%d' % world})
     out['ranks'] = {'world_size_seen': world, 'backend': server.backend,
                     'ms_per_step_per_rank': [round(t / args.steps * 1e3, 3) for t in per_rank],
-                    'allreduce': getattr(args, 'allreduce', 'flat') if world > 1 else None,
+                    'allreduce': ('flat' if getattr(args, 'allreduce', 'flat') == 'both' else getattr(args, 'allreduce', 'flat'))
+                                 if world > 1 else None,
                     'allreduce_ms_per_step': [round(v, 3) for v in ar_ranks] if world > 1 else None,
                     'ranks_share_devices': bool(getattr(server, 'shared_devices', False)),
+                    # which path every rank ran: a rank that fell to the step-wise recurrence (occupancy check, a
+                    # partitioned device) or the decoder's step chain shows here, not only as a slow rank
+                    'recurrence_persistent_per_rank': [int(v) for v in rec_ranks],
+                    'decoder_persistent_per_rank': [int(v) for v in dec_ranks],
                     'bucket_schedule_last_step': wl.bucket_schedule()}
+    if both is not None:
+        both['flat'] = {'ms_per_step': out['ms_per_step'], 'value': out['value'],
+                        'exposed_allreduce_ms_per_step': out['ranks']['allreduce_ms_per_step']}
+        out['ranks']['allreduce_both'] = both
     for i, (key, conf, _, alt_loss) in enumerate(alt):
         n = args.steps
         step_bytes_total = 2 * 2 * sum(wl.layer_t) * step_bytes(wl.B, wl.H)
@@ -662,6 +741,7 @@ def run(args, server, wl):
             'roofline_frac': round(step_bytes_total / (red[1 + i] / n) / (HBM_PEAK_GBS * 1e9), 4)}
     if not args.no_cpu_baseline and wl.wants_cpu_baseline():
         out['cpu_baseline'] = cpu_baseline() if world == 1 else cached_cpu_baseline()
+
     return out
 
 

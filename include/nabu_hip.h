@@ -202,16 +202,16 @@ int nabu_colsum_f32(int M, int N, const float *A, int lda, float beta, float *ou
  * for the backward pass; ws (nabu_blstm_ws_bytes) is scratch.
  * mode: NABU_LSTM_AUTO picks the persistent whole-sequence kernel when the
  * shape is supported, else one launch per timestep.
- * Persistent kernels, by shape (nabu_amd/csrc/): H in {128, 256, 512} on a whole MI355X (256 CUs): the recurrent
- * product on the 16-bit matrix pipe — by default three fp16 plane products of row-scaled operands (lstm_persist_mxh.hip:
- * launches of up to 32 batch rows, 8 per unit, 16 hidden units per workgroup; lstm_persist_mxf.hip: 33..64 rows at
- * H = 512 as sixteen units of 8 rows, 32 hidden units per workgroup), with NABU_PERSIST_MXH=0 — and for 33..64 rows at
- * H < 512 in the backward pass — seven bf16 plane products of exactly split operands (lstm_persist_mx.hip,
- * lstm_persist_mx16.hip); both fp32-equivalent: outputs and gradients agree with the exact-fp32 kernels to rounding and
- * are as close to a float64 layer (tests/test_hip_fullsize.py); larger batches as consecutive launches; otherwise
- * (H = 64, fewer CUs, NABU_PERSIST_MX=0) the exact-fp32 v_mfma_f32_4x4x1 kernels of
- * lstm_persist.hip.  All need their whole grid co-resident: every launch is validated against the occupancy query
- * first (all chunks of a call before the first is enqueued) and NABU_LSTM_AUTO steps instead where it does not fit. */
+ * Persistent kernels, by shape (nabu_amd/csrc/), three families: H in {128, 256, 512} on a whole MI355X (256 CUs): the
+ * recurrent product on the 16-bit matrix pipe as three fp16 plane products of row-scaled operands — lstm_persist_mxh.hip:
+ * launches of up to 32 batch rows, 8 per unit, 16 hidden units per workgroup (a narrow first-layer input, D <= 64, is
+ * projected inside the forward kernel); lstm_persist_mxf.hip: 33..64 rows at H = 512 as sixteen units of 8 rows, 32 hidden
+ * units per workgroup; fp32-equivalent: outputs and gradients agree with the exact-fp32 kernels to rounding and are as
+ * close to a float64 layer (tests/test_hip_fullsize.py, tests/test_hip_real_operands.py); larger batches as consecutive
+ * launches; otherwise (H = 64, fewer CUs, NABU_PERSIST_MX=0, recurrent_precision = NABU_REC_F32) the exact-fp32
+ * v_mfma_f32_4x4x1 kernels of lstm_persist.hip.  All need their whole grid co-resident: every launch is validated against
+ * the occupancy query first (all chunks of a call before the first is enqueued) and NABU_LSTM_AUTO steps instead where it
+ * does not fit. */
 #define NABU_LSTM_AUTO       0
 #define NABU_LSTM_STEPWISE   1
 #define NABU_LSTM_PERSISTENT 2

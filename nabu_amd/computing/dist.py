@@ -61,6 +61,21 @@ class ProcessGroup(object):
             dist.destroy_process_group()
 
 
+def ranks_share_devices(world, ngpu, env=None):
+    """True when THIS NODE runs more ranks than it has GPUs, i.e. ranks share a device.  Decided per node: the launcher's
+    LOCAL_WORLD_SIZE (torch.distributed.run sets it) against the visible GPU count, or a LOCAL_RANK beyond the last
+    device; the global WORLD_SIZE says nothing about it on a multi-node job (2 nodes x 8 GPUs: WORLD_SIZE 16, 8 per
+    node, nothing shared — such a job keeps RCCL).  Without either variable a single-node launch is assumed."""
+    env = os.environ if env is None else env
+    if ngpu <= 0:
+        return False
+    if 'LOCAL_WORLD_SIZE' in env:
+        return int(env['LOCAL_WORLD_SIZE']) > ngpu
+    if 'LOCAL_RANK' in env and int(env['LOCAL_RANK']) >= ngpu:
+        return True
+    return world > ngpu
+
+
 def create_server(backend=None):
     """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR /
     MASTER_PORT (set by torch.distributed.run).  Single-process when unset —
@@ -70,7 +85,7 @@ def create_server(backend=None):
     if world == 1:
         return ProcessGroup(0, 1, None)
     ngpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    shared = ngpu > 0 and world > ngpu          # more ranks than GPUs on this node: they share the devices
+    shared = ranks_share_devices(world, ngpu)
     if backend is None:
         backend = 'gloo' if (shared or not ngpu) else 'nccl'
     if ngpu:

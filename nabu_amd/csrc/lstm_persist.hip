@@ -2,11 +2,16 @@
 // layer (both directions in one launch), MI355X / gfx950.
 //
 // THIS FILE: the host side of every persistent recurrent kernel (geometry, workspace, validation, chunking: run /
-// run_chunk at the end) and the exact-fp32 kernels of rounds 1-3 (v_mfma_f32_4x4x1, 4 or 8 rows per unit) — since
-// round 4 the fallback for H = 64, partitioned devices and NABU_PERSIST_MX=0.  The kernels that run by default for
-// H in {128, 256, 512} multiply on the bf16 matrix pipe over exactly split operands: lstm_persist_mx.hip (launches of up
-// to 32 rows, 8 per unit) and lstm_persist_mx16.hip (33 .. 64 rows, 16 per unit); they share the exchange protocol
-// described below (lstm_persist_dev.h).
+// run_chunk at the end) and the exact-fp32 kernels of rounds 1-3 (v_mfma_f32_4x4x1, 4 or 8 rows per unit).
+// DISPATCH (run_chunk), three kernel families since round 5:
+//   1. lstm_persist_mxf.hip   fp16-plane product, 32 hidden units per workgroup: 33 .. 64 rows at H = 512 in one launch;
+//   2. lstm_persist_mxh.hip   fp16-plane product, 16 hidden units per workgroup: launches of <= 32 rows, H in {128, 256, 512}
+//                             (larger batches as consecutive launches) — the default on a whole MI355X;
+//   3. this file              exact fp32: H = 64, devices with fewer than 256 CUs, NABU_PERSIST_MX=0, and per call
+//                             nabu_blstm_desc.recurrent_precision = NABU_REC_F32 (bench.py's fp32_end_to_end leg).
+// All share the exchange protocol described below (lstm_persist_dev.h); the bf16-plane kernels of round 4's first half and
+// the 16-rows-per-unit kernels are parked under tools/experiments/variants/ (lstm_persist_mx.hip, lstm_persist_mx16.hip,
+// lstm_persist_mxh16_fwd.inc).
 //
 // WHY: the recurrence is 2 x sum(T_l) strictly sequential steps per pass; one
 // launch per timestep pays a kernel boundary (>=1.5 us) plus a cold re-read of
@@ -688,33 +693,20 @@ static int cu_count() {
   return cached;
 }
 
-// lstm_persist_mx.hip: 8 rows per unit, bf16-plane product (the default wherever it applies; NABU_PERSIST_MX=0: off)
+// lstm_persist_mxh.hip: the fp16-plane kernels — three fp16 plane products of row-scaled operands, 8 rows per unit, launches
+// of <= 32 rows (the default wherever H is 128, 256 or 512 on a whole MI355X; NABU_PERSIST_MX=0 or
+// nabu_blstm_desc.recurrent_precision = NABU_REC_F32: the exact-fp32 kernels of this file)
 bool lstm_mx_supported(int B, int H);
 int lstm_mx_chunk_rows();
-size_t lstm_mx_ring_bytes(bool fwd, int H);
-int lstm_mx_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry);
-// lstm_persist_mxh.hip: the same kernels with three fp16 plane products of row-scaled operands instead of seven bf16 plane
-// products (NABU_PERSIST_MXH=0: the bf16-plane kernels); rings never larger than lstm_mx_ring_bytes
-bool lstm_mxh_on(bool fwd);
 size_t lstm_mxh_ring_bytes(bool fwd, int H);
 int lstm_mxh_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry);
-size_t lstm_mxh16_ring_bytes(int H);
-int lstm_mxh16_fwd_launch(int H, const PersistArgs &a, hipStream_t stream, bool dry);
 size_t lstm_mxh_xws_bytes(int B, int T);
 int lstm_mxh_prepare_x(int B, int T, int D, const float *x, void *ws, hipStream_t stream);
-// lstm_persist_mxf.hip: fp16 planes, 32 hidden units per workgroup, two units of 8 rows per XCD: 33 .. 64 batch rows at
-// H = 512 in one launch (NABU_PERSIST_MXF=0: the 16-rows-per-unit kernels below)
+// lstm_persist_mxf.hip: the same arithmetic with 32 hidden units per workgroup, two units of 8 rows per XCD: 33 .. 64 batch
+// rows at H = 512 in one launch (NABU_PERSIST_MXF=0: launches of <= 32 rows on the kernels above)
 bool lstm_mxf_supported(int B, int H);
 size_t lstm_mxf_ring_bytes(bool fwd, int H);
 int lstm_mxf_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry);
-// lstm_persist_mx16.hip: 16 rows per unit, 33 .. 64 batch rows in one launch (NABU_PERSIST_MX16=0: chunks of 32 rows)
-size_t lstm_mx16_ring_bytes(bool fwd, int H);
-int lstm_mx16_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry);
-static bool mx16_on() {
-  static int env = -1;
-  if (env < 0) { const char *e = getenv("NABU_PERSIST_MX16"); env = e ? atoi(e) : 1; }
-  return env != 0;
-}
 
 // geometry: BS = 4 (two 256-thread workgroups per CU) when the batch fits, else BS = 8
 bool lstm_persist_fuses_input(int B, int T, int D, int H);
@@ -736,10 +728,10 @@ static int pick_bs(int B, int H, bool fwd) {
 // launch takes up to 64 rows (BS = 8, two workgroups per CU), B = 96 is a launch of 64 and one of 32.
 static int chunk_rows(int B, int H, bool fwd, int T = 0) {
   if (lstm_mx_supported(B, H)) {
-    // up to 32 rows: 8 per unit; 33 .. 64: 16 per unit; more: launches of 64 rows (and a remainder) — unless a slab of
-    // 64 rows x T frames of gates is beyond the 32-bit buffer offsets of one launch: then launches of 32 rows
-    int c = lstm_mx_chunk_rows() * (mx16_on() && B > lstm_mx_chunk_rows() ? 2 : 1);
-    if (T > 0 && c > lstm_mx_chunk_rows() && (size_t)c * T * 4 * H * 4 >= 0x80000000ull) c = lstm_mx_chunk_rows();
+    // up to 32 rows: one launch of 8-row units; 33 .. 64 rows at H = 512: one launch of lstm_persist_mxf.hip (unless a slab
+    // of 64 rows x T frames of gates is beyond the 32-bit buffer offsets of one launch); otherwise launches of 32 rows
+    int c = lstm_mx_chunk_rows();
+    if (B > c && lstm_mxf_supported(B > 2 * c ? 2 * c : B, H) && !(T > 0 && (size_t)2 * c * T * 4 * H * 4 >= 0x80000000ull)) c *= 2;
     return B < c ? B : c;
   }
   if (pick_bs(B, H, fwd)) return B;
@@ -777,14 +769,10 @@ size_t lstm_persist_ws_bytes(int B, int T, int H) {
   }
   if (lstm_mx_supported(B, H))
     for (int f = 0; f < 2; ++f) {
-      if (lstm_mx_ring_bytes(f != 0, H) > m) m = lstm_mx_ring_bytes(f != 0, H);
       if (lstm_mxh_ring_bytes(f != 0, H) > m) m = lstm_mxh_ring_bytes(f != 0, H);
-      if (mx16_on() && B > lstm_mx_chunk_rows()) {
-        if (lstm_mx16_ring_bytes(f != 0, H) > m) m = lstm_mx16_ring_bytes(f != 0, H);
-        if (f && lstm_mxh16_ring_bytes(H) > m) m = lstm_mxh16_ring_bytes(H);
-        // (a batch of more than 64 rows runs as launches of 64 rows and a remainder)
-        if (lstm_mxf_supported(B > 64 ? 64 : B, H) && lstm_mxf_ring_bytes(f != 0, H) > m) m = lstm_mxf_ring_bytes(f != 0, H);
-      }
+      // (a batch of more than 64 rows runs as launches of 64 rows and a remainder)
+      if (B > lstm_mx_chunk_rows() && lstm_mxf_supported(B > 64 ? 64 : B, H) && lstm_mxf_ring_bytes(f != 0, H) > m)
+        m = lstm_mxf_ring_bytes(f != 0, H);
     }
   return TABLE_BYTES + m + db_part_bytes(B, H);
 }
@@ -887,16 +875,15 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
   a.rowmax_part = nullptr; a.rowmax_stride = 0;
   { const char *e = getenv("NABU_PERSIST_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   if (lstm_mx_supported(B, H)) {
-    const bool r16 = B > lstm_mx_chunk_rows();        // 33 .. 64 rows: 16 per unit
     const bool xin = fwd && x != nullptr;
-    if (xin && (r16 || !lstm_mxh_on(true) || lstm_mxf_supported(B, H) || !bias || !xws || D > 64 || D % 8))
-      return fail(NABU_EINVAL, "persistent LSTM (mx): the in-kernel input projection does not take this shape");
-    a.B = B; a.T = T; a.D = D; a.H = H; a.max_len = max_len; a.nshard = r16 ? (B + 15) / 16 : (B + 7) / 8;
+    if (xin && (lstm_mxf_supported(B, H) || B > lstm_mx_chunk_rows() || !bias || !xws || D > 64 || D % 8))
+      return fail(NABU_EINVAL, "persistent LSTM (mxh): the in-kernel input projection does not take this shape");
+    a.B = B; a.T = T; a.D = D; a.H = H; a.max_len = max_len; a.nshard = (B + 7) / 8;
     a.len = len;
     for (int i = 0; i < 2; ++i) { a.kernel[i] = kernel[i]; a.gates[i] = gates[i]; a.cs[i] = cs[i]; a.bias[i] = nullptr; }
     a.out = out; a.dout = dout; a.x = nullptr;
     a.xplanes = nullptr; a.xscale = nullptr;
-    if (xin) {       // (the planes of the whole batch were written by lstm_persist_fwd; this chunk's rows)
+    if (xin) {       // (the planes of the whole batch were written by run(); this chunk's rows)
       a.xscale = static_cast<const float *>(xws);
       a.xplanes = static_cast<const char *>(xws) + 1024 + (size_t)xrow0 * T * 256;
       a.bias[0] = bias[0]; a.bias[1] = bias[1];
@@ -907,24 +894,19 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
     a.table = static_cast<unsigned *>(ws);
     a.xbuf = static_cast<char *>(ws) + TABLE_BYTES;
     a.timeout_ticks = g_timeout_ticks;
-    if (lstm_mxh_on(fwd) && lstm_mxf_supported(B, H)) {     // 8 rows per unit, 16 units, 128 columns per workgroup
-      *shard_base += (B + 7) / 8 - a.nshard;
-      a.nshard = (B + 7) / 8;
+    if (lstm_mxf_supported(B, H)) {     // 33 .. 64 rows at H = 512: sixteen units of 8 rows, 128 gate columns per workgroup
       if (!dry)
         if (int e = ring_reset(ws, TABLE_BYTES + lstm_mxf_ring_bytes(fwd, H), stream)) return e;
       return lstm_mxf_launch(fwd, H, a, stream, dry);
     }
-    const bool f16 = lstm_mxh_on(fwd) && (!r16 || fwd);     // 16 rows per unit: the forward kernel only
-    const size_t ring = r16 ? (f16 ? lstm_mxh16_ring_bytes(H) : lstm_mx16_ring_bytes(fwd, H))
-                            : (f16 ? lstm_mxh_ring_bytes(fwd, H) : lstm_mx_ring_bytes(fwd, H));
+    if (B > lstm_mx_chunk_rows()) return fail(NABU_EINVAL, "persistent LSTM (mxh): a launch takes <= %d rows", lstm_mx_chunk_rows());
     if (!dry)
-      if (int e = ring_reset(ws, TABLE_BYTES + ring, stream)) return e;
-    if (r16) return f16 ? lstm_mxh16_fwd_launch(H, a, stream, dry) : lstm_mx16_launch(fwd, H, a, stream, dry);
-    if (f16 && !fwd && rm->part) {     // the fp16-plane backward kernel keeps the frames' maxima of dz
+      if (int e = ring_reset(ws, TABLE_BYTES + lstm_mxh_ring_bytes(fwd, H), stream)) return e;
+    if (!fwd && rm->part) {     // the backward kernel keeps the frames' maxima of dz
       a.rowmax_part = rm->part; a.rowmax_stride = rm->stride;
       rm->kept = true;
     }
-    return f16 ? lstm_mxh_launch(fwd, H, a, stream, dry) : lstm_mx_launch(fwd, H, a, stream, dry);
+    return lstm_mxh_launch(fwd, H, a, stream, dry);
   }
   int BS = pick_bs(B, H, fwd);
   if ((a.dbg & 16) && 2 * ((B + 7) / 8) * (H / UC) <= cu_count()) BS = 8;
@@ -985,7 +967,7 @@ bool lstm_persist_fuses_input(int B, int T, int D, int H) {
   if (env < 0) { const char *e = getenv("NABU_PERSIST_FUSE_INPUT"); env = e ? atoi(e) : 1; }
   if (!env || !lstm_persist_supported(B, T, H)) return false;
   if (lstm_mx_supported(B, H))     // fp16-plane kernels: any narrow input of <= 64 features, one launch of <= 32 rows
-    return D <= 64 && D % 8 == 0 && B <= lstm_mx_chunk_rows() && lstm_mxh_on(true) && !lstm_mxf_supported(B, H);
+    return D <= 64 && D % 8 == 0 && B <= lstm_mx_chunk_rows() && !lstm_mxf_supported(B, H);
   if (D != 40) return false;
   if ((size_t)B * T * D * 4 >= 0x80000000ull) return false;
   const int Bc = chunk_rows(B, H, true, T);

@@ -1,5 +1,5 @@
 // lstm_persist_dev.h — device-side helpers shared by the persistent recurrent kernels
-// (lstm_persist.hip: exact-fp32 4x4x1 product, 4 / 8 rows per unit; lstm_persist_mx.hip: bf16-plane product on
+// (lstm_persist.hip: exact-fp32 4x4x1 product, 4 / 8 rows per unit; lstm_persist_mxh.hip / _mxf.hip: fp16-plane product on
 // v_mfma_f32_16x16x32_bf16, 8 rows per unit).  Protocol description: header of lstm_persist.hip.
 #pragma once
 #include "lstm_persist.h"
@@ -139,6 +139,24 @@ struct SpinGuard {
     return wall_clock64() - t0 > p.timeout_ticks;
   }
 };
+
+// A poll round that did not find its data (fp16-plane kernels: lstm_persist_mxh.hip, lstm_persist_mxf.hip): bounded-spin
+// bookkeeping in ONE place — the clock is first read here, every 8th failed round the wave naps, looks at the status word
+// (another workgroup gave up, or an earlier launch on this workspace did) and at the clock; on expiry it raises the
+// workgroup's flag and the status word (code: 1 forward, 2 backward, + 4 x block) and tells the caller to leave its loop.
+__device__ __forceinline__ bool poll_round_failed(const PersistArgs &p, int *flag, int lane, int &fails,
+                                                  unsigned long long &t_fail, int code) {
+  if (fails == 0) t_fail = wall_clock64();
+  if ((++fails & 7) != 0) return false;
+  __builtin_amdgcn_s_sleep(1);
+  if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && wall_clock64() - t_fail <= p.timeout_ticks)
+    return false;
+  if (lane == 0) {
+    flag[0] = 1;
+    __hip_atomic_store(p.status, code + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return true;
+}
 
 // NABU_PERSIST_DEBUG & 4: block 0 / thread 0 records the wall clock (10 ns units) at phase
 // boundaries of the middle timestep into status[320 + 32*pass + i] (pass 0 fwd, 1 bwd).

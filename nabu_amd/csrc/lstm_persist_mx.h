@@ -1,5 +1,5 @@
 // lstm_persist_mx.h — device helpers shared by the bf16-plane persistent recurrent kernels
-// (lstm_persist_mx.hip: 8 batch rows per unit; lstm_persist_mx16.hip: 16 rows per unit, batches of 33..64 rows)
+// (lstm_persist_mxh.hip, lstm_persist_mxf.hip; the bf16 helpers served the parked kernels of tools/experiments/variants/)
 #pragma once
 #include "lstm_persist_dev.h"
 

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   fetch_x(0);
   wait_vm<0>();
   __builtin_amdgcn_s_waitcnt(0x0F70);
-  // results of step s go to HBM at the top of step s + 1, behind that step's exchange loads (lstm_persist_mx.hip)
+  // results of step s go to HBM at the top of step s + 1, behind that step's exchange loads (lstm_persist_mxh.hip)
   float d_g[4] = {0.f, 0.f, 0.f, 0.f}, d_c = 0.f, d_h = 0.f;
   int d_t = 0, d_to = 0;
   bool d_act = false, d_any = false;
@@ -192,18 +192,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int j = 0; j < NKS; ++j) mx = mx_max4(mx, b1[j]);
         if (__all(mx != SENT)) break;
-        if (fails == 0) t_fail = wall_clock64();
-        if ((++fails & 7) == 0) {
-          __builtin_amdgcn_s_sleep(1);
-          if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-              wall_clock64() - t_fail > p.timeout_ticks) {
-            if (lane == 0) {
-              flag[0] = 1;
-              __hip_atomic_store(p.status, 1 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            break;
-          }
-        }
+        if (poll_round_failed(p, flag, lane, fails, t_fail, 1)) break;
       }
     } else {
       result_stores();
@@ -452,7 +441,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       int fails = 0;
       bool first = true;
       const bool want1 = (((it - 1) >> 1) & 1) != 0;        // the tag of the pieces published in iteration it - 1
-      __builtin_amdgcn_s_sleep(4);      // (lstm_persist_mx.hip: a first round issued at once fails)
+      __builtin_amdgcn_s_sleep(4);      // (a first round issued at once fails)
       for (;;) {
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps)
@@ -469,18 +458,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             o |= v[ps][i].x | v[ps][i].y | v[ps][i].z | v[ps][i].w;
           }
         if (__all(want1 ? (a & 1u) != 0 : (o & 1u) == 0)) break;
-        if (fails == 0) t_fail = wall_clock64();
-        if ((++fails & 7) == 0) {
-          __builtin_amdgcn_s_sleep(1);
-          if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-              wall_clock64() - t_fail > p.timeout_ticks) {
-            if (lane == 0) {
-              flag[0] = 1;
-              __hip_atomic_store(p.status, 2 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            break;
-          }
-        }
+        if (poll_round_failed(p, flag, lane, fails, t_fail, 2)) break;
       }
     } else {
       dz_stores();

@@ -1,4 +1,4 @@
-// lstm_persist_mxh.hip — the persistent recurrence of lstm_persist_mx.hip with its product as THREE fp16 plane
+// lstm_persist_mxh.hip — the persistent whole-sequence recurrence with its product as THREE fp16 plane
 // products of row-scaled operands (the arithmetic of the step's dense products, gemm_pk.hip NP = 2 / DESIGN.md
 // section 4.4) instead of seven bf16 plane products: half the matrix instructions per step.  Round 4.
 //
@@ -16,10 +16,15 @@
 // Against float64 the recurrence with this product is as close as with the exact-fp32 kernels
 // (tests/test_hip_fullsize.py::test_plane_recurrence_is_as_close_to_float64_as_the_fp32_kernels).
 //
-// GEOMETRY, PROTOCOL, DEFERRED STORES: lstm_persist_mx.hip (same units, rings, in-order arguments).  What changes: the
-// forward exchange cell array is [k / 8][16 = plane * 8 + row] (4 loads per lane instead of 6, 4 KiB per wave), the N
-// side of every instruction is B = [h | l] of 8 rows, 32 instructions per wave and step: W_l.B, W_h.B per (16 columns x
-// 32 k).
+// GEOMETRY.  unit = (direction, 8 batch rows) = the 32 workgroups (256 threads, ONE per CU, one wave per SIMD) of ONE XCD:
+// block b -> unit b % 8 -> XCD b % 8 (checked at run time: a unit that is not co-located publishes write-through); a
+// workgroup owns 16 hidden units = 64 gate columns = a [H x 64] slice of W_h held as planes in registers for the whole
+// sequence.  Forward exchange slot of a unit: cells of 16 bytes = 8 consecutive k of one (plane, row),
+// [k / 8][16 = plane * 8 + row] — a lane's 16-byte load IS its B operand, the poll loop is the operand fetch; the N side
+// of every instruction is B = [h | l] of 8 rows, 32 instructions per wave and step: W_l.B, W_h.B per (16 columns x 32 k).
+// PROTOCOL ("the data is the flag", rings, in-order arguments, deferred result stores): header of lstm_persist.hip and
+// lstm_persist_mxh.h; the bf16-plane predecessors of these kernels (rounds 4a: lstm_persist_mx.hip, lstm_persist_mx16.hip)
+// are parked under tools/experiments/variants/.
 #include "lstm_persist_mxh.h"
 
 namespace nabu {
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   wait_vm<0>();
   __builtin_amdgcn_s_waitcnt(0x0F70);
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  // RESULT STORES ARE DEFERRED to the top of the next step, behind its exchange loads (lstm_persist_mx.hip); always
+  // RESULT STORES ARE DEFERRED to the top of the next step, behind its exchange loads; always
   // issued, inactive lanes out of range: the wait counts of the loads in front stay exact
   float d_g0 = 0.f, d_g1 = 0.f, d_v = 0.f;
   int d_t = 0, d_to = 0;
@@ -280,18 +285,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int j = 0; j < NKS; ++j) mx = mx_max4(mx, b1[j]);
         if (__all(mx != SENT)) break;
         // a failed round: bounded-spin bookkeeping (the clock is first read here)
-        if (fails == 0) t_fail = wall_clock64();
-        if ((++fails & 7) == 0) {
-          __builtin_amdgcn_s_sleep(1);
-          if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-              wall_clock64() - t_fail > p.timeout_ticks) {
-            if (lane == 0) {
-              flag[0] = 1;
-              __hip_atomic_store(p.status, 1 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            break;
-          }
-        }
+        if (poll_round_failed(p, flag, lane, fails, t_fail, 1)) break;
       }
     } else {
       result_stores();
@@ -390,253 +384,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       d_v = gp ? (act ? h_new : 0.f) : c_new;
     }
     MXH_STAMP(0, 5);
-  }
-  result_stores();
-}
-
-// ===========================================================================
-// forward, SIXTEEN rows per unit (batches of 33 .. 64 rows; geometry and protocol of lstm_persist_mx16.hip): one plane of
-// h fills the N side, three instructions per (16 columns x 32 k) — W_l.h_h, W_h.h_l, W_h.h_h — where the bf16-plane
-// kernel issues six; cells [k / 8][32 = plane * 16 + row], 8 KiB per wave and step instead of 12
-constexpr int MXHR16 = 16;
-template <int H>
-struct Mxh16FwdLds {
-  static constexpr int ROWF = 17 * 4;                          // floats per (wave, row): 16 units x 4 gates + pad
-  static constexpr int PART = 0;                               // [2][4 waves][16 rows][ROWF]
-  static constexpr int XST = PART + 2 * 4 * MXHR16 * ROWF;     // [2][4 gates][256] prefetched x-projection
-  static constexpr int FLAG = XST + 2 * 4 * 256;
-  static constexpr int TOTAL = FLAG + 4;
-};
-
-template <int H>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_mxh16_fwd_kernel(PersistArgs p) {
-  using L = Mxh16FwdLds<H>;
-  constexpr int P = H / UC;
-  constexpr int KW = H / 4;          // k values multiplied by one wave
-  constexpr int NKS = KW / 32;       // k-steps of 32 per wave
-  static_assert(NKS >= 1, "mxh16 forward: H >= 128");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *part = smem + L::PART, *xst = smem + L::XST;
-  int *flag = reinterpret_cast<int *>(smem + L::FLAG);
-
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  const int NU = 2 * p.nshard;
-  int unit, slot;
-  mx_identity(&unit, &slot);
-  if (unit >= NU) return;
-  const int dir = unit & 1, shard = unit >> 1;
-  const int U0 = slot * UC, b0 = shard * MXHR16;
-  const int T = p.T;
-  const int n = lane & 15, q = lane >> 4;          // matrix phase: n = batch row (N index), q = k group / column group
-  const int u16 = lane & 15, r4 = lane >> 4;       // finishing phase: (row 4 w + r4, unit u16), one per lane
-  const int frow = 4 * w + r4, fb = b0 + frow;
-  const int n_f = fb < p.B ? p.len[fb] : 0;
-
-  // W_h slice as two scaled fp16 planes (A operands): column (gate c, unit U0 + n), k = w KW + 32 j + 8 q + e; column
-  // scales and inv[] as in lstm_mxh_fwd_kernel (the lane that multiplies column n finishes unit n)
-  u32x4 Wp[2][4][NKS];
-  float inv[4];
-  {
-    const float *Wh = p.kernel[dir] + ((size_t)p.D + (size_t)w * KW + 8 * q) * 4 * H + U0 + n;
-    float mx[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      mx[c] = 0.f;
-#pragma unroll
-      for (int j = 0; j < NKS; ++j)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) mx[c] = fmaxf(mx[c], fabsf(Wh[((size_t)32 * j + e) * 4 * H + (size_t)c * H]));
-      mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], 16));
-      mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], 32));
-      if (q == 0) part[w * 64 + c * 16 + n] = mx[c];
-    }
-    __syncthreads();
-    float sc[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float m = fmaxf(fmaxf(part[c * 16 + n], part[64 + c * 16 + n]), fmaxf(part[128 + c * 16 + n], part[192 + c * 16 + n]));
-      sc[c] = mxh_scale_of(m);
-      inv[c] = mxh_inv_scale_of(m) * MXH_HINV;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int j = 0; j < NKS; ++j) {
-        float x[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = Wh[((size_t)32 * j + e) * 4 * H + (size_t)c * H] * sc[c];
-        mxh_split8(x, Wp[0][c][j], Wp[1][c][j]);
-      }
-  }
-  float c_state = 0.f, h_state = 0.f;
-  if (!unit_handshake(p, unit, slot, MXNU, P, flag)) return;
-  const bool coloc = flag[1] != 0;
-
-  // exchange slot of a unit: cells of 16 bytes = 8 consecutive k of one (plane, row): [k / 8][32 = plane * 16 + row]
-  constexpr int NSL = 2 * MXHR16;
-  const size_t slot_bytes = (size_t)NSL * H * 2;
-  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-      p.xbuf + (size_t)unit * RING * slot_bytes, 0, (int)(RING * slot_bytes), 0x00020000);
-  constexpr int KGW = KW / 8;
-  constexpr unsigned KSTEP_BYTES = 4 * NSL * 16;
-  const unsigned off0 = (unsigned)((((size_t)w * KGW + q) * NSL + n) * 16);      // plane p: + p * 256
-  const int ppl = u16 & 7;
-  const bool pub_lane = ppl < 2;
-  const unsigned pub_off = (unsigned)((((size_t)(U0 >> 3) + (u16 >> 3)) * NSL + ppl * MXHR16 + frow) * 16);
-  const u32x4 sent4 = {SENT, SENT, SENT, SENT};
-
-  // x-projection of step s (bias included): the four gates of (row frow, unit u16), one step ahead by LDS-DMA
-  const i32x4 rg = raw_rsrc(p.gates[dir], (unsigned)((size_t)p.B * T * 4 * H * 4));
-  const unsigned goff = (unsigned)(((size_t)fb * T * 4 * H + U0 + u16) * 4);
-  auto fetch_x_part = [&](int s, int g) {
-    const int t = dir ? n_f - 1 - s : s;
-    const bool act = s < n_f && !(p.dbg & 64);
-    prefetch_lds_b32(rg, act ? goff + (unsigned)t * (unsigned)(16 * H) + (unsigned)g * (unsigned)(4 * H) : OOB, smem,
-                     xst + (s & 1) * 1024 + g * 256 + 64 * w);
-  };
-  auto fetch_x = [&](int s) {
-    for (int g = 0; g < 4; ++g) fetch_x_part(s, g);
-  };
-  fetch_x(0);
-  wait_vm<0>();
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  // results of step s go to HBM at the top of step s + 1, behind that step's exchange loads (lstm_persist_mx.hip)
-  float d_g[4] = {0.f, 0.f, 0.f, 0.f}, d_c = 0.f, d_h = 0.f;
-  int d_t = 0, d_to = 0;
-  bool d_act = false, d_any = false;
-  __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(p.gates[dir], 0, (int)((size_t)p.B * T * 4 * H * 4), 0x00020000);
-  __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(p.cs[dir], 0, (int)((size_t)p.B * T * H * 4), 0x00020000);
-  __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)p.B * T * 2 * H * 4), 0x00020000);
-  const unsigned coff = (unsigned)(((size_t)fb * T * H + U0 + u16) * 4);
-  const unsigned ooff = (unsigned)(((size_t)fb * T * 2 * H + (size_t)dir * H + U0 + u16) * 4);
-  const bool st_ok = fb < p.B && !(p.dbg & 128);
-  auto result_stores = [&]() {
-    const bool on = d_any && st_ok;
-    const unsigned go_ = (on && d_act) ? goff + (unsigned)d_t * (unsigned)(16 * H) : OOB;
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d_g[g]), rsg,
-                                            go_ == OOB ? OOB : go_ + (unsigned)g * (unsigned)(4 * H), 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d_c), rsc,
-                                          (on && d_act) ? coff + (unsigned)d_t * (unsigned)(4 * H) : OOB, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d_h), rso,
-                                          on ? ooff + (unsigned)d_to * (unsigned)(8 * H) : OOB, 0, 0);
-  };
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
-  for (int s = 0; s < p.max_len; ++s) {
-    mxf32x4 acc[4];
-    unsigned long long t_fail = 0;
-    int fails = 0;
-    // (a) h_{s-1} as planes: the poll loop IS the operand fetch (8 KiB of full lines per wave)
-    u32x4 bp[2][NKS];
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-      for (int j = 0; j < NKS; ++j) bp[pl][j] = zero4;
-    if (s > 0 && !(p.dbg & 1)) {
-      const unsigned base = (unsigned)(((s - 1) % RING) * slot_bytes);
-      bool first = true;
-      for (;;) {
-        unsigned mx = 0u;
-#pragma unroll
-        for (int j = 0; j < NKS; ++j)
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl)
-            bp[pl][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + off0 + pl * 256u + j * KSTEP_BYTES, 0, 16);
-        if (first) { result_stores(); first = false; }
-#pragma unroll
-        for (int j = 0; j < NKS; ++j)
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl) mx = mx_max4(mx, bp[pl][j]);
-        if (__all(mx != SENT)) break;
-        if (fails == 0) t_fail = wall_clock64();
-        if ((++fails & 7) == 0) {
-          __builtin_amdgcn_s_sleep(1);
-          if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-              wall_clock64() - t_fail > p.timeout_ticks) {
-            if (lane == 0) {
-              flag[0] = 1;
-              __hip_atomic_store(p.status, 1 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            break;
-          }
-        }
-      }
-    } else {
-      result_stores();
-      wait_vm<0>();
-    }
-    // (b) product: 4 column tiles (gate c) x NKS k-steps x {W_l.h_h, W_h.h_l, W_h.h_h}, small terms first; next step's
-    // x-projection is requested from inside the matrix stream
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = (mxf32x4){0.f, 0.f, 0.f, 0.f};
-    if (s > 0 && !(p.dbg & 2)) {
-#pragma unroll
-      for (int j = 0; j < NKS; ++j) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = MXH_MFMA(Wp[1][c][j], bp[0][j], acc[c]);
-        if (j == 0) { fetch_x_part(s + 1, 0); __builtin_amdgcn_sched_barrier(0); }
-        if (j == 1 || NKS == 1) { fetch_x_part(s + 1, 3); __builtin_amdgcn_sched_barrier(0); }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = MXH_MFMA(Wp[0][c][j], bp[1][j], acc[c]);
-        if (j == 0) { fetch_x_part(s + 1, 1); __builtin_amdgcn_sched_barrier(0); }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = MXH_MFMA(Wp[0][c][j], bp[0][j], acc[c]);
-        if (j == 0) { fetch_x_part(s + 1, 2); __builtin_amdgcn_sched_barrier(0); }
-      }
-    } else {
-      fetch_x(s + 1);
-    }
-    // partial sums -> LDS [wave][row n][unit 4 q + i][4 gates]
-    float *const pbuf = part + (s & 1) * (4 * MXHR16 * L::ROWF);
-    {
-      float *d = pbuf + ((size_t)(w * MXHR16 + n)) * L::ROWF + (4 * q) * 4;
-      *reinterpret_cast<mxf32x4 *>(d) = (mxf32x4){acc[0].x, acc[1].x, acc[2].x, acc[3].x};
-      *reinterpret_cast<mxf32x4 *>(d + 4) = (mxf32x4){acc[0].y, acc[1].y, acc[2].y, acc[3].y};
-      *reinterpret_cast<mxf32x4 *>(d + 8) = (mxf32x4){acc[0].z, acc[1].z, acc[2].z, acc[3].z};
-      *reinterpret_cast<mxf32x4 *>(d + 12) = (mxf32x4){acc[0].w, acc[1].w, acc[2].w, acc[3].w};
-    }
-    __syncthreads();                                            // the step's only barrier
-    if (flag[0]) return;
-
-    // (c) gates of (row frow, unit u16): the four waves' partial sums, descaled (exact), plus the x-projection
-    mxf32x4 z;
-    {
-      const float *xs = xst + (s & 1) * 1024 + tid;
-      const float *pr = pbuf + (size_t)frow * L::ROWF + u16 * 4;
-      mxf32x4 sum = *reinterpret_cast<const mxf32x4 *>(pr);
-#pragma unroll
-      for (int ww = 1; ww < 4; ++ww) sum += *reinterpret_cast<const mxf32x4 *>(pr + (size_t)ww * MXHR16 * L::ROWF);
-      z = (mxf32x4){xs[0] + sum.x * inv[0], xs[256] + sum.y * inv[1], xs[512] + sum.z * inv[2], xs[768] + sum.w * inv[3]};
-    }
-    const float gi = fast_sigmoid(z.x), gj = fast_tanh(z.y), gf = fast_sigmoid(z.z + 1.0f), go = fast_sigmoid(z.w);
-    const bool act = s < n_f;
-    const float c_new = c_state * gf + gi * gj;
-    const float h_new = fast_tanh(c_new) * go;
-    if (act) { c_state = c_new; h_state = h_new; }
-
-    // (d) publish h_s as two planes: lane 8 g + pl collects the four pair words of plane pl -> one 16-byte store
-    {
-      const float hs = h_state * MXH_HSCALE;
-      const unsigned w0 = mxh_cvt2(hs, 0.f) & 0xFFFFu;
-      const float r = hs - (float)__builtin_bit_cast(mxh16x2, w0).x;
-      const unsigned w1 = mxh_cvt2(r, 0.f) & 0xFFFFu;
-      const unsigned pr0 = w0 | (mx_dppu<DPP_XOR1>(w0) << 16), pr1 = w1 | (mx_dppu<DPP_XOR1>(w1) << 16);
-      const u32x4 v0 = {pr0, mx_dppu<0x102>(pr0), mx_dppu<0x104>(pr0), mx_dppu<0x106>(pr0)};
-      const u32x4 v1 = {mx_dppu<0x111>(pr1), mx_dppu<0x101>(pr1), mx_dppu<0x103>(pr1), mx_dppu<0x105>(pr1)};
-      const u32x4 pv = ppl == 0 ? v0 : v1;
-      xstore(pv, rs, (pub_lane && s + 1 < p.max_len) ? (unsigned)((s % RING) * slot_bytes) + pub_off : OOB, coloc);
-      xstore(sent4, rs, (pub_lane && s >= 2) ? (unsigned)(((s - 2) % RING) * slot_bytes) + pub_off : OOB, coloc);
-    }
-    {
-      const int t_g = dir ? n_f - 1 - s : s;
-      d_any = true; d_act = act; d_t = t_g; d_to = act ? t_g : s;
-      d_g[0] = gi; d_g[1] = gj; d_g[2] = gf; d_g[3] = go;
-      d_c = c_new;
-      d_h = act ? h_new : 0.f;
-    }
   }
   result_stores();
 }
@@ -831,7 +578,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       unsigned long long t_fail = 0;
       int fails = 0;
       const bool want1 = (((it - 1) >> 1) & 1) != 0;        // the tag of the pieces published in iteration it - 1
-      // (a first round issued at once fails and costs the memory queue a round trip: lstm_persist_mx.hip)
+      // (a first round issued at once fails and costs the memory queue a round trip)
       __builtin_amdgcn_s_sleep(4);
       // (re-loading only the cells that failed, the others out of range, was measured: 2.11 against 2.02 us per step)
       bool first = true;
@@ -853,18 +600,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           o |= v[i].x | v[i].y | v[i].z | v[i].w;
         }
         if (__all(MXH_QVOL(kq) || (want1 ? (a & 1u) != 0 : (o & 1u) == 0))) break;
-        if (fails == 0) t_fail = wall_clock64();
-        if ((++fails & 7) == 0) {
-          __builtin_amdgcn_s_sleep(1);
-          if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-              wall_clock64() - t_fail > p.timeout_ticks) {
-            if (lane == 0) {
-              flag[0] = 1;
-              __hip_atomic_store(p.status, 2 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            break;
-          }
-        }
+        if (poll_round_failed(p, flag, lane, fails, t_fail, 2)) break;
       }
     } else {
       dz_stores();
@@ -1051,19 +787,40 @@ int lstm_mxh_prepare_x(int B, int T, int D, const float *x, void *ws, hipStream_
 
 // ===========================================================================
 // host side (called from lstm_persist.hip's run_chunk)
-// NABU_PERSIST_MXH: bit 0 = forward, bit 1 = backward
-bool lstm_mxh_on(bool fwd) {
+// NABU_PERSIST_MX=0: the exact-fp32 kernels of lstm_persist.hip for every shape (a per-call form of the same switch:
+// nabu_blstm_desc.recurrent_precision = NABU_REC_F32, lstm_persist_set_exact)
+static int mx_env() {
   static int env = -1;
-  if (env < 0) { const char *e = getenv("NABU_PERSIST_MXH"); env = e ? atoi(e) : 3; }
-  return (env & (fwd ? 1 : 2)) != 0;
+  if (env < 0) { const char *e = getenv("NABU_PERSIST_MX"); env = e ? atoi(e) : 1; }
+  return env;
 }
+
+// the geometry needs a whole MI355X: 8 XCDs of 32 CUs, one workgroup per CU
+static bool mx_device_ok() {
+  static thread_local int cached_dev = -1;
+  static thread_local bool ok = false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (dev != cached_dev) {
+    int cus = 0;
+    ok = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= NCU;
+    if (!ok) (void)hipGetLastError();
+    cached_dev = dev;
+  }
+  return ok;
+}
+
+// do the fp16-plane kernels (this file, lstm_persist_mxf.hip) take the shape?
+bool lstm_mx_supported(int B, int H) {
+  if (!mx_env() || lstm_persist_exact() || !mx_device_ok()) return false;
+  return (H == 128 || H == 256 || H == 512) && B >= 1;
+}
+int lstm_mx_chunk_rows() { return MXR * MXNU / 2; }   // 32 batch rows per launch (8 per unit)
 
 size_t lstm_mxh_ring_bytes(bool fwd, int H) {
   const size_t P = H / UC;
   return fwd ? (size_t)MXNU * RING * 16 * H * 2 : (size_t)MXNU * MXHRINGB * P * P * MXR * UC * 4;
 }
-
-size_t lstm_mxh16_ring_bytes(int H) { return (size_t)MXNU * RING * 2 * MXHR16 * H * 2; }   // forward only
 
 template <typename K>
 static int mxh_launch(K kernel, const PersistArgs &a, int grid, size_t lds, hipStream_t stream, bool dry) {
@@ -1107,19 +864,6 @@ int lstm_mxh_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, b
     NABU_MXH_CASE(512)
   }
   return fail(NABU_EUNSUP, "persistent LSTM (mxh): unsupported H=%d", H);
-}
-
-// forward of 33 .. 64 rows (16 per unit).  The backward kernels of that geometry stay lstm_persist_mx16.hip's: the
-// reduce-scatter with fp16 planes and the tagged ring of 2 was built and measured SLOWER there (H = 512: 4.05 us per step
-// against 3.27 for the two-dimensional split; H = 256: 2.61 against 2.47; tools/experiments/variants/lstm_persist_mxh16_bwd.inc)
-int lstm_mxh16_fwd_launch(int H, const PersistArgs &a, hipStream_t stream, bool dry) {
-  const int grid = MXNU * (H / UC);
-  switch (H) {
-    case 128: return mxh_launch(lstm_mxh16_fwd_kernel<128>, a, grid, Mxh16FwdLds<128>::TOTAL * sizeof(float), stream, dry);
-    case 256: return mxh_launch(lstm_mxh16_fwd_kernel<256>, a, grid, Mxh16FwdLds<256>::TOTAL * sizeof(float), stream, dry);
-    case 512: return mxh_launch(lstm_mxh16_fwd_kernel<512>, a, grid, Mxh16FwdLds<512>::TOTAL * sizeof(float), stream, dry);
-  }
-  return fail(NABU_EUNSUP, "persistent LSTM (mxh16): unsupported H=%d", H);
 }
 
 }  // namespace nabu

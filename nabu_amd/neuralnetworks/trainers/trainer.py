@@ -101,6 +101,14 @@ class Trainer(object, metaclass=ABCMeta):
             raise Exception('cut_sequence_length is not supported (it requires inputs and targets of equal '
                             'lengths and fails at graph construction in the reference, DESIGN.md section 8)')
         self.model = Model(conf=modelconf, trainlabels=int(self.conf['trainlabels']), constraint=None)
+        if bool(getattr(server, 'shared_devices', False)):
+            # ranks that share a GPU (more ranks than devices on this node: first-contact runs, tests): the persistent
+            # recurrent kernels need every CU of the device for their own workgroups, two processes' launches would each
+            # hold a part of it and spin into the bounded time-out — decided HERE, where the process group is known, for
+            # every layer this process builds (training and validation alike)
+            from nabu_amd import ops as _hip_ops
+            from nabu_amd.neuralnetworks.components import layer as _layer
+            _layer.LSTM_MODE[0] = _hip_ops.LSTM_STEPWISE
         self._graph = None
         self.schedule_log = None       # a list here records the bucketed exchange: (bucket key, 'hook' | 'final')
 

@@ -1,5 +1,5 @@
 """Helper of tests/test_hip_fullsize.py::test_alternative_persistent_kernel_families: one BLSTM layer forward + backward
-on the persistent kernels the environment of THIS process selects (NABU_PERSIST_MX / _MXH / _MX16 are read once per
+on the persistent kernels the environment of THIS process selects (NABU_PERSIST_MX, NABU_PERSIST_MXF, NABU_PERSIST_FUSE_INPUT are read once per
 process), against the step-wise fp32 kernels; prints 'FAMILY OK <largest relative error>'.
 usage: python tests/persist_family_check.py B T D H"""
 import os

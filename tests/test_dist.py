@@ -169,3 +169,15 @@ def test_single_process_group_is_trivial(monkeypatch):
     t = torch.ones(3)
     assert g.all_reduce_sum_(t) is t and g.broadcast_(t) is t
     g.barrier()
+
+
+def test_ranks_share_devices_is_decided_per_node():
+    """computing/dist.py: sharing = more ranks ON THIS NODE than visible GPUs (LOCAL_WORLD_SIZE / LOCAL_RANK), not the
+    global world size: a 2-node x 8-GPU job (WORLD_SIZE 16) shares nothing and keeps RCCL"""
+    from nabu_amd.computing.dist import ranks_share_devices as share
+    assert not share(16, 8, {'LOCAL_WORLD_SIZE': '8', 'LOCAL_RANK': '3', 'RANK': '11'})
+    assert share(2, 1, {'LOCAL_WORLD_SIZE': '2', 'LOCAL_RANK': '1', 'RANK': '1'})
+    assert share(4, 2, {'LOCAL_RANK': '2', 'RANK': '2'})            # no LOCAL_WORLD_SIZE, but a local rank beyond the devices
+    assert not share(8, 8, {'LOCAL_WORLD_SIZE': '8', 'LOCAL_RANK': '7', 'RANK': '7'})
+    assert share(2, 1, {})                                          # plain environment: a single-node launch is assumed
+    assert not share(2, 0, {'LOCAL_WORLD_SIZE': '2'})               # no GPU: nothing to share (gloo on the host)

@@ -40,7 +40,7 @@ def test_bench_two_rank_dry_run_on_one_gpu():
     assert out['ok'] and out['world_size_seen'] == 2 and out['all_reduce_sum'] == 3.0
 
 
-def _two_rank_line(extra):
+def _two_rank_line(extra, with_cache=True):
     """python bench.py --gpus 2 --shrink ...: two REAL ranks on the one-GPU test box (they share the device, so the
     group is gloo and the recurrence runs step-wise), 2 timed training steps, the whole JSON line"""
     import json
@@ -50,9 +50,12 @@ def _two_rank_line(extra):
     cache = os.path.join(root, 'gpurun_out', 'cpu_baseline_cache.json')
     os.makedirs(os.path.dirname(cache), exist_ok=True)
     keep = open(cache).read() if os.path.exists(cache) else None
-    with open(cache, 'w') as fid:      # what an N = 1 run on this host leaves behind; the N > 1 line carries it
-        json.dump({'host': socket.gethostname(), 'time': time.time(),
-                   'cpu_baseline': {'value': 0.5, 'unit': 'utterances/sec', 'cores': 8, 'kind': 'port', 'sample': 'test'}}, fid)
+    if with_cache:
+        with open(cache, 'w') as fid:      # what an N = 1 run on this host leaves behind; the N > 1 line carries it
+            json.dump({'host': socket.gethostname(), 'time': time.time(),
+                       'cpu_baseline': {'value': 0.5, 'unit': 'utterances/sec', 'cores': 8, 'kind': 'port', 'sample': 'test'}}, fid)
+    elif os.path.exists(cache):
+        os.remove(cache)
     try:
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
         r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--shrink', '--steps', '2',
@@ -60,7 +63,8 @@ def _two_rank_line(extra):
                            text=True, timeout=900)
     finally:
         if keep is None:
-            os.remove(cache)
+            if os.path.exists(cache):
+                os.remove(cache)
         else:
             with open(cache, 'w') as fid:
                 fid.write(keep)
@@ -80,6 +84,8 @@ def test_bench_two_rank_line_end_to_end_on_one_gpu():
     assert flat['cpu_baseline']['value'] == 0.5 and 'carried_from' in flat['cpu_baseline']
     assert flat['roofline']['bound'] == 'hbm' and flat['roofline']['frac'] > 0 and flat['value'] > 0
     assert flat['scaling'] == 'weak' and flat['higher_is_better'] is True
+    # which path every rank ran is part of the line (here: ranks share the device -> step-wise recurrence, no decoder)
+    assert flat['ranks']['recurrence_persistent_per_rank'] == [0, 0] and flat['ranks']['decoder_persistent_per_rank'] == [-1, -1]
     buck = _two_rank_line(['--allreduce', 'bucketed'])
     assert buck['ranks']['allreduce'] == 'bucketed'
     assert buck['final_loss'] == flat['final_loss']
@@ -88,3 +94,17 @@ def test_bench_two_rank_line_end_to_end_on_one_gpu():
                                      'Listener/features/layer1', 'Listener/features/layer0'], sched
     # every bucket but the last one to become final leaves from a hook between kernels, not at the optimiser
     assert [w for _, w in sched][:4] == ['hook'] * 4, sched
+
+
+def test_bench_two_rank_line_without_an_n1_run_and_both_exchanges():
+    """first contact with a multi-GPU node: no N = 1 run of this host left a cache, and still the line carries a
+    cpu_baseline (the last committed N = 1 figure, labelled with where it came from); --allreduce both times the flat and
+    the bucketed exchange in ONE run"""
+    line = _two_rank_line(['--allreduce', 'both'], with_cache=False)
+    cb = line['cpu_baseline']
+    assert cb is not None and cb['value'] > 0 and cb['kind'] == 'port'
+    assert 'profiles/cpu_baseline_last.json' in cb['carried_from']
+    both = line['ranks']['allreduce_both']
+    assert line['ranks']['allreduce'] == 'flat' and both['flat']['ms_per_step'] == line['ms_per_step']
+    assert both['bucketed']['ms_per_step'] > 0 and len(both['bucketed']['exposed_allreduce_ms_per_step']) == 2
+    assert [k for k, _ in both['bucketed']['bucket_schedule_last_step']][0] == 'decoder'

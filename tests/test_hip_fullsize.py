@@ -68,7 +68,7 @@ def _rel(a, b):
     (32, 500, 2048, 512),       # cfg2 layer 1
     (32, 125, 2048, 512),       # cfg2 final layer
     (8, 200, 40, 256),          # cfg1 layer 0
-    (64, 400, 2048, 512),       # cfg5 layer 2 (16 rows per unit: one launch, lstm_persist_mx16.hip)
+    (64, 400, 2048, 512),       # cfg5 layer 2 (sixteen units of 8 rows in one launch: lstm_persist_mxf.hip)
     (45, 33, 40, 128),          # 16 rows per unit with a partial last unit (3 units per direction, 13 rows in the last)
     (96, 50, 256, 256),         # a launch of 64 rows (16 per unit) and one of 32 (8 per unit)
 ])
@@ -251,12 +251,11 @@ def _blstm_float64(x, lens, p, dout):
 
 def test_plane_recurrence_is_as_close_to_float64_as_the_fp32_kernels():
     """the persistent recurrence multiplies on the 16-bit matrix pipe — three fp16 plane products of row-scaled operands
-    (lstm_persist_mxh.hip, the default; the backward exchange carries a tag in the last bit of every partial sum) or,
-    with NABU_PERSIST_MXH=0, seven bf16 plane products of exactly split operands (lstm_persist_mx.hip); the step-wise
+    (lstm_persist_mxh.hip; the backward exchange carries a tag in the last bit of every partial sum); the step-wise
     kernels multiply in fp32.  Both against a float64 layer on the device, cfg2's last-layer shape with ragged lengths,
     exact-fp32 input products for both: the plane kernels' error must not exceed the fp32 kernels' (observed with either
-    family: outputs 1.00 x, recurrent weight gradients 0.99 x, bias gradients 1.11-1.13 x; asserted with a margin for
-    run-to-run layout)."""
+    family: outputs 1.00 x, recurrent weight gradients 0.99 x, bias gradients 1.04-1.05 x with the float64 sums of round
+    5 (1.11-1.13 x before); asserted: outputs and kernel gradients <= 1.05 x, bias gradients <= 1.06 x)."""
     from nabu_amd import ops
     B, T, D, H = 32, 125, 2048, 512
     lens, x, p, dout = _layer_case(B, T, D, H, seed=77)
@@ -273,11 +272,11 @@ def test_plane_recurrence_is_as_close_to_float64_as_the_fp32_kernels():
         return float((a.double() - b).pow(2).mean().sqrt())
     e_out = rms(out_p, ref), rms(out_s, ref)
     print('\nout rms error vs float64: plane kernels %.3e, fp32 step kernels %.3e (ratio %.2f)' % (e_out + (e_out[0] / e_out[1],)))
-    assert e_out[0] <= 1.25 * e_out[1]
+    assert e_out[0] <= 1.05 * e_out[1]
     for k in ('fw_kernel', 'bw_kernel', 'fw_bias', 'bw_bias'):
         e = rms(g_p[k], gref[k]), rms(g_s[k], gref[k])
         print('%s gradient rms error vs float64: plane kernels %.3e, fp32 step kernels %.3e (ratio %.2f)' % ((k,) + e + (e[0] / e[1],)))
-        assert e[0] <= 1.25 * e[1], k
+        assert e[0] <= (1.06 if k.endswith('bias') else 1.05) * e[1], k
 
 
 @pytest.mark.parametrize('B,T,D,H,lens', [
@@ -291,7 +290,7 @@ def test_plane_recurrence_is_as_close_to_float64_as_the_fp32_kernels():
     (64, 3, 40, 256, [3] * 32 + [1] * 32),
 ])
 def test_bf16_plane_recurrence_edge_shapes(B, T, D, H, lens):
-    """the kernels of lstm_persist_mx.hip / lstm_persist_mx16.hip (H in {128, 256, 512}) on the shapes the small-H parity
+    """the fp16-plane kernels (lstm_persist_mxh.hip, lstm_persist_mxf.hip; H in {128, 256, 512}) on the shapes the small-H parity
     tests of tests/test_hip_ops.py cover for the other kernels: single frames, single rows, empty rows, partial units,
     max(len) < T — against the step-wise kernels"""
     from nabu_amd import ops
@@ -327,12 +326,10 @@ def test_bf16_plane_recurrence_edge_shapes(B, T, D, H, lens):
 
 
 @pytest.mark.parametrize('env,shape', [
-    ({'NABU_PERSIST_MXH': '0'}, (32, 60, 1024, 512)),     # bf16-plane kernels, sentinel rings (lstm_persist_mx.hip)
-    ({'NABU_PERSIST_MXH': '1'}, (20, 40, 256, 256)),      # fp16-plane forward, bf16-plane backward
-    ({'NABU_PERSIST_MXH': '2'}, (9, 33, 40, 128)),        # bf16-plane forward, fp16-plane backward with tag bits
-    ({'NABU_PERSIST_MX': '0'}, (32, 60, 1024, 512)),      # exact-fp32 4x4x1 kernels (lstm_persist.hip)
-    ({'NABU_PERSIST_MX16': '0'}, (48, 30, 256, 512)),     # 33 .. 64 rows as two launches of <= 32 rows
-    ({'NABU_PERSIST_MXF': '0'}, (48, 30, 256, 512)),      # 33 .. 64 rows at 16 rows per unit (lstm_persist_mx16.hip, mxh16 forward)
+    ({'NABU_PERSIST_MX': '0'}, (32, 60, 1024, 512)),      # exact-fp32 4x4x1 kernels (lstm_persist.hip), 4 rows per unit
+    ({'NABU_PERSIST_MX': '0'}, (9, 33, 40, 128)),         # ... with the first layer's input projection inside (XK kernel)
+    ({'NABU_PERSIST_MXF': '0'}, (48, 30, 256, 512)),      # 33 .. 64 rows as two launches of <= 32 rows (lstm_persist_mxh.hip)
+    ({'NABU_PERSIST_FUSE_INPUT': '0'}, (32, 50, 40, 512)),  # narrow input projected by a GEMM in front of the fp16-plane kernel
 ])
 def test_alternative_persistent_kernel_families(env, shape):
     """the kernel families the defaults do not select (environment switches of INTEGRATION.md) stay parity-green:
