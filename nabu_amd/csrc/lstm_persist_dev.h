@@ -69,8 +69,23 @@ __device__ __forceinline__ float dpp_f(float v, const int ctrl_sel) {
 #define QUAD_XOR2(v) dpp_f(v, 1)
 #define QUAD_BCAST(v, i) dpp_f(v, 2 + (i))
 
-__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
+// Gate functions.  v_rcp_f32 is good to one unit in the last place but not centred (mean -0.06 .. -0.08 ulp on [1, 2),
+// tools/experiments/ub/rcp_bias.hip), and 2 r - 1 turns that into a RELATIVE bias of tanh that grows as tanh shrinks: one
+// cell update came out 3e-8 low in h on average (tools/experiments/ub/cell_bias.hip; the step kernels' true divisions:
+// 4e-9) — invisible in any single value, but a sum over 32 000 frames (a bias gradient) or a thousand dependent steps
+// collects it: at T = 1000 the persistent kernels' gradients stood at 1.4-5 x the step kernels' error against float64.
+// So: one Newton step behind the reciprocal (two fused multiply-adds: centred again, mean as the division's), and tanh
+// as (1 - e) / (1 + e), whose numerator cancels nothing behind the reciprocal (half the rms error of 2 r - 1 besides);
+// the clamp keeps e = exp(-2x) finite (|tanh| = 1 to the last bit beyond |x| = 9 already).
+__device__ __forceinline__ float rcp_newton(float d) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float fast_sigmoid(float x) { return rcp_newton(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __expf(-2.0f * __builtin_amdgcn_fmed3f(x, -30.0f, 30.0f));
+  return (1.0f - e) * rcp_newton(1.0f + e);
+}
 
 __device__ __forceinline__ bool has_sentinel(const u32x4 v) {
   return v.x == SENT || v.y == SENT || v.z == SENT || v.w == SENT;

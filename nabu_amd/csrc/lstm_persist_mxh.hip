@@ -35,6 +35,9 @@ namespace nabu {
 #ifndef MXH_ACC_L
 #define MXH_ACC_L 0
 #endif
+#ifndef MXH_TAG_MODE
+#define MXH_TAG_MODE 0
+#endif
 #if MXH_ACC_L
 #define MXH_MFMA_L(a, b, c) mxf_mfma_acc(a, b, c)
 #else
@@ -702,7 +705,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           const mxf32x4 o = {(n < 8 ? lo.x : hi.x) * inv_sel[hf][t][0] * idz, (n < 8 ? lo.y : hi.y) * inv_sel[hf][t][1] * idz,
                              (n < 8 ? lo.z : hi.z) * inv_sel[hf][t][2] * idz, (n < 8 ? lo.w : hi.w) * inv_sel[hf][t][3] * idz};
           const u32x4 ob = __builtin_bit_cast(u32x4, o);
+#if MXH_TAG_MODE == 1      // diagnostic: unbiased tagging (a wrong last bit moves the word up or down by its own bit 1)
+          auto tg = [&](unsigned b) {
+            const unsigned wrong = (b ^ tag) & 1u;
+            const bool up = (b & 2u) != 0 || (b & 0x7FFFFFFEu) == 0;
+            return wrong ? (up ? b + 1u : b - 1u) : b;
+          };
+          const u32x4 ot = {tg(ob.x), tg(ob.y), tg(ob.z), tg(ob.w)};
+#else
           const u32x4 ot = {(ob.x & ~1u) | tag, (ob.y & ~1u) | tag, (ob.z & ~1u) | tag, (ob.w & ~1u) | tag};
+#endif
           // (HT = 1, H = 128: one tile per half, published by the lanes n < 8 only)
           xstore(ot, rs, ((HT >= 2 || n < 8) && !MXH_QVOL(q)) ? pbase + (unsigned)t * (unsigned)block_bytes : OOB, coloc);
         }

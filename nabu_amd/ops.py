@@ -196,7 +196,9 @@ class BlstmPlan(object):
         """x_bound > 0: |x| <= x_bound is guaranteed (the previous layer's LSTM outputs) — the f16x3 packs of x skip their
         measuring pass; fwd_only: no backward pass follows (validation): the reserve holds the activations only;
         recurrent_precision 'f32': the exact-fp32 recurrent kernels (include/nabu_hip.h, nabu_blstm_desc)"""
-        self.desc = _hip.BlstmDesc(ctypes.sizeof(_hip.BlstmDesc), B, T, D, H, int(max_len), mode,
+        import os
+        # (NABU_DESC_V1=1: the 32-byte ABI-version-1 descriptor — A/B runs against a library built before round 5)
+        self.desc = _hip.BlstmDesc(32 if os.environ.get('NABU_DESC_V1') == '1' else ctypes.sizeof(_hip.BlstmDesc), B, T, D, H, int(max_len), mode,
                                    _hip.GEMM_PRECISIONS[gemm_precision], float(x_bound),
                                    _hip.BLSTM_FWD_ONLY if fwd_only else 0, _hip.REC_PRECISIONS[recurrent_precision])
         L = _hip.lib()
