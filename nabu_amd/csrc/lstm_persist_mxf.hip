@@ -368,7 +368,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
   }
   float dc_state[2] = {0.f, 0.f};
-  float db0[2] = {0.f, 0.f}, db1[2] = {0.f, 0.f}, am0[2] = {0.f, 0.f}, am1[2] = {0.f, 0.f};
+  // bias-gradient sums in float64, added behind the publish (lstm_persist_mxh.hip, backward kernel)
+  double db0[2] = {0.0, 0.0}, db1[2] = {0.0, 0.0};
+  float am0[2] = {0.f, 0.f}, am1[2] = {0.f, 0.f};
   if (!unit_handshake(p, unit, slot, MXF_NU, P, flag)) return;
   const bool coloc = flag[1] != 0;
 
@@ -425,6 +427,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   };
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  // GATE FACTORS AHEAD OF THE EXCHANGE (lstm_persist_mxh.hip, backward kernel): the saved values of the step were
+  // prefetched a step ahead; claimed by a counted wait behind the first poll round's loads (everything but the VM_AFTER
+  // operations issued since the prefetch: last step's publishes, this round's loads, the result stores) they become the
+  // factors A, F0, F1, G of  dct = dc + (dout + dh) A,  dz = dct F0, (dct | dht) F1,  dc' = dct G  while the exchange is in flight
+  constexpr int VM_AFTER = 2 * QT + 2 * NQ + 4;
+  float fA[2], f0[2], f1[2], fG[2], f_dout[2];
+  auto gate_factors = [&](int s) {
+    asm volatile("" ::: "memory");
+    const bool act = s < n_g;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const float *st = xst + ((s & 1) * 2 + ps) * 1024 + tid;
+      const float sA = st[0], sB = st[256], sC = st[512], sD = st[768];
+      const float pA = mx_dpp<DPP_XOR1>(sA), pB = mx_dpp<DPP_XOR1>(sB), pC = mx_dpp<DPP_XOR1>(sC), pD = mx_dpp<DPP_XOR1>(sD);
+      const float gi = dup ? pA : sA, gj = dup ? pB : sB, gf = dup ? sA : pA, go = dup ? sB : pB;
+      const float c = dup ? pC : sC, cprev = dup ? sC : pC;
+      f_dout[ps] = dup ? pD : sD;
+      const float tc = fast_tanh(c);
+      fA[ps] = go * (1.f - tc * tc);
+      const float a0 = dup ? cprev * gf * (1.f - gf) : gj * gi * (1.f - gi);
+      const float a1 = dup ? tc * go * (1.f - go) : gi * (1.f - gj * gj);
+      f0[ps] = act ? a0 : 0.f;
+      f1[ps] = act ? a1 : 0.f;
+      fG[ps] = gf;
+    }
+  };
 
   for (int s = p.max_len - 1; s >= 0; --s) {
     // (a) reduce-scatter input: the partial products of the previous iteration addressed to my 32 units, two passes
@@ -448,7 +476,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int i = 0; i < NQ; ++i)
             v[ps][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, sbase + in_off[ps] + (unsigned)i * SRC8, 0, 16);
-        if (first) { dz_stores(); first = false; }
+        if (first) {
+          dz_stores();
+          wait_vm<VM_AFTER>();
+          gate_factors(s);
+          first = false;
+        }
         unsigned a = ~0u, o = 0u;
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps)
@@ -463,6 +496,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     } else {
       dz_stores();
       wait_vm<0>();
+      gate_factors(s);
     }
     char *const dzb = dzs + (s & 1) * (16 * L::DROWB);
     const bool act_g = s < n_g;
@@ -480,23 +514,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       sum.z += mx_dpp<DPP_XOR2>(sum.z); sum.w += mx_dpp<DPP_XOR2>(sum.w);
       const float dh = sel4(s8 >> 1, sum.x, sum.y, sum.z, sum.w);
 
-      // (b) gate gradients of (row, unit): the pair shares its saved values
-      const float *st = xst + ((s & 1) * 2 + ps) * 1024 + tid;
-      const float sA = st[0], sB = st[256], sC = st[512], sD = st[768];
-      const float pA = mx_dpp<DPP_XOR1>(sA), pB = mx_dpp<DPP_XOR1>(sB), pC = mx_dpp<DPP_XOR1>(sC), pD = mx_dpp<DPP_XOR1>(sD);
-      const float gi = dup ? pA : sA, gj = dup ? pB : sB, gf = dup ? sA : pA, go = dup ? sB : pB;
-      const float c = dup ? pC : sC, cprev = dup ? sC : pC, dout = dup ? pD : sD;
-      const float tc = fast_tanh(c);
-      const float dht = dout + dh;
-      const float dct = dc_state[ps] + dht * go * (1.f - tc * tc);
-      d0[ps] = 0.f; d1[ps] = 0.f;
-      if (act_g) {
-        d0[ps] = dup ? dct * cprev * gf * (1.f - gf) : dct * gj * gi * (1.f - gi);
-        d1[ps] = dup ? dht * tc * go * (1.f - go) : dct * gi * (1.f - gj * gj);
-        dc_state[ps] = dct * gf;
-      }
-      db0[ps] += d0[ps]; db1[ps] += d1[ps];
-      am0[ps] = fmaxf(am0[ps], fabsf(d0[ps])); am1[ps] = fmaxf(am1[ps], fabsf(d1[ps]));
+      // (b) gate gradients of (row, unit) from the factors computed ahead of the exchange
+      const float dht = f_dout[ps] + dh;
+      const float dct = dc_state[ps] + dht * fA[ps];
+      d0[ps] = dct * f0[ps];
+      d1[ps] = (dup ? dht : dct) * f1[ps];
+      if (act_g) dc_state[ps] = dct * fG[ps];
     }
     {
       // this row's largest |dz| over the workgroup's 128 columns = both passes of the row's 32 lanes (bit patterns)
@@ -574,21 +597,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
       }
     }
+    // (behind the publish: nothing waits for these)
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      db0[ps] += (double)d_0[ps]; db1[ps] += (double)d_1[ps];
+      am0[ps] = fmaxf(am0[ps], fabsf(d_0[ps])); am1[ps] = fmaxf(am1[ps], fabsf(d_1[ps]));
+    }
   }
   dz_stores();
   // bias gradient / column maxima of my 128 gate columns over the unit's 8 rows
   __syncthreads();
+  double *redd = reinterpret_cast<double *>(smem);      // [8 rows][128] doubles over the dz plane / staging area
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
-    red[grow * 128 + (2 * dup) * 32 + gu[ps]] = db0[ps];
-    red[grow * 128 + (2 * dup + 1) * 32 + gu[ps]] = db1[ps];
+    redd[grow * 128 + (2 * dup) * 32 + gu[ps]] = db0[ps];
+    redd[grow * 128 + (2 * dup + 1) * 32 + gu[ps]] = db1[ps];
   }
   __syncthreads();
   if (tid < 128) {
-    float sum = 0.f;
+    double sum = 0.0;
 #pragma unroll
-    for (int r = 0; r < MXR; ++r) sum += red[r * 128 + tid];
-    p.db_part[((size_t)(p.shard_base + shard) * 2 + dir) * 4 * H + (size_t)(tid >> 5) * H + U0 + (tid & 31)] = sum;
+    for (int r = 0; r < MXR; ++r) sum += redd[r * 128 + tid];
+    p.db_part[((size_t)(p.shard_base + shard) * 2 + dir) * 4 * H + (size_t)(tid >> 5) * H + U0 + (tid & 31)] = (float)sum;
   }
   __syncthreads();
 #pragma unroll

@@ -59,8 +59,8 @@ struct MxhFwdLds {
   static constexpr int ROWF = 17 * 4;                        // floats per (wave, row): 16 units x 4 gates + pad
   static constexpr int PART = 0;                             // [2][4 waves][8 rows][ROWF]
   static constexpr int XST = PART + 2 * 4 * MXR * ROWF;      // [2][4 waves][64 lanes x 4] prefetched x-projection
-                                                             // XIN: [2][4 waves][2 k-steps][64 lanes x 4] planes of x_t
-  static constexpr int FLAG = XST + 2 * 4 * 512;
+                                                             // XIN: [3][4 waves][2 k-steps][64 lanes x 4] planes of x_t
+  static constexpr int FLAG = XST + 3 * 4 * 512;
   static constexpr int TOTAL = FLAG + 4;
 };
 
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if constexpr (XIN) {
       const int t = dir ? n_x - 1 - s : s;
       const bool act = s < n_x && !(dbg & (64 | 1024));
-      float *st = xst + (s & 1) * 2048 + 512 * w;
+      float *st = xst + (s % 3) * 2048 + 512 * w;
       prefetch_lds_b128(rxp, act ? xoff + (unsigned)t * 256u : OOB, smem, st);
       prefetch_lds_b128(rxp, act ? xoff + (unsigned)t * 256u + 64u : OOB, smem, st + 256);
     } else {
@@ -216,7 +216,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       prefetch_lds_b128(rg, act ? goff4 + (unsigned)t * (unsigned)(16 * H) : OOB, smem, xst + (s & 1) * 1024 + 256 * w);
     }
   };
+  // XIN: the planes are fetched TWO steps ahead (ring of three staging buffers per wave): they are multiplied at the very
+  // top of a step, and one step (1.3 us) is less than an HBM round trip behind a cold start — a late fetch stalled the
+  // wave in front of its first poll round (1.62 us per step inside the training step against 1.47 alone)
   fetch_x(0);
+  if constexpr (XIN) fetch_x(1);
   wait_vm<0>();
   __builtin_amdgcn_s_waitcnt(0x0F70);
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -243,13 +247,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // XIN: x_s . Wx for gate w's columns does not depend on the exchange: it is multiplied while the first poll round is in
   // flight.  The staged planes (this lane's own fetch of a step ago) are claimed by a counted wait: everything but the
   // XVM_AFTER vector-memory operations issued since — publish + hand-back, the round's loads, the four result stores.
-  constexpr int XVM_AFTER = NKS + 6;
+  // (two steps of them: the fetch of step s is issued in the matrix stream of step s - 2)
+  constexpr int XVM_AFTER = 2 * NKS + 14;
   const int wu = __builtin_amdgcn_readfirstlane(w);
   mxf32x4 ax = {0.f, 0.f, 0.f, 0.f};
   auto x_product = [&](int s) {
     if constexpr (XIN) {
       asm volatile("" ::: "memory");
-      const float *xs = xst + (s & 1) * 2048 + 512 * w + 4 * lane;
+      const float *xs = xst + (s % 3) * 2048 + 512 * w + 4 * lane;
       const u32x4 bx0 = *reinterpret_cast<const u32x4 *>(xs), bx1 = *reinterpret_cast<const u32x4 *>(xs + 256);
       mxf32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
       if (!(dbg & (2 | 512))) {
@@ -305,12 +310,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int j = 0; j < NKS; ++j) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = MXH_MFMA_L(Wp[1][c][j], b1[j], acc[c]);
-        if (j == 0) { fetch_x(s + 1); __builtin_amdgcn_sched_barrier(0); }
+        if (j == 0) { fetch_x(XIN ? s + 2 : s + 1); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = MXH_MFMA(Wp[0][c][j], b1[j], acc[c]);
       }
     } else {
-      fetch_x(s + 1);
+      fetch_x(XIN ? s + 2 : s + 1);
     }
     if constexpr (XIN) {      // the input's part joins gate w's sums (same scales: see the weights above)
       if (wu == 0) acc[0] += ax;
