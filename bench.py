@@ -603,7 +603,7 @@ class HipWorkload(object):
         # WRITE_SIZE, separate runs of this command; summarised by tools/pmc_summary.py with the
         # gfx950 corrections of MI355X_MICROARCH.md).  null when this workload was not profiled.
         traffic = None
-        for name in ('r04b_cfg2_pmc_traffic.json', 'r04_cfg2_pmc_traffic.json', 'r03_cfg2_pmc_traffic.json'):
+        for name in ('r05_cfg2_pmc_traffic.json', 'r04b_cfg2_pmc_traffic.json', 'r04_cfg2_pmc_traffic.json', 'r03_cfg2_pmc_traffic.json'):
             pmc = os.path.join(ROOT, 'profiles', name)
             if persistent and args.workload == 'cfg2' and os.path.exists(pmc):
                 with open(pmc) as fid:

@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256) void ctc_wave_kernel(CtcArgs p) {
     }
     for (int i = n + tid; i < T * C; i += 256) dl[i] = 0.f;
     for (int c = tid; c < C; c += 256) csum[c] = 0.f;
+    if (tid < 2) (nxtl + 64)[tid] = 0;           // the sweep / worker hand-over words (below)
   }
   const int lab = lane < L ? p.labels[(size_t)b * p.Lmax + lane] : -1;
   if (tid < 64) lbl[lane] = lab;
@@ -282,11 +283,57 @@ __global__ __launch_bounds__(256) void ctc_wave_kernel(CtcArgs p) {
     lse[t] = m + __logf(z);
   }
   __syncthreads();
-  if (tid >= 64) return;
+  // ONE wave runs the two sweeps (the dependent chain: 2 T frames of a few dozen instructions); the other three turn the
+  // frames it has finished into gradients BESIDE it — occupation sums per class, softmax, the stores: what used to sit
+  // in the beta sweep's own instruction stream (round 5).  Hand-over through LDS: the sweeping wave overwrites alpha[t]
+  // with the frame's occupations and then raises `prog` (release); a worker polls it (acquire).  LDS operations of a
+  // wave are performed in order, so a worker that sees the counter sees the frame.
+  const int wv = tid >> 6;
+  int *prog = nxtl + 64;                 // [0] frames finished by the beta sweep, [1] 1 = go
+  float *llp = reinterpret_cast<float *>(prog + 2);
+  float *gamw = llp + 2;                 // [3][64] occupation of the label states, per worker wave
+  float *csumw = gamw + 3 * 64;          // [3][C]  class sums of the worker's current frame
   const int lab_up = lane >= 1 ? lbl[lane - 1] : -1, lab_dn = lane < 63 ? lbl[lane + 1] : -1;
   const bool badl = lane < L && (lab < 0 || lab >= blank);
   const int rep = (int)wave_sum64((lane >= 1 && lane < L && lab == lab_up) ? 1.f : 0.f);
   const bool bad = __any(badl) || Tb <= 0 || L + rep > Tb;   // tf: "Not enough time for target transition sequence"
+  // occurrence chains of the labels (fixed order -> deterministic class sums); every wave keeps its own copy in registers
+  bool first = lane < L;
+  int nxt = -1;
+  if (lane < L) {
+    for (int j = 0; j < lane; ++j) first = first && lbl[j] != lab;
+    for (int j = L - 1; j > lane; --j) nxt = lbl[j] == lab ? j : nxt;
+  }
+  const bool hasB = lane <= L, hasL = lane < L;
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  if (wv > 0) {
+    if (bad) return;                     // (every wave reaches the same verdict from the same LDS contents)
+    // (nxtl is written by the sweeping wave below; read here only behind `go`)
+    while (__hip_atomic_load(prog + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+    float *gam = gamw + (wv - 1) * 64, *csum_w = csumw + (wv - 1) * C;
+    for (int c = lane; c < C; c += 64) csum_w[c] = 0.f;
+    for (int i = wv - 1; i < Tb; i += 3) {
+      const int t = Tb - 1 - i;
+      while (__hip_atomic_load(prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= i) __builtin_amdgcn_s_sleep(1);
+      const float z = lse[t];
+      const float gB = hasB ? as[(size_t)t * Smax + 2 * lane] : 0.f;
+      const float gL = hasL ? as[(size_t)t * Smax + 2 * lane + 1] : 0.f;
+      const float sumB = wave_sum_dpp(gB);
+      gam[lane] = gL;
+      WSYNC();
+      if (first) {
+        float v = gL;
+        for (int j = nxt; j >= 0; j = nxtl[j]) v += gam[j];
+        csum_w[lab] = v;
+      }
+      if (lane == 0) csum_w[blank] = sumB;
+      WSYNC();
+      for (int c = lane; c < C; c += 64)
+        dl[(size_t)t * C + c] = p.scale * (__builtin_amdgcn_exp2f((xs[(size_t)t * C + c] - z) * LOG2E) - csum_w[c]);
+      WSYNC();
+    }
+    return;
+  }
   if (bad) {
     for (int i = lane; i < Tb * C; i += 64) dl[i] = 0.f;
     if (lane == 0) {
@@ -295,23 +342,14 @@ __global__ __launch_bounds__(256) void ctc_wave_kernel(CtcArgs p) {
     }
     return;
   }
-  // occurrence chains of the labels (fixed order -> deterministic class sums)
-  bool first = lane < L;
-  int nxt = -1;
-  if (lane < L) {
-    for (int j = 0; j < lane; ++j) first = first && lbl[j] != lab;
-    for (int j = L - 1; j > lane; --j) nxt = lbl[j] == lab ? j : nxt;
-  }
   nxtl[lane] = nxt;
   WSYNC();
   const bool skipA = lane >= 1 && lane < L && lab != lab_up;   // 2i-1 -> 2i+1
   const bool skipB = lane + 1 < L && lab_dn != lab;            // 2i+1 -> 2i+3
-  const bool hasB = lane <= L, hasL = lane < L;
   const int labc = hasL ? lab : blank;                          // a valid column for idle lanes
 
   // ---- alpha sweep --------------------------------------------------------
   float aB = CTC_NEG, aL = CTC_NEG;
-  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   float yB = (xs[blank] - lse[0]) * LOG2E, yL = (xs[labc] - lse[0]) * LOG2E;     // base-2 from here on
   for (int t = 0; t < Tb; ++t) {
     // next frame's emission log-probabilities: independent of the recursion, issued first
@@ -335,8 +373,9 @@ __global__ __launch_bounds__(256) void ctc_wave_kernel(CtcArgs p) {
   const float ll = L >= 1 ? lse2_fast(__shfl(aB, L), __shfl(aL, L - 1)) : __shfl(aB, 0);
   if (lane == 0) p.nll[b] = -ll * LN2;
   WSYNC();
+  if (lane == 0) __hip_atomic_store(prog + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 
-  // ---- beta sweep + gradient ------------------------------------------------
+  // ---- beta sweep: the frame's occupations replace alpha[t], the workers take it from there ----------
   float bB = CTC_NEG, bL = CTC_NEG;
   for (int t = Tb - 1; t >= 0; --t) {
     const float z = lse[t];
@@ -354,27 +393,16 @@ __global__ __launch_bounds__(256) void ctc_wave_kernel(CtcArgs p) {
       bB = hasB ? nB : CTC_NEG;
       bL = hasL ? nL : CTC_NEG;
     }
-    const float gB = hasB ? __builtin_amdgcn_exp2f((aB0 - ll) + (bB - yB)) : 0.f;
-    const float gL = hasL ? __builtin_amdgcn_exp2f((aL0 - ll) + (bL - yL)) : 0.f;
-    const float sumB = wave_sum_dpp(gB);
-    gam[lane] = gL;
+    if (hasB) as[(size_t)t * Smax + 2 * lane] = __builtin_amdgcn_exp2f((aB0 - ll) + (bB - yB));
+    if (hasL) as[(size_t)t * Smax + 2 * lane + 1] = __builtin_amdgcn_exp2f((aL0 - ll) + (bL - yL));
     WSYNC();
-    if (first) {
-      float v = gL;
-      for (int j = nxt; j >= 0; j = nxtl[j]) v += gam[j];
-      csum[lab] = v;
-    }
-    if (lane == 0) csum[blank] = sumB;
-    WSYNC();
-    for (int c = lane; c < C; c += 64)
-      dl[(size_t)t * C + c] = p.scale * (__builtin_amdgcn_exp2f((xs[(size_t)t * C + c] - z) * LOG2E) - csum[c]);
-    WSYNC();
+    if (lane == 0) __hip_atomic_store(prog, Tb - t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 }
 
 #undef WSYNC
 static size_t ctc_wave_lds_bytes(int T, int C, int Smax) {
-  return ((size_t)T * C + T + (size_t)T * Smax + C + 64) * sizeof(float) + 128 * sizeof(int);
+  return ((size_t)T * C + T + (size_t)T * Smax + C + 64 + 2 + 3 * 64 + 3 * (size_t)C) * sizeof(float) + (128 + 2) * sizeof(int);
 }
 
 static size_t ctc_lds_bytes(int T, int C, int Smax) {

@@ -109,9 +109,17 @@ __device__ __forceinline__ float quad_bcast(float v, int i) {
     default: return dppf<0xFF, 0xF>(v, v);
   }
 }
-// one exp + one rcp (lstm_persist.hip uses the same forms; relative error ~1e-7)
-__device__ __forceinline__ float fsig(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float ftanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
+// gate functions as in lstm_persist_dev.h (round 5): v_rcp_f32 is not centred and 2 r - 1 amplifies its bias into a relative
+// bias of tanh — one Newton step behind the reciprocal, tanh as (1 - e) / (1 + e)
+__device__ __forceinline__ float rcpn(float d) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float fsig(float x) { return rcpn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) {
+  const float e = __expf(-2.0f * __builtin_amdgcn_fmed3f(x, -30.0f, 30.0f));
+  return (1.0f - e) * rcpn(1.0f + e);
+}
 
 struct Spin {
   unsigned long long t0;

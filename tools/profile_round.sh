@@ -3,7 +3,7 @@
 # gpurun_out/<tag>_prof/; the summaries that are judged are then copied into profiles/.
 # Counter passes are separate runs with --kernel-trace only (MI355X_MICROARCH.md, rocprofv3 PMC slots).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/${TAG}_prof
 mkdir -p $OUT
