@@ -362,6 +362,11 @@ def parse_args(argv=None):
                     help='NOT a measurement: cfg2\'s recipe at 4 utterances x 64 frames, 64 units — lets the tests run the '
                          'whole multi-rank line (ranks, exchange, carried cpu_baseline, roofline object) in seconds; the '
                          'line says config.shrunk = true')
+    ap.add_argument('--training-defaults', action='store_true',
+                    help='NOT the headline: the workload with the REFERENCE\'s regularisation defaults switched on — Listener '
+                         'input_noise 0.6 and dropout keep 0.5 (ed_encoders/defaults/listener.cfg), Speller output dropout keep '
+                         '0.5 and sample_prob 0.1 (ed_decoders/defaults/speller.cfg) — instead of the deterministic settings '
+                         'the parity configs of SURVEY.md 8(d) prescribe; the line says config.training_defaults = true')
     ap.add_argument('--allreduce', default='flat', choices=['flat', 'bucketed', 'both'],
                     help='gradient exchange of the data-parallel mode (trainer cfg key allreduce_buckets).  both: the '
                          'headline is timed with the flat exchange, then the same steps once more with the bucketed one '
@@ -456,6 +461,10 @@ class HipWorkload(object):
         over = {'trainer.allreduce_buckets': 'True' if args.allreduce == 'bucketed' else 'False'}   # (both: flat first)
         if args.gemm_precision:          # otherwise: the arithmetic the recipe ships
             over['encoder.gemm_precision'] = args.gemm_precision
+        if getattr(args, 'training_defaults', False):
+            over.update({'encoder.input_noise': '0.6', 'encoder.dropout': '0.5'})
+            if args.workload in ('cfg3', 'cfg5'):
+                over.update({'decoder.dropout': '0.5', 'decoder.sample_prob': '0.1'})
         if args.workload == 'cfg1':
             # BASELINE.json configs[0]: DBLSTM 2 x 256 + CTC, 8 x 200 x 40 (the reference's CPU-runnable case)
             self.B, self.T, self.D, self.H = 8, 200, 40, 256
@@ -638,7 +647,8 @@ class HipWorkload(object):
                        'recurrent_path': 'persistent' if persistent else 'stepwise',
                        'gemm_arith': GEMM_ARITH[self.precision],
                        'gemm_precision_from': 'command line' if args.gemm_precision else 'recipe (encoder.gemm_precision)',
-                       'shrunk': bool(getattr(args, 'shrink', False))},
+                       'shrunk': bool(getattr(args, 'shrink', False)),
+                       'training_defaults': bool(getattr(args, 'training_defaults', False))},
             'roofline': roofline,
             'roofline_gemm': (None if args.workload != 'cfg2' or args.no_gemm_roofline
                               else gemm_roofline(B_, T_, D_, H_, self.precision) if self.precision == 'f32'

@@ -40,6 +40,10 @@ constexpr int DPP_ROW_MIRROR = 0x140;
 // place — the size of the rounding it went through anyway — low in even generations, high in odd ones: no bias over
 // time.  Ring of 2 is safe without hand-back: a slot written in iteration it is overwritten in it + 2 by a writer that
 // has polled the reader's own publish of it + 1, issued behind the barrier that follows the reader's poll of the slot.
+// Non-finite values: the tag replaces the last mantissa bit whatever the exponent, so a +-Inf partial sum (0x7F800000)
+// published with tag 1 reads as a NaN pattern, and exact zeros (padded rows) travel as the smallest denormal — an
+// overflow in the backward recurrence therefore shows up as NaN where the exact-fp32 and step-wise kernels show Inf;
+// finite training is unaffected (the denormal is below every other term of the sum it joins).
 constexpr int MXHRINGB = 2;
 constexpr float MXH_HSCALE = 16384.f, MXH_HINV = 1.f / 16384.f;     // forward h: |h| < 1 + 2^-22
 

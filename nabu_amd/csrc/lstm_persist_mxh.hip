@@ -38,6 +38,9 @@ namespace nabu {
 #ifndef MXH_TAG_MODE
 #define MXH_TAG_MODE 0
 #endif
+#ifndef MXH_BWD_ORDER
+#define MXH_BWD_ORDER 0
+#endif
 #if MXH_ACC_L
 #define MXH_MFMA_L(a, b, c) mxf_mfma_acc(a, b, c)
 #else
@@ -587,7 +590,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       int fails = 0;
       const bool want1 = (((it - 1) >> 1) & 1) != 0;        // the tag of the pieces published in iteration it - 1
       // (a first round issued at once fails and costs the memory queue a round trip)
+#if MXH_BWD_ORDER == 1
+      // experiment: the idle time in front of the first round spent on the gate factors (claimed behind the previous
+      // step's publishes only), the result stores still behind the round's loads
+      wait_vm<2 * QT>();
+      gate_factors(s);
+#else
       __builtin_amdgcn_s_sleep(4);
+#endif
       // (re-loading only the cells that failed, the others out of range, was measured: 2.11 against 2.02 us per step)
       bool first = true;
       for (;;) {
@@ -596,8 +606,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, MXH_QVOL(kq) ? OOB : base + (unsigned)(8 * i) * (unsigned)(MXR * 64), 0, 16);
         if (first) {
           dz_stores();
+#if MXH_BWD_ORDER != 1
           wait_vm<VM_AFTER>();
           gate_factors(s);
+#endif
           first = false;
         }
         // every word must carry the tag: AND of the last bits (tag 1) / OR of the last bits (tag 0)
