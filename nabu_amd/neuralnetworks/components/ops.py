@@ -46,9 +46,14 @@ def pyramid_stack(inputs, sequence_lengths, numsteps, axis=2, scope=None):
         return [d if Tp == T else hip.unpad_time(d, T)]
     record([inputs], [outputs], backward)
     lens = SeqLen.wrap(sequence_lengths)
-    new_host = -(-lens.host // numsteps)
-    # the device copy is derived on the device: an upload here would block the host on the stream
-    return outputs, SeqLen(new_host.astype(np.int32), dev_tensor=hip.ceil_div_i32(lens.dev, numsteps))
+    # (a length vector is immutable: the stacked lengths of a SeqLen OBJECT that comes round again — a batch kept on the
+    # device, the layers of one step sharing it — are derived once)
+    cache = lens.__dict__.setdefault('_stacked', {})
+    if numsteps not in cache:
+        new_host = -(-lens.host // numsteps)
+        # the device copy is derived on the device: an upload here would block the host on the stream
+        cache[numsteps] = SeqLen(new_host.astype(np.int32), dev_tensor=hip.ceil_div_i32(lens.dev, numsteps))
+    return outputs, cache[numsteps]
 
 
 def dense_sequence_to_sparse(sequences, sequence_lengths):
