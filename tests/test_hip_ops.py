@@ -489,3 +489,88 @@ def test_cross_entropy_losses_match_oracle():
         loss_functions.factory('marigin')
     with pytest.raises(Exception, match='unknown loss function'):
         loss_functions.factory('nope')
+
+
+# ------------------------------------------------------------------ descriptor version 2 (include/nabu_hip.h)
+def _layer_call(B, T, D, H, seed=0, **plan_kw):
+    """one forward (+ optionally backward) call of a BLSTM layer on seeded operands; returns the tensors"""
+    from nabu_amd import ops
+    rng = np.random.default_rng(seed)
+    x = dev(np.tanh(rng.normal(size=(B, T, D))))                # |x| <= 1: what a previous LSTM layer hands over
+    p = {k: dev(v) for k, v in _blstm_params(rng, D, H).items()}
+    lens = dev(np.full(B, T), torch.int32)
+    plan = ops.BlstmPlan(B, T, D, H, T, ops.LSTM_AUTO, **plan_kw)
+    out = torch.full((B, T, 2 * H), float('nan'), device='cuda')
+    reserve = torch.empty(plan.reserve_bytes, dtype=torch.uint8, device='cuda')
+    ops.blstm_fwd(plan, x, lens, p['fw_kernel'], p['fw_bias'], p['bw_kernel'], p['bw_bias'], out, reserve)
+    return plan, x, lens, p, out, reserve, dev(rng.normal(size=(B, T, 2 * H)))
+
+
+def _backward(plan, x, lens, p, out, reserve, dout):
+    from nabu_amd import ops
+    dx = torch.full(x.shape, float('nan'), device='cuda')
+    g = {k: torch.full(v.shape, float('nan'), device='cuda') for k, v in p.items()}
+    ops.blstm_bwd(plan, x, lens, p['fw_kernel'], p['bw_kernel'], out, dout, reserve, dx,
+                  g['fw_kernel'], g['fw_bias'], g['bw_kernel'], g['bw_bias'])
+    torch.cuda.synchronize()
+    return dx, g
+
+
+def test_backward_rejects_a_reserve_of_another_layout():
+    """nabu_blstm_fwd records (reserve pointer, layout) and the backward entry points check it (lstm.hip, tag_check):
+    a reserve written under another gemm_precision / recurrent_precision / FWD_ONLY flag has its regions elsewhere —
+    reading it would hand back numbers, not an error."""
+    from nabu_amd import ops, _hip
+    # (a shape the packed-operand products take: >= 1024 frames, D >= 256 — below that both plans have ONE layout)
+    plan, x, lens, p, out, reserve, dout = _layer_call(8, 256, 256, 64, gemm_precision='f16x3')
+    other = ops.BlstmPlan(8, 256, 256, 64, 256, ops.LSTM_AUTO, 'f32')
+    assert other.reserve_bytes != plan.reserve_bytes
+    big = torch.empty(max(other.reserve_bytes, plan.reserve_bytes), dtype=torch.uint8, device='cuda')
+    big[:plan.reserve_bytes].copy_(reserve)                     # same bytes at an address no forward call wrote
+    with pytest.raises(_hip.NabuHipError, match='reserve'):
+        _backward(plan, x, lens, p, out, big, dout)
+    with pytest.raises(_hip.NabuHipError, match='reserve'):     # right address, another layout
+        _backward(other, x, lens, p, out, reserve, dout)
+    dx, g = _backward(plan, x, lens, p, out, reserve, dout)     # the matching plan still runs after the refusals
+    assert torch.isfinite(dx).all() and all(torch.isfinite(v).all() for v in g.values())
+
+
+@pytest.mark.parametrize('B,T,D,H', [(32, 40, 40, 512), (8, 25, 1024, 256), (5, 9, 16, 64)])
+def test_forward_only_plan_has_the_same_outputs_in_a_smaller_reserve(B, T, D, H):
+    """NABU_BLSTM_FWD_ONLY (validation, decoding): no dz / dzT / packed-operand regions in the reserve, bit-identical
+    outputs, and the backward entry points refuse the plan."""
+    from nabu_amd import _hip
+    plan, x, lens, p, out, reserve, dout = _layer_call(B, T, D, H, seed=3, gemm_precision='f16x3')
+    fplan, _, _, _, fout, freserve, _ = _layer_call(B, T, D, H, seed=3, gemm_precision='f16x3', fwd_only=True)
+    assert torch.equal(out, fout)
+    assert fplan.reserve_bytes < plan.reserve_bytes
+    with pytest.raises(_hip.NabuHipError):
+        _backward(fplan, x, lens, p, fout, freserve, dout)
+
+
+def test_input_bound_replaces_the_measuring_pass():
+    """x_bound: the caller's guarantee |x| <= bound (an LSTM layer's outputs: 1) sets the f16x3 row scale of x without
+    reading x.  A bound is looser than the measured maximum by at most the ratio bound/max|x| — one binade here — so the
+    outputs agree to the planes' 22 bits, and the gradients with them."""
+    a = _layer_call(16, 30, 256, 128, seed=5, gemm_precision='f16x3')
+    b = _layer_call(16, 30, 256, 128, seed=5, gemm_precision='f16x3', x_bound=1.0)
+    assert (a[4] - b[4]).abs().max().item() < 2e-6
+    da, ga = _backward(*a)
+    db, gb = _backward(*b)
+    assert rel_err(host(db), host(da)) < 1e-5
+    for k in ga:
+        assert rel_err(host(gb[k]), host(ga[k])) < 1e-5, k
+
+
+def test_recurrent_precision_f32_selects_the_exact_kernels_per_call():
+    """recurrent_precision = f32 in ONE call's descriptor: that call runs the exact-fp32 persistent kernels, the next
+    default call the fp16-plane ones again (no process-wide switch is left behind)."""
+    from nabu_amd import ops
+    args = (32, 24, 40, 512)
+    d0 = _layer_call(*args, seed=7)
+    e = _layer_call(*args, seed=7, recurrent_precision='f32')
+    d1 = _layer_call(*args, seed=7)
+    ops.check_persist_status()
+    assert torch.equal(d0[4], d1[4])
+    diff = (d0[4] - e[4]).abs().max().item()
+    assert 0 < diff < 2e-4                                       # different arithmetic, same function
