@@ -535,7 +535,7 @@ def test_backward_rejects_a_reserve_of_another_layout():
     assert torch.isfinite(dx).all() and all(torch.isfinite(v).all() for v in g.values())
 
 
-@pytest.mark.parametrize('B,T,D,H', [(32, 40, 40, 512), (8, 25, 1024, 256), (5, 9, 16, 64)])
+@pytest.mark.parametrize('B,T,D,H', [(32, 40, 40, 512), (8, 25, 1024, 256), (16, 80, 1024, 256), (5, 9, 16, 64)])
 def test_forward_only_plan_has_the_same_outputs_in_a_smaller_reserve(B, T, D, H):
     """NABU_BLSTM_FWD_ONLY (validation, decoding): no dz / dzT / packed-operand regions in the reserve, bit-identical
     outputs, and the backward entry points refuse the plan."""
@@ -543,7 +543,8 @@ def test_forward_only_plan_has_the_same_outputs_in_a_smaller_reserve(B, T, D, H)
     plan, x, lens, p, out, reserve, dout = _layer_call(B, T, D, H, seed=3, gemm_precision='f16x3')
     fplan, _, _, _, fout, freserve, _ = _layer_call(B, T, D, H, seed=3, gemm_precision='f16x3', fwd_only=True)
     assert torch.equal(out, fout)
-    assert fplan.reserve_bytes < plan.reserve_bytes
+    # (the packed dz^T region exists from 1024 frames on: below that the two reserves are the same activations)
+    assert fplan.reserve_bytes < plan.reserve_bytes if B * T >= 1024 else fplan.reserve_bytes <= plan.reserve_bytes
     with pytest.raises(_hip.NabuHipError):
         _backward(fplan, x, lens, p, fout, freserve, dout)
 
