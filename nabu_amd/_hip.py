@@ -137,6 +137,9 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if handle.nabu_version() != ABI_VERSION:
+            raise NabuHipError('libnabu_hip.so reports ABI version %d, this binding is written against %d: rebuild '
+                               '(python -m nabu_amd.build)' % (handle.nabu_version(), ABI_VERSION))
         _lib = handle
     return _lib
 
@@ -181,6 +184,9 @@ class Workspace(object):
 
 SPELLER_MAX_LAYERS = 4
 GEMM_DEFAULT, GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_BF16X6 = 0, 1, 2, 3, 4
+# NABU_ABI_VERSION of include/nabu_hip.h this binding was written against (lib() refuses another library)
+ABI_VERSION = 2
+
 GEMM_PRECISIONS = {'default': 0, 'f32': 1, 'bf16': 2, 'bf16x3': 3, 'bf16x6': 4, 'f16x3': 5}
 
 

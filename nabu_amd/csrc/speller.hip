@@ -787,6 +787,212 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
   }
 }
 
+// Location-aware attention backward of the step chain with its two small dense products on the matrix pipe (exact fp32:
+// v_mfma_f32_16x16x4_f32) and every load that depends on nothing issued before the first wait (DEFER only; U <= 512,
+// F <= 12, <= 32 frames per slice).  attn_bwd_kernel<2, true> spends its 29 us per launch (cfg5: 16 utterances x 8 slices
+// of 25 frames) on ~9 dependent round trips to memory — values in 4, keys in 4, one frame pair of a wave at a time,
+// 96 registers of projection rows and 24 of feature sums leaving room for nothing in flight — not on arithmetic.  Here
+//   x^T[16 units x 16 frames]   = conv_proj^T[16 x 12] . features^T[12 x 16] + (keys^T + q)        3 instructions
+//   d features[16 frames x 16]  = d[16 frames x 16 units] . conv_proj^T[16 units x 16 filters]      4 instructions
+// per (unit tile, frame tile): the first product's accumulator IS the second one's A operand (lane = frame, register r =
+// unit 4 kq + r of the tile: the k index of the second product is permuted the same way on both sides), so tanh and
+// the score gradient are applied in place and nothing goes through LDS between the two.  A wave owns U/128 unit tiles
+// and both frame tiles; d features are added over the waves in LDS, dq over the 16 frame lanes in the wave.
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+template <int UT>
+__global__ __launch_bounds__(AT) void attn_bwd_loc_mfma_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, sl = blockIdx.y, S = gridDim.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int Te = p.Te, U = p.U, E = p.E, F = p.F;
+  constexpr int NW = AT / 64;
+  float *base = smem + ck_floats(p);
+  float *alp = base;                       // [Te] previous alignment
+  float *ds = alp + Te;                    // [Te] d score
+  float *cf = ds + Te;                     // [Te*F]
+  float *red = base + ((2 * Te + Te * F + 3) & ~3);       // [NW][2][16 frames][16 filters] (also scalars)
+  if (p.step >= p.dec_len[b]) return;      // finished row: the finish kernel writes its zeros
+  const int n = min(max(p.enc_len[b], 0), Te);
+  const int per = (Te + S - 1) / S, lo = min(sl * per, n), hi = min(lo + per, n);
+  float *dcf = p.dcf_g + (size_t)b * Te * F;
+  const float *keys = p.keys + (size_t)b * Te * U;
+  const float *vals = p.values + (size_t)b * Te * E;
+  const float *q = p.q + (size_t)b * U;
+  const float *al = p.align + (size_t)b * Te;
+  const float *dctx = p.dctx + (size_t)b * E;
+  const float *cx = p.ctx + (size_t)b * E;
+  const float *dal_in = p.dalign_in ? p.dalign_in + (size_t)b * Te : nullptr;
+  const int fl = lane & 15, kq = lane >> 4;
+  const int E4 = E / 4, EC = (E4 + 63) / 64;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // ---- every load that depends on nothing, in the order of use (vector loads return in order)
+  // (1) previous alignment and conv kernel -> LDS
+  float alp_r[(1024 + AT - 1) / AT], ck_r[8];
+#pragma unroll
+  for (int i = 0; i < (1024 + AT - 1) / AT; ++i) alp_r[i] = tid + AT * i < Te ? p.align_prev[(size_t)b * Te + tid + AT * i] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ck_r[i] = tid + AT * i < p.K * F ? p.ck[tid + AT * i] : 0.f;
+  // (2) sum_t a[t] da[t] = dctx . context + sum_t a[t] dalign_in[t]
+  float r = 0.f;
+  {
+    float dr[4], cr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + AT * i;
+      dr[i] = e < E ? dctx[e] : 0.f;
+      cr[i] = e < E ? cx[e] : 0.f;
+    }
+    float ar = 0.f, gr = 0.f;
+    if (dal_in && tid < n) { ar = al[tid]; gr = dal_in[tid]; }
+    // (3) values of my frames (wave w: lo + w + NW i), first 4 chunks of 64 x 16 bytes of the encoder dimension
+    float4 vv[4][4], dc[4];
+    auto issue_vals = [&](int c0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int e4 = lane + 64 * (c0 + c);
+        dc[c] = e4 < E4 ? reinterpret_cast<const float4 *>(dctx)[e4] : z4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int t = lo + w + NW * i;
+          vv[i][c] = (e4 < E4 && t < hi) ? reinterpret_cast<const float4 *>(vals + (size_t)t * E)[e4] : z4;
+        }
+      }
+    };
+    issue_vals(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- conv features of my frames
+#pragma unroll
+    for (int i = 0; i < (1024 + AT - 1) / AT; ++i)
+      if (tid + AT * i < Te) alp[tid + AT * i] = alp_r[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (tid + AT * i < p.K * F) smem[tid + AT * i] = ck_r[i];
+    for (int i = tid + 8 * AT; i < p.K * F; i += AT) smem[i] = p.ck[i];          // (K F > 4096: not a shape of this path)
+    for (int t = tid + AT * ((1024 + AT - 1) / AT); t < Te; t += AT) alp[t] = p.align_prev[(size_t)b * Te + t];
+    __syncthreads();
+    conv_features(p, alp, cf, lo, hi, smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r = fmaf(dr[i], cr[i], r);
+    for (int e = tid + 4 * AT; e < E; e += AT) r = fmaf(dctx[e], cx[e], r);
+    r = fmaf(ar, gr, r);
+    if (dal_in)
+      for (int t = tid + AT; t < n; t += AT) r = fmaf(al[t], dal_in[t], r);
+    r = wave_sum(r);
+    if (lane == 0) red[w] = r;
+    // ---- d alignment[t] = dctx . values[t] (+ the gradient arriving through next step's location features)
+    float sda[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < EC; c0 += 4) {
+      if (c0) issue_vals(c0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          sda[i] = fmaf(dc[c].x, vv[i][c].x, sda[i]); sda[i] = fmaf(dc[c].y, vv[i][c].y, sda[i]);
+          sda[i] = fmaf(dc[c].z, vv[i][c].z, sda[i]); sda[i] = fmaf(dc[c].w, vv[i][c].w, sda[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = lo + w + NW * i;
+      const float tot = wave_sum(sda[i]);
+      if (lane == 0 && t < hi) ds[t] = tot + (dal_in ? dal_in[t] : 0.f);
+    }
+  }
+  // (4) operands of the two products: keys (accumulator init), q, v, conv_proj in both layouts
+  float4 kc[2][UT], qv[UT], v4[UT], b2[UT];
+  float a1[UT][3];
+#pragma unroll
+  for (int j = 0; j < UT; ++j) {
+    const int u0 = 16 * (w + NW * j);
+    const bool ok = u0 < U;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+      const int t = lo + 16 * ft + fl;
+      kc[ft][j] = (ok && t < hi) ? *reinterpret_cast<const float4 *>(keys + (size_t)t * U + u0 + 4 * kq) : z4;
+    }
+    qv[j] = ok ? *reinterpret_cast<const float4 *>(q + u0 + 4 * kq) : z4;
+    v4[j] = ok ? *reinterpret_cast<const float4 *>(p.v + u0 + 4 * kq) : z4;
+    b2[j] = (ok && fl < F) ? *reinterpret_cast<const float4 *>(p.wf + (size_t)fl * U + u0 + 4 * kq) : z4;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) a1[j][ks] = (ok && 4 * ks + kq < F) ? p.wf[(size_t)(4 * ks + kq) * U + u0 + fl] : 0.f;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  // softmax backward: dscore = a * (da - sum a*da)
+  r = 0.f;
+  for (int i = 0; i < NW; ++i) r += red[i];
+  __syncthreads();
+  if (p.prob_fn == 0) {
+    for (int t = lo + tid; t < hi; t += AT) ds[t] = al[t] * (ds[t] - r);
+  } else if (p.prob_fn == 1) {
+    for (int t = lo + tid; t < hi; t += AT) ds[t] = ds[t] * al[t] * (1.f - al[t]);
+  } else {
+    const float z = p.znorm[b];
+    for (int t = lo + tid; t < hi; t += AT) ds[t] = (ds[t] - r) * al[t] * (1.f - al[t] * z);
+  }
+  __syncthreads();
+  for (int t = lo + tid; t < hi; t += AT) p.ds_out[(size_t)b * Te + t] = ds[t];
+  for (int i = lo * F + tid; i < hi * F; i += AT) p.cf_out[(size_t)b * Te * F + i] = cf[i];
+  // ---- through v . tanh(keys + q + features . conv_proj)
+  float b1[2][3], g[2];
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft) {
+    const int t = lo + 16 * ft + fl;
+    g[ft] = t < hi ? ds[t] : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) b1[ft][ks] = (t < hi && 4 * ks + kq < F) ? cf[t * F + 4 * ks + kq] : 0.f;
+  }
+  f32x4_ acc2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int j = 0; j < UT; ++j) {
+    const int u0 = 16 * (w + NW * j);
+    if (u0 >= U) break;
+    f32x4_ dqa = {0.f, 0.f, 0.f, 0.f};
+    const f32x4_ vj = {v4[j].x, v4[j].y, v4[j].z, v4[j].w};
+    const f32x4_ bj = {b2[j].x, b2[j].y, b2[j].z, b2[j].w};
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+      f32x4_ x = {kc[ft][j].x + qv[j].x, kc[ft][j].y + qv[j].y, kc[ft][j].z + qv[j].z, kc[ft][j].w + qv[j].w};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) x = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j][ks], b1[ft][ks], x, 0, 0, 0);
+      f32x4_ d;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float th = tanhf_(x[c]);
+        d[c] = g[ft] * vj[c] * (1.f - th * th);
+      }
+      dqa += d;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc2[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[c], bj[c], acc2[ft], 0, 0, 0);
+    }
+    // dq of my 4 units: the 16 frame lanes of my k group
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = dqa[c];
+      v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+      dqa[c] = v;
+    }
+    if (fl == 0)
+      *reinterpret_cast<float4 *>(p.dq_part + ((size_t)b * S + sl) * U + u0 + 4 * kq) = make_float4(dqa[0], dqa[1], dqa[2], dqa[3]);
+  }
+  // d features: add the waves (fixed order); accumulator register c = frame 4 kq + c of the tile, lane fl = filter
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[((w * 2 + ft) * 16 + 4 * kq + c) * 16 + fl] = acc2[ft][c];
+  __syncthreads();
+  {
+    const int ft = tid >> 8, fr = (tid >> 4) & 15, f = tid & 15, t = lo + 16 * ft + fr;
+    if (t < hi && f < F) {
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) sm += red[((i * 2 + ft) * 16 + fr) * 16 + f];
+      dcf[t * F + f] = sm;
+    }
+  }
+}
+
 // The sums over decoder steps that the step chain does not wait for (DEFER): for its frames [lo, hi) of utterance b a
 // workgroup walks the steps l < dec_len[b] and accumulates in registers
 //   d keys[t,u] = sum_l d_l[t,u],  d v[u] += sum_{l,t} ds_l[t] tanh(x_l[t,u]),  d conv_proj[f,u] += sum_{l,t} cf_l[t,f] d_l[t,u]
@@ -1275,11 +1481,22 @@ static int attn_bwd_impl(const nabu_attn_desc *d, int step, const int32_t *dec_l
   p.ds_out = ds_out; p.cf_out = cf_out;
   const bool defer = ds_out != nullptr;
   NABU_CHECK_ARG(d->prob_fn != 2 || znorm, "attn_bwd: normalized_sigmoid needs the normalisers of the forward pass");
-  const size_t shm = attn_lds(d, true);
+  size_t shm = attn_lds(d, true);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool reg = d->kind == 1 && d->U <= 256 * RJ && d->F <= RF;
   auto kern = defer ? (d->kind != 1 ? attn_bwd_kernel<0, true> : reg ? attn_bwd_kernel<2, true> : attn_bwd_kernel<1, true>)
                     : (d->kind != 1 ? attn_bwd_kernel<0, false> : reg ? attn_bwd_kernel<2, false> : attn_bwd_kernel<1, false>);
+  // the matrix-pipe kernel of the deferred location-aware chain (NABU_ATTN_BWD_MFMA=0: attn_bwd_kernel<2, true>)
+  static const int mfma_env = [] { const char *e = getenv("NABU_ATTN_BWD_MFMA"); return e ? atoi(e) : 1; }();
+  if (defer && reg && mfma_env && cf_out && d->U % 16 == 0 && (d->Te + S - 1) / S <= 32 && d->Te <= 1024 && d->K * d->F <= 8 * AT &&
+      d->E <= 16 * AT) {
+    const int UT = (d->U / 16 + AT / 64 - 1) / (AT / 64);
+    kern = UT <= 1 ? attn_bwd_loc_mfma_kernel<1> : UT == 2 ? attn_bwd_loc_mfma_kernel<2> : UT == 3 ? attn_bwd_loc_mfma_kernel<3>
+                                                                                                   : attn_bwd_loc_mfma_kernel<4>;
+    // its LDS: conv kernel, previous alignment, d scores, features, the waves' d-feature tiles [NW][2][16][16]
+    const size_t need = ((((size_t)d->K * d->F + 3) & ~(size_t)3) + 2 * (size_t)d->Te + (size_t)d->Te * d->F + 4 + (AT / 64) * 512) * sizeof(float);
+    if (need > shm) shm = need;
+  }
   if (shm > 64 * 1024)
     NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));

@@ -25,7 +25,18 @@ def test_library_exports_every_declared_symbol():
         assert n in _hip.SIGNATURES, 'no ctypes signature for %s' % n
     for n in _hip.SIGNATURES:
         assert n in names, '%s bound in _hip.py but not declared in nabu_hip.h' % n
-    assert lib.nabu_version() == 2
+    assert lib.nabu_version() == 2 == _hip.ABI_VERSION
+
+
+def test_graft_entry_build_checks_the_same_version():
+    """__graft_entry__.build() is the driver's "does it build" check: its version assertion must follow the header
+    (round 5 bumped NABU_ABI_VERSION and the literal there stayed behind)."""
+    from nabu_amd import _hip
+    hdr = open(os.path.join(ROOT, 'include', 'nabu_hip.h')).read()
+    version = int(re.search(r'#define\s+NABU_ABI_VERSION\s+(\d+)', hdr).group(1))
+    assert version == _hip.ABI_VERSION
+    src = open(os.path.join(ROOT, '__graft_entry__.py')).read()
+    assert '_hip.ABI_VERSION' in src and not re.search(r'nabu_version\(\)\s*==\s*\d', src)
 
 
 def test_host_side_queries_and_argument_errors():
