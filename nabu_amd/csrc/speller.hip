@@ -799,6 +799,13 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
 // the score gradient are applied in place and nothing goes through LDS between the two.  A wave owns U/128 unit tiles
 // and both frame tiles; d features are added over the waves in LDS, dq over the 16 frame lanes in the wave.
 typedef float f32x4_ __attribute__((ext_vector_type(4)));
+// -DATTN_STAMPS: wall_clock64 at the phase boundaries of workgroup (0, 0) (10 ns ticks), printed by attn_bwd_impl
+#ifdef ATTN_STAMPS
+__device__ unsigned long long g_attn_stamps[16];
+#define ASTAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_attn_stamps[i] = wall_clock64(); } while (0)
+#else
+#define ASTAMP(i) do { } while (0)
+#endif
 template <int UT>
 __global__ __launch_bounds__(AT) void attn_bwd_loc_mfma_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -824,73 +831,94 @@ __global__ __launch_bounds__(AT) void attn_bwd_loc_mfma_kernel(AttnArgs p) {
   const float *dal_in = p.dalign_in ? p.dalign_in + (size_t)b * Te : nullptr;
   const int fl = lane & 15, kq = lane >> 4;
   const int E4 = E / 4, EC = (E4 + 63) / 64;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  ASTAMP(0);
 
-  // ---- every load that depends on nothing, in the order of use (vector loads return in order)
+  // ---- every load that depends on nothing, in the order of use (vector loads return in order).  Every address is
+  // clamped into its array and the value masked afterwards: a conditional load is a branch around the load and a
+  // wait in front of the next one (the first version of this kernel had 60 of them)
+  typedef const f32x4_ *V4;
+  const f32x4_ zv = {0.f, 0.f, 0.f, 0.f};
+  constexpr int NAL = (1024 + AT - 1) / AT;
   // (1) previous alignment and conv kernel -> LDS
-  float alp_r[(1024 + AT - 1) / AT], ck_r[8];
+  float alp_r[NAL], ck_r[8];
 #pragma unroll
-  for (int i = 0; i < (1024 + AT - 1) / AT; ++i) alp_r[i] = tid + AT * i < Te ? p.align_prev[(size_t)b * Te + tid + AT * i] : 0.f;
+  for (int i = 0; i < NAL; ++i) alp_r[i] = p.align_prev[(size_t)b * Te + min(tid + AT * i, Te - 1)];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) ck_r[i] = tid + AT * i < p.K * F ? p.ck[tid + AT * i] : 0.f;
+  for (int i = 0; i < 8; ++i) ck_r[i] = p.ck[min(tid + AT * i, p.K * F - 1)];
   // (2) sum_t a[t] da[t] = dctx . context + sum_t a[t] dalign_in[t]
-  float r = 0.f;
-  {
-    float dr[4], cr[4];
+  float dr[4], cr[4], ar = 0.f, gr = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + AT * i;
-      dr[i] = e < E ? dctx[e] : 0.f;
-      cr[i] = e < E ? cx[e] : 0.f;
+  for (int i = 0; i < 4; ++i) {
+    const int e = min(tid + AT * i, E - 1);
+    dr[i] = dctx[e];
+    cr[i] = cx[e];
+  }
+  if (dal_in) { ar = al[min(tid, Te - 1)]; gr = dal_in[min(tid, Te - 1)]; }
+  // (3) values of my frames (wave w: lo + w + NW i), 4 chunks of 64 x 16 bytes of the encoder dimension at a time
+  f32x4_ vv[4][4], dc[4];
+  const int tl = max(hi - 1, 0);
+  auto issue_vals = [&](int c0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int e4 = min(lane + 64 * (c0 + c), E4 - 1);
+      dc[c] = reinterpret_cast<V4>(dctx)[e4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vv[i][c] = reinterpret_cast<V4>(vals + (size_t)min(lo + w + NW * i, tl) * E)[e4];
     }
-    float ar = 0.f, gr = 0.f;
-    if (dal_in && tid < n) { ar = al[tid]; gr = dal_in[tid]; }
-    // (3) values of my frames (wave w: lo + w + NW i), first 4 chunks of 64 x 16 bytes of the encoder dimension
-    float4 vv[4][4], dc[4];
-    auto issue_vals = [&](int c0) {
+  };
+  issue_vals(0);
+  // (4) operands of the two products: keys (accumulator init), q, v, conv_proj in both layouts
+  f32x4_ kc[2][UT], qv[UT], v4[UT], b2[UT];
+  float a1[UT][3];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int e4 = lane + 64 * (c0 + c);
-        dc[c] = e4 < E4 ? reinterpret_cast<const float4 *>(dctx)[e4] : z4;
+  for (int j = 0; j < UT; ++j) {
+    const int u0 = min(16 * (w + NW * j), U - 16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int t = lo + w + NW * i;
-          vv[i][c] = (e4 < E4 && t < hi) ? reinterpret_cast<const float4 *>(vals + (size_t)t * E)[e4] : z4;
-        }
-      }
-    };
-    issue_vals(0);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- conv features of my frames
+    for (int ft = 0; ft < 2; ++ft)
+      kc[ft][j] = *reinterpret_cast<V4>(keys + (size_t)min(lo + 16 * ft + fl, tl) * U + u0 + 4 * kq);
+    qv[j] = *reinterpret_cast<V4>(q + u0 + 4 * kq);
+    v4[j] = *reinterpret_cast<V4>(p.v + u0 + 4 * kq);
+    b2[j] = *reinterpret_cast<V4>(p.wf + (size_t)min(fl, F - 1) * U + u0 + 4 * kq);
 #pragma unroll
-    for (int i = 0; i < (1024 + AT - 1) / AT; ++i)
-      if (tid + AT * i < Te) alp[tid + AT * i] = alp_r[i];
+    for (int ks = 0; ks < 3; ++ks) a1[j][ks] = p.wf[(size_t)min(4 * ks + kq, F - 1) * U + u0 + fl];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- conv features of my frames
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (tid + AT * i < p.K * F) smem[tid + AT * i] = ck_r[i];
-    for (int i = tid + 8 * AT; i < p.K * F; i += AT) smem[i] = p.ck[i];          // (K F > 4096: not a shape of this path)
-    for (int t = tid + AT * ((1024 + AT - 1) / AT); t < Te; t += AT) alp[t] = p.align_prev[(size_t)b * Te + t];
-    __syncthreads();
-    conv_features(p, alp, cf, lo, hi, smem);
+  for (int i = 0; i < NAL; ++i)
+    if (tid + AT * i < Te) alp[tid + AT * i] = alp_r[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r = fmaf(dr[i], cr[i], r);
-    for (int e = tid + 4 * AT; e < E; e += AT) r = fmaf(dctx[e], cx[e], r);
-    r = fmaf(ar, gr, r);
-    if (dal_in)
-      for (int t = tid + AT; t < n; t += AT) r = fmaf(al[t], dal_in[t], r);
-    r = wave_sum(r);
-    if (lane == 0) red[w] = r;
-    // ---- d alignment[t] = dctx . values[t] (+ the gradient arriving through next step's location features)
+  for (int i = 0; i < 8; ++i)
+    if (tid + AT * i < p.K * F) smem[tid + AT * i] = ck_r[i];
+  for (int i = tid + 8 * AT; i < p.K * F; i += AT) smem[i] = p.ck[i];          // (K F > 4096: not a shape of this path)
+  for (int t = tid + AT * NAL; t < Te; t += AT) alp[t] = p.align_prev[(size_t)b * Te + t];
+  __syncthreads();
+  ASTAMP(1);
+  conv_features(p, alp, cf, lo, hi, smem);
+  ASTAMP(2);
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r = fmaf(tid + AT * i < E ? dr[i] : 0.f, cr[i], r);
+  for (int e = tid + 4 * AT; e < E; e += AT) r = fmaf(dctx[e], cx[e], r);
+  r = fmaf(tid < n ? ar : 0.f, gr, r);
+  if (dal_in)
+    for (int t = tid + AT; t < n; t += AT) r = fmaf(al[t], dal_in[t], r);
+  r = wave_sum(r);
+  if (lane == 0) red[w] = r;
+  // ---- d alignment[t] = dctx . values[t] (+ the gradient arriving through next step's location features)
+  {
     float sda[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c0 = 0; c0 < EC; c0 += 4) {
       if (c0) issue_vals(c0);
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+      for (int c = 0; c < 4; ++c) {
+        const f32x4_ dcm = lane + 64 * (c0 + c) < E4 ? dc[c] : zv;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          sda[i] = fmaf(dc[c].x, vv[i][c].x, sda[i]); sda[i] = fmaf(dc[c].y, vv[i][c].y, sda[i]);
-          sda[i] = fmaf(dc[c].z, vv[i][c].z, sda[i]); sda[i] = fmaf(dc[c].w, vv[i][c].w, sda[i]);
+          const f32x4_ m = dcm * vv[i][c];
+          sda[i] += (m[0] + m[1]) + (m[2] + m[3]);
         }
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -899,23 +927,14 @@ __global__ __launch_bounds__(AT) void attn_bwd_loc_mfma_kernel(AttnArgs p) {
       if (lane == 0 && t < hi) ds[t] = tot + (dal_in ? dal_in[t] : 0.f);
     }
   }
-  // (4) operands of the two products: keys (accumulator init), q, v, conv_proj in both layouts
-  float4 kc[2][UT], qv[UT], v4[UT], b2[UT];
-  float a1[UT][3];
+  ASTAMP(3);
+  // mask what the clamped loads brought in for tiles / filters / frames that do not exist
 #pragma unroll
   for (int j = 0; j < UT; ++j) {
-    const int u0 = 16 * (w + NW * j);
-    const bool ok = u0 < U;
+    if (fl >= F) b2[j] = zv;
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
-      const int t = lo + 16 * ft + fl;
-      kc[ft][j] = (ok && t < hi) ? *reinterpret_cast<const float4 *>(keys + (size_t)t * U + u0 + 4 * kq) : z4;
-    }
-    qv[j] = ok ? *reinterpret_cast<const float4 *>(q + u0 + 4 * kq) : z4;
-    v4[j] = ok ? *reinterpret_cast<const float4 *>(p.v + u0 + 4 * kq) : z4;
-    b2[j] = (ok && fl < F) ? *reinterpret_cast<const float4 *>(p.wf + (size_t)fl * U + u0 + 4 * kq) : z4;
-#pragma unroll
-    for (int ks = 0; ks < 3; ++ks) a1[j][ks] = (ok && 4 * ks + kq < F) ? p.wf[(size_t)(4 * ks + kq) * U + u0 + fl] : 0.f;
+    for (int ks = 0; ks < 3; ++ks)
+      if (4 * ks + kq >= F) a1[j][ks] = 0.f;
   }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
@@ -934,6 +953,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_loc_mfma_kernel(AttnArgs p) {
   __syncthreads();
   for (int t = lo + tid; t < hi; t += AT) p.ds_out[(size_t)b * Te + t] = ds[t];
   for (int i = lo * F + tid; i < hi * F; i += AT) p.cf_out[(size_t)b * Te * F + i] = cf[i];
+  ASTAMP(4);
   // ---- through v . tanh(keys + q + features . conv_proj)
   float b1[2][3], g[2];
 #pragma unroll
@@ -949,11 +969,10 @@ __global__ __launch_bounds__(AT) void attn_bwd_loc_mfma_kernel(AttnArgs p) {
     const int u0 = 16 * (w + NW * j);
     if (u0 >= U) break;
     f32x4_ dqa = {0.f, 0.f, 0.f, 0.f};
-    const f32x4_ vj = {v4[j].x, v4[j].y, v4[j].z, v4[j].w};
-    const f32x4_ bj = {b2[j].x, b2[j].y, b2[j].z, b2[j].w};
+    const f32x4_ vj = v4[j], bj = b2[j];
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) {
-      f32x4_ x = {kc[ft][j].x + qv[j].x, kc[ft][j].y + qv[j].y, kc[ft][j].z + qv[j].z, kc[ft][j].w + qv[j].w};
+      f32x4_ x = kc[ft][j] + qv[j];
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) x = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j][ks], b1[ft][ks], x, 0, 0, 0);
       f32x4_ d;
@@ -976,6 +995,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_loc_mfma_kernel(AttnArgs p) {
     if (fl == 0)
       *reinterpret_cast<float4 *>(p.dq_part + ((size_t)b * S + sl) * U + u0 + 4 * kq) = make_float4(dqa[0], dqa[1], dqa[2], dqa[3]);
   }
+  ASTAMP(5);
   // d features: add the waves (fixed order); accumulator register c = frame 4 kq + c of the tile, lane fl = filter
 #pragma unroll
   for (int ft = 0; ft < 2; ++ft)
@@ -991,6 +1011,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_loc_mfma_kernel(AttnArgs p) {
       dcf[t * F + f] = sm;
     }
   }
+  ASTAMP(6);
 }
 
 // The sums over decoder steps that the step chain does not wait for (DEFER): for its frames [lo, hi) of utterance b a
@@ -1135,19 +1156,24 @@ __global__ __launch_bounds__(PT) void attn_param_grads_kernel(int B, int Te, int
 // written as one dependent load + fma per iteration, so the work is spread over 1024 threads (four
 // threads per output frame, one per conv-kernel entry) with independent accumulator chains.
 constexpr int FT = 1024;
+constexpr int FPA = 4, FPK = 2;      // location-aware: workgroups per utterance for d previous alignment / d conv kernel
 __global__ __launch_bounds__(FT) void attn_bwd_finish_kernel(AttnArgs p, int S) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // grid (B, 1) or, location-aware, (B, FPA + FPK): y < FPA: a quarter of the output frames of d previous alignment
+  // (y = 0 also sums dq), y >= FPA: half of the conv kernel's entries.  Both sums are LDS-latency bound chains of one
+  // load pair + fma, so they are spread wide: 16 threads per output frame, one per conv-kernel entry.
   const int b = blockIdx.x, part = blockIdx.y, tid = threadIdx.x, NT = blockDim.x;
   const int Te = p.Te, U = p.U, F = p.F;
   const bool loc = p.kind == 1;
   float *dq = p.dq + (size_t)b * U;
   float *dal_out = p.dalign_out ? p.dalign_out + (size_t)b * Te : nullptr;
+  const int tper = loc ? (Te + FPA - 1) / FPA : Te;             // output frames of a part
+  const int ta = loc ? min(part * tper, Te) : 0, tb = loc ? min(ta + tper, Te) : Te;
   if (p.step >= p.dec_len[b]) {            // finished row: no gradient of its own, pass dalign through
-    if (part == 0) {
+    if (part == 0)
       for (int u = tid; u < U; u += NT) dq[u] = 0.f;
-      if (dal_out)
-        for (int t = tid; t < Te; t += NT) dal_out[t] = p.dalign_in ? p.dalign_in[(size_t)b * Te + t] : 0.f;
-    }
+    if (dal_out && (!loc || part < FPA))
+      for (int t = ta + tid; t < tb; t += NT) dal_out[t] = p.dalign_in ? p.dalign_in[(size_t)b * Te + t] : 0.f;
     return;
   }
   if (part == 0)
@@ -1169,22 +1195,22 @@ __global__ __launch_bounds__(FT) void attn_bwd_finish_kernel(AttnArgs p, int S) 
   for (int i = tid; i < p.K * F; i += NT) ck[i] = p.ck[i];
   __syncthreads();
   const int pb = (p.K - 1) / 2;
-  if (part == 0) {
-    // out frame to = t - d + pb receives a[t] * ck[d,f]; thread (t, q) takes the taps d = d0 + q, +4, ...
-    for (int t0 = 0; t0 < Te; t0 += NT / 4) {
-      const int t = t0 + (tid >> 2), q = tid & 3;
+  if (part < FPA) {
+    // out frame to = t - d + pb receives a[t] * ck[d,f]; thread (t, q) takes the taps d = d0 + q, + 16, ...
+    for (int t0 = ta; t0 < tb; t0 += NT / 16) {
+      const int t = t0 + (tid >> 4), q = tid & 15;
       float s0 = 0.f, s1 = 0.f;
-      if (t < Te) {
+      if (t < tb) {
         const int d0 = max(0, t + pb - (n - 1)), d1 = min(p.K, t + pb + 1);
         int d = d0 + q;
-        for (; d + 4 < d1; d += 8) {
+        for (; d + 16 < d1; d += 32) {
           const float *g = dcf + (t - d + pb) * F, *c = ck + d * F;
           for (int f = 0; f < F; ++f) {
             s0 = fmaf(g[f], c[f], s0);
-            s1 = fmaf(g[f - 4 * F], c[f + 4 * F], s1);
+            s1 = fmaf(g[f - 16 * F], c[f + 16 * F], s1);
           }
         }
-        for (; d < d1; d += 4) {
+        for (; d < d1; d += 16) {
           const float *g = dcf + (t - d + pb) * F, *c = ck + d * F;
           for (int f = 0; f < F; ++f) s0 = fmaf(g[f], c[f], s0);
         }
@@ -1192,10 +1218,13 @@ __global__ __launch_bounds__(FT) void attn_bwd_finish_kernel(AttnArgs p, int S) 
       float s = s0 + s1;
       s += __shfl_xor(s, 1);
       s += __shfl_xor(s, 2);
-      if (t < Te && q == 0) dal_out[t] = s;
+      s += __shfl_xor(s, 4);
+      s += __shfl_xor(s, 8);
+      if (t < tb && q == 0) dal_out[t] = s;
     }
   } else {
-    for (int i = tid; i < p.K * F; i += NT) {
+    const int KF = p.K * F, half = (KF + FPK - 1) / FPK, i0 = (part - FPA) * half, i1 = min(i0 + half, KF);
+    for (int i = i0 + tid; i < i1; i += NT) {
       const int d = i / F, f = i % F;
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
       const int to0 = max(0, pb - d), to1 = min(n, Te + pb - d);
@@ -1502,12 +1531,25 @@ static int attn_bwd_impl(const nabu_attn_desc *d, int step, const int32_t *dec_l
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   hipLaunchKernelGGL(kern, dim3(d->B, S), dim3(AT), shm, s, p);
   NABU_LAUNCH_CHECK();
+#ifdef ATTN_STAMPS
+  {
+    static int calls = 0;
+    if (++calls == 2000) {
+      unsigned long long st[16];
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_attn_stamps), sizeof(st));
+      fprintf(stderr, "attn_bwd stamps (us):");
+      for (int i = 1; i <= 6; ++i) fprintf(stderr, " %.2f", (double)(st[i] - st[i - 1]) / 100.0);
+      fprintf(stderr, "  total %.2f\n", (double)(st[6] - st[0]) / 100.0);
+    }
+  }
+#endif
   if (p.tickets) return 0;
   const size_t shm2 = ((size_t)d->Te + (d->kind == 1 ? (size_t)d->Te * d->F + (size_t)d->K * d->F : 0) + 4) * sizeof(float);
   if (shm2 > 64 * 1024)
     NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_finish_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2));
-  hipLaunchKernelGGL(attn_bwd_finish_kernel, dim3(d->B, d->kind == 1 ? 2 : 1), dim3(d->kind == 1 ? FT : 256), shm2, s, p, S);
+  hipLaunchKernelGGL(attn_bwd_finish_kernel, dim3(d->B, d->kind == 1 ? FPA + FPK : 1), dim3(d->kind == 1 ? FT : 256), shm2, s, p, S);
   NABU_LAUNCH_CHECK();
   return 0;
 }

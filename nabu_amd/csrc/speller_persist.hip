@@ -120,6 +120,10 @@ __device__ __forceinline__ float ftanh(float x) {
   const float e = __expf(-2.0f * __builtin_amdgcn_fmed3f(x, -30.0f, 30.0f));
   return (1.0f - e) * rcpn(1.0f + e);
 }
+// the tanh inside the attention score v . tanh(keys + q + ...): not part of a recurrent state (nothing accumulates its
+// ~1e-7 bias over the steps), and FS x U of them per workgroup and step — the centred form above costs the forward
+// kernel 14 % (cfg3) to 19 % (cfg5) of its time there
+__device__ __forceinline__ float ftanh_s(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 struct Spin {
   unsigned long long t0;
@@ -567,10 +571,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const f32x4 kk = kx[i];
-          sacc[i] = fmaf(vv.x, ftanh(kk.x + qq.x), sacc[i]);
-          sacc[i] = fmaf(vv.y, ftanh(kk.y + qq.y), sacc[i]);
-          sacc[i] = fmaf(vv.z, ftanh(kk.z + qq.z), sacc[i]);
-          sacc[i] = fmaf(vv.w, ftanh(kk.w + qq.w), sacc[i]);
+          sacc[i] = fmaf(vv.x, ftanh_s(kk.x + qq.x), sacc[i]);
+          sacc[i] = fmaf(vv.y, ftanh_s(kk.y + qq.y), sacc[i]);
+          sacc[i] = fmaf(vv.z, ftanh_s(kk.z + qq.z), sacc[i]);
+          sacc[i] = fmaf(vv.w, ftanh_s(kk.w + qq.w), sacc[i]);
         }
       }
 #pragma unroll
@@ -1192,10 +1196,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
                   xB += cf_s[fB * Fc + c] * wc;
                 }
               f32x4 th, ddA, ddB;
-              th.x = ftanh(xA.x); th.y = ftanh(xA.y); th.z = ftanh(xA.z); th.w = ftanh(xA.w);
+              th.x = ftanh_s(xA.x); th.y = ftanh_s(xA.y); th.z = ftanh_s(xA.z); th.w = ftanh_s(xA.w);
               ddA.x = gA * vv[j].x * (1.f - th.x * th.x); ddA.y = gA * vv[j].y * (1.f - th.y * th.y);
               ddA.z = gA * vv[j].z * (1.f - th.z * th.z); ddA.w = gA * vv[j].w * (1.f - th.w * th.w);
-              th.x = ftanh(xB.x); th.y = ftanh(xB.y); th.z = ftanh(xB.z); th.w = ftanh(xB.w);
+              th.x = ftanh_s(xB.x); th.y = ftanh_s(xB.y); th.z = ftanh_s(xB.z); th.w = ftanh_s(xB.w);
               ddB.x = gB * vv[j].x * (1.f - th.x * th.x); ddB.y = gB * vv[j].y * (1.f - th.y * th.y);
               ddB.z = gB * vv[j].z * (1.f - th.z * th.z); ddB.w = gB * vv[j].w * (1.f - th.w * th.w);
               dq_l[j] += ddA + ddB;
@@ -1282,7 +1286,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
             const float g = redw[64 + f];
             const f32x4 kk = *reinterpret_cast<const f32x4 *>(keys_s + (size_t)f * U + 4 * uq);
             f32x4 th, dd;
-            th.x = ftanh(kk.x + qq.x); th.y = ftanh(kk.y + qq.y); th.z = ftanh(kk.z + qq.z); th.w = ftanh(kk.w + qq.w);
+            th.x = ftanh_s(kk.x + qq.x); th.y = ftanh_s(kk.y + qq.y); th.z = ftanh_s(kk.z + qq.z); th.w = ftanh_s(kk.w + qq.w);
             dd.x = g * vv.x * (1.f - th.x * th.x); dd.y = g * vv.y * (1.f - th.y * th.y);
             dd.z = g * vv.z * (1.f - th.z * th.z); dd.w = g * vv.w * (1.f - th.w * th.w);
             dq4 += dd;
