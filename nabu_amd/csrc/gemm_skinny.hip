@@ -273,6 +273,137 @@ int gemm_skinny_fused(int M, int N, int K1, const float *A, int lda, const float
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// The decoder chain's products of a sub-batch of <= 16 utterances, C[M <= 16, N] = A[M, K] . W^T with W the weight
+// in its ORIGINAL row-major form [N][K] (dq . Wq^T, dz . [Kx | Kh]^T).  gemm_skinny_fused_kernel spends its 13 us on
+// memory round trips one behind the other — operand tiles, write-through partial tiles, the stores' acknowledgement,
+// the ticket, the partials again, then the epilogue's own operands — not on the 2 x 16 x 2048 x 1536 flops.  Here a
+// workgroup owns 16 output columns over the WHOLE reduction (8 waves x K/8), nothing is handed between workgroups,
+// and every load of the launch — both operands and what the epilogue reads — is issued before the first wait:
+//   * the weights are re-blocked once per backward pass (rows16_swizzle) into the B-operand order of
+//     v_mfma_f32_16x16x4_f32: float4 block ((column tile, k group of 16), lane (kq, fl)) = W[16 tile + fl][16 kg + 4 kq ..+3]
+//     — a lane's 16-byte load is its B operand of four instructions, a wave's load one contiguous KiB;
+//   * A's 16-byte load of lane (row fl, kq) = A[fl][16 kg + 4 kq ..+3] is the A operand of the same four instructions
+//     (the k index inside a group is permuted identically on both sides);
+//   * the eight waves' accumulators meet in LDS (fixed order), thread (row, column) runs the epilogue.
+struct Rows16Args {
+  const float *A, *Wsw;
+  float *C, *C2;
+  int M, N, K, lda, ldc, ldc2, split;
+  float beta, beta2;
+  SkinnyEpilogue ep;
+};
+typedef float r16f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void rows16_swizzle_kernel(int N, int K, const float *__restrict__ W, int ldw,
+                                                           float *__restrict__ out) {
+  const size_t total = (size_t)N * K / 4;
+  const int KG = K / 16;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int lane = (int)(i & 63), kg = (int)((i >> 6) % KG), nt = (int)((i >> 6) / KG);
+    const int fl = lane & 15, kq = lane >> 4;
+    reinterpret_cast<r16f4 *>(out)[i] = *reinterpret_cast<const r16f4 *>(W + (size_t)(16 * nt + fl) * ldw + 16 * kg + 4 * kq);
+  }
+}
+int rows16_swizzle(int N, int K, const float *W, int ldw, float *out, hipStream_t s) {
+  if (N % 16 || K % 16 || ldw % 4) return fail(NABU_EUNSUP, "rows16_swizzle: N=%d K=%d ld=%d", N, K, ldw);
+  size_t blocks = ((size_t)N * K / 4 + 255) / 256;
+  hipLaunchKernelGGL(rows16_swizzle_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, N, K, W, ldw, out);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int KG>      // k groups of 16 per wave: K = 128 KG
+__global__ __launch_bounds__(512) void rows16_kernel(Rows16Args a) {
+  __shared__ float red[8][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 15, kq = lane >> 4;
+  const int nt = blockIdx.x, n0 = 16 * nt;
+  const int em = min(tid >> 4, a.M - 1), en = tid & 15;       // the epilogue's (row, column) of threads < 256
+  const SkinnyEpilogue &ep = a.ep;
+  const int U = ep.U;
+  // ---- loads: operands first, then what the epilogue reads (clamped addresses, masked later: no branch around a load)
+  r16f4 bv[KG], av[KG];
+  {
+    const r16f4 *Bp = reinterpret_cast<const r16f4 *>(a.Wsw) + ((size_t)nt * (a.K / 16) + (size_t)w * KG) * 64 + lane;
+    const float *Ap = a.A + (size_t)min(fl, a.M - 1) * a.lda + 16 * (w * KG) + 4 * kq;
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      bv[g] = Bp[(size_t)g * 64];
+      av[g] = *reinterpret_cast<const r16f4 *>(Ap + 16 * g);
+    }
+  }
+  const bool second = n0 >= a.split;
+  float *cdst = second ? a.C2 + (size_t)em * a.ldc2 + (n0 - a.split) + en : a.C + (size_t)em * a.ldc + n0 + en;
+  const float beta = second ? a.beta2 : a.beta;
+  float cold = 0.f, e_i = 0.f, e_g = 0.f, e_f = 0.f, e_o = 0.f, e_cn = 0.f, e_cp = 0.f, e_dc = 0.f, e_dh2 = 0.f;
+  int e_len = 0;
+  const size_t eidx = (size_t)em * U + n0 + en, ezo = (size_t)em * 4 * U + n0 + en;
+  if (beta != 0.f) cold = *cdst;
+  if (ep.kind == 2) {
+    e_len = ep.seq_len[em];
+    e_i = ep.acts[ezo]; e_g = ep.acts[ezo + U]; e_f = ep.acts[ezo + 2 * U]; e_o = ep.acts[ezo + 3 * U];
+    e_cn = ep.c_new[eidx]; e_cp = ep.c_prev[eidx]; e_dc = ep.dc_in[eidx];
+    if (ep.dh2) e_dh2 = ep.dh2[(size_t)em * ep.ld_dh2 + n0 + en];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  r16f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < KG; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][r], bv[g][r], acc, 0, 0, 0);
+  // accumulator register c = row 4 kq + c, lane fl = column
+#pragma unroll
+  for (int c = 0; c < 4; ++c) red[w][4 * kq + c][fl] = acc[c];
+  __syncthreads();
+  if (tid >= 256 || (tid >> 4) >= a.M) return;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v += red[i][em][en];
+  if (beta != 0.f) v = fmaf(beta, cold, v);
+  if (ep.kind == 0) { *cdst = v; return; }
+  // kind 2: v = d h of unit n0 + en (the query projection's gradient added to the direct one): LSTM cell backward
+  if (ep.step >= e_len) {
+    ep.dz[ezo] = ep.dz[ezo + U] = ep.dz[ezo + 2 * U] = ep.dz[ezo + 3 * U] = 0.f;
+    ep.dc_out[eidx] = e_dc;
+    return;
+  }
+  const float tc = tanhf_(e_cn);
+  const float dht = v + e_dh2;
+  const float dct = e_dc + dht * e_o * (1.f - tc * tc);
+  ep.dz[ezo] = dct * e_g * e_i * (1.f - e_i);
+  ep.dz[ezo + U] = dct * e_i * (1.f - e_g * e_g);
+  ep.dz[ezo + 2 * U] = dct * e_cp * e_f * (1.f - e_f);
+  ep.dz[ezo + 3 * U] = dht * tc * e_o * (1.f - e_o);
+  ep.dc_out[eidx] = dct * e_f;
+}
+
+bool rows16_ok(int M, int N, int K, int lda) {
+  const int kg = K / 128;
+  return M >= 1 && M <= 16 && N % 16 == 0 && K % 128 == 0 && lda % 4 == 0 && (kg == 1 || kg == 2 || kg == 4 || kg == 8 || kg == 16);
+}
+// C[M, N] = A . W^T (+ beta C); ep: kind 0 (plain) or 2 (LSTM cell backward on the finished tile, as gemm_skinny_fused);
+// split: columns >= split->split (a multiple of 16) go to split->C2 with split->beta2
+int rows16(int M, int N, int K, const float *A, int lda, const float *Wsw, float beta, float *C, int ldc, hipStream_t s,
+           const SkinnyEpilogue *ep, const SkinnySplit *split) {
+  if (!rows16_ok(M, N, K, lda) || (ep && ep->kind != 0 && ep->kind != 2) || (split && (split->split % 16 || (ep && ep->kind))))
+    return fail(NABU_EUNSUP, "rows16 product: unsupported shape M=%d N=%d K=%d", M, N, K);
+  Rows16Args a = {};
+  a.A = A; a.Wsw = Wsw; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.beta = beta;
+  a.C2 = nullptr; a.ldc2 = 0; a.split = N; a.beta2 = 0.f;
+  if (split) { a.C2 = split->C2; a.ldc2 = split->ldc2; a.split = split->split; a.beta2 = split->beta2; }
+  if (ep) a.ep = *ep; else a.ep.kind = 0;
+  const dim3 grid(N / 16), block(512);
+  switch (K / 128) {
+    case 1: hipLaunchKernelGGL(rows16_kernel<1>, grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(rows16_kernel<2>, grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL(rows16_kernel<4>, grid, block, 0, s, a); break;
+    case 8: hipLaunchKernelGGL(rows16_kernel<8>, grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL(rows16_kernel<16>, grid, block, 0, s, a); break;
+  }
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
 // k-chunk of the skinny kernel: the largest of 256/128/64 that divides K (0 = not eligible)
 int gemm_skinny_chunk(int M, int N, int K) {
   if (M > 64 || N % 32 != 0 || K < 64) return 0;

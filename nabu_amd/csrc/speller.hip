@@ -1665,6 +1665,7 @@ struct SpWs {
   size_t wqT, kxT[NABU_SPELLER_MAX_LAYERS], khT[NABU_SPELLER_MAX_LAYERS];   // transposed weights (backward)
   size_t kperm[NABU_SPELLER_MAX_LAYERS];   // gate-interleaved copies of the cell kernels' dense rows (forward)
   size_t kxhT, dxh[2];     // [4U, E+U] transposed rows of layer 0's kernel; [B, E+U] carries d(context | h) of a step
+  size_t wq_sw, kxh_sw;    // the same two weights re-blocked for rows16_kernel (gemm_skinny.hip): [U, U], [E+U, 4U]
   size_t tickets, fpart;   // fused skinny products: per-column-slice tickets (zeroed per call), partial tiles
   size_t status, persist, persist_bytes;   // persistent decoder kernel: status word (ws[0]), XCC table + exchange rings
   size_t dv8;                              // its d attention_v partial rows [B*8, U]
@@ -1815,6 +1816,8 @@ static SpWs sp_ws(const nabu_speller_desc *d) {
   }
   for (int n = 0; n < d->num_layers; ++n) s.kperm[n] = take((n == 0 ? E + U : 2 * U) * 4 * U);
   s.kxhT = take(4 * U * (E + U));
+  s.wq_sw = take(U * U);
+  s.kxh_sw = take(4 * U * (E + U));
   for (int i = 0; i < 2; ++i) s.dxh[i] = take(B * (E + U));
   s.tickets = take(NS * 1024 + B + 4);   // + one counter per utterance for the attention launches
   {
@@ -2149,6 +2152,14 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   const bool fuse_b = fuse_shapes && (!drop || persist);      // the chain's cell epilogue has no dropout
   if (fuse_b) SP_TRY(transpose(E + U, 4 * U, p->lstm_kernel[0] + (size_t)C * 4 * U, 4 * U, w + W.kxhT, s));
   const bool split_b = fuse_b && E % 32 == 0 && env_int("NABU_SPELLER_SPLIT", 1);
+  // sub-batches of <= 16 utterances: both products of a step by rows16_kernel (no split-K hand-off between workgroups:
+  // 13 -> 7 us per launch); NABU_SPELLER_ROWS16=0: gemm_skinny_fused
+  const bool r16 = fuse_b && split_b && !persist && env_int("NABU_SPELLER_ROWS16", 1) && rows16_ok(Bn, U, U, U) &&
+                   rows16_ok(Bn, E + U, 4 * U, 4 * U) && E % 16 == 0;
+  if (r16) {
+    SP_TRY(rows16_swizzle(U, U, p->query_kernel, U, w + W.wq_sw, s));
+    SP_TRY(rows16_swizzle(E + U, 4 * U, p->lstm_kernel[0] + (size_t)C * 4 * U, 4 * U, w + W.kxh_sw, s));
+  }
   if (persist)
     SP_TRY(speller_persist_bwd(pd, dec_len, enc_len, w + W.kxhT, p->query_kernel, p->attention_v, r + R.keys, values,
                                r + R.acts[0], r + R.Cs[0], r + R.q, r + R.ctx, r + R.align, dH, dCtx, dq, w + W.dz[0],
@@ -2215,6 +2226,17 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
         ep.dc_out = w + W.dc[cur ^ 1][0] + (size_t)b0 * U;
         float *fp = w + W.fpart + (size_t)sub * W.fpart_each;
         unsigned *tk = reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)sub * 1024;
+        if (r16) {
+          SP_TRY(rows16(Bn, U, U, dqt, U, w + W.wq_sw, 1.f, dHt, U, ss.st[sub], &ep));
+          if (t > 0) {
+            SkinnySplit sp = {w + W.dxh[t & 1] + (size_t)b0 * (E + U) + E, E + U, E, 0.f};
+            SP_TRY(rows16(Bn, E + U, 4 * U, dzt, 4 * U, w + W.kxh_sw, 1.f, dCtx + (size_t)(t - 1) * B * E + (size_t)b0 * E, E,
+                          ss.st[sub], nullptr, &sp));
+          }
+          have_carry = true;
+          cur ^= 1;
+          continue;
+        }
         SP_TRY(gemm_skinny_fused(Bn, U, U, dqt, U, w + W.wqT, U, 0, nullptr, 0, nullptr, 0, 1.f, dHt, U, nullptr, fp, tk,
                                  ss.st[sub], &ep));
         if (split_b && t > 0) {
