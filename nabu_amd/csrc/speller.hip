@@ -894,7 +894,29 @@ __global__ __launch_bounds__(AT) void attn_bwd_loc_mfma_kernel(AttnArgs p) {
   for (int t = tid + AT * NAL; t < Te; t += AT) alp[t] = p.align_prev[(size_t)b * Te + t];
   __syncthreads();
   ASTAMP(1);
-  conv_features(p, alp, cf, lo, hi, smem);
+  {
+    // location features of my frames, two threads per (frame, filter): the chain of one load pair + fma per tap is
+    // LDS-latency bound, and (hi - lo) F outputs would leave half of the workgroup idle
+    const int pb = (p.K - 1) / 2, nout = (hi - lo) * F, hf = tid & 1;
+    for (int o = tid >> 1; o < nout; o += AT / 2) {
+      const int i = lo * F + o, t = i / F, f = i % F;
+      const int d0 = max(0, pb - t), d1 = min(p.K, Te + pb - t), mid = (d0 + d1 + 1) >> 1;
+      const float *a = alp + t - pb, *c = smem + f;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int d = hf ? mid : d0;
+      const int de = hf ? d1 : mid;
+      for (; d + 3 < de; d += 4) {
+        s0 = fmaf(a[d], c[d * F], s0);
+        s1 = fmaf(a[d + 1], c[(d + 1) * F], s1);
+        s2 = fmaf(a[d + 2], c[(d + 2) * F], s2);
+        s3 = fmaf(a[d + 3], c[(d + 3) * F], s3);
+      }
+      for (; d < de; ++d) s0 = fmaf(a[d], c[d * F], s0);
+      float sm = (s0 + s1) + (s2 + s3);
+      sm += __shfl_xor(sm, 1);
+      if (!hf) cf[i] = sm;
+    }
+  }
   ASTAMP(2);
   float r = 0.f;
 #pragma unroll
@@ -978,7 +1000,8 @@ __global__ __launch_bounds__(AT) void attn_bwd_loc_mfma_kernel(AttnArgs p) {
       f32x4_ d;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float th = tanhf_(x[c]);
+        // one exp + one rcp per tanh (as attn_param_grads_kernel and the persistent kernels' score; relative error ~1e-7)
+        const float th = 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x[c])) - 1.0f;
         d[c] = g[ft] * vj[c] * (1.f - th * th);
       }
       dqa += d;

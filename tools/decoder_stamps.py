@@ -33,6 +33,10 @@ def main():
     for i, n in enumerate(NAMES):
         print('  %-44s %6.2f' % (n, ((x[i + 1] - x[i]) & 0xffffffff) / 100.0))
     print('  %-44s %6.2f' % ('step', ((x[10] - x[0]) & 0xffffffff) / 100.0))
+    y = st[16:32]
+    if y[12] and y[13]:
+        print('  inside "C scores": alignments gather %.2f, location features %.2f, scores %.2f' % (
+            ((y[12] - y[6]) & 0xffffffff) / 100.0, ((y[13] - y[12]) & 0xffffffff) / 100.0, ((y[7] - y[13]) & 0xffffffff) / 100.0))
 
 
 if __name__ == '__main__':
