@@ -1171,6 +1171,126 @@ __global__ __launch_bounds__(PT) void attn_param_grads_kernel(int B, int Te, int
   }
 }
 
+// attn_param_grads_kernel<true, .> with its two small dense products on the matrix pipe (exact fp32,
+// v_mfma_f32_16x16x4_f32), U <= 512, F <= 12, <= 16 * FTN frames per slice.  Orientation: x[16 frames x 16 units], so
+// that accumulator register c of lane (kq, fl) = frame 4 kq + c, unit 16 T + fl — keys, d keys (registers for the whole
+// launch) and the stores run along the units, and d IS the A operand of
+//   d conv_proj^T[16 units x 16 filters] += d^T[16 units x 16 frames] . features[16 frames x 16 filters]
+// (k = frame 4 kq + c on both sides).  A wave owns the unit tiles T = w + 8 j; nothing crosses waves.
+template <int FTN>
+__global__ __launch_bounds__(PT) void attn_param_grads_mfma_kernel(int B, int Te, int U, int F, int L, const int32_t *dec_len,
+                                                                   const int32_t *enc_len, const float *keys,
+                                                                   const float *q_all, const float *v, const float *wf,
+                                                                   const float *ds_all, const float *cf_all, float *dkeys,
+                                                                   float *dv_part, float *dwf_part) {
+  extern __shared__ __attribute__((aligned(16))) float psm[];
+  constexpr int UT = 4, NWV = PT / 64;
+  const int b = blockIdx.x, sl = blockIdx.y, S = gridDim.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fl = lane & 15, kq = lane >> 4;
+  const int n = min(max(enc_len[b], 0), Te);
+  const int per = (Te + S - 1) / S, lo = min(sl * per, n), hi = min(lo + per, n), nf = hi - lo;
+  const int DSP = 16 * FTN, CFP = (16 * FTN * F + 3) & ~3;
+  float *ds_s = psm;                      // [PSB][16 FTN] d scores of the steps in flight (zero past my frames)
+  float *cf_s = ds_s + PSB * DSP;         // [PSB][16 FTN][F]
+  const int tl = max(hi - 1, 0);
+  f32x4_ kx[FTN][UT], dk[FTN][UT], dwf[UT];
+  float b1[UT][3], vv[UT], dv[UT];
+  const f32x4_ zv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < UT; ++j) {
+    const int u = min(16 * (w + NWV * j), U - 16) + fl;
+    vv[j] = v[u];
+    dv[j] = 0.f;
+    dwf[j] = zv;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) b1[j][ks] = wf[(size_t)min(4 * ks + kq, F - 1) * U + u];
+#pragma unroll
+    for (int ft = 0; ft < FTN; ++ft) {
+      dk[ft][j] = zv;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) kx[ft][j][c] = keys[((size_t)b * Te + min(lo + 16 * ft + 4 * kq + c, tl)) * U + u];
+    }
+  }
+  const int steps = min(max(dec_len[b], 0), L);
+  for (int l0 = 0; l0 < steps; l0 += PSB) {
+    __syncthreads();
+    for (int i = tid; i < PSB * DSP; i += PT) {
+      const int sb = i / DSP, t = i % DSP;
+      ds_s[i] = (l0 + sb < steps && t < nf) ? ds_all[((size_t)(l0 + sb) * B + b) * Te + lo + t] : 0.f;
+    }
+    for (int i = tid; i < PSB * DSP * F; i += PT) {
+      const int sb = i / (DSP * F), r = i % (DSP * F);
+      cf_s[sb * CFP + r] = (l0 + sb < steps && r < nf * F) ? cf_all[((size_t)(l0 + sb) * B + b) * Te * F + lo * F + r] : 0.f;
+    }
+    float qs[PSB][UT];
+#pragma unroll
+    for (int sb = 0; sb < PSB; ++sb)
+#pragma unroll
+      for (int j = 0; j < UT; ++j)
+        qs[sb][j] = q_all[((size_t)min(l0 + sb, steps - 1) * B + b) * U + min(16 * (w + NWV * j), U - 16) + fl];
+    __syncthreads();
+#pragma unroll
+    for (int sb = 0; sb < PSB; ++sb) {
+      if (l0 + sb >= steps) break;
+      const float *dss = ds_s + sb * DSP, *cfs = cf_s + sb * CFP;
+      // operands of the step shared by my unit tiles: features as A (frame fl, filter 4 ks + kq) and as B (frame
+      // 4 kq + c, filter fl); d scores of frames 4 kq + c
+      float a1[FTN][3];
+      f32x4_ b3[FTN], g[FTN];
+#pragma unroll
+      for (int ft = 0; ft < FTN; ++ft) {
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) a1[ft][ks] = 4 * ks + kq < F ? cfs[(16 * ft + fl) * F + min(4 * ks + kq, F - 1)] : 0.f;
+        g[ft] = *reinterpret_cast<const f32x4_ *>(dss + 16 * ft + 4 * kq);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) b3[ft][c] = fl < F ? cfs[(16 * ft + 4 * kq + c) * F + min(fl, F - 1)] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < UT; ++j) {
+        if (16 * (w + NWV * j) >= U) break;
+        const float qq = qs[sb][j];
+#pragma unroll
+        for (int ft = 0; ft < FTN; ++ft) {
+          f32x4_ x = kx[ft][j] + qq;
+#pragma unroll
+          for (int ks = 0; ks < 3; ++ks) x = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ft][ks], b1[j][ks], x, 0, 0, 0);
+          f32x4_ d;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float th = 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x[c])) - 1.0f;
+            d[c] = g[ft][c] * vv[j] * (1.f - th * th);
+            dv[j] = fmaf(g[ft][c], th, dv[j]);
+          }
+          dk[ft][j] += d;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) dwf[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[c], b3[ft][c], dwf[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // d keys of my frames (frames >= enc_len keep the caller's zeros); d v: my frames' sum, the four k groups added;
+  // d conv_proj^T: accumulator register r = unit 4 kq + r of the tile, lane fl = filter
+#pragma unroll
+  for (int j = 0; j < UT; ++j) {
+    const int u0 = 16 * (w + NWV * j);
+    if (u0 >= U) break;
+#pragma unroll
+    for (int ft = 0; ft < FTN; ++ft)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int t = lo + 16 * ft + 4 * kq + c;
+        if (t < hi) dkeys[((size_t)b * Te + t) * U + u0 + fl] = dk[ft][j][c];
+      }
+    float sv = dv[j];
+    sv += __shfl_xor(sv, 16);
+    sv += __shfl_xor(sv, 32);
+    if (kq == 0) dv_part[((size_t)b * S + sl) * U + u0 + fl] = sv;
+    if (fl < F)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dwf_part[(((size_t)b * S + sl) * F + fl) * U + u0 + 4 * kq + r] = dwf[j][r];
+  }
+}
+
 // What needs every frame of an utterance: dq = sum of the slices' partials; for location-aware
 // attention the gradient w.r.t. the previous alignments and the conv kernel, from the d location
 // features the slices left in HBM.  grid (B, 2) for location-aware attention (y = 0: dq and d previous
@@ -1292,34 +1412,49 @@ __global__ __launch_bounds__(256) void swap01_kernel(int L, int B, int F, const 
 // Workgroup (column block, class c): the ids are scanned 256 at a time through LDS (one coalesced load
 // per chunk instead of a dependent global load per row), matching rows are added in increasing row
 // order (deterministic).
+// Two passes per segment of SEG rows: (1) the segment's matching row numbers into LDS (ballots, no loads of dz),
+// (2) the rows added eight loads at a time.  (The first version added each chunk's ~5 hits as they were found: one
+// dependent global load per hit behind four barriers per 256 ids — 0.62 ms for cfg5's [10 176 x 2048].)
+constexpr int SCATTER_SEG = 8192;
 __global__ __launch_bounds__(256) void scatter_rows_kernel(int C, int N, int W, const int32_t *__restrict__ ids,
                                                            const float *__restrict__ dz, float *__restrict__ dK) {
-  __shared__ int hit[256];
+  __shared__ int hit[SCATTER_SEG];
+  __shared__ int wcount[4];
   __shared__ int nhit;
   const int c = blockIdx.y, tid = threadIdx.x;
-  const int col = blockIdx.x * 256 + tid;
+  const int col = min(blockIdx.x * 256 + tid, W - 1);
   float s = 0.f;
-  for (int base = 0; base < N; base += 256) {
+  for (int seg = 0; seg < N; seg += SCATTER_SEG) {
+    const int send = min(seg + SCATTER_SEG, N);
     if (tid == 0) nhit = 0;
     __syncthreads();
-    const int i = base + tid;
-    const bool m = i < N && ids[i] == c;
-    // order-preserving compaction: matches of wave w go after those of the waves before it
-    const unsigned long long bal = __ballot(m);
-    __shared__ int wcount[4];
-    if ((tid & 63) == 0) wcount[tid >> 6] = __popcll(bal);
-    __syncthreads();
-    int off = 0;
-    for (int w = 0; w < (tid >> 6); ++w) off += wcount[w];
-    if (m) hit[off + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = i;
-    if (tid == 0) nhit = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    for (int base = seg; base < send; base += 256) {
+      const int i = base + tid;
+      const bool m = i < send && ids[i] == c;
+      // order-preserving compaction: matches of wave w go after those of the waves before it
+      const unsigned long long bal = __ballot(m);
+      if ((tid & 63) == 0) wcount[tid >> 6] = __popcll(bal);
+      __syncthreads();
+      int off = nhit;
+      for (int w = 0; w < (tid >> 6); ++w) off += wcount[w];
+      if (m) hit[off + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = i;
+      __syncthreads();
+      if (tid == 0) nhit += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    }
     __syncthreads();
     const int n = nhit;
-    if (col < W)
-      for (int j = 0; j < n; ++j) s += dz[(size_t)hit[j] * W + col];
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {          // increasing row order, eight loads in flight
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = dz[(size_t)hit[j + k] * W + col];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; j < n; ++j) s += dz[(size_t)hit[j] * W + col];
     __syncthreads();
   }
-  if (col < W) dK[(size_t)c * W + col] = s;
+  if (blockIdx.x * 256 + tid < W) dK[(size_t)c * W + col] = s;
 }
 
 // out[c][r] = in[r][c] (32x32 LDS tiles); used once per backward pass to turn the per-step
@@ -1605,10 +1740,17 @@ static int attn_param_grads(const nabu_attn_desc *d, int S, int L, const int32_t
                             const float *keys, const float *q_all, const float *v, const float *wf, const float *ds_all,
                             const float *cf_all, float *dkeys, float *dv_part, float *dwf_part, hipStream_t s) {
   const int per = (d->Te + S - 1) / S, NG = PT / (d->U / 4);
-  const size_t shm = (PSB * (((size_t)per + 3) / 4 * 4 + ((size_t)per * (d->kind == 1 ? d->F : 0) + 3) / 4 * 4) + (size_t)NG * d->U + 4) * sizeof(float);
+  size_t shm = (PSB * (((size_t)per + 3) / 4 * 4 + ((size_t)per * (d->kind == 1 ? d->F : 0) + 3) / 4 * 4) + (size_t)NG * d->U + 4) * sizeof(float);
   const bool four = (per + NG - 1) / NG <= 4;
   auto kern = d->kind == 1 ? (four ? attn_param_grads_kernel<true, 4> : attn_param_grads_kernel<true, 8>)
                            : (four ? attn_param_grads_kernel<false, 4> : attn_param_grads_kernel<false, 8>);
+  // location-aware, U <= 512, <= 32 frames per slice: the matrix-pipe kernel (NABU_ATTN_GRADS_MFMA=0: the vector one)
+  static const int mfma_env = [] { const char *e = getenv("NABU_ATTN_GRADS_MFMA"); return e ? atoi(e) : 1; }();
+  if (mfma_env && d->kind == 1 && d->U % 16 == 0 && d->U <= 512 && d->F <= 12 && per <= 32) {
+    kern = per <= 16 ? attn_param_grads_mfma_kernel<1> : attn_param_grads_mfma_kernel<2>;
+    const size_t need = (size_t)PSB * (32 + 32 * d->F + 4) * sizeof(float);
+    if (need > shm) shm = need;
+  }
   if (shm > 64 * 1024)
     NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   hipLaunchKernelGGL(kern, dim3(d->B, S), dim3(PT), shm, s, d->B, d->Te, d->U, d->kind == 1 ? d->F : 0, L, dec_len, enc_len,
