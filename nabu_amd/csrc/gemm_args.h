@@ -68,6 +68,12 @@ struct SkinnyEpilogue {
   int ld_dh2;
   const float *dc_in;
   float *dz, *dc_out;
+  // backward, rows16_kernel only: output dropout of the cell (0 or 1 = off): the gradient of the cell OUTPUT (projection +
+  // query) goes through mask / keep, the recurrent carry dh2 does not; element (row0 + m) U + u of the Philox stream
+  // (seed, seed_offset) — dropout_scale4 of common.h, the masks of the forward pass
+  float keep;
+  unsigned long long seed, seed_offset;
+  int row0;
 };
 
 // optional second destination of the fused skinny product: columns >= split (a multiple of 32) are written to

@@ -367,6 +367,12 @@ __global__ __launch_bounds__(512) void rows16_kernel(Rows16Args a) {
     ep.dc_out[eidx] = e_dc;
     return;
   }
+  if (ep.keep > 0.f && ep.keep < 1.f) {
+    const size_t e = (size_t)(ep.row0 + em) * U + n0 + en;
+    const float4 sc = dropout_scale4(e >> 2, ep.keep, ep.seed, ep.seed_offset);
+    const int j = (int)(e & 3);
+    v *= j == 0 ? sc.x : j == 1 ? sc.y : j == 2 ? sc.z : sc.w;
+  }
   const float tc = tanhf_(e_cn);
   const float dht = v + e_dh2;
   const float dct = e_dc + dht * e_o * (1.f - tc * tc);

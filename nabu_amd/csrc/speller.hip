@@ -2314,13 +2314,13 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   pd.kind = d->kind; pd.K = d->K; pd.F = d->F;
   pd.keep_prob = d->keep_prob; pd.seed = d->seed; pd.seed_offset = d->seed_offset;
   const bool persist = bwd_takes_persistent(d, W);
-  const bool fuse_b = fuse_shapes && (!drop || persist);      // the chain's cell epilogue has no dropout
+  // sub-batches of <= 16 utterances: both products of a step by rows16_kernel (no split-K hand-off between workgroups:
+  // 13 -> 7 us per launch; its cell epilogue applies the output dropout's mask); NABU_SPELLER_ROWS16=0: gemm_skinny_fused
+  const bool r16 = fuse_shapes && !persist && E % 32 == 0 && env_int("NABU_SPELLER_SPLIT", 1) && env_int("NABU_SPELLER_ROWS16", 1) &&
+                   rows16_ok(Bn, U, U, U) && rows16_ok(Bn, E + U, 4 * U, 4 * U);
+  const bool fuse_b = fuse_shapes && (!drop || persist || r16);      // (gemm_skinny_fused's cell epilogue has no dropout)
   if (fuse_b) SP_TRY(transpose(E + U, 4 * U, p->lstm_kernel[0] + (size_t)C * 4 * U, 4 * U, w + W.kxhT, s));
   const bool split_b = fuse_b && E % 32 == 0 && env_int("NABU_SPELLER_SPLIT", 1);
-  // sub-batches of <= 16 utterances: both products of a step by rows16_kernel (no split-K hand-off between workgroups:
-  // 13 -> 7 us per launch); NABU_SPELLER_ROWS16=0: gemm_skinny_fused
-  const bool r16 = fuse_b && split_b && !persist && env_int("NABU_SPELLER_ROWS16", 1) && rows16_ok(Bn, U, U, U) &&
-                   rows16_ok(Bn, E + U, 4 * U, 4 * U) && E % 16 == 0;
   if (r16) {
     SP_TRY(rows16_swizzle(U, U, p->query_kernel, U, w + W.wq_sw, s));
     SP_TRY(rows16_swizzle(E + U, 4 * U, p->lstm_kernel[0] + (size_t)C * 4 * U, 4 * U, w + W.kxh_sw, s));
@@ -2389,6 +2389,8 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
         ep.dc_in = w + W.dc[cur][0] + (size_t)b0 * U;
         ep.dz = dzt;
         ep.dc_out = w + W.dc[cur ^ 1][0] + (size_t)b0 * U;
+        ep.keep = drop ? d->keep_prob : 1.f; ep.seed = d->seed; ep.seed_offset = d->seed_offset + (unsigned long long)t;
+        ep.row0 = b0;
         float *fp = w + W.fpart + (size_t)sub * W.fpart_each;
         unsigned *tk = reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)sub * 1024;
         if (r16) {

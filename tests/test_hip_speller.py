@@ -273,6 +273,44 @@ def test_persistent_decoder_with_output_dropout(attention):
         assert rel(got[2][k], ref[2][k]) < 2e-4, k
 
 
+@pytest.mark.parametrize('attention,dropout', [('location_aware', 0.7), ('location_aware', 1.0), ('vanilla', 0.7)])
+def test_step_chain_rows16_products_with_output_dropout(attention, dropout):
+    """The step chain's backward products of a 16-utterance sub-batch (rows16_kernel, gemm_skinny.hip: dq . Wq^T with the
+    LSTM cell's backward pass as epilogue, dz . [Kx | Kh]^T) against the chain's older forms (NABU_SPELLER_ROWS16=0:
+    gemm_skinny_fused without dropout, separate GEMM + dropout + cell kernels with it): the same masks from the same
+    Philox stream, so every gradient agrees to fp32 summation order."""
+    import os
+    rng = np.random.default_rng(37)
+    B, Te, E, C, U = 32, 40, 64, 8, 128                                # two sub-batches of 16; K = U and 4U multiples of 128
+    enc_len = rng.integers(Te // 2, Te + 1, B).astype(np.int32)
+    enc_len[0] = Te
+    tlen = rng.integers(1, 9, B).astype(np.int32)
+    tlen[3] = 8
+    enc = rng.normal(size=(B, Te, E)).astype(np.float32)
+    enc *= (np.arange(Te)[None, :, None] < enc_len[:, None, None])
+    tg = rng.integers(0, C - 1, (B, int(tlen.max()))).astype(np.int32)
+    for b in range(B):
+        tg[b, tlen[b] - 1] = C - 1
+        tg[b, tlen[b]:] = 0
+    over = {'decoder.num_layers': 1, 'decoder.num_units': U, 'decoder.attention': attention, 'decoder.dropout': dropout}
+    if attention == 'location_aware':
+        over.update({'decoder.numfilt': 3, 'decoder.filtersize': 7})
+    os.environ['NABU_SPELLER_PERSIST'] = os.environ['NABU_SPELLER_PERSIST_BWD'] = '0'
+    try:
+        got = _decoder_run(over, enc, enc_len, tg, tlen, C, seed=77)
+        os.environ['NABU_SPELLER_ROWS16'] = '0'
+        ref = _decoder_run(over, enc, enc_len, tg, tlen, C, seed=77)
+    finally:
+        del os.environ['NABU_SPELLER_PERSIST'], os.environ['NABU_SPELLER_PERSIST_BWD']
+        os.environ.pop('NABU_SPELLER_ROWS16', None)
+    assert got[4] == (0, 0) and ref[4] == (0, 0)
+    assert np.array_equal(got[0], ref[0])                               # the forward pass is the same code
+    rel = lambda a, b_: np.abs(a - b_).max() / (np.abs(b_).max() + 1e-12)
+    assert rel(got[1], ref[1]) < 2e-5
+    for k in ref[2]:
+        assert rel(got[2][k], ref[2][k]) < 2e-5, k
+
+
 @pytest.mark.parametrize('attention,dropout', [('vanilla', 1.0), ('location_aware', 1.0), ('vanilla', 0.8)])
 def test_persistent_decoder_with_scheduled_sampling(attention, dropout):
     """sample_prob > 0 (the reference default is 0.1, defaults/speller.cfg:15; 0.5 here so that many inputs are drawn)
