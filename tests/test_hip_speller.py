@@ -80,6 +80,37 @@ def test_speller_step_at_the_cfg5_attention_geometry():
     check_speller('vanilla', 1, 64, 0, 0, enc_len, tlen)
 
 
+@pytest.mark.parametrize('B,U,E,K,F,Te', [
+    (5, 48, 24, 5, 3, 70),        # 3 unit tiles over 8 waves: most waves own none; 5 slices of 14 frames
+    (5, 320, 32, 11, 12, 40),     # 20 unit tiles: a third tile only for waves 0-3; 12 filters (the operand's full k range)
+    (16, 128, 64, 101, 10, 200),  # the cfg5 attention geometry at U = 128: rows16 products (K = 128 / 512), 25-frame slices
+    (7, 256, 48, 4, 1, 9),        # fewer frames than one tile, one filter, even filter width; rows16 with 7 rows
+    (3, 512, 16, 7, 2, 33),       # the kernel's widest U; two frame tiles, the second nearly empty
+])
+def test_step_chain_location_aware_matrix_pipe_kernels(B, U, E, K, F, Te):
+    """The round-5 kernels of the location-aware step chain — attn_bwd_loc_mfma_kernel, attn_param_grads_mfma_kernel,
+    rows16_kernel (speller.hip, gemm_skinny.hip) — at shapes that reach their edges, against the float64 oracle: the
+    chain is forced (the persistent decoder would take most of these shapes), then run again with each kernel's
+    predecessor (NABU_ATTN_BWD_MFMA / NABU_ATTN_GRADS_MFMA / NABU_SPELLER_ROWS16 = 0): both agree with the oracle
+    inside check_speller, and with each other to fp32 summation order."""
+    import os
+    rng = np.random.default_rng(B * 1000 + U)
+    enc_len = rng.integers(max(Te // 2, 1), Te + 1, B).astype(np.int32)
+    enc_len[0] = Te
+    tlen = rng.integers(1, 6, B).astype(np.int32)
+    tlen[-1] = 5
+    os.environ['NABU_SPELLER_PERSIST'] = os.environ['NABU_SPELLER_PERSIST_BWD'] = '0'
+    try:
+        got = check_speller('location_aware', 1, U, K, F, enc_len, tlen, E=E)
+        for k in ('NABU_ATTN_BWD_MFMA', 'NABU_ATTN_GRADS_MFMA', 'NABU_SPELLER_ROWS16'):
+            os.environ[k] = '0'
+        ref = check_speller('location_aware', 1, U, K, F, enc_len, tlen, E=E)
+    finally:
+        for k in ('NABU_SPELLER_PERSIST', 'NABU_SPELLER_PERSIST_BWD', 'NABU_ATTN_BWD_MFMA', 'NABU_ATTN_GRADS_MFMA', 'NABU_SPELLER_ROWS16'):
+            os.environ.pop(k, None)
+    assert np.abs(got - ref).max() < 1e-5
+
+
 @pytest.mark.parametrize('attention,nl,K,F', [('vanilla', 1, 0, 0), ('location_aware', 1, 5, 3), ('vanilla', 2, 0, 0),
                                               ('windowed', 1, 2, 3)])
 def test_speller_step_on_the_fused_and_multi_stream_paths(attention, nl, K, F):
