@@ -1674,7 +1674,8 @@ static int attn_bwd_impl(const nabu_attn_desc *d, int step, const int32_t *dec_l
   auto kern = defer ? (d->kind != 1 ? attn_bwd_kernel<0, true> : reg ? attn_bwd_kernel<2, true> : attn_bwd_kernel<1, true>)
                     : (d->kind != 1 ? attn_bwd_kernel<0, false> : reg ? attn_bwd_kernel<2, false> : attn_bwd_kernel<1, false>);
   // the matrix-pipe kernel of the deferred location-aware chain (NABU_ATTN_BWD_MFMA=0: attn_bwd_kernel<2, true>)
-  static const int mfma_env = [] { const char *e = getenv("NABU_ATTN_BWD_MFMA"); return e ? atoi(e) : 1; }();
+  const char *mfma_e = getenv("NABU_ATTN_BWD_MFMA");      // (read per call, like every switch of this file)
+  const int mfma_env = mfma_e ? atoi(mfma_e) : 1;
   if (defer && reg && mfma_env && cf_out && d->U % 16 == 0 && (d->Te + S - 1) / S <= 32 && d->Te <= 1024 && d->K * d->F <= 8 * AT &&
       d->E <= 16 * AT) {
     const int UT = (d->U / 16 + AT / 64 - 1) / (AT / 64);
@@ -1745,7 +1746,8 @@ static int attn_param_grads(const nabu_attn_desc *d, int S, int L, const int32_t
   auto kern = d->kind == 1 ? (four ? attn_param_grads_kernel<true, 4> : attn_param_grads_kernel<true, 8>)
                            : (four ? attn_param_grads_kernel<false, 4> : attn_param_grads_kernel<false, 8>);
   // location-aware, U <= 512, <= 32 frames per slice: the matrix-pipe kernel (NABU_ATTN_GRADS_MFMA=0: the vector one)
-  static const int mfma_env = [] { const char *e = getenv("NABU_ATTN_GRADS_MFMA"); return e ? atoi(e) : 1; }();
+  const char *mfma_e = getenv("NABU_ATTN_GRADS_MFMA");
+  const int mfma_env = mfma_e ? atoi(mfma_e) : 1;
   if (mfma_env && d->kind == 1 && d->U % 16 == 0 && d->U <= 512 && d->F <= 12 && per <= 32) {
     kern = per <= 16 ? attn_param_grads_mfma_kernel<1> : attn_param_grads_mfma_kernel<2>;
     const size_t need = (size_t)PSB * (32 + 32 * d->F + 4) * sizeof(float);
