@@ -87,8 +87,12 @@ struct SkinnySplit {
 // the decoder chain's products of a sub-batch of <= 16 rows (gemm_skinny.hip): weights re-blocked once per pass
 bool rows16_ok(int M, int N, int K, int lda);
 int rows16_swizzle(int N, int K, const float *W, int ldw, float *out, hipStream_t s);
+int rows16_swizzle_kn(int N, int K, const float *W, int ldw, float *out, int gate_units, hipStream_t s);
+// K1 / A2 / lda2: reduction indices >= K1 come from a second operand (the cell's [context | h]); ep kinds 0, 1 (forward
+// cell: the weights' columns gate-interleaved, rows16_swizzle_kn(gate_units = U)), 2 (cell backward)
 int rows16(int M, int N, int K, const float *A, int lda, const float *Wsw, float beta, float *C, int ldc, hipStream_t s,
-           const SkinnyEpilogue *ep = nullptr, const SkinnySplit *split = nullptr);
+           const SkinnyEpilogue *ep = nullptr, const SkinnySplit *split = nullptr, int K1 = 0, const float *A2 = nullptr,
+           int lda2 = 0);
 int gemm_skinny_fused(int M, int N, int K1, const float *A, int lda, const float *B, int ldb, int K2, const float *A2,
                       int lda2, const float *B2, int ldb2, float beta, float *C, int ldc, const float *bias,
                       float *partial, unsigned *tickets, hipStream_t s, const SkinnyEpilogue *ep = nullptr,

@@ -291,6 +291,8 @@ struct Rows16Args {
   float *C, *C2;
   int M, N, K, lda, ldc, ldc2, split;
   float beta, beta2;
+  const float *A2;          // reduction indices >= K1 (a multiple of 16) come from A2[m][k - K1] (the cell's [context | h])
+  int lda2, K1;
   SkinnyEpilogue ep;
 };
 typedef float r16f4 __attribute__((ext_vector_type(4)));
@@ -304,6 +306,30 @@ __global__ __launch_bounds__(256) void rows16_swizzle_kernel(int N, int K, const
     const int fl = lane & 15, kq = lane >> 4;
     reinterpret_cast<r16f4 *>(out)[i] = *reinterpret_cast<const r16f4 *>(W + (size_t)(16 * nt + fl) * ldw + 16 * kg + 4 * kq);
   }
+}
+// the same blocks from a weight stored [K][N] (forward products h . W): out block ((nt, kg), lane (kq, fl))[r] =
+// W[16 kg + 4 kq + r][col(16 nt + fl)]; gate_units > 0: col(n) = (n % 4) * gate_units + n / 4 — output column 4 u + g
+// is gate g of unit u, so that a 16-column tile holds the four gates of four units (the cell epilogue)
+__global__ __launch_bounds__(256) void rows16_swizzle_kn_kernel(int N, int K, const float *__restrict__ W, int ldw,
+                                                              float *__restrict__ out, int gate_units) {
+  const size_t total = (size_t)N * K / 4;
+  const int KG = K / 16;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int lane = (int)(i & 63), kg = (int)((i >> 6) % KG), nt = (int)((i >> 6) / KG);
+    const int fl = lane & 15, kq = lane >> 4, n = 16 * nt + fl;
+    const int col = gate_units > 0 ? (n & 3) * gate_units + (n >> 2) : n;
+    const float *src = W + (size_t)(16 * kg + 4 * kq) * ldw + col;
+    const r16f4 v = {src[0], src[ldw], src[2 * (size_t)ldw], src[3 * (size_t)ldw]};
+    reinterpret_cast<r16f4 *>(out)[i] = v;
+  }
+}
+int rows16_swizzle_kn(int N, int K, const float *W, int ldw, float *out, int gate_units, hipStream_t s) {
+  if (N % 16 || K % 16 || (gate_units > 0 && N != 4 * gate_units)) return fail(NABU_EUNSUP, "rows16_swizzle_kn: N=%d K=%d", N, K);
+  size_t blocks = ((size_t)N * K / 4 + 255) / 256;
+  hipLaunchKernelGGL(rows16_swizzle_kn_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, N, K, W, ldw, out,
+                     gate_units);
+  NABU_LAUNCH_CHECK();
+  return 0;
 }
 int rows16_swizzle(int N, int K, const float *W, int ldw, float *out, hipStream_t s) {
   if (N % 16 || K % 16 || ldw % 4) return fail(NABU_EUNSUP, "rows16_swizzle: N=%d K=%d ld=%d", N, K, ldw);
@@ -325,11 +351,13 @@ __global__ __launch_bounds__(512) void rows16_kernel(Rows16Args a) {
   r16f4 bv[KG], av[KG];
   {
     const r16f4 *Bp = reinterpret_cast<const r16f4 *>(a.Wsw) + ((size_t)nt * (a.K / 16) + (size_t)w * KG) * 64 + lane;
-    const float *Ap = a.A + (size_t)min(fl, a.M - 1) * a.lda + 16 * (w * KG) + 4 * kq;
+    const int row = min(fl, a.M - 1);
+    const float *Ap = a.A + (size_t)row * a.lda + 4 * kq, *Ap2 = a.A2 + (size_t)row * a.lda2 - a.K1 + 4 * kq;
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
+      const int k = 16 * (w * KG + g);
       bv[g] = Bp[(size_t)g * 64];
-      av[g] = *reinterpret_cast<const r16f4 *>(Ap + 16 * g);
+      av[g] = *reinterpret_cast<const r16f4 *>((k < a.K1 ? Ap : Ap2) + k);
     }
   }
   const bool second = n0 >= a.split;
@@ -345,6 +373,22 @@ __global__ __launch_bounds__(512) void rows16_kernel(Rows16Args a) {
     e_cn = ep.c_new[eidx]; e_cp = ep.c_prev[eidx]; e_dc = ep.dc_in[eidx];
     if (ep.dh2) e_dh2 = ep.dh2[(size_t)em * ep.ld_dh2 + n0 + en];
   }
+  // kind 1 (forward cell): thread (row m = tid / 4, unit n0 / 4 + tid % 4) of the first wave
+  const int fm = min(tid >> 2, a.M - 1), fu = (n0 >> 2) + (tid & 3);
+  float f_b[4] = {0.f, 0.f, 0.f, 0.f}, f_e[4] = {0.f, 0.f, 0.f, 0.f}, f_cp = 0.f, f_hp = 0.f;
+  int f_len = 0;
+  if (ep.kind == 1 && tid < 64) {
+    f_len = ep.seq_len[fm];
+    f_cp = ep.c_prev[(size_t)fm * U + fu];
+    f_hp = ep.h_prev[(size_t)fm * U + fu];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) f_b[g] = ep.bias[g * U + fu];
+    if (ep.emb) {   // one-hot input times kernel == one row of the (unpermuted) kernel
+      const float *em_row = ep.emb + (size_t)ep.ids[fm] * 4 * U + fu;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) f_e[g] = em_row[g * U];
+    }
+  }
   __builtin_amdgcn_sched_barrier(0);
   r16f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -355,6 +399,33 @@ __global__ __launch_bounds__(512) void rows16_kernel(Rows16Args a) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) red[w][4 * kq + c][fl] = acc[c];
   __syncthreads();
+  if (ep.kind == 1) {
+    // the finished tile's columns 4 j + g: gates i, j, f, o of unit n0 / 4 + j (TF LSTMCell, forget bias 1)
+    __shared__ float zt[16][17];
+    if (tid < 256) {
+      float zs = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) zs += red[i][tid >> 4][en];
+      zt[tid >> 4][en] = zs;
+    }
+    __syncthreads();
+    if (tid >= 64 || (tid >> 2) >= a.M) return;
+    const size_t idx = (size_t)fm * U + fu, zo = (size_t)fm * 4 * U + fu;
+    if (ep.step >= f_len) {   // finished row: dynamic_decode(impute_finished) freezes the state
+      ep.c_new[idx] = f_cp;
+      ep.h_new[idx] = f_hp;
+      ep.acts[zo] = ep.acts[zo + U] = ep.acts[zo + 2 * U] = ep.acts[zo + 3 * U] = 0.f;
+      return;
+    }
+    const float *zr = &zt[fm][4 * (tid & 3)];
+    const float zi = zr[0] + f_b[0] + f_e[0], zj = zr[1] + f_b[1] + f_e[1], zf = zr[2] + f_b[2] + f_e[2], zq = zr[3] + f_b[3] + f_e[3];
+    const float i = sigmoidf_(zi), g = tanhf_(zj), fg = sigmoidf_(zf + 1.0f), o = sigmoidf_(zq);
+    const float c = f_cp * fg + i * g;
+    ep.acts[zo] = i; ep.acts[zo + U] = g; ep.acts[zo + 2 * U] = fg; ep.acts[zo + 3 * U] = o;
+    ep.c_new[idx] = c;
+    ep.h_new[idx] = tanhf_(c) * o;
+    return;
+  }
   if (tid >= 256 || (tid >> 4) >= a.M) return;
   float v = 0.f;
 #pragma unroll
@@ -385,25 +456,32 @@ __global__ __launch_bounds__(512) void rows16_kernel(Rows16Args a) {
 
 bool rows16_ok(int M, int N, int K, int lda) {
   const int kg = K / 128;
-  return M >= 1 && M <= 16 && N % 16 == 0 && K % 128 == 0 && lda % 4 == 0 && (kg == 1 || kg == 2 || kg == 4 || kg == 8 || kg == 16);
+  return M >= 1 && M <= 16 && N % 16 == 0 && K % 128 == 0 && lda % 4 == 0 &&
+         (kg == 1 || kg == 2 || kg == 3 || kg == 4 || kg == 6 || kg == 8 || kg == 12 || kg == 16);
 }
 // C[M, N] = A . W^T (+ beta C); ep: kind 0 (plain) or 2 (LSTM cell backward on the finished tile, as gemm_skinny_fused);
 // split: columns >= split->split (a multiple of 16) go to split->C2 with split->beta2
 int rows16(int M, int N, int K, const float *A, int lda, const float *Wsw, float beta, float *C, int ldc, hipStream_t s,
-           const SkinnyEpilogue *ep, const SkinnySplit *split) {
-  if (!rows16_ok(M, N, K, lda) || (ep && ep->kind != 0 && ep->kind != 2) || (split && (split->split % 16 || (ep && ep->kind))))
+           const SkinnyEpilogue *ep, const SkinnySplit *split, int K1, const float *A2, int lda2) {
+  if (!rows16_ok(M, N, K, lda) || (ep && ep->kind != 0 && ep->kind != 1 && ep->kind != 2) ||
+      (split && (split->split % 16 || (ep && ep->kind))) || (A2 && (K1 % 16 || K1 <= 0 || K1 >= K || lda2 % 4)))
     return fail(NABU_EUNSUP, "rows16 product: unsupported shape M=%d N=%d K=%d", M, N, K);
   Rows16Args a = {};
   a.A = A; a.Wsw = Wsw; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.beta = beta;
   a.C2 = nullptr; a.ldc2 = 0; a.split = N; a.beta2 = 0.f;
+  a.A2 = A2 ? A2 : A; a.lda2 = A2 ? lda2 : lda; a.K1 = A2 ? K1 : K;
   if (split) { a.C2 = split->C2; a.ldc2 = split->ldc2; a.split = split->split; a.beta2 = split->beta2; }
   if (ep) a.ep = *ep; else a.ep.kind = 0;
+  if (a.ep.kind == 1) { a.C = nullptr; a.beta = 0.f; }      // the forward cell writes its state, not the product
   const dim3 grid(N / 16), block(512);
   switch (K / 128) {
     case 1: hipLaunchKernelGGL(rows16_kernel<1>, grid, block, 0, s, a); break;
     case 2: hipLaunchKernelGGL(rows16_kernel<2>, grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(rows16_kernel<3>, grid, block, 0, s, a); break;
     case 4: hipLaunchKernelGGL(rows16_kernel<4>, grid, block, 0, s, a); break;
+    case 6: hipLaunchKernelGGL(rows16_kernel<6>, grid, block, 0, s, a); break;
     case 8: hipLaunchKernelGGL(rows16_kernel<8>, grid, block, 0, s, a); break;
+    case 12: hipLaunchKernelGGL(rows16_kernel<12>, grid, block, 0, s, a); break;
     default: hipLaunchKernelGGL(rows16_kernel<16>, grid, block, 0, s, a); break;
   }
   NABU_LAUNCH_CHECK();

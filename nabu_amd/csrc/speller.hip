@@ -2164,6 +2164,14 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
                                p->out_bias, ids_used));
   unsigned *atk = env_int("NABU_SPELLER_ATTN_FUSED", 1) ? reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)NS * 1024 : nullptr;
   SubStreams ss;
+  // sub-batches of <= 16 utterances: the cell's product ([context | h] . kernel with the cell as epilogue) and the query
+  // by rows16_kernel (gemm_skinny.hip) over weights re-blocked once per pass; NABU_SPELLER_ROWS16=0: gemm_skinny_fused
+  const bool r16 = !persist && nl == 1 && cell_epi[0] && env_int("NABU_SPELLER_ROWS16", 1) && E % 16 == 0 &&
+                   rows16_ok(Bn, 4 * U, E + U, E) && rows16_ok(Bn, U, U, U);
+  if (r16) {
+    SP_TRY(rows16_swizzle_kn(4 * U, E + U, p->lstm_kernel[0] + (size_t)C * 4 * U, 4 * U, w + W.kxh_sw, U, s));
+    SP_TRY(rows16_swizzle_kn(U, U, p->query_kernel, U, w + W.wq_sw, 0, s));
+  }
   if (!persist) {
   SP_TRY(sub_streams(NS, s, &ss));
   SP_TRY(sub_fork(ss));
@@ -2191,6 +2199,9 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
           const int K1 = n == 0 ? E : U;
           const float *x1 = n == 0 ? r + R.ctx + (size_t)t * B * E + (size_t)b0 * E : r + R.Ho[n - 1] + nxt + (size_t)b0 * U;
           const float *Kp = w + W.kperm[n];
+          if (r16)
+            SP_TRY(rows16(Bn, 4 * U, E + U, x1, E, w + W.kxh_sw, 0.f, nullptr, 0, ss.st[sub], &ep, nullptr, E, Hn + cur, U));
+          else
           SP_TRY(gemm_skinny_fused(Bn, 4 * U, K1, x1, K1, Kp, 4 * U, U, Hn + cur, U, Kp + (size_t)K1 * 4 * U, 4 * U, 0.f, z,
                                    4 * U, nullptr, w + W.fpart + (size_t)sub * W.fpart_each,
                                    reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)sub * 1024, ss.st[sub], &ep));
@@ -2212,6 +2223,8 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
       }
       const float *htop = r + R.Ho[nl - 1] + (size_t)(t + 1) * B * U + (size_t)b0 * U;
       float *qt = r + R.q + (size_t)t * B * U + (size_t)b0 * U;
+      if (r16) SP_TRY(rows16(Bn, U, U, htop, U, w + W.wq_sw, 0.f, qt, U, ss.st[sub]));
+      else
       SP_TRY(mm2(Bn, U, U, htop, U, p->query_kernel, U, 0, nullptr, 0, nullptr, 0, 0.f, qt, U, w, W, sub, gws, gwb, st));
       SP_TRY(attn_fwd_impl(&adn, t, dlen, enc_len + b0, r + R.keys + (size_t)b0 * Te * U, values + (size_t)b0 * Te * E, qt,
                            p->attention_v, p->conv_kernel, p->conv_proj,

@@ -335,7 +335,7 @@ def test_step_chain_rows16_products_with_output_dropout(attention, dropout):
         del os.environ['NABU_SPELLER_PERSIST'], os.environ['NABU_SPELLER_PERSIST_BWD']
         os.environ.pop('NABU_SPELLER_ROWS16', None)
     assert got[4] == (0, 0) and ref[4] == (0, 0)
-    assert np.array_equal(got[0], ref[0])                               # the forward pass is the same code
+    assert np.abs(got[0] - ref[0]).max() < 2e-5                         # (the forward products differ the same way)
     rel = lambda a, b_: np.abs(a - b_).max() / (np.abs(b_).max() + 1e-12)
     assert rel(got[1], ref[1]) < 2e-5
     for k in ref[2]:
