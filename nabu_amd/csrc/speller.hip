@@ -22,6 +22,7 @@
 
 namespace nabu {
 
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
 constexpr int AT = 512;   // threads per attention workgroup (8 wave64)
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -445,6 +446,210 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs p) {
   }
 }
 
+// Location-aware attention forward of the step chain's sliced form (softmax, S > 1 slices of <= 32 frames, the last
+// slice to arrive finishes the utterance; U <= 512, F <= 12, E <= 2 AT): attn_fwd_kernel<2> with everything that depends
+// on nothing — previous alignment, conv kernel, the slice's values and keys, q, v, conv_proj — loaded at clamped addresses
+// before the first wait, and the score's feature projection on the matrix pipe (exact fp32):
+//   x^T[16 units x 16 frames] = conv_proj^T[16 x 12] . features^T[12 x 16] + (keys^T + q),  score[frame] = sum_u v[u] tanh(x)
+// (lane = frame, register r = unit 4 kq + r of the tile, as in attn_bwd_loc_mfma_kernel).  21.9 -> see profiles.
+template <int UT>
+__global__ __launch_bounds__(AT) void attn_fwd_loc_mfma_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, sl = blockIdx.y, S = gridDim.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int Te = p.Te, U = p.U, E = p.E, F = p.F;
+  constexpr int NW = AT / 64;
+  float *base = smem + ck_floats(p);
+  float *alp = base, *sc = alp + Te, *cf = sc + Te, *red = cf + Te * F;
+  float4 *part = reinterpret_cast<float4 *>(base + ((2 * Te + Te * F + 64 + 3) & ~3));      // [2][AT / 2] (also the waves' scores)
+  float *align = p.align + (size_t)b * Te;
+  float *ctx = p.fwd_part + ((size_t)b * S + sl) * (E + 4);
+  __shared__ int last_flag;
+  if (p.step >= p.dec_len[b]) {   // finished row: state frozen (by slice 0)
+    if (sl != 0) return;
+    float *cx = p.ctx + (size_t)b * E;
+    for (int t = tid; t < Te; t += AT) align[t] = p.align_prev[(size_t)b * Te + t];
+    for (int e = tid; e < E; e += AT) cx[e] = p.ctx_prev[(size_t)b * E + e];
+    return;
+  }
+  const int nfull = min(max(p.enc_len[b], 0), Te);
+  const int per = (Te + S - 1) / S, lo = min(sl * per, nfull), n = min(lo + per, nfull);   // my frames [lo, n)
+  const float *keys = p.keys + (size_t)b * Te * U;
+  const float *vals = p.values + (size_t)b * Te * E;
+  const float *q = p.q + (size_t)b * U;
+  const int fl = lane & 15, kq = lane >> 4;
+  const int tl = max(n - 1, 0);
+  typedef const f32x4_ *V4;
+  const f32x4_ zv = {0.f, 0.f, 0.f, 0.f};
+  // ---- loads that depend on nothing, in the order of use
+  constexpr int NAL = (1024 + AT - 1) / AT;
+  float alp_r[NAL], ck_r[8];
+#pragma unroll
+  for (int i = 0; i < NAL; ++i) alp_r[i] = p.align_prev[(size_t)b * Te + min(tid + AT * i, Te - 1)];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ck_r[i] = p.ck[min(tid + AT * i, p.K * F - 1)];
+  f32x4_ kc[2][UT], qv[UT], v4[UT];
+  float a1[UT][3];
+#pragma unroll
+  for (int j = 0; j < UT; ++j) {
+    const int u0 = min(16 * (w + NW * j), U - 16);
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+      kc[ft][j] = *reinterpret_cast<V4>(keys + (size_t)min(lo + 16 * ft + fl, tl) * U + u0 + 4 * kq);
+    qv[j] = *reinterpret_cast<V4>(q + u0 + 4 * kq);
+    v4[j] = *reinterpret_cast<V4>(p.v + u0 + 4 * kq);
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) a1[j][ks] = p.wf[(size_t)min(4 * ks + kq, F - 1) * U + u0 + fl];
+  }
+  // values of the context: thread (frame partition pt, 16-byte column e4), frames lo + pt, lo + pt + 2, ...
+  const int E4 = E / 4, e4 = min(tid & (AT / 2 - 1), E4 - 1), pt = tid / (AT / 2);
+  f32x4_ vv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) vv[i] = reinterpret_cast<V4>(vals + (size_t)min(lo + pt + 2 * i, tl) * E)[e4];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < NAL; ++i)
+    if (tid + AT * i < Te) alp[tid + AT * i] = alp_r[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (tid + AT * i < p.K * F) smem[tid + AT * i] = ck_r[i];
+  for (int i = tid + 8 * AT; i < p.K * F; i += AT) smem[i] = p.ck[i];
+  for (int t = tid + AT * NAL; t < Te; t += AT) alp[t] = p.align_prev[(size_t)b * Te + t];
+  __syncthreads();
+  {
+    // location features of my frames, two threads per (frame, filter)
+    const int pb = (p.K - 1) / 2, nout = (n - lo) * F, hf = tid & 1;
+    for (int o = tid >> 1; o < nout; o += AT / 2) {
+      const int i = lo * F + o, t = i / F, f = i % F;
+      const int d0 = max(0, pb - t), d1 = min(p.K, Te + pb - t), mid = (d0 + d1 + 1) >> 1;
+      const float *a = alp + t - pb, *c = smem + f;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int d = hf ? mid : d0;
+      const int de = hf ? d1 : mid;
+      for (; d + 3 < de; d += 4) {
+        s0 = fmaf(a[d], c[d * F], s0);
+        s1 = fmaf(a[d + 1], c[(d + 1) * F], s1);
+        s2 = fmaf(a[d + 2], c[(d + 2) * F], s2);
+        s3 = fmaf(a[d + 3], c[(d + 3) * F], s3);
+      }
+      for (; d < de; ++d) s0 = fmaf(a[d], c[d * F], s0);
+      float sm = (s0 + s1) + (s2 + s3);
+      sm += __shfl_xor(sm, 1);
+      if (!hf) cf[i] = sm;
+    }
+  }
+  __syncthreads();
+  // ---- scores
+  {
+    float b1[2][3];
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+      const int t = lo + 16 * ft + fl;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) b1[ft][ks] = (t < n && 4 * ks + kq < F) ? cf[min(t, Te - 1) * F + min(4 * ks + kq, F - 1)] : 0.f;
+    }
+    float sacc[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < UT; ++j) {
+      if (16 * (w + NW * j) >= U) break;
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        f32x4_ x = kc[ft][j] + qv[j];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) x = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j][ks], b1[ft][ks], x, 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)      // one exp + one rcp per tanh (as the persistent kernel's score; relative error ~1e-7)
+          sacc[ft] = fmaf(v4[j][c], 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x[c])) - 1.0f, sacc[ft]);
+      }
+    }
+    float *wsc = reinterpret_cast<float *>(part);          // [NW][32]
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+      float v = sacc[ft];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (kq == 0) wsc[w * 32 + 16 * ft + fl] = v;
+    }
+    __syncthreads();
+    if (tid < 32 && lo + tid < n) {
+      float tot = 0.f;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) tot += wsc[i * 32 + tid];
+      sc[lo + tid] = tot;
+    }
+    __syncthreads();
+  }
+  // ---- partial result of this slice: e[t] = exp(score - local max), the local max and sum
+  float m = -3.0e38f;
+  for (int t = lo + tid; t < n; t += AT) m = fmaxf(m, sc[t]);
+  m = fmaxf(m, __shfl_xor(m, 32)); m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 8));
+  m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 1));
+  if (lane == 0) red[w] = m;
+  __syncthreads();
+  m = red[0];
+  for (int i = 1; i < NW; ++i) m = fmaxf(m, red[i]);
+  __syncthreads();
+  float z = 0.f;
+  for (int t = lo + tid; t < n; t += AT) {
+    const float e = expf(sc[t] - m);
+    sc[t] = e;
+    xst(align + t, e, true);
+    z += e;
+  }
+  z = wave_sum(z);
+  if (lane == 0) red[w] = z;
+  __syncthreads();
+  z = 0.f;
+  for (int i = 0; i < NW; ++i) z += red[i];
+  if (tid == 0) { xst(ctx + E, m, true); xst(ctx + E + 1, z, true); }
+  // ---- partial context = e^T . values over my frames
+  {
+    f32x4_ c = zv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = lo + pt + 2 * i;
+      const float wgt = t < n ? sc[t] : 0.f;
+      c += wgt * vv[i];
+    }
+    part[tid] = make_float4(c[0], c[1], c[2], c[3]);
+    __syncthreads();
+    if (tid < AT / 2 && tid < E4) {
+      const float4 c0 = part[tid], c1 = part[AT / 2 + tid];
+      float *o = ctx + 4 * tid;
+      xst(o, c0.x + c1.x, true); xst(o + 1, c0.y + c1.y, true); xst(o + 2, c0.z + c1.z, true); xst(o + 3, c0.w + c1.w, true);
+    }
+  }
+  // ---- the slice that arrives last combines the utterance's slices (attn_fwd_finish_kernel's work)
+  if (!last_arriver(p.tickets + b, (unsigned)S, &last_flag)) return;
+  {
+    float *fac = red;
+    const float *pr = p.fwd_part + (size_t)b * S * (E + 4);
+    if (tid == 0) {
+      float M = -3.0e38f, Z = 0.f;
+      for (int i = 0; i < S; ++i) M = fmaxf(M, xld(pr + (size_t)i * (E + 4) + E));
+      for (int i = 0; i < S; ++i) {
+        const float f = expf(xld(pr + (size_t)i * (E + 4) + E) - M);
+        fac[i] = f;
+        Z += f * xld(pr + (size_t)i * (E + 4) + E + 1);
+      }
+      const float inv = 1.0f / Z;
+      for (int i = 0; i < S; ++i) fac[i] *= inv;
+    }
+    __syncthreads();
+    for (int t = tid; t < Te; t += AT) align[t] = t < nfull ? xld(align + t) * fac[t / per] : 0.f;
+    float *cx = p.ctx + (size_t)b * E;
+    for (int e = tid; e < E; e += AT) {
+      float pv[8];                        // S <= 8 (attn_bwd_nslices): every slice's load in flight before the first fma
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pv[i] = xld(pr + (size_t)min(i, S - 1) * (E + 4) + e);
+      float c = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) c = i < S ? fmaf(fac[i], pv[i], c) : c;
+      cx[e] = c;
+    }
+  }
+}
+
 // Combines the slices of a sliced forward pass (flash-style): M = max of the local maxima, every
 // slice's weights and partial context are rescaled by exp(m_s - M) / Z.  grid B, 256 threads.
 __global__ __launch_bounds__(256) void attn_fwd_finish_kernel(AttnArgs p, int S) {
@@ -798,7 +1003,6 @@ __global__ __launch_bounds__(AT) void attn_bwd_kernel(AttnArgs p) {
 // unit 4 kq + r of the tile: the k index of the second product is permuted the same way on both sides), so tanh and
 // the score gradient are applied in place and nothing goes through LDS between the two.  A wave owns U/128 unit tiles
 // and both frame tiles; d features are added over the waves in LDS, dq over the 16 frame lanes in the wave.
-typedef float f32x4_ __attribute__((ext_vector_type(4)));
 // -DATTN_STAMPS: wall_clock64 at the phase boundaries of workgroup (0, 0) (10 ns ticks), printed by attn_bwd_impl
 #ifdef ATTN_STAMPS
 __device__ unsigned long long g_attn_stamps[16];
@@ -1598,6 +1802,14 @@ static int attn_fwd_impl(const nabu_attn_desc *d, int step, const int32_t *dec_l
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool reg = d->kind == 1 && d->U <= 256 * RJ && d->F <= RF;
   auto kern = d->kind != 1 ? attn_fwd_kernel<0> : reg ? attn_fwd_kernel<2> : attn_fwd_kernel<1>;
+  // the sliced location-aware softmax form of the step chain: the matrix-pipe kernel (NABU_ATTN_FWD_MFMA=0: attn_fwd_kernel<2>)
+  const char *mfma_e = getenv("NABU_ATTN_FWD_MFMA");
+  if ((mfma_e ? atoi(mfma_e) : 1) && d->kind == 1 && reg && d->prob_fn == 0 && S > 1 && tickets && (d->Te + S - 1) / S <= 32 &&
+      d->U % 16 == 0 && d->E / 4 <= AT / 2 && d->Te <= 1024 && d->K * d->F <= 8 * AT) {
+    const int UT = (d->U / 16 + AT / 64 - 1) / (AT / 64);
+    kern = UT <= 1 ? attn_fwd_loc_mfma_kernel<1> : UT == 2 ? attn_fwd_loc_mfma_kernel<2> : UT == 3 ? attn_fwd_loc_mfma_kernel<3>
+                                                                                                   : attn_fwd_loc_mfma_kernel<4>;
+  }
   if (shm > 64 * 1024)
     NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
@@ -2078,8 +2290,16 @@ static bool fwd_takes_persistent(const nabu_speller_desc *d, const SpWs &W) {
   SpPersistDesc pd = {B, d->L, U, E, d->Te, d->C};
   pd.kind = d->kind; pd.K = d->K; pd.F = d->F;
   pd.sample_prob = d->sample_prob;
-  return d->num_layers == 1 && (d->kind == 0 || d->kind == 1) && d->prob_fn == 0 && cell_epi0 &&
-         W.persist_bytes > 0 && speller_persist_ok(pd);
+  if (!(d->num_layers == 1 && (d->kind == 0 || d->kind == 1) && d->prob_fn == 0 && cell_epi0 && W.persist_bytes > 0 &&
+        speller_persist_ok(pd)))
+    return false;
+  // Location-aware attention, more than one launch of 32 utterances, values streamed from L2 (cfg5's geometry): the step
+  // chain on sub-batches of 16 with its round-5 kernels (rows16_kernel, attn_fwd_loc_mfma_kernel) is faster than two
+  // persistent launches (cfg5: 41.0 against 42.7 ms per training step).  NABU_SPELLER_PERSIST=2: the persistent kernel anyway.
+  const char *env = getenv("NABU_SPELLER_PERSIST");
+  const bool chain_fast = d->kind == 1 && B > 32 && Bn <= 16 && E % 16 == 0 && d->sample_prob == 0.f && rows16_ok(Bn, 4 * U, E + U, E) &&
+                          rows16_ok(Bn, U, U, U) && env_int("NABU_SPELLER_ROWS16", 1) && speller_persist_streams_values(pd);
+  return !(chain_fast && !(env && atoi(env) == 2));
 }
 static bool bwd_takes_persistent(const nabu_speller_desc *d, const SpWs &W) {
   const int B = d->B, U = d->U, E = d->E, Bn = B / W.NS;

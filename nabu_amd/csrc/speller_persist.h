@@ -22,6 +22,7 @@ struct SpPersistDesc {
 // scheduled sampling are checked by the caller): B = 32 or 64 (two launches of 32 rows), U and E multiples of 32, the
 // keys slice of a workgroup (and the location-aware filters) fit the LDS; the values slice too, or it is streamed
 bool speller_persist_ok(const SpPersistDesc &d);
+bool speller_persist_streams_values(const SpPersistDesc &d);
 size_t speller_persist_ws_bytes(const SpPersistDesc &d);
 
 // kperm: [(E+U), 4U] gate-interleaved dense rows of the cell kernel (column 4u+g); emb: the kernel's first C rows

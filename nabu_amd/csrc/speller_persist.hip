@@ -1800,6 +1800,9 @@ bool speller_persist_ok(const SpPersistDesc &d) {
   return shape_ok(d) && device_fits();
 }
 
+// would the forward kernel read its values slice from L2 in every step (the slice does not fit the LDS next to the keys)?
+bool speller_persist_streams_values(const SpPersistDesc &d) { return shape_ok(d) && stream_values(d, frames_per_slice(d)); }
+
 size_t speller_persist_ws_bytes(const SpPersistDesc &d) {   // (independent of the switch: the workspace layout is)
   if (!shape_ok(d)) return 0;
   return TABLE_BYTES + ring_bytes(d);

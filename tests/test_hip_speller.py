@@ -88,10 +88,10 @@ def test_speller_step_at_the_cfg5_attention_geometry():
     (3, 512, 16, 7, 2, 33),       # the kernel's widest U; two frame tiles, the second nearly empty
 ])
 def test_step_chain_location_aware_matrix_pipe_kernels(B, U, E, K, F, Te):
-    """The round-5 kernels of the location-aware step chain — attn_bwd_loc_mfma_kernel, attn_param_grads_mfma_kernel,
-    rows16_kernel (speller.hip, gemm_skinny.hip) — at shapes that reach their edges, against the float64 oracle: the
+    """The round-5 kernels of the location-aware step chain — attn_fwd_loc_mfma_kernel, attn_bwd_loc_mfma_kernel,
+    attn_param_grads_mfma_kernel, rows16_kernel (speller.hip, gemm_skinny.hip) — at shapes that reach their edges, against the float64 oracle: the
     chain is forced (the persistent decoder would take most of these shapes), then run again with each kernel's
-    predecessor (NABU_ATTN_BWD_MFMA / NABU_ATTN_GRADS_MFMA / NABU_SPELLER_ROWS16 = 0): both agree with the oracle
+    predecessor (NABU_ATTN_FWD_MFMA / NABU_ATTN_BWD_MFMA / NABU_ATTN_GRADS_MFMA / NABU_SPELLER_ROWS16 = 0): both agree with the oracle
     inside check_speller, and with each other to fp32 summation order."""
     import os
     rng = np.random.default_rng(B * 1000 + U)
@@ -102,11 +102,12 @@ def test_step_chain_location_aware_matrix_pipe_kernels(B, U, E, K, F, Te):
     os.environ['NABU_SPELLER_PERSIST'] = os.environ['NABU_SPELLER_PERSIST_BWD'] = '0'
     try:
         got = check_speller('location_aware', 1, U, K, F, enc_len, tlen, E=E)
-        for k in ('NABU_ATTN_BWD_MFMA', 'NABU_ATTN_GRADS_MFMA', 'NABU_SPELLER_ROWS16'):
+        for k in ('NABU_ATTN_BWD_MFMA', 'NABU_ATTN_GRADS_MFMA', 'NABU_ATTN_FWD_MFMA', 'NABU_SPELLER_ROWS16'):
             os.environ[k] = '0'
         ref = check_speller('location_aware', 1, U, K, F, enc_len, tlen, E=E)
     finally:
-        for k in ('NABU_SPELLER_PERSIST', 'NABU_SPELLER_PERSIST_BWD', 'NABU_ATTN_BWD_MFMA', 'NABU_ATTN_GRADS_MFMA', 'NABU_SPELLER_ROWS16'):
+        for k in ('NABU_SPELLER_PERSIST', 'NABU_SPELLER_PERSIST_BWD', 'NABU_ATTN_BWD_MFMA', 'NABU_ATTN_GRADS_MFMA', 'NABU_ATTN_FWD_MFMA',
+                  'NABU_SPELLER_ROWS16'):
             os.environ.pop(k, None)
     assert np.abs(got - ref).max() < 1e-5
 
