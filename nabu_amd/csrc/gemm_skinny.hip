@@ -339,7 +339,9 @@ int rows16_swizzle(int N, int K, const float *W, int ldw, float *out, hipStream_
   return 0;
 }
 
-template <int KG>      // k groups of 16 per wave: K = 128 KG
+// FWD: the forward cell's form (two A segments, epilogue kind 1) — a separate instantiation so that the backward products
+// keep one base pointer with immediate offsets and none of the cell's code (they lost ~1 us per launch to it)
+template <int KG, bool FWD>      // k groups of 16 per wave: K = 128 KG
 __global__ __launch_bounds__(512) void rows16_kernel(Rows16Args a) {
   __shared__ float red[8][16][17];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 15, kq = lane >> 4;
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(512) void rows16_kernel(Rows16Args a) {
     for (int g = 0; g < KG; ++g) {
       const int k = 16 * (w * KG + g);
       bv[g] = Bp[(size_t)g * 64];
-      av[g] = *reinterpret_cast<const r16f4 *>((k < a.K1 ? Ap : Ap2) + k);
+      av[g] = *reinterpret_cast<const r16f4 *>(((!FWD || k < a.K1) ? Ap : Ap2) + k);
     }
   }
   const bool second = n0 >= a.split;
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(512) void rows16_kernel(Rows16Args a) {
   const int fm = min(tid >> 2, a.M - 1), fu = (n0 >> 2) + (tid & 3);
   float f_b[4] = {0.f, 0.f, 0.f, 0.f}, f_e[4] = {0.f, 0.f, 0.f, 0.f}, f_cp = 0.f, f_hp = 0.f;
   int f_len = 0;
-  if (ep.kind == 1 && tid < 64) {
+  if (FWD && ep.kind == 1 && tid < 64) {
     f_len = ep.seq_len[fm];
     f_cp = ep.c_prev[(size_t)fm * U + fu];
     f_hp = ep.h_prev[(size_t)fm * U + fu];
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(512) void rows16_kernel(Rows16Args a) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) red[w][4 * kq + c][fl] = acc[c];
   __syncthreads();
-  if (ep.kind == 1) {
+  if (FWD && ep.kind == 1) {
     // the finished tile's columns 4 j + g: gates i, j, f, o of unit n0 / 4 + j (TF LSTMCell, forget bias 1)
     __shared__ float zt[16][17];
     if (tid < 256) {
@@ -474,16 +476,19 @@ int rows16(int M, int N, int K, const float *A, int lda, const float *Wsw, float
   if (ep) a.ep = *ep; else a.ep.kind = 0;
   if (a.ep.kind == 1) { a.C = nullptr; a.beta = 0.f; }      // the forward cell writes its state, not the product
   const dim3 grid(N / 16), block(512);
+  const bool fwd = a.ep.kind == 1 || A2 != nullptr;
+#define ROWS16_CASE(kg)                                                                    \
+  case kg:                                                                                 \
+    if (fwd) hipLaunchKernelGGL((rows16_kernel<kg, true>), grid, block, 0, s, a);          \
+    else     hipLaunchKernelGGL((rows16_kernel<kg, false>), grid, block, 0, s, a);         \
+    break;
   switch (K / 128) {
-    case 1: hipLaunchKernelGGL(rows16_kernel<1>, grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL(rows16_kernel<2>, grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL(rows16_kernel<3>, grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL(rows16_kernel<4>, grid, block, 0, s, a); break;
-    case 6: hipLaunchKernelGGL(rows16_kernel<6>, grid, block, 0, s, a); break;
-    case 8: hipLaunchKernelGGL(rows16_kernel<8>, grid, block, 0, s, a); break;
-    case 12: hipLaunchKernelGGL(rows16_kernel<12>, grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL(rows16_kernel<16>, grid, block, 0, s, a); break;
+    ROWS16_CASE(1) ROWS16_CASE(2) ROWS16_CASE(3) ROWS16_CASE(4) ROWS16_CASE(6) ROWS16_CASE(8) ROWS16_CASE(12)
+    default:
+      if (fwd) hipLaunchKernelGGL((rows16_kernel<16, true>), grid, block, 0, s, a);
+      else     hipLaunchKernelGGL((rows16_kernel<16, false>), grid, block, 0, s, a);
   }
+#undef ROWS16_CASE
   NABU_LAUNCH_CHECK();
   return 0;
 }
