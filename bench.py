@@ -367,6 +367,15 @@ def parse_args(argv=None):
                          'input_noise 0.6 and dropout keep 0.5 (ed_encoders/defaults/listener.cfg), Speller output dropout keep '
                          '0.5 and sample_prob 0.1 (ed_decoders/defaults/speller.cfg) — instead of the deterministic settings '
                          'the parity configs of SURVEY.md 8(d) prescribe; the line says config.training_defaults = true')
+    ap.add_argument('--repeats', type=int, default=3,
+                    help='the K timed steps are repeated this many times inside the same command (same bracket each time); '
+                         'the headline value is the FIRST region — warm-up W, then exactly K steps — the line carries all of '
+                         'them as ms_per_step_repeats with their spread, and the shader clock the recurrent kernels ran at '
+                         '(effective_clock), so that a slow box of the pool is visible as such')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the other single-GPU BASELINE.json configs (cfg1, cfg3, cfg5\'s per-GPU share) and the '
+                         'training-defaults legs that the default N = 1 cfg2 run times after the headline (other_configs)')
+    ap.add_argument('--other-steps', type=int, default=10, help='timed steps of every other_configs leg (3 warm-up steps each)')
     ap.add_argument('--allreduce', default='flat', choices=['flat', 'bucketed', 'both'],
                     help='gradient exchange of the data-parallel mode (trainer cfg key allreduce_buckets).  both: the '
                          'headline is timed with the flat exchange, then the same steps once more with the bucketed one '
@@ -549,6 +558,39 @@ class HipWorkload(object):
         self.torch.distributed.all_gather(out, t)
         return [float(o.item()) for o in out]
 
+    def gather_i64(self, value):
+        t = self.torch.tensor([int(value)], dtype=self.torch.int64, device='cuda')
+        if self.server.world_size == 1:
+            return [int(value)]
+        if self.server.backend == 'gloo':
+            t = t.cpu()
+        out = [self.torch.zeros_like(t) for _ in range(self.server.world_size)]
+        self.torch.distributed.all_gather(out, t)
+        return [int(o.item()) for o in out]
+
+    def weights_checksum(self):
+        '''order-independent, bit-exact fingerprint of this replica's parameters: the int64 sum of the flat fp32 buffer's
+        bit patterns (measurement code: torch arithmetic is fine here, the product path has none)'''
+        flat = self.tr.model.store.flat
+        return int(flat.view(self.torch.int32).to(self.torch.int64).sum().item())
+
+    def replicas_identical(self, when):
+        '''collective: every rank's weights checksum; raises on every rank when they differ (a silent replica drift would
+        otherwise read as a loss difference).  Returns the entry for the line's `ranks` object.'''
+        sums = self.gather_i64(self.weights_checksum())
+        same = len(set(sums)) == 1
+        if not same:
+            raise SystemExit('bench.py: the replicas hold DIFFERENT weights %s the timed region: checksums %s'
+                             % (when, ['%016x' % (v & 0xFFFFFFFFFFFFFFFF) for v in sums]))
+        return {'identical': True, 'checksum': '%016x' % (sums[0] & 0xFFFFFFFFFFFFFFFF)}
+
+    def effective_clock(self):
+        '''GHz the chip sustained under the last recurrent launches (ops.persist_clocks: in-kernel clock stamps)'''
+        try:
+            return self.ops.persist_clocks()
+        except Exception as exc:          # noqa: BLE001 — a diagnostic must not take the line down
+            return {'error': str(exc)}
+
     def allreduce_ms_per_step(self):
         ev = getattr(self.tr, 'allreduce_ms', [])
         if not ev:
@@ -674,6 +716,9 @@ def run(args, server, wl):
         wl.step(i)
     wl.check()
     wl.sync()
+    replica = {}
+    if hasattr(wl, 'replicas_identical'):
+        replica['before_timed_region'] = wl.replicas_identical('before')
     wl.start_timed_region()
     server.barrier()
     t0 = time.perf_counter()
@@ -684,6 +729,22 @@ def run(args, server, wl):
     dt_rank = time.perf_counter() - t0
     wl.end_timed_region()
     wl.check()
+    if hasattr(wl, 'replicas_identical'):
+        replica['after_timed_region'] = wl.replicas_identical('after')
+    clocks = wl.effective_clock() if hasattr(wl, 'effective_clock') else None
+    # the same K steps again (same bracket), repeats - 1 times: the headline stays the first region
+    dt_repeats = []
+    for _ in range(max(getattr(args, 'repeats', 1), 1) - 1):
+        wl.sync()
+        server.barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            wl.step(i)
+        wl.sync()
+        server.barrier()
+        dt_repeats.append(time.perf_counter() - t1)
+    if dt_repeats:
+        wl.check()
     ar_ms = wl.allreduce_ms_per_step()
     ar_ranks = wl.gather(ar_ms if ar_ms is not None else 0.0)
     both = None
@@ -709,7 +770,9 @@ def run(args, server, wl):
                                             'bucket_schedule_last_step': wl.bucket_schedule()}}
         wl.set_allreduce('flat')
     alt = wl.alt(args.steps)
-    red = wl.reduce_max([dt_rank] + [a[2] for a in alt])
+    red = wl.reduce_max([dt_rank] + [a[2] for a in alt] + dt_repeats)
+    rep = [red[0]] + red[1 + len(alt):]
+    red = red[:1 + len(alt)]
     per_rank = wl.gather(dt_rank)
     paths = wl.rank_paths() if hasattr(wl, 'rank_paths') else (-1, -1)
     rec_ranks, dec_ranks = wl.gather(paths[0]), wl.gather(paths[1])
@@ -720,6 +783,19 @@ def run(args, server, wl):
            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
            'vs_baseline': None, 'dtype': None, 'data': 'synthetic'}
+    rep_ms = [round(t / args.steps * 1e3, 3) for t in rep]
+    out['ms_per_step_repeats'] = rep_ms
+    out['repeats'] = {'n': len(rep_ms), 'steps_each': args.steps, 'median_ms_per_step': sorted(rep_ms)[len(rep_ms) // 2],
+                      'min_ms_per_step': min(rep_ms), 'max_ms_per_step': max(rep_ms),
+                      'spread': round((max(rep_ms) - min(rep_ms)) / min(rep_ms), 4),
+                      'note': 'the K timed steps repeated inside the same command, same barrier + sync bracket, MAX over '
+                              'ranks each; ms_per_step / value are the FIRST region (W warm-up steps, then exactly K steps)'}
+    out['effective_clock'] = None if clocks is None else {
+        'recurrent_fwd_ghz': clocks.get('fwd'), 'recurrent_bwd_ghz': clocks.get('bwd'), 'spec_max_ghz': 2.4,
+        'note': 'shader cycles (s_memtime) over wall time (100 MHz counter) between the first and the last instruction of '
+                'the LAST fp16-plane recurrent launch of each pass in the headline region, stamped by the kernels '
+                'themselves (lstm_persist_dev.h, clock_stamp): the clock the chip sustained under the latency-bound '
+                'kernels — boxes of the pool differ by a few per cent here'}
     out.update(wl.describe(dt))
     out['config'].update({'global_batch': world * wl.units_per_step, 'parallelism': 'dp%d' % world})
     out['ranks'] = {'world_size_seen': world, 'backend': server.backend,
@@ -732,7 +808,11 @@ def run(args, server, wl):
                     # partitioned device) or the decoder's step chain shows here, not only as a slow rank
                     'recurrence_persistent_per_rank': [int(v) for v in rec_ranks],
                     'decoder_persistent_per_rank': [int(v) for v in dec_ranks],
-                    'bucket_schedule_last_step': wl.bucket_schedule()}
+                    'bucket_schedule_last_step': wl.bucket_schedule(),
+                    # bit-identical replicas, asserted (all-gather of a checksum of the flat parameter buffer) before the
+                    # timed region and after its last step: a drift would otherwise read as a loss difference
+                    'replica_weights': replica or None,
+                    'collective_library': collective_library_info(server) if world > 1 else None}
     if both is not None:
         both['flat'] = {'ms_per_step': out['ms_per_step'], 'value': out['value'],
                         'exposed_allreduce_ms_per_step': out['ranks']['allreduce_ms_per_step']}
@@ -749,9 +829,102 @@ def run(args, server, wl):
             'value': round(world * wl.units_per_step * n / red[1 + i], 2), 'ms_per_step': round(red[1 + i] / n * 1e3, 3),
             'steps': n, 'final_loss': round(alt_loss, 4),
             'roofline_frac': round(step_bytes_total / (red[1 + i] / n) / (HBM_PEAK_GBS * 1e9), 4)}
+    if (world == 1 and getattr(args, 'workload', None) == 'cfg2' and not getattr(args, 'no_other_configs', True)
+            and not getattr(args, 'shrink', False) and not getattr(args, 'training_defaults', False)
+            and isinstance(wl, HipWorkload)):
+        out['other_configs'] = other_configs(args, server)
     if not args.no_cpu_baseline and wl.wants_cpu_baseline():
         out['cpu_baseline'] = cpu_baseline() if world == 1 else cached_cpu_baseline()
 
+    return out
+
+
+def collective_library_info(server):
+    '''what the SCALE line needs to explain itself: the collective library's version, the environment switches that
+    steer it, and the xGMI links the topology files of this node show'''
+    info = {'backend': server.backend}
+    try:
+        import torch
+        if server.backend == 'nccl':
+            info['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        info['torch'] = torch.__version__
+        info['hip'] = getattr(torch.version, 'hip', None)
+    except Exception as exc:              # noqa: BLE001
+        info['version_error'] = str(exc)
+    info['env'] = {k: v for k, v in sorted(os.environ.items())
+                   if k.startswith(('NCCL_', 'RCCL_', 'HSA_ENABLE_IPC', 'HSA_FORCE', 'HIP_VISIBLE', 'ROCR_VISIBLE'))}
+    info['nccl_algo_set'] = 'NCCL_ALGO' in os.environ
+    links = {'xgmi': 0, 'pcie': 0}
+    try:                                   # KFD topology: io_links/*/properties, type 11 = xGMI, 2 = PCIe
+        base = '/sys/class/kfd/kfd/topology/nodes'
+        for node in sorted(os.listdir(base)):
+            d = os.path.join(base, node, 'io_links')
+            if not os.path.isdir(d):
+                continue
+            for link in os.listdir(d):
+                with open(os.path.join(d, link, 'properties')) as fid:
+                    props = dict(line.split()[:2] for line in fid if len(line.split()) >= 2)
+                t = int(props.get('type', -1))
+                if t == 11:
+                    links['xgmi'] += 1
+                elif t == 2:
+                    links['pcie'] += 1
+        info['io_links_seen'] = links
+    except (OSError, ValueError):
+        info['io_links_seen'] = None
+    return info
+
+
+OTHER_LEGS = [('cfg1', False), ('cfg3', False), ('cfg5', False), ('cfg2', True), ('cfg3', True), ('cfg5', True)]
+
+
+def other_configs(args, server):
+    '''The other single-GPU configs of BASELINE.json — configs[0] (cfg1), configs[2] (cfg3), one GPU's share of
+    configs[4] (cfg5) — and the cfg2 / cfg3 / cfg5 recipes with the REFERENCE's regularisation defaults switched on
+    (training_defaults), each timed in this same command with the headline's bracket (3 warm-up steps, --other-steps
+    timed steps, device sync on both sides): their numbers are then in the driver's record, not only in profiles/.'''
+    import torch
+    out = {'protocol': '3 warm-up + %d timed steps each, sync bracket, same process as the headline' % args.other_steps}
+    for w, td in OTHER_LEGS:
+        a = argparse.Namespace(**vars(args))
+        a.workload, a.training_defaults, a.steps, a.warmup = w, td, args.other_steps, 3
+        a.gemm_precision, a.no_gemm_roofline, a.no_alt, a.allreduce = None, True, True, 'flat'
+        key = w if not td else 'training_defaults'
+        try:
+            wl = HipWorkload(a, server)
+            for i in range(a.warmup):
+                wl.step(i)
+            wl.check()
+            wl.sync()
+            wl.start_timed_region()
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                wl.step(i)
+            wl.sync()
+            dt = time.perf_counter() - t0
+            wl.end_timed_region()
+            wl.check()
+            d = wl.describe(dt)
+            rk = d['roofline']['recurrent_kernels']
+            entry = {'metric': d['metric'], 'workload': d['config']['workload'], 'ms_per_step': round(dt / a.steps * 1e3, 3),
+                     'value': round(wl.units_per_step * a.steps / dt, 2), 'unit': 'utterances/sec', 'steps': a.steps, 'warmup': a.warmup,
+                     'final_loss': d['final_loss'], 'dtype': d['dtype'], 'recurrent_path': d['config']['recurrent_path'],
+                     'decoder_persistent': wl.rank_paths()[1],
+                     'roofline_frac_step': d['roofline']['frac'],
+                     'recurrent_kernels': {'frac': rk['frac'], 'us_per_sequential_step': rk['us_per_sequential_step'],
+                                           'ms_per_step': rk['ms_per_step']},
+                     'effective_clock': wl.effective_clock()}
+            del wl
+        except Exception as exc:          # noqa: BLE001 — one leg must not take the headline's line down
+            entry = {'error': '%s: %s' % (type(exc).__name__, exc)}
+        torch.cuda.empty_cache()
+        if td:
+            out.setdefault('training_defaults', {
+                'note': 'the same recipes with the reference\'s regularisation defaults ON: Listener input_noise 0.6 + dropout '
+                        'keep 0.5 (ed_encoders/defaults/listener.cfg), Speller dropout 0.5 + sample_prob 0.1 '
+                        '(ed_decoders/defaults/speller.cfg); BASELINE.json\'s configs state none, so the headline has none'})[w] = entry
+        else:
+            out[w] = entry
     return out
 
 

@@ -181,6 +181,20 @@ __device__ __forceinline__ bool poll_round_failed(const PersistArgs &p, int *fla
       p.status[320 + 32 * (pass) + (i)] = (int)(wall_clock64());                  \
   } while (0)
 
+// CLOCK STAMPS (always on, fp16-plane kernels): block 0 / thread 0 leaves the shader-clock counter (s_memtime: one tick per
+// shader cycle) and the constant 100 MHz wall clock at the start and at the end of the launch in
+// status[280 + 4 pass + {0: clock, 1: wall at start; 2: clock, 3: wall at end}] (pass 0 forward, 1 backward; low 32 bits:
+// differences are exact for launches shorter than 1.8 s).  (clock_end - clock_start) / (wall_end - wall_start) x 100 MHz
+// is the clock the chip actually sustained under THIS kernel — bench.py prints it (`effective_clock`), so that a slow
+// box of the pool is visible as such.  Two stores per launch, outside the step loop and outside every counted wait.
+constexpr int CLOCK_STAMP_BASE = 280;
+__device__ __forceinline__ void clock_stamp(const PersistArgs &p, int pass, int end) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    p.status[CLOCK_STAMP_BASE + 4 * pass + 2 * end] = (int)__builtin_readcyclecounter();
+    p.status[CLOCK_STAMP_BASE + 4 * pass + 2 * end + 1] = (int)wall_clock64();
+  }
+}
+
 // Kernel start: publish my XCC id, wait for the ids of my unit, decide whether the unit
 // is co-located on one XCD.  Returns false on timeout.  flag[0] = failure, flag[1] = coloc.
 // Logical identity of a block.  Blocks b and b+256 share a CU (measured: the dispatcher fills

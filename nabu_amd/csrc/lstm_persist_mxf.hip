@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float c_state = 0.f, h_state = 0.f;
   if (!unit_handshake(p, unit, slot, MXF_NU, P, flag)) return;
   const bool coloc = flag[1] != 0;
+  clock_stamp(p, 0, 0);
 
   // exchange slot of a unit: cells of 16 bytes = 8 consecutive k of one (plane, row): [k / 8][16 = plane * 8 + row]
   const size_t slot_bytes = (size_t)16 * H * 2;
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   }
   result_stores();
+  clock_stamp(p, 0, 1);
 }
 
 // ===========================================================================
@@ -373,6 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float am0[2] = {0.f, 0.f}, am1[2] = {0.f, 0.f};
   if (!unit_handshake(p, unit, slot, MXF_NU, P, flag)) return;
   const bool coloc = flag[1] != 0;
+  clock_stamp(p, 1, 0);
 
   // ring slot = [dest P][src P][8 rows][8 k quads] x 16 bytes: a piece = the 32 units of its destination
   const size_t piece_bytes = (size_t)MXR * MXF_UC * 4;
@@ -605,6 +608,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   }
   dz_stores();
+  clock_stamp(p, 1, 1);
   // bias gradient / column maxima of my 128 gate columns over the unit's 8 rows
   __syncthreads();
   double *redd = reinterpret_cast<double *>(smem);      // [8 rows][128] doubles over the dz plane / staging area

@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float c_state = 0.f, h_state = 0.f;
   if (!unit_handshake(p, unit, slot, MXNU, P, flag)) return;
   const bool coloc = flag[1] != 0;
+  clock_stamp(p, 0, 0);
 
   // exchange slot of a unit: cells of 16 bytes = 8 consecutive k of one (plane, row): [k / 8][16 = plane * 8 + row]
   // — a k group's 16 cells are 256 contiguous bytes, a wave's k range 4 KiB of full 128-byte lines
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     MXH_STAMP(0, 5);
   }
   result_stores();
+  clock_stamp(p, 0, 1);
 }
 
 // ===========================================================================
@@ -492,6 +494,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float am0 = 0.f, am1 = 0.f;
   if (!unit_handshake(p, unit, slot, MXNU, P, flag)) return;
   const bool coloc = flag[1] != 0;
+  clock_stamp(p, 1, 0);
 
   // ring slot = [dest P][src P][8 rows][4 k quads] x 16 bytes
   const size_t piece_bytes = (size_t)MXR * UC * 4;
@@ -744,6 +747,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     MXH_STAMP(1, 5);
   }
   dz_stores();
+  clock_stamp(p, 1, 1);
   // bias gradient / column maxima of my 64 gate columns over the unit's 8 rows
   __syncthreads();
   // (the rows' sums meet in float64 as well: red as [8 rows][64] doubles fits the dz plane + staging area in front of it)

@@ -1623,27 +1623,28 @@ constexpr int SCATTER_SEG = 8192;
 __global__ __launch_bounds__(256) void scatter_rows_kernel(int C, int N, int W, const int32_t *__restrict__ ids,
                                                            const float *__restrict__ dz, float *__restrict__ dK) {
   __shared__ int hit[SCATTER_SEG];
-  __shared__ int wcount[4];
-  __shared__ int nhit;
+  __shared__ int wcount[2][4];      // double-buffered by chunk parity: ONE barrier per chunk, no re-read behind it
   const int c = blockIdx.y, tid = threadIdx.x;
   const int col = min(blockIdx.x * 256 + tid, W - 1);
   float s = 0.f;
   for (int seg = 0; seg < N; seg += SCATTER_SEG) {
     const int send = min(seg + SCATTER_SEG, N);
-    if (tid == 0) nhit = 0;
-    __syncthreads();
-    for (int base = seg; base < send; base += 256) {
+    // every thread keeps the running number of hits itself (the same sum in every thread): no shared counter that a
+    // fast wave could overwrite while a slow one still reads it
+    int nhit = 0, par = 0;
+    for (int base = seg; base < send; base += 256, par ^= 1) {
       const int i = base + tid;
       const bool m = i < send && ids[i] == c;
       // order-preserving compaction: matches of wave w go after those of the waves before it
       const unsigned long long bal = __ballot(m);
-      if ((tid & 63) == 0) wcount[tid >> 6] = __popcll(bal);
+      if ((tid & 63) == 0) wcount[par][tid >> 6] = __popcll(bal);
       __syncthreads();
-      int off = nhit;
-      for (int w = 0; w < (tid >> 6); ++w) off += wcount[w];
+      const int c0 = wcount[par][0], c1 = wcount[par][1], c2 = wcount[par][2], c3 = wcount[par][3];
+      const int wv = tid >> 6;
+      const int off = nhit + (wv > 0 ? c0 : 0) + (wv > 1 ? c1 : 0) + (wv > 2 ? c2 : 0);
       if (m) hit[off + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = i;
-      __syncthreads();
-      if (tid == 0) nhit += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+      nhit += c0 + c1 + c2 + c3;
+      // (the next chunk writes wcount[par ^ 1]; wcount[par] is rewritten two chunks on, behind the next barrier)
     }
     __syncthreads();
     const int n = nhit;

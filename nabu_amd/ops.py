@@ -626,3 +626,20 @@ def beam_gather(fresh, old, parent, stay):
     check(_hip.lib().nabu_beam_gather(B, W, F, ptr(fresh.contiguous()), ptr(old.contiguous()), ptr(parent),
                                       ptr(stay), ptr(dst), stream()), 'nabu_beam_gather')
     return dst
+
+
+def persist_clocks(device=None):
+    """{'fwd': GHz, 'bwd': GHz} — the shader clock the chip sustained under the LAST fp16-plane recurrent launch of each
+    pass on this device's 'blstm' workspace (lstm_persist_dev.h, clock_stamp: shader-cycle and 100 MHz wall-clock ticks
+    left by block 0 at the start and the end of the launch).  None for a pass that has not run.  Synchronises."""
+    out = {'fwd': None, 'bwd': None}
+    for (dev, tag), buf in list(Workspace._bufs.items()):
+        if tag != 'blstm' or (device is not None and dev != str(device)):
+            continue
+        w = buf[4 * 280:4 * 288].view(torch.int32).cpu().tolist()
+        for i, name in enumerate(('fwd', 'bwd')):
+            c0, w0, c1, w1 = w[4 * i:4 * i + 4]
+            dc, dw = (c1 - c0) & 0xFFFFFFFF, (w1 - w0) & 0xFFFFFFFF
+            if dw > 0 and dc > 0:
+                out[name] = round(dc / dw * 0.1, 4)
+    return out

@@ -27,9 +27,9 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 
-def _layer(B, T, D, H, lens, mode, x, p, dout, need_dx=True):
+def _layer(B, T, D, H, lens, mode, x, p, dout, need_dx=True, recurrent_precision='default'):
     from nabu_amd import ops
-    plan = ops.BlstmPlan(B, T, D, H, int(max(lens)), mode)
+    plan = ops.BlstmPlan(B, T, D, H, int(max(lens)), mode, recurrent_precision=recurrent_precision)
     ld = torch.tensor(np.asarray(lens), dtype=torch.int32, device=DEV)
     out = torch.full((B, T, 2 * H), float('nan'), device=DEV)
     reserve = torch.empty(plan.reserve_bytes, dtype=torch.uint8, device=DEV)
@@ -277,6 +277,54 @@ def test_plane_recurrence_is_as_close_to_float64_as_the_fp32_kernels():
         e = rms(g_p[k], gref[k]), rms(g_s[k], gref[k])
         print('%s gradient rms error vs float64: plane kernels %.3e, fp32 step kernels %.3e (ratio %.2f)' % ((k,) + e + (e[0] / e[1],)))
         assert e[0] <= (1.06 if k.endswith('bias') else 1.05) * e[1], k
+
+
+def test_plane_recurrence_at_T1000_on_a_synthetic_layer_states_its_bias_gradient_error():
+    """The property of the DEFAULT recurrence the float64 comparison at T = 125 does not show (W_h
+    lives in registers as two fp16 planes for the whole sequence — a STATIC 22-bit rounding where an fp32 chain's roundings
+    vary from step to step): on a synthetic layer with random weights and T = 1000 (32 x 1000 x 256, H = 512, ragged)
+    per-element errors stay at the fp32 step kernels' (outputs, kernel gradients <= 1.05 x), but the BIAS gradient — a sum
+    of up to 32 000 values per gate column — collects the static rounding: observed 3-4 x the step kernels' error on
+    that vector (1.2e-6 relative to its rms).  Pinned here with the bound actually observed, and next to it the documented
+    way out: recurrent_precision = f32 (the exact-fp32 persistent kernels, nabu_blstm_desc.recurrent_precision; what
+    bench.py's fp32_end_to_end leg runs) on the same layer."""
+    from nabu_amd import ops
+    B, T, D, H = 32, 1000, 256, 512
+    lens, x, p, dout = _layer_case(B, T, D, H, seed=77)
+    old = ops.get_gemm_precision()
+    ops.set_gemm_precision('f32')
+    try:
+        out_p, _, g_p = _layer(B, T, D, H, lens, ops.LSTM_PERSISTENT, x, p, dout, True)
+        out_e, _, g_e = _layer(B, T, D, H, lens, ops.LSTM_PERSISTENT, x, p, dout, True, recurrent_precision='f32')
+        out_s, _, g_s = _layer(B, T, D, H, lens, ops.LSTM_STEPWISE, x, p, dout, True)
+    finally:
+        ops.set_gemm_precision(old)
+    ref, gref = _blstm_float64(x, lens, p, dout)
+
+    def rms(a, b):
+        return float((a.double() - b).pow(2).mean().sqrt())
+    ratios = {}
+    for tag, out_k, g_k in (('planes', out_p, g_p), ('rec_f32', out_e, g_e)):
+        ratios[tag, 'out'] = rms(out_k, ref) / rms(out_s, ref)
+        for k in ('fw_kernel', 'bw_kernel', 'fw_bias', 'bw_bias'):
+            ratios[tag, k] = rms(g_k[k], gref[k]) / rms(g_s[k], gref[k])
+    print('\nerror vs float64 relative to the fp32 step kernels, T = 1000:',
+          {'%s:%s' % k: round(v, 3) for k, v in ratios.items()})
+    for k in ('fw_bias', 'bw_bias'):
+        print(k, 'relative to the gradient rms: planes %.2e, rec_f32 %.2e, step kernels %.2e' % (
+            rms(g_p[k], gref[k]) / float(gref[k].pow(2).mean().sqrt()), rms(g_e[k], gref[k]) / float(gref[k].pow(2).mean().sqrt()),
+            rms(g_s[k], gref[k]) / float(gref[k].pow(2).mean().sqrt())))
+    for tag in ('planes', 'rec_f32'):
+        assert ratios[tag, 'out'] <= 1.05, (tag, ratios)
+        assert ratios[tag, 'fw_kernel'] <= 1.05 and ratios[tag, 'bw_kernel'] <= 1.05, (tag, ratios)
+    # the stated property of the default path, with the bound observed (3-4 x), and an absolute one: < 3e-6 of the rms
+    for k in ('fw_bias', 'bw_bias'):
+        assert ratios['planes', k] <= 5.0, ratios
+        assert rms(g_p[k], gref[k]) <= 3e-6 * float(gref[k].pow(2).mean().sqrt()), k
+        assert ratios['rec_f32', k] <= BIAS_T1000_REC_F32_BOUND, ratios
+
+
+BIAS_T1000_REC_F32_BOUND = 2.0
 
 
 @pytest.mark.parametrize('B,T,D,H,lens', [

@@ -133,7 +133,8 @@ def test_cfg1_exact_matches_golden():
     assert rel.max() < 1e-3 and rel.max() < 5e-5, (losses, fx['losses'])
 
 
-@pytest.mark.parametrize('name', ['cfg2_exact', 'cfg2_exact:bf16x6', 'cfg2_exact:f16x3', 'cfg3_exact', 'cfg5_exact'])
+@pytest.mark.parametrize('name', ['cfg2_exact', 'cfg2_exact:f32', 'cfg2_exact:f32+rec_f32', 'cfg2_exact:bf16x6',
+                                  'cfg2_exact:f16x3', 'cfg2_exact:f16x3+rec_f32', 'cfg3_exact', 'cfg5_exact'])
 def test_full_size_configs_match_the_oracle_goldens(name):
     """BASELINE.json configs[1], [2] and (one GPU's share of) [4] at their FULL size — the headline
     config 32 x 1000 x 40, 4 x 512 included — against numbers the float64 oracle produced in the
@@ -143,15 +144,27 @@ def test_full_size_configs_match_the_oracle_goldens(name):
     variable's gradient norm and 32 sampled gradient entries <= 3e-4.  Ragged lengths (parity
     batches of SURVEY.md 8(d)).  cfg5 runs its products in exact fp32 here (the bf16 variant of the
     recipe is bounded against the fp32 goldens by the small-size test below and, at full size, by
-    the 1e-3 loss bar in test_cfg5_exact_bf16_loss)."""
+    the 1e-3 loss bar in test_cfg5_exact_bf16_loss).
+    The headline config runs under EVERY arithmetic bench.py times it in, named explicitly: 'cfg2_exact' = what the
+    recipe ships (asserted below to be f16x3 products + the fp16-plane recurrence), ':f32' = exact-fp32 dense products
+    (bench.py's `f32_products` leg), ':f32+rec_f32' = exact-fp32 products AND the exact-fp32 recurrent kernels (the
+    `fp32_end_to_end` leg: float32 from the features to the update), ':bf16x6' (`alt_bf16x6`), ':f16x3' spelled out,
+    ':f16x3+rec_f32' (the documented way out of the plane recurrence's static rounding of W_h)."""
     from tests.golden import make_golden as G       # generators only (seeded numpy); no oracle math runs
-    name, _, prec = name.partition(':')              # 'cfg2_exact:bf16x6': the headline config with its dense products as
+    name, _, arith = name.partition(':')             # 'cfg2_exact:bf16x6': the headline config with its dense products as
     fx = load(name)                                  # six bf16 / three scaled-fp16 plane products (gemm_pk.hip) — same tolerances
     names, data, _, loss_name, recipe, steps = G.exact_setup(name)
     w = G.draw_weights(names)
     over = {'encoder.gemm_precision': 'f32'} if name == 'cfg5_exact' else {}
-    if prec:
+    if arith:
+        prec, _, rec = arith.partition('+')
         over = {'encoder.gemm_precision': prec}
+        if rec:
+            assert rec == 'rec_f32'
+            over['encoder.recurrent_precision'] = 'f32'
+    elif name == 'cfg2_exact':
+        mc, _, _ = recipes.load_recipe(recipe)       # the default case IS the shipped arithmetic: say which one that is
+        assert mc.get('encoder', 'gemm_precision') == 'f16x3' and not mc.has_option('encoder', 'recurrent_precision')
     tr = trainer_with_weights(recipe, over, data, w, data.batch(0))
     loss0 = step0_grads(tr, data.batch(0), loss_name)
     assert abs(loss0 - fx['losses'][0]) / fx['losses'][0] < 5e-5, (loss0, fx['losses'][0])

@@ -651,3 +651,26 @@ def test_scheduled_sampling_matches_oracle_given_its_samples(attention):
         dec({'features': torch.tensor(enc, device=dev)}, {'features': SeqLen(enc_len, dev)},
             {'text': tgd}, {'text': SeqLen(tlen, dev)}, True)
     assert not np.array_equal(rnn_decoder.decoder_inputs().cpu().numpy().T, used)
+
+
+@pytest.mark.parametrize('C,N,W', [(7, 20000, 300), (40, 10176, 2048), (3, 255, 64), (5, 8192 + 257, 260)])
+def test_scatter_rows_one_hot_gradient_is_the_ordered_sum(C, N, W):
+    """dK[c] = the sum of the dz rows whose id is c, added in increasing row order (bit-exact against a float32
+    sequential sum): dense hits (every chunk of 256 ids and every wave contributes, several LDS segments) — the
+    compaction offsets of scatter_rows_kernel are what a stale shared counter would corrupt (one-hot input rows of
+    tf's LSTMCell kernel, rnn_decoder.py:59-66)."""
+    from nabu_amd import ops
+    g = torch.Generator().manual_seed(C * 1000 + W)
+    ids = torch.randint(0, C, (N,), generator=g, dtype=torch.int32)
+    dz = torch.randn(N, W, generator=g)
+    dK = torch.full((C, W), float('nan'), device='cuda')
+    for _ in range(3):          # repeated launches: a latency-dependent race does not show on every run
+        ops.scatter_rows(ids.cuda(), dz.cuda(), dK)
+        got = dK.cpu().numpy()
+        dzn, idn = dz.numpy(), ids.numpy()
+        for c in range(C):
+            rows = np.nonzero(idn == c)[0]
+            ref = np.zeros(W, np.float32)
+            for r in rows:
+                ref = ref + dzn[r]
+            np.testing.assert_array_equal(got[c], ref)
