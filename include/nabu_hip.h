@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NABU_ABI_VERSION 2
+#define NABU_ABI_VERSION 3
 
 #define NABU_EINVAL   (-1)  /* bad argument (shape, null pointer, alignment) */
 #define NABU_EUNSUP   (-2)  /* shape not supported by the requested kernel   */
@@ -241,7 +241,48 @@ typedef struct {
                          measured (the first layer's features) */
   int32_t flags;      /* NABU_BLSTM_* */
   int32_t recurrent_precision;   /* NABU_REC_* */
+  /* ---- ABI version 3 (the 44-byte layout of version 2 — everything up to recurrent_precision — is still accepted).
+   * PACKED COMPANIONS of the layer's output and input.  With gemm_precision = NABU_GEMM_F16X3 every dense product of a
+   * layer reads its operands as two fp16 planes (nabu_pk_pack_f16's layout); up to ABI version 2 each call converted
+   * x, x^T and h^T itself, re-reading tensors the previous recurrent kernel had written microseconds earlier (0.44 ms of
+   * a 12 ms cfg2 step).  |h| = |o tanh c| <= 1 is known a priori, so the forward recurrent kernel can write the planes
+   * itself, next to `out`, at the scale 2^14 it already uses for its own exchange (row maxima = the bit pattern of
+   * 1.0f for every packed row):
+   *   out_pk_rows  `out` as the NEXT layer's input operand: rows = frames after stacking `out_stack` consecutive
+   *                frames (ops.pyramid_stack, components/ops.py:6-60, as a view: T %% out_stack == 0), k = out_stack 2H;
+   *                nabu_pk_bytes(B T / out_stack, out_stack 2H, 2) bytes
+   *   out_pk_cols  the transposed operand of the same matrix (the next layer's x^T . dZ): nabu_pk_bytes(out_stack 2H,
+   *                B T / out_stack, 2)
+   *   hT_pk        this layer's own h_(t-1)^T operands of dWh, forward cell then backward cell, each
+   *                nabu_pk_bytes(Mw, B T, 2), Mw = H (D + H where the first layer's x^T shares the operand: D < 256);
+   *                written by nabu_blstm_fwd, read by nabu_blstm_bwd / _bwd_weights of the SAME descriptor
+   *   x_pk_rows / x_pk_cols   this layer's input as the producer layer wrote it (its out_pk_rows / out_pk_cols): the
+   *                call reads no fp32 x for its products
+   * All optional (NULL = the call packs for itself, as before).  Buffers are caller-owned and must be ZERO-FILLED ONCE
+   * before their first use (the kernels write only positions that exist: k-blocks beyond the reduction length and rows
+   * beyond the operand stay zero) and may then be reused call after call.  nabu_blstm_fwd GUARANTEES the buffers it is
+   * given are complete on return, whatever path it takes: written by the recurrent kernel where that is possible
+   * (fp16-plane kernels, launches of <= 32 rows, max_len == T: nabu_blstm_emits_packed), by the pack kernels otherwise.
+   * nabu_blstm_pk_bytes reports the sizes and whether the layer described would use the companions at all. */
+  int32_t out_stack;            /* frames of `out` per packed row of out_pk_rows / out_pk_cols: 1 or 2 (0 reads as 1) */
+  void *out_pk_rows;
+  void *out_pk_cols;
+  void *hT_pk;
+  const void *x_pk_rows;
+  const void *x_pk_cols;
 } nabu_blstm_desc;
+
+/* sizes of the packed companions of d (bytes; 0 where the layer described does not use that companion: another
+ * gemm_precision, fewer than 2048 frames, an input of fewer than 256 features ...):
+ *   bytes[0], bytes[1]  x_pk_rows, x_pk_cols as THIS layer would read them (its input [B, T, D])
+ *   bytes[2]            hT_pk of this layer
+ *   bytes[3], bytes[4]  out_pk_rows, out_pk_cols for d->out_stack (0 when T is not a multiple of it)
+ * returns 0, or NABU_EINVAL for a bad descriptor */
+int nabu_blstm_pk_bytes(const nabu_blstm_desc *d, size_t bytes[5]);
+/* which of the companions d names nabu_blstm_fwd's recurrent kernel writes ITSELF: bit 0 out_pk_rows, bit 1 out_pk_cols,
+ * bit 2 hT_pk (the others are made by pack kernels behind the recurrence — a caller that can pack lazily may prefer to
+ * leave those out of the descriptor) */
+int nabu_blstm_emits_packed(const nabu_blstm_desc *d);
 
 size_t nabu_blstm_reserve_bytes(const nabu_blstm_desc *d);
 size_t nabu_blstm_ws_bytes(const nabu_blstm_desc *d);

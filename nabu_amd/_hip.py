@@ -19,7 +19,10 @@ class BlstmDesc(_c.Structure):
     _fields_ = [('size', _c.c_uint32), ('B', _c.c_int32), ('T', _c.c_int32), ('D', _c.c_int32),
                 ('H', _c.c_int32), ('max_len', _c.c_int32), ('mode', _c.c_int32),
                 ('gemm_precision', _c.c_int32), ('x_bound', _c.c_float), ('flags', _c.c_int32),
-                ('recurrent_precision', _c.c_int32)]
+                ('recurrent_precision', _c.c_int32),
+                # ABI version 3: packed companions (include/nabu_hip.h)
+                ('out_stack', _c.c_int32), ('out_pk_rows', _c.c_void_p), ('out_pk_cols', _c.c_void_p),
+                ('hT_pk', _c.c_void_p), ('x_pk_rows', _c.c_void_p), ('x_pk_cols', _c.c_void_p)]
 
 
 BLSTM_FWD_ONLY = 1
@@ -70,6 +73,8 @@ SIGNATURES = {
     'nabu_blstm_bwd_data': (_i, [_c.POINTER(BlstmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nabu_blstm_bwd_weights': (_i, [_c.POINTER(BlstmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nabu_blstm_uses_persistent': (_i, [_c.POINTER(BlstmDesc)]),
+    'nabu_blstm_pk_bytes': (_i, [_c.POINTER(BlstmDesc), _c.POINTER(_c.c_size_t)]),
+    'nabu_blstm_emits_packed': (_i, [_c.POINTER(BlstmDesc)]),
     'nabu_blstm_set_profile_events': (_i, [_vp, _vp]),
     'nabu_persist_set_timeout_us': (_i, [_ll]),
     'nabu_blstm_set_phase_hook': (_i, [_vp, _vp]),
@@ -185,7 +190,7 @@ class Workspace(object):
 SPELLER_MAX_LAYERS = 4
 GEMM_DEFAULT, GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_BF16X6 = 0, 1, 2, 3, 4
 # NABU_ABI_VERSION of include/nabu_hip.h this binding was written against (lib() refuses another library)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 GEMM_PRECISIONS = {'default': 0, 'f32': 1, 'bf16': 2, 'bf16x3': 3, 'bf16x6': 4, 'f16x3': 5}
 

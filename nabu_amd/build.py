@@ -16,12 +16,16 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=f
          '-Wall', '-Wno-unused-function']
 
 
+# per-file additions (lstm_persist_mxh_bwd.hip: its header says why)
+EXTRA_FLAGS = {'lstm_persist_mxh_bwd.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
+
+
 def _sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
 
 
 def _digest():
-    h = hashlib.sha256(' '.join(FLAGS).encode())
+    h = hashlib.sha256((' '.join(FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
     files = _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h') or f.endswith('.inc'))
     files.append(os.path.join(os.path.dirname(HERE), 'include', 'nabu_hip.h'))
     for f in files:
@@ -45,7 +49,7 @@ def build(force=False, verbose=True):
     for src in _sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + '.o')
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -208,6 +208,13 @@ struct Layout {
   // 0 bytes where the layer has no input gradient): the row scales of dZ as [BT, 8H] without a pass over dz
   size_t pk_rowmax, pk_rowmax_bytes;
   bool fwd_only;    // NABU_BLSTM_FWD_ONLY: the reserve ends behind the activations
+  // ABI version 3, packed companions (include/nabu_hip.h): x_pk = the input operands come packed from the caller;
+  // hT_ext = h^T lives in the caller's hT_pk, written by the forward call; cmp_* = sizes (nabu_blstm_pk_bytes) and a
+  // scratch array of row maxima (all 1.0f) for the pack-kernel fallback
+  bool x_pk, hT_ext;
+  int out_stack;
+  size_t cmp_bytes[5];
+  size_t cmp_amax_off, cmp_amax_bytes;
   // dZ^T packed [8H, BT] lives in the layer's RESERVE (behind the activations): it is written by the data part of
   // the backward pass and read by the weight-gradient part, which may run later (nabu_blstm_bwd_weights)
   size_t res_dzT_off, res_dzT_bytes;
@@ -215,8 +222,9 @@ struct Layout {
 
 // ABI version 1 callers pass the 32-byte descriptor (everything up to gemm_precision): the later fields read as 0
 static int load_desc(const nabu_blstm_desc *in, nabu_blstm_desc *out) {
-  constexpr uint32_t V1 = 8 * sizeof(int32_t);
-  if (!in || (in->size != sizeof(nabu_blstm_desc) && in->size != V1)) return fail(NABU_EINVAL, "blstm: bad descriptor size");
+  constexpr uint32_t V1 = 8 * sizeof(int32_t), V2 = 11 * sizeof(int32_t);
+  if (!in || (in->size != sizeof(nabu_blstm_desc) && in->size != V1 && in->size != V2))
+    return fail(NABU_EINVAL, "blstm: bad descriptor size");
   *out = nabu_blstm_desc{};
   memcpy(out, in, in->size);
   out->size = sizeof(nabu_blstm_desc);
@@ -224,6 +232,10 @@ static int load_desc(const nabu_blstm_desc *in, nabu_blstm_desc *out) {
   if (out->flags & ~NABU_BLSTM_FWD_ONLY) return fail(NABU_EINVAL, "blstm: unknown flag bits %d", out->flags);
   if (out->recurrent_precision != NABU_REC_DEFAULT && out->recurrent_precision != NABU_REC_F32)
     return fail(NABU_EINVAL, "blstm: recurrent_precision must be NABU_REC_DEFAULT or NABU_REC_F32");
+  if (out->out_stack < 0 || out->out_stack > 2) return fail(NABU_EINVAL, "blstm: out_stack must be 0, 1 or 2");
+  if (out->out_stack == 0) out->out_stack = 1;
+  if ((out->x_pk_rows == nullptr) != (out->x_pk_cols == nullptr) && !(out->flags & NABU_BLSTM_FWD_ONLY))
+    return fail(NABU_EINVAL, "blstm: x_pk_rows and x_pk_cols come as a pair (a forward-only descriptor may give the rows alone)");
   return 0;
 }
 // every entry point works on the normalised copy and, for its duration, tells the persistent-kernel dispatch whether
@@ -409,9 +421,31 @@ static Layout make_layout(const nabu_blstm_desc *d) {
       L.gemm_bytes += grow; L.persist_off += grow; L.xws_off += grow; L.bf16_off += grow; L.pk_off += grow; off += grow;
     }
   }
+  // packed companions (ABI version 3)
+  {
+    const int BT = (int)(B * T), S = d->out_stack > 0 ? d->out_stack : 1;
+    const bool P2 = L.pk_planes == 2;
+    const int Mw = (int)(L.pk_whole ? D + H : H);
+    L.out_stack = S;
+    L.cmp_bytes[0] = (P2 && L.pk_in) ? nabu_pk_bytes(BT, (int)D, 2) : 0;
+    L.cmp_bytes[1] = (P2 && L.pk_in) ? nabu_pk_bytes((int)D, BT, 2) : 0;
+    L.cmp_bytes[2] = (P2 && L.pk_rec) ? 2 * nabu_pk_bytes(Mw, BT, 2) : 0;
+    L.cmp_bytes[3] = (T % S == 0 && BT / S >= 1) ? nabu_pk_bytes(BT / S, (int)(2 * H) * S, 2) : 0;
+    L.cmp_bytes[4] = (T % S == 0 && BT / S >= 1) ? nabu_pk_bytes((int)(2 * H) * S, BT / S, 2) : 0;
+    L.x_pk = d->x_pk_rows != nullptr && L.cmp_bytes[0] != 0 && (L.fwd_only || d->x_pk_cols != nullptr);
+    L.hT_ext = d->hT_pk != nullptr && L.cmp_bytes[2] != 0 && !L.fwd_only;
+    size_t rows = nabu_pk_rows_pad(BT);
+    rows = max_sz(rows, nabu_pk_rows_pad((int)(4 * H)));
+    rows = max_sz(rows, nabu_pk_rows_pad((int)(D + H)));
+    L.cmp_amax_bytes = align_up(4 * rows, 256);
+    L.cmp_amax_off = off; off += L.cmp_amax_bytes;
+  }
   L.total = off;
   return L;
 }
+
+// the row "maximum" of a packed companion: |h| <= 1 at the scale 2^14 the recurrent kernel splits its planes at
+static constexpr unsigned CMP_AMAX_BITS = 0x3F800000u;
 
 static int check_desc(const nabu_blstm_desc *d) {
   if (d->B <= 0 || d->T <= 0 || d->D <= 0 || d->H <= 0) return fail(NABU_EINVAL, "blstm: non-positive dimension");
@@ -510,6 +544,50 @@ extern "C" int nabu_blstm_uses_persistent(const nabu_blstm_desc *d_in) {
   return use_persistent(d) ? 1 : 0;
 }
 
+extern "C" int nabu_blstm_pk_bytes(const nabu_blstm_desc *d_in, size_t bytes[5]) {
+  DescScope scope(d_in);
+  if (scope.err) return scope.err;
+  const nabu_blstm_desc *d = &scope.d;
+  if (int e = check_desc(d)) return e;
+  NABU_CHECK_ARG(bytes, "blstm_pk_bytes: null pointer");
+  const Layout L = make_layout(d);
+  for (int i = 0; i < 5; ++i) bytes[i] = L.cmp_bytes[i];
+  return 0;
+}
+static bool wants_companions(const nabu_blstm_desc *d, const Layout &L) {
+  return ((d->out_pk_rows || d->out_pk_cols) && L.cmp_bytes[3] != 0) || L.hT_ext;
+}
+static bool kernel_emits(const nabu_blstm_desc *d, const Layout &L) {
+  const int max_len = d->max_len > 0 ? d->max_len : d->T;
+  if (!wants_companions(d, L) || !use_persistent(d) || !lstm_persist_emits(d->B, d->T, d->H, max_len)) return false;
+  for (int i = 2; i < 5; ++i)
+    if (L.cmp_bytes[i] >= 0x7FFFFFF0ull) return false;      // 32-bit buffer offsets inside the kernel
+  return true;
+}
+// which companions the recurrent kernel writes itself: bit 0 rows, bit 1 transposed, bit 2 h^T.  Default 4: measured on
+// cfg2, the 2-byte stores of the transposed operand and the extra live state of the rows cost the forward kernel what the
+// pack kernels they replace cost; NABU_PERSIST_EMIT_MASK=7 writes all three from the kernel, 0 none
+static int emit_mask_env() {
+  static int m = -1;
+  if (m < 0) { const char *e = getenv("NABU_PERSIST_EMIT_MASK"); m = e ? (atoi(e) & 7) : 4; }
+  return m;
+}
+static int emitted_by_kernel(const nabu_blstm_desc *d, const Layout &L) {
+  if (!kernel_emits(d, L)) return 0;
+  int m = emit_mask_env();
+  const bool want_out = (d->out_pk_rows || d->out_pk_cols) && L.cmp_bytes[3] != 0;
+  if (!want_out || !d->out_pk_rows) m &= ~1;
+  if (!want_out || !d->out_pk_cols) m &= ~2;
+  if (!L.hT_ext) m &= ~4;
+  return m;
+}
+extern "C" int nabu_blstm_emits_packed(const nabu_blstm_desc *d_in) {
+  DescScope scope(d_in);
+  const nabu_blstm_desc *d = &scope.d;
+  if (scope.err || check_desc(d)) return 0;
+  return emitted_by_kernel(d, make_layout(d));
+}
+
 extern "C" size_t nabu_blstm_reserve_bytes(const nabu_blstm_desc *d_in) {
   DescScope scope(d_in);
   const nabu_blstm_desc *d = &scope.d;
@@ -566,7 +644,7 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d_in, const float *x, const
       // and wait in the reserve — unless no backward pass follows.
       uint32_t *axT = L.fwd_only ? nullptr : reinterpret_cast<uint32_t *>(static_cast<char *>(reserve) + L.res_axT_off);
       uint32_t *aw2 = L.fwd_only ? nullptr : reinterpret_cast<uint32_t *>(static_cast<char *>(reserve) + L.res_aw2_off);
-      const unsigned xb = bound_bits(d->x_bound);
+      const unsigned xb = L.x_pk ? CMP_AMAX_BITS : bound_bits(d->x_bound);     // (a packed companion: scale 2^14)
       const int rpD = nabu_pk_rows_pad(D);
       const FillSeg fill[4] = {{ax, (size_t)rpBT, xb}, {aw, (size_t)rpG, 0u}, {axT, axT ? (size_t)rpD : 0, xb}, {aw2, aw2 ? (size_t)rpD : 0, 0u}};
       if (int e = multi_fill(fill, 4, s)) return e;
@@ -574,14 +652,17 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d_in, const float *x, const
         if (int e = nabu_pk_amax(x, D, BT, D, ax, axT, stream)) return e;
       if (int e = pk_amax_pair(kern[0], kern[1], G, D, G, aw2, aw, aw + G, nullptr, s)) return e;
     }
-    if (int e = pk_pack_any(P, 0, x, D, BT, D, pk + L.pk_x, rpBT, 0, 0, rpBT, nkb, 0, 0, ax, stream)) return e;
+    // the input operand: the producer layer's forward kernel wrote it (x_pk_rows) — or one pass over x here
+    const void *xop = L.x_pk ? d->x_pk_rows : pk + L.pk_x;
+    if (!L.x_pk)
+      if (int e = pk_pack_any(P, 0, x, D, BT, D, pk + L.pk_x, rpBT, 0, 0, rpBT, nkb, 0, 0, ax, stream)) return e;
     {   // Wx^T of both cells: one launch
       PkPackReq rq[2];
       for (int dir = 0; dir < 2; ++dir)
         rq[dir] = PkPackReq{kern[dir], G, D, G, pk + L.pk_w, rpG, dir * G, 0, dir ? rpG - G : G, nkb, 0, 0, P == 2 ? aw : nullptr};
       if (int e = pk_pack_multi(P, 1, rq, 2, s)) return e;
     }
-    nabu_pk_gemm_desc g = pk_desc(P, BT, 2 * G, nkb, pk + L.pk_x, rpBT, pk + L.pk_w, rpG, gates[0], G);
+    nabu_pk_gemm_desc g = pk_desc(P, BT, 2 * G, nkb, xop, rpBT, pk + L.pk_w, rpG, gates[0], G);
     g.C2[0] = gates[1]; g.n_split = G; g.bias = bias[0]; g.bias2 = bias[1];
     if (P == 2) { g.a_amax[0] = ax; g.b_amax[0] = aw; g.direct = 2; }
     if (int e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream)) return e;
@@ -614,15 +695,56 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d_in, const float *x, const
     NABU_HIP(hipMemset2DAsync(out + (size_t)max_len * 2 * H, (size_t)T * 2 * H * sizeof(float), 0,
                               (size_t)(T - max_len) * 2 * H * sizeof(float), B, s));
 
+  // packed companions of the output (ABI version 3): out of the recurrent kernel itself where that is possible, by the
+  // pack kernels behind the recurrence otherwise — complete on return either way
+  const bool want_cmp = wants_companions(d, L);
+  const int S = L.out_stack, rpW = nabu_pk_rows_pad(L.pk_whole ? D + H : H), r0 = L.pk_whole ? D : 0;
+  char *hTp[2] = {nullptr, nullptr};
+  if (L.hT_ext) { hTp[0] = static_cast<char *>(d->hT_pk); hTp[1] = hTp[0] + L.cmp_bytes[2] / 2; }
+  const bool want_out = (d->out_pk_rows || d->out_pk_cols) && L.cmp_bytes[3] != 0;
+  const int by_kernel = emitted_by_kernel(d, L);
+  const bool emit = by_kernel != 0;
+  auto companions_by_pack_kernels = [&](int todo) -> int {
+    if (!todo) return 0;
+    uint32_t *am = reinterpret_cast<uint32_t *>(w + L.cmp_amax_off);
+    const FillSeg fill = {am, L.cmp_amax_bytes / 4, CMP_AMAX_BITS};
+    if (int e = multi_fill(&fill, 1, s)) return e;
+    const int R = B * T / S, C = 2 * H * S;
+    if (want_out && d->out_pk_rows && (todo & 1))
+      if (int e = pk_pack_any(2, 0, out, C, R, C, d->out_pk_rows, nabu_pk_rows_pad(R), 0, 0, nabu_pk_rows_pad(R), nabu_pk_kblocks(C, 2), 0, 0, am, stream)) return e;
+    if (want_out && d->out_pk_cols && (todo & 2))
+      if (int e = pk_pack_any(2, 1, out, C, R, C, d->out_pk_cols, nabu_pk_rows_pad(C), 0, 0, nabu_pk_rows_pad(C), nabu_pk_kblocks(R, 2), 0, 0, am, stream)) return e;
+    if (L.hT_ext && (todo & 4)) {
+      PkPackReq rq[2];
+      for (int dir = 0; dir < 2; ++dir)
+        rq[dir] = PkPackReq{out + (size_t)dir * H, 2 * H, B * T, H, hTp[dir], rpW, r0, 0, rpW - r0, nabu_pk_kblocks(B * T, 2), T, dir ? 1 : -1, am};
+      if (int e = pk_pack_multi(2, 1, rq, 2, s)) return e;
+    }
+    return 0;
+  };
+  EmitArgs em = {};
+  if (emit) {
+    em.x_rows = (want_out && (by_kernel & 1)) ? static_cast<char *>(d->out_pk_rows) : nullptr;
+    em.x_cols = (want_out && (by_kernel & 2)) ? static_cast<char *>(d->out_pk_cols) : nullptr;
+    em.hT[0] = (by_kernel & 4) ? hTp[0] : nullptr; em.hT[1] = (by_kernel & 4) ? hTp[1] : nullptr;
+    em.x_rows_pad = (unsigned)nabu_pk_rows_pad(B * T / S);
+    em.x_cols_pad = (unsigned)nabu_pk_rows_pad(2 * H * S);
+    em.hT_rows_pad = (unsigned)rpW;
+    em.hT_row0 = r0;
+    em.stack_shift = S == 2 ? 1 : 0;
+    em.b0 = 0;
+  }
+
   if (use_persistent(d)) {
     NABU_PROFILE_MARK(g_ev_begin, s);
     int e = lstm_persist_fwd(B, T, D, H, max_len, len, kern, gates, cs, out, reinterpret_cast<int *>(w), w + L.persist_off,
                              L.persist_bytes, s, fuse_in ? x : nullptr, fuse_in ? bias : nullptr,
-                             L.xws_bytes ? w + L.xws_off : nullptr);
+                             L.xws_bytes ? w + L.xws_off : nullptr, emit ? &em : nullptr);
     // the grid cannot be co-resident on this device (occupancy check before the launch): LSTM_AUTO steps instead
     if (!(e == NABU_EUNSUP && d->mode == NABU_LSTM_AUTO)) {
       if (e) return e;
       NABU_PROFILE_MARK(g_ev_end, s);
+      if (want_cmp) return companions_by_pack_kernels(7 & ~by_kernel);
       return 0;
     }
     if (fuse_in)      // the step kernels read the projection from the gate buffers
@@ -647,6 +769,7 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d_in, const float *x, const
   }
   NABU_LAUNCH_CHECK();
   NABU_PROFILE_MARK(g_ev_end, s);
+  if (want_cmp) return companions_by_pack_kernels(7);
   return 0;
 }
 
@@ -770,8 +893,12 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
       }
     }
     if ((parts & 2) && L.pk_in) {
-      if ((e = pk_pack_any(P, 1, x, D, M, D, pk + L.pk_xT, rpD, 0, 0, rpD, nkbT, 0, 0, axT, stream))) return e;
-      nabu_pk_gemm_desc g = pk_desc(P, D, 2 * G, nkbT, pk + L.pk_xT, rpD, dzTp, rpG, dkern[0], G);
+      // x^T: the producer layer's forward kernel wrote it (x_pk_cols; its row maxima were set by this layer's forward
+      // call) — or one transposing pass over x here
+      const void *xTop = L.x_pk ? d->x_pk_cols : pk + L.pk_xT;
+      if (!L.x_pk)
+        if ((e = pk_pack_any(P, 1, x, D, M, D, pk + L.pk_xT, rpD, 0, 0, rpD, nkbT, 0, 0, axT, stream))) return e;
+      nabu_pk_gemm_desc g = pk_desc(P, D, 2 * G, nkbT, xTop, rpD, dzTp, rpG, dkern[0], G);
       g.C2[0] = dkern[1]; g.n_split = G;
       // direct = 2: the three plane products chained directly into the accumulators wherever that rounds less often
       // than the exact-fp32 kernel would (gemm_pk.hip; 0.6-0.8 x its error at these shapes, tests/test_hip_gemm_pk.py)
@@ -783,8 +910,11 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
       // Narrow input (the first layer, D = 40): x^T sits in front of h^T in the same operand and the whole kernel
       // gradient [(D+H), 4H] of a cell is ONE product (its dWx alone cost more on the in-kernel-split kernel)
       const int r0 = L.pk_whole ? D : 0, Mw = r0 + H, rpW = nabu_pk_rows_pad(Mw);
+      // h^T: in the caller's hT_pk, written by the forward call (ABI version 3) — or packed here from `out`
+      char *hTb[2] = {pk + L.pk_hT[0], pk + L.pk_hT[1]};
+      if (L.hT_ext) { hTb[0] = static_cast<char *>(d->hT_pk); hTb[1] = hTb[0] + L.cmp_bytes[2] / 2; }
       if (P == 2) {   // |h| <= 1 by construction (o · tanh c): one fill for both cells; the input features are measured
-        const unsigned hb = bound_bits(1.0f);
+        const unsigned hb = L.hT_ext ? CMP_AMAX_BITS : bound_bits(1.0f);
         const FillSeg fill[4] = {{ahT[0], (size_t)r0, 0u}, {ahT[0] + r0, (size_t)(rpW - r0), hb},
                                  {ahT[1], (size_t)r0, 0u}, {ahT[1] + r0, (size_t)(rpW - r0), hb}};
         // (r0 = D is a multiple of 4: every region starts 16-byte aligned)
@@ -796,13 +926,14 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
         int n = 0;
         for (int dir = 0; dir < 2; ++dir) {
           const uint32_t *am = P == 2 ? ahT[dir] : nullptr;
-          if (L.pk_whole) rq[n++] = PkPackReq{x, D, M, D, pk + L.pk_hT[dir], rpW, 0, 0, D, nkbT, 0, 0, am};
-          rq[n++] = PkPackReq{out + (size_t)dir * H, 2 * H, M, H, pk + L.pk_hT[dir], rpW, r0, 0, rpW - r0, nkbT, T, dir ? 1 : -1, am};
+          if (L.pk_whole) rq[n++] = PkPackReq{x, D, M, D, hTb[dir], rpW, 0, 0, D, nkbT, 0, 0, am};
+          if (!L.hT_ext)
+            rq[n++] = PkPackReq{out + (size_t)dir * H, 2 * H, M, H, hTb[dir], rpW, r0, 0, rpW - r0, nkbT, T, dir ? 1 : -1, am};
         }
-        if ((e = pk_pack_multi(P, 1, rq, n, s))) return e;
+        if (n && (e = pk_pack_multi(P, 1, rq, n, s))) return e;
       }
-      nabu_pk_gemm_desc g = pk_desc(P, Mw, G, nkbT, pk + L.pk_hT[0], rpW, dzTp, rpG, dkern[0] + (size_t)(D - r0) * G, G);
-      g.nbatch = 2; g.A[1] = pk + L.pk_hT[1]; g.B[1] = dzTp + (size_t)G * 32; g.C[1] = dkern[1] + (size_t)(D - r0) * G;
+      nabu_pk_gemm_desc g = pk_desc(P, Mw, G, nkbT, hTb[0], rpW, dzTp, rpG, dkern[0] + (size_t)(D - r0) * G, G);
+      g.nbatch = 2; g.A[1] = hTb[1]; g.B[1] = dzTp + (size_t)G * 32; g.C[1] = dkern[1] + (size_t)(D - r0) * G;
       if (P == 2) { g.a_amax[0] = ahT[0]; g.a_amax[1] = ahT[1]; g.b_amax[0] = adzT; g.b_amax[1] = adzT + G; g.direct = 2; }
       if ((e = nabu_gemm_pk(&g, w + L.gemm_off, L.gemm_bytes, stream))) return e;
     }

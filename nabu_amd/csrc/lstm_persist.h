@@ -3,6 +3,23 @@
 #include "common.h"
 
 namespace nabu {
+// PACKED COMPANIONS written by the forward fp16-plane kernel next to `out` (include/nabu_hip.h, nabu_blstm_desc ABI version
+// 3): the layer's output as f16x3 operands in gemm_pk.hip's layout [k / 16][plane][rows_pad][16 k] (halves of a 32-byte
+// record swapped when bit 3 of the row is set), scaled by 2^14 (row maxima = the bit pattern of 1.0f).  Null pointer =
+// that companion is not written.  Offsets inside one companion stay below 2^31 (checked by the caller).
+struct EmitArgs {
+  char *x_rows;            // out, `stack` frames per row: row = b (T / stack) + t / stack, k = (t % stack) 2H + dir H + unit
+  char *x_cols;            // the transposed operand: row = that k, reduction index = that row
+  char *hT[2];             // h_(t-1)^T of the forward / backward cell: row = hT_row0 + unit, reduction index = b T + t, shifted
+                           // by one frame (fw: out[b, t - 1], bw: out[b, t + 1]; 0 at the ends)
+  unsigned x_rows_pad, x_cols_pad, hT_rows_pad;
+  int hT_row0;
+  int stack_shift;         // log2(stack): 0 or 1
+  int b0;                  // first batch row of this launch within the whole batch
+};
+// does a forward launch of this shape write companions itself? (fp16-plane kernels of lstm_persist_mxh.hip, launches of
+// <= 32 rows, every frame visited)
+bool lstm_persist_emits(int B, int T, int H, int max_len);
 bool lstm_persist_supported(int B, int T, int H);
 void lstm_persist_set_timeout_us(long long us);
 unsigned long long lstm_persist_timeout_ticks();   // bound of every in-kernel wait (wall_clock64 ticks)
@@ -10,7 +27,7 @@ size_t lstm_persist_ws_bytes(int B, int T, int H);
 int lstm_persist_fwd(int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2],
                      float *out, int *status, void *ws, size_t ws_bytes, hipStream_t stream, const float *x = nullptr,
-                     const float *const bias[2] = nullptr, void *xws = nullptr);
+                     const float *const bias[2] = nullptr, void *xws = nullptr, const EmitArgs *emit = nullptr);
 // xws: lstm_persist_xws_bytes(B, T, D) bytes of workspace for the fp16-plane kernels' copy of x (two fp16 planes per frame)
 size_t lstm_persist_xws_bytes(int B, int T, int D);
 // x, bias given (only when lstm_persist_fuses_input says so: the fp16-plane kernels with D <= 64, one launch of <= 32 rows;

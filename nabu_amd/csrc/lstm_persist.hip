@@ -817,7 +817,7 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
                      const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
                      const float *dout, int *status, void *ws, size_t ws_bytes, float *db_part, float *amax_part,
                      int *shard_base, hipStream_t stream, const float *x, const float *const bias[2], bool dry, RowMax *rm,
-                     const void *xws, int xrow0);
+                     const void *xws, int xrow0, const EmitArgs *emit);
 
 // exchange ring + XCC table back to 0xFF bytes: one small kernel (a hipMemsetAsync is its own kind of dispatch and
 // costs ~6 us of queue gap in front of every recurrent launch)
@@ -834,7 +834,7 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
                const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
                const float *dout, int *status, void *ws, size_t ws_bytes, float **db_part_out, int *db_rows_out,
                hipStream_t stream, const float *x = nullptr, const float *const bias[2] = nullptr, uint32_t *rowmax = nullptr,
-               bool *rowmax_done = nullptr, void *xws = nullptr) {
+               bool *rowmax_done = nullptr, void *xws = nullptr, const EmitArgs *emit = nullptr) {
   if (!lstm_persist_supported(B, T, H)) return fail(NABU_EUNSUP, "persistent LSTM: unsupported B=%d H=%d", B, H);
   const size_t need = lstm_persist_ws_bytes(B, T, H);
   if (ws_bytes < need) return fail(NABU_EWS, "persistent LSTM: workspace %zu < %zu", ws_bytes, need);
@@ -855,7 +855,7 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
       const int e = run_chunk(fwd, nb, T, D, H, max_len, len + b0, kernel, g2, c2,
                               out ? out + (size_t)b0 * T * 2 * H : nullptr,
                               dout ? dout + (size_t)b0 * T * 2 * H : nullptr, status, ws, ws_bytes, db_part, amax_part, &shards,
-                              stream, x ? x + (size_t)b0 * T * D : nullptr, bias, pass == 0, &rm, xws, b0);
+                              stream, x ? x + (size_t)b0 * T * D : nullptr, bias, pass == 0, &rm, xws, b0, emit);
       if (e) return e;
       kept = kept && rm.kept;
     }
@@ -870,8 +870,16 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
                      const float *const kernel[2], float *const gates[2], float *const cs[2], float *out,
                      const float *dout, int *status, void *ws, size_t ws_bytes, float *db_part, float *amax_part,
                      int *shard_base, hipStream_t stream, const float *x, const float *const bias[2], bool dry, RowMax *rm,
-                     const void *xws, int xrow0) {
+                     const void *xws, int xrow0, const EmitArgs *emit) {
   PersistArgs a;
+  a.emit = EmitArgs{};
+  if (emit && fwd) {
+    // only the fp16-plane kernels with 16 units per workgroup write companions (the caller asked lstm_persist_emits)
+    if (!lstm_persist_emits(B, T, H, max_len) || xrow0 != 0)
+      return fail(NABU_EINVAL, "persistent LSTM: this launch cannot write the packed companions");
+    a.emit = *emit;
+    a.emit.b0 = xrow0;
+  }
   a.rowmax_part = nullptr; a.rowmax_stride = 0;
   { const char *e = getenv("NABU_PERSIST_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   if (lstm_mx_supported(B, H)) {
@@ -954,9 +962,19 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
 int lstm_persist_fwd(int B, int T, int D, int H, int max_len, const int32_t *len,
                      const float *const kernel[2], float *const gates[2], float *const cs[2],
                      float *out, int *status, void *ws, size_t ws_bytes, hipStream_t stream, const float *x,
-                     const float *const bias[2], void *xws) {
+                     const float *const bias[2], void *xws, const EmitArgs *emit) {
   return run(true, B, T, D, H, max_len, len, kernel, gates, cs, out, nullptr, status, ws, ws_bytes, nullptr, nullptr,
-             stream, x, bias, nullptr, nullptr, xws);
+             stream, x, bias, nullptr, nullptr, xws, emit);
+}
+// companions come out of the kernel itself only on the fp16-plane kernels with 16 units per workgroup, ONE launch of
+// <= 32 rows (lstm_persist_mxh.hip), when the recurrence visits every frame (a frame it never visits is never written)
+// and no debug variant is selected
+bool lstm_persist_emits(int B, int T, int H, int max_len) {
+  if (getenv("NABU_PERSIST_DEBUG") && atoi(getenv("NABU_PERSIST_DEBUG"))) return false;
+  static int env = -1;
+  if (env < 0) { const char *e = getenv("NABU_PERSIST_EMIT"); env = e ? atoi(e) : 1; }
+  if (!env || max_len != T || !lstm_persist_supported(B, T, H) || !lstm_mx_supported(B, H)) return false;
+  return B <= lstm_mx_chunk_rows() && !lstm_mxf_supported(B, H);
 }
 size_t lstm_persist_xws_bytes(int B, int T, int D) { return (D <= 64 && D % 8 == 0) ? lstm_mxh_xws_bytes(B, T) : 0; }
 

@@ -49,6 +49,7 @@ struct PersistArgs {
   unsigned long long timeout_ticks;  // wall_clock64 ticks (100 MHz)
   int dbg;  // NABU_PERSIST_DEBUG: 1 no exchange wait, 2 no matrix product, 4 phase stamps,
             // 8 force write-through publishing, 16 force BS = 8 (timing experiments only)
+  EmitArgs emit;      // forward, fp16-plane kernels <.., EMIT = true>: packed companions of `out` (lstm_persist.h)
 };
 
 __device__ __forceinline__ float dpp_f(float v, const int ctrl_sel) {

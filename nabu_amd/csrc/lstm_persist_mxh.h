@@ -82,4 +82,30 @@ __device__ __forceinline__ float mxh_xor16(float v) {      // lane ^ 16 inside e
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
 }
 
+// launch of one fp16-plane kernel (256 threads): the grid is validated against the runtime's occupancy answer first
+template <typename K>
+static int mxh_launch(K kernel, const PersistArgs &a, int grid, size_t lds, hipStream_t stream, bool dry) {
+  const void *fn = reinterpret_cast<const void *>(kernel);
+  struct Seen { const void *fn; int dev, blocks; };
+  static thread_local Seen seen[16] = {};
+  int dev = 0;
+  NABU_HIP(hipGetDevice(&dev));
+  int blocks = -1;
+  for (const Seen &c : seen)
+    if (c.fn == fn && c.dev == dev) blocks = c.blocks;
+  if (blocks < 0) {
+    NABU_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 256, lds));
+    for (Seen &c : seen)
+      if (!c.fn) { c = Seen{fn, dev, blocks}; break; }
+  }
+  if (blocks < 1 || grid > NCU)
+    return fail(NABU_EUNSUP, "persistent LSTM (mxh): %d workgroups cannot be co-resident (%d per CU)", grid, blocks);
+  if (dry) return 0;          // validation pass (lstm_persist.hip, run)
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, stream, a);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+
+int lstm_mxh_bwd_launch(int H, const PersistArgs &a, hipStream_t stream, bool dry);   // lstm_persist_mxh_bwd.hip
+
 }  // namespace nabu

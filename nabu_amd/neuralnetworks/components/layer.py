@@ -28,7 +28,12 @@ DEFER_WEIGHT_GRADS = [_os.environ.get('NABU_DEFER_WGRAD', '1') != '0']
 CAPTURE = [None]
 
 
-def blstm(inputs, sequence_length, num_units, layer_norm=False, scope=None):
+# packed companions (include/nabu_hip.h, ABI version 3): the forward recurrent kernel writes the layer's output also as the
+# next layer's f16x3 operands and its own h^T operand.  NABU_PACKED_COMPANIONS=0: every call packs for itself as before.
+PACKED_COMPANIONS = [_os.environ.get('NABU_PACKED_COMPANIONS', '1') != '0']
+
+
+def blstm(inputs, sequence_length, num_units, layer_norm=False, scope=None, out_stack=0):
     """A BLSTM layer (reference layer.py:8-51).
 
     inputs [B,T,D] fp32 contiguous on the GPU; sequence_length [B];
@@ -51,12 +56,39 @@ def blstm(inputs, sequence_length, num_units, layer_norm=False, scope=None):
     # reserve then holds the activations only
     training = Tape.current is not None
     plan = hip.BlstmPlan(B, T, D, H, min(lens.max(), T), LSTM_MODE[0], GEMM_PRECISION[0], x_bound=ops.value_bound(inputs),
-                         fwd_only=not training, recurrent_precision=RECURRENT_PRECISION[0])
+                         fwd_only=not training, recurrent_precision=RECURRENT_PRECISION[0], out_stack=out_stack)
     x = inputs if inputs.is_contiguous() else inputs.contiguous()
+    out_pk = None
+    if PACKED_COMPANIONS[0]:
+        where = (vs.current_scope(), scope or 'BLSTM', B, T, D, H)
+        # input: the producer layer's kernel wrote it (ops.packed), if this layer's products read packed operands at all
+        x_pk = ops.packed(inputs, 1) if x is inputs else None
+        if x_pk is not None and plan.pk_bytes[0] and (x_pk[0].numel(), x_pk[1].numel()) == tuple(plan.pk_bytes[:2]):
+            hip.blstm_set_companions(plan, x_pk=x_pk)
+        # output, for the consumer behind `out_stack` stacked frames: only if that layer (same units, same arithmetic)
+        # would read them
+        if out_stack in (1, 2) and T % out_stack == 0 and plan.pk_bytes[3]:
+            nxt = hip.BlstmPlan(B, T // out_stack, 2 * H * out_stack, H, T // out_stack, LSTM_MODE[0], GEMM_PRECISION[0], x_bound=1.0,
+                                fwd_only=not training, recurrent_precision=RECURRENT_PRECISION[0])
+            if nxt.pk_bytes[0] == plan.pk_bytes[3] and nxt.pk_bytes[1] == plan.pk_bytes[4]:
+                out_pk = (ops.resident_zeros(where + ('rows',), plan.pk_bytes[3], x.device, Tape.current),
+                          ops.resident_zeros(where + ('cols',), plan.pk_bytes[4], x.device, Tape.current))
+                hip.blstm_set_companions(plan, out_pk=out_pk)
+        if training and plan.pk_bytes[2]:
+            hip.blstm_set_companions(plan, hT_pk=ops.resident_zeros(where + ('hT',), plan.pk_bytes[2], x.device, Tape.current))
+        # what the recurrent kernel does not write itself is packed where it is needed, as before (no companion)
+        mask = hip.blstm_emits_packed(plan)
+        if out_pk is not None and (mask & 3) != 3:
+            hip.blstm_drop_companions(plan, out_pk=True)
+            out_pk = None
+        if not mask & 4:
+            hip.blstm_drop_companions(plan, hT_pk=True)
     out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
     reserve = torch.empty(plan.reserve_bytes, dtype=torch.uint8, device=x.device)
     hip.blstm_fwd(plan, x, lens.dev, kf.data, bf.data, kb.data, bb.data, out, reserve)
     ops.set_value_bound(out, 1.0)
+    if out_pk is not None:
+        ops.set_packed(out, out_stack, out_pk)
     need_dx = requires_grad(inputs)
 
     def backward(dout):
@@ -86,6 +118,6 @@ def pblstm(inputs, sequence_length, num_units, num_steps=2, layer_norm=False, sc
     ``num_steps`` consecutive output frames.  Returns (outputs, new lengths)."""
     with vs.variable_scope(scope or 'PBLSTM'):
         outputs = blstm(inputs=inputs, sequence_length=sequence_length, num_units=num_units,
-                        layer_norm=layer_norm)
+                        layer_norm=layer_norm, out_stack=num_steps if num_steps in (1, 2) else 0)
         outputs, output_seq_lengths = ops.pyramid_stack(outputs, sequence_length, num_steps)
     return outputs, output_seq_lengths

@@ -24,6 +24,47 @@ def value_bound(tensor):
     return e[1] if e is not None and e[0]() is tensor else 0.0
 
 
+# PACKED COMPANIONS of tensors on the path (include/nabu_hip.h, nabu_blstm_desc ABI version 3): id(tensor) -> (weak reference,
+# stack, (rows, cols)) — layer.blstm asks the forward recurrent kernel to write its output ALSO as the next layer's
+# f16x3 operands (for the frame stacking `stack` that pyramid_stack is about to apply), and the next layer.blstm hands
+# them to the C ABI instead of packing its input.  Only the stacking view carries a companion along; any op that makes a
+# new tensor (dropout, noise) drops it, and the next layer packs for itself as before.
+_PACKED = {}
+
+
+def set_packed(tensor, stack, bufs):
+    key = id(tensor)
+    _PACKED[key] = (weakref.ref(tensor, lambda _r, k=key: _PACKED.pop(k, None)), int(stack), bufs)
+
+
+def packed(tensor, stack):
+    """the (rows, cols) companion of `tensor` written for frame stacking `stack`, or None"""
+    e = _PACKED.get(id(tensor))
+    return e[2] if e is not None and e[0]() is tensor and e[1] == stack else None
+
+
+# Zero-filled device buffers that live as long as the process, keyed by their user (a layer's scope and shape): a
+# companion is rewritten in full by every forward call and its padding stays zero, so the same buffer serves step after
+# step.  `holder` = the Tape whose backward pass still reads the content (None: nobody behind this call): a forward pass
+# that finds the buffer held by ANOTHER tape whose backward pass has not run yet (two forward passes of one layer before
+# the first backward) gets a buffer of its own instead of overwriting it.
+_RESIDENT = {}
+
+
+def resident_zeros(key, nbytes, device, holder=None):
+    import torch
+    slots = _RESIDENT.setdefault(key, [])
+    for slot in slots:
+        buf, ref = slot
+        h = ref() if ref is not None else None
+        if (h is None or h is holder or not h.ops) and buf.numel() == nbytes and buf.device == device:
+            slot[1] = weakref.ref(holder) if holder is not None else None
+            return buf
+    buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+    slots.append([buf, weakref.ref(holder) if holder is not None else None])
+    return buf
+
+
 def pyramid_stack(inputs, sequence_lengths, numsteps, axis=2, scope=None):
     """Concatenate ``numsteps`` consecutive frames on the feature axis
     (reference ops.py:6-60).
@@ -40,6 +81,8 @@ def pyramid_stack(inputs, sequence_lengths, numsteps, axis=2, scope=None):
     outputs = src.view(B, Tp // numsteps, numsteps * F)
     if value_bound(inputs):
         set_value_bound(outputs, value_bound(inputs))
+    if Tp == T and packed(inputs, numsteps) is not None:        # the companion was written for exactly this stacking
+        set_packed(outputs, 1, packed(inputs, numsteps))
 
     def backward(dout):
         d = dout.reshape(B, Tp, F)

@@ -192,7 +192,7 @@ class BlstmPlan(object):
     """Shape descriptor + buffers of one BLSTM layer call."""
 
     def __init__(self, B, T, D, H, max_len, mode=LSTM_AUTO, gemm_precision='default', x_bound=0.0, fwd_only=False,
-                 recurrent_precision='default'):
+                 recurrent_precision='default', out_stack=0):
         """x_bound > 0: |x| <= x_bound is guaranteed (the previous layer's LSTM outputs) — the f16x3 packs of x skip their
         measuring pass; fwd_only: no backward pass follows (validation): the reserve holds the activations only;
         recurrent_precision 'f32': the exact-fp32 recurrent kernels (include/nabu_hip.h, nabu_blstm_desc)"""
@@ -200,13 +200,51 @@ class BlstmPlan(object):
         # (NABU_DESC_V1=1: the 32-byte ABI-version-1 descriptor — A/B runs against a library built before round 5)
         self.desc = _hip.BlstmDesc(32 if os.environ.get('NABU_DESC_V1') == '1' else ctypes.sizeof(_hip.BlstmDesc), B, T, D, H, int(max_len), mode,
                                    _hip.GEMM_PRECISIONS[gemm_precision], float(x_bound),
-                                   _hip.BLSTM_FWD_ONLY if fwd_only else 0, _hip.REC_PRECISIONS[recurrent_precision])
+                                   _hip.BLSTM_FWD_ONLY if fwd_only else 0, _hip.REC_PRECISIONS[recurrent_precision],
+                                   int(out_stack), None, None, None, None, None)
         L = _hip.lib()
+        # packed companions (ABI version 3): sizes of x_pk_rows, x_pk_cols, hT_pk, out_pk_rows, out_pk_cols for this layer
+        # (0 = the layer would not use that companion); the buffers themselves are attached by the caller (set_companions)
+        pkb = (ctypes.c_size_t * 5)()
+        self.pk_bytes = [0] * 5
+        if self.desc.size == ctypes.sizeof(_hip.BlstmDesc) and L.nabu_blstm_pk_bytes(ctypes.byref(self.desc), pkb) == 0:
+            self.pk_bytes = [int(v) for v in pkb]
+        self._keep = []
         self.reserve_bytes = L.nabu_blstm_reserve_bytes(ctypes.byref(self.desc))
         self.ws_bytes = L.nabu_blstm_ws_bytes(ctypes.byref(self.desc))
         if self.reserve_bytes == 0:
             raise _hip.NabuHipError('blstm: unsupported shape B=%d T=%d D=%d H=%d: %s' % (
                 B, T, D, H, L.nabu_last_error().decode()))
+
+
+def blstm_set_companions(plan, x_pk=None, out_pk=None, hT_pk=None):
+    """attach packed companions to a plan (include/nabu_hip.h, nabu_blstm_desc ABI version 3): x_pk / out_pk = (rows, cols)
+    uint8 tensors of plan.pk_bytes[0:2] / [3:5] bytes, hT_pk one tensor of plan.pk_bytes[2] bytes, each zero-filled once
+    by its owner.  The plan keeps them alive."""
+    d = plan.desc
+    if x_pk is not None:
+        assert x_pk[0].numel() == plan.pk_bytes[0] and x_pk[1].numel() == plan.pk_bytes[1]
+        d.x_pk_rows, d.x_pk_cols = x_pk[0].data_ptr(), x_pk[1].data_ptr()
+    if out_pk is not None:
+        assert out_pk[0].numel() == plan.pk_bytes[3] and out_pk[1].numel() == plan.pk_bytes[4]
+        d.out_pk_rows, d.out_pk_cols = out_pk[0].data_ptr(), out_pk[1].data_ptr()
+    if hT_pk is not None:
+        assert hT_pk.numel() == plan.pk_bytes[2]
+        d.hT_pk = hT_pk.data_ptr()
+    plan._keep += [t for t in (x_pk or ()) + (out_pk or ()) + ((hT_pk,) if hT_pk is not None else ())]
+
+
+def blstm_emits_packed(plan):
+    """which companions attached to `plan` nabu_blstm_fwd's recurrent kernel writes itself: bit 0 rows, 1 transposed, 2 h^T"""
+    return int(_hip.lib().nabu_blstm_emits_packed(ctypes.byref(plan.desc)))
+
+
+def blstm_drop_companions(plan, out_pk=False, hT_pk=False):
+    d = plan.desc
+    if out_pk:
+        d.out_pk_rows, d.out_pk_cols = None, None
+    if hT_pk:
+        d.hT_pk = None
 
 
 def blstm_fwd(plan, x, lens_dev, k_fw, b_fw, k_bw, b_bw, out, reserve):

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert n in _hip.SIGNATURES, 'no ctypes signature for %s' % n
     for n in _hip.SIGNATURES:
         assert n in names, '%s bound in _hip.py but not declared in nabu_hip.h' % n
-    assert lib.nabu_version() == 2 == _hip.ABI_VERSION
+    assert lib.nabu_version() == 3 == _hip.ABI_VERSION
 
 
 def test_graft_entry_build_checks_the_same_version():
