@@ -39,6 +39,12 @@ int first_col_one(int rows, int ld, float *x, hipStream_t s);
 // elementwise.hip: dropout / scheduled sampling on a sub-batch of rows with the whole batch's random stream
 int dropout_rows(size_t n, const float *x, float *y, float keep_prob, unsigned long long seed, unsigned long long offset,
                  size_t first_elem, hipStream_t stream);
+// one decoder step's scheduled sampling in one launch ([h | ctx] . Wout + bias evaluated only for the rows that are
+// sampled): elementwise.hip, sample_step_kernel
+bool sample_step_ok(int C);
+int sample_step(int B, int C, int U, int E, const float *h, int ldh, const float *ctx, int ldc, const float *Wout,
+                const float *bias, float prob, unsigned long long seed, unsigned long long offset, const int32_t *teacher_ids,
+                int32_t *out_ids, int b0, hipStream_t stream);
 int sample_ids_rows(int B, int C, const float *logits, float prob, unsigned long long seed, unsigned long long offset,
                     const int32_t *teacher_ids, int32_t *out_ids, int b0, hipStream_t stream);
 

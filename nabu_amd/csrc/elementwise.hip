@@ -170,6 +170,63 @@ __global__ __launch_bounds__(256) void sample_ids_kernel(int B, int C, const flo
   out[b] = id;
 }
 
+// Scheduled sampling of ONE decoder step in ONE launch (the step chain of nabu_speller_fwd): row b draws the Bernoulli of
+// sample_ids_kernel first and only a row that IS to be sampled (sample_prob = 0.1 in the reference's defaults: one in
+// ten) evaluates its logits [h | ctx] . W_out + b — 25 k slots x (C / 4) class quads, 16-byte loads of the weight rows —
+// and draws from softmax(logits) by the inverse CDF in class order, exactly as sample_ids_kernel does.  Replaces two
+// [Bn, C] products through the general GEMM entry point and the sampling launch per step and sub-batch
+// (rnn_decoder.py:59-66, ScheduledEmbeddingTrainingHelper).  Requires C % 4 == 0, C <= 256.
+constexpr int SAMPLE_KS = 25;
+__global__ __launch_bounds__(256) void sample_step_kernel(int C, int U, int E, const float *__restrict__ h, int ldh,
+                                                          const float *__restrict__ ctx, int ldc,
+                                                          const float *__restrict__ Wout, const float *__restrict__ bias,
+                                                          float prob, unsigned long long seed, unsigned long long offset,
+                                                          const int32_t *__restrict__ teacher, int32_t *__restrict__ out, int b0) {
+  __shared__ float part[SAMPLE_KS][256];
+  __shared__ float lg[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const uint4 r = philox4x32_10(make_uint4((unsigned)(b + b0), 0u, (unsigned)offset, (unsigned)(offset >> 32)),
+                                make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+  if (!(u01(r.x) < prob)) {
+    if (tid == 0) out[b] = teacher[b];
+    return;
+  }
+  const int CQ = C / 4, ks = tid / CQ, cq = tid - ks * CQ, K = U + E;
+  if (ks < SAMPLE_KS) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *hb = h + (size_t)b * ldh, *cb = ctx + (size_t)b * ldc;
+#pragma unroll 8
+    for (int k = ks; k < K; k += SAMPLE_KS) {
+      const float x = k < U ? hb[k] : cb[k - U];
+      const float4 wv = *reinterpret_cast<const float4 *>(Wout + (size_t)k * C + 4 * cq);
+      acc.x = fmaf(x, wv.x, acc.x); acc.y = fmaf(x, wv.y, acc.y); acc.z = fmaf(x, wv.z, acc.z); acc.w = fmaf(x, wv.w, acc.w);
+    }
+    *reinterpret_cast<float4 *>(&part[ks][4 * cq]) = acc;
+  }
+  __syncthreads();
+  if (tid < C) {
+    float v = bias[tid];
+    const int nks = min(SAMPLE_KS, 256 / CQ);
+    for (int i = 0; i < nks; ++i) v += part[i][tid];
+    lg[tid] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float m = lg[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, lg[c]);
+    float tot = 0.f;
+    for (int c = 0; c < C; ++c) tot += expf(lg[c] - m);
+    const float target = u01(r.y) * tot;        // inverse CDF of softmax(l)
+    float acc = 0.f;
+    int id = C - 1;
+    for (int c = 0; c < C; ++c) {
+      acc += expf(lg[c] - m);
+      if (acc > target) { id = c; break; }
+    }
+    out[b] = id;
+  }
+}
+
 __global__ __launch_bounds__(256) void gaussian_noise_kernel(size_t n, const float *__restrict__ x,
                                                              float *__restrict__ y, float stddev,
                                                              unsigned long long seed,
@@ -460,6 +517,17 @@ int dropout_rows(size_t n, const float *x, float *y, float keep_prob, unsigned l
   if (n == 0) return 0;
   hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, stream, n, x, y, keep_prob, seed, offset,
                      first_elem / 4);
+  NABU_LAUNCH_CHECK();
+  return 0;
+}
+bool sample_step_ok(int C) { return C % 4 == 0 && C >= 4 && C <= 256; }
+int sample_step(int B, int C, int U, int E, const float *h, int ldh, const float *ctx, int ldc, const float *Wout,
+                const float *bias, float prob, unsigned long long seed, unsigned long long offset, const int32_t *teacher_ids,
+                int32_t *out_ids, int b0, hipStream_t stream) {
+  if (B == 0) return 0;
+  if (!sample_step_ok(C)) return fail(NABU_EUNSUP, "sample_step: C = %d", C);
+  hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(256), 0, stream, C, U, E, h, ldh, ctx, ldc, Wout, bias, prob, seed,
+                     offset, teacher_ids, out_ids, b0);
   NABU_LAUNCH_CHECK();
   return 0;
 }

@@ -63,6 +63,8 @@ struct SkinnyEpilogue {
   const int32_t *ids;
   const float *c_prev, *h_prev;
   float *acts, *c_new, *h_new;
+  float *ho_new;   // forward, rows16_kernel only (may be null): the cell output behind its dropout (keep, seed, seed_offset,
+                   // row0 below: element (row0 + m) U + u of the stream, the mask dropout_rows would apply to h_new)
   // backward (acts, c_new = c of this step, c_prev as above are inputs)
   const float *dh2;
   int ld_dh2;

@@ -413,9 +413,17 @@ __global__ __launch_bounds__(512) void rows16_kernel(Rows16Args a) {
     __syncthreads();
     if (tid >= 64 || (tid >> 2) >= a.M) return;
     const size_t idx = (size_t)fm * U + fu, zo = (size_t)fm * 4 * U + fu;
+    float dsc = 1.f;          // output dropout of the cell (the mask of dropout_rows on this step's h)
+    if (ep.ho_new && ep.keep > 0.f && ep.keep < 1.f) {
+      const size_t e = (size_t)(ep.row0 + fm) * U + fu;
+      const float4 sc = dropout_scale4(e >> 2, ep.keep, ep.seed, ep.seed_offset);
+      const int j = (int)(e & 3);
+      dsc = j == 0 ? sc.x : j == 1 ? sc.y : j == 2 ? sc.z : sc.w;
+    }
     if (ep.step >= f_len) {   // finished row: dynamic_decode(impute_finished) freezes the state
       ep.c_new[idx] = f_cp;
       ep.h_new[idx] = f_hp;
+      if (ep.ho_new) ep.ho_new[idx] = f_hp * dsc;
       ep.acts[zo] = ep.acts[zo + U] = ep.acts[zo + 2 * U] = ep.acts[zo + 3 * U] = 0.f;
       return;
     }
@@ -425,7 +433,9 @@ __global__ __launch_bounds__(512) void rows16_kernel(Rows16Args a) {
     const float c = f_cp * fg + i * g;
     ep.acts[zo] = i; ep.acts[zo + U] = g; ep.acts[zo + 2 * U] = fg; ep.acts[zo + 3 * U] = o;
     ep.c_new[idx] = c;
-    ep.h_new[idx] = tanhf_(c) * o;
+    const float hn = tanhf_(c) * o;
+    ep.h_new[idx] = hn;
+    if (ep.ho_new) ep.ho_new[idx] = hn * dsc;
     return;
   }
   if (tid >= 256 || (tid >> 4) >= a.M) return;

@@ -2298,7 +2298,7 @@ static bool fwd_takes_persistent(const nabu_speller_desc *d, const SpWs &W) {
   // chain on sub-batches of 16 with its round-5 kernels (rows16_kernel, attn_fwd_loc_mfma_kernel) is faster than two
   // persistent launches (cfg5: 41.0 against 42.7 ms per training step).  NABU_SPELLER_PERSIST=2: the persistent kernel anyway.
   const char *env = getenv("NABU_SPELLER_PERSIST");
-  const bool chain_fast = d->kind == 1 && B > 32 && Bn <= 16 && E % 16 == 0 && d->sample_prob == 0.f && rows16_ok(Bn, 4 * U, E + U, E) &&
+  const bool chain_fast = d->kind == 1 && B > 32 && Bn <= 16 && E % 16 == 0 && (d->sample_prob == 0.f || (sample_step_ok(d->C) && env_int("NABU_SPELLER_CHAIN_SAMPLING", 1))) && rows16_ok(Bn, 4 * U, E + U, E) &&
                           rows16_ok(Bn, U, U, U) && env_int("NABU_SPELLER_ROWS16", 1) && speller_persist_streams_values(pd);
   return !(chain_fast && !(env && atoi(env) == 2));
 }
@@ -2420,9 +2420,14 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
           const int K1 = n == 0 ? E : U;
           const float *x1 = n == 0 ? r + R.ctx + (size_t)t * B * E + (size_t)b0 * E : r + R.Ho[n - 1] + nxt + (size_t)b0 * U;
           const float *Kp = w + W.kperm[n];
-          if (r16)
+          if (r16) {
+            if (drop) {      // the cell's output dropout in the same launch (the mask of dropout_rows below)
+              ep.ho_new = r + R.Ho[n] + nxt + (size_t)b0 * U;
+              ep.keep = d->keep_prob; ep.seed = d->seed; ep.seed_offset = d->seed_offset + (unsigned long long)t * nl + n;
+              ep.row0 = b0;
+            }
             SP_TRY(rows16(Bn, 4 * U, E + U, x1, E, w + W.kxh_sw, 0.f, nullptr, 0, ss.st[sub], &ep, nullptr, E, Hn + cur, U));
-          else
+          } else
           SP_TRY(gemm_skinny_fused(Bn, 4 * U, K1, x1, K1, Kp, 4 * U, U, Hn + cur, U, Kp + (size_t)K1 * 4 * U, 4 * U, 0.f, z,
                                    4 * U, nullptr, w + W.fpart + (size_t)sub * W.fpart_each,
                                    reinterpret_cast<unsigned *>(w + W.tickets) + (size_t)sub * 1024, ss.st[sub], &ep));
@@ -2438,7 +2443,7 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
           SP_TRY(nabu_lstm_cell_fwd(Bn, U, t, dlen, z, p->lstm_bias[n], nullptr, nullptr, Cn + cur, Hn + cur,
                                     r + R.acts[n] + (size_t)t * B * 4 * U + (size_t)b0 * 4 * U, Cn + nxt, Hn + nxt, st));
         }
-        if (drop)
+        if (drop && !(r16 && cell_epi[n]))
           SP_TRY(dropout_rows((size_t)Bn * U, Hn + nxt, r + R.Ho[n] + nxt + (size_t)b0 * U, d->keep_prob, d->seed,
                               d->seed_offset + (unsigned long long)t * nl + n, (size_t)b0 * U, ss.st[sub]));
       }
@@ -2456,6 +2461,12 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
       if (sampling && t + 1 < L) {
         // ScheduledEmbeddingTrainingHelper: the step's logits decide the next input of selected rows
         float *lt = r + R.logits_tm + (size_t)t * B * C + (size_t)b0 * C;
+        if (sample_step_ok(C) && env_int("NABU_SPELLER_SAMPLE_STEP", 1)) {     // one launch, logits only for sampled rows
+          SP_TRY(sample_step(Bn, C, U, E, htop, U, r + R.ctx + (size_t)(t + 1) * B * E + (size_t)b0 * E, E, p->out_kernel,
+                             p->out_bias, d->sample_prob, d->sample_seed, d->sample_offset + (unsigned long long)t,
+                             ids + (size_t)(t + 1) * B + b0, ids_used + (size_t)(t + 1) * B + b0, b0, ss.st[sub]));
+          continue;
+        }
         SP_TRY(mm(false, false, Bn, C, U, htop, U, p->out_kernel, C, 0.f, lt, C, p->out_bias, gws, gwb, st));
         SP_TRY(mm(false, false, Bn, C, E, r + R.ctx + (size_t)(t + 1) * B * E + (size_t)b0 * E, E,
                   p->out_kernel + (size_t)U * C, C, 1.f, lt, C, nullptr, gws, gwb, st));

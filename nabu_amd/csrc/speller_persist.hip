@@ -168,6 +168,146 @@ __device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(u
     }                                                                                                       \
   } while (0)
 
+// Scheduled sampling, the RARE path (sample_prob = 0.1 in the reference's defaults): the row of this workgroup is to be
+// sampled — gather [ho_t | ctx_t] from the exchange, logits = row . Wout + b, draw from softmax(logits) exactly as
+// sample_ids_kernel does.  NOT inlined: inside the forward kernel these ~150 lines cost the common path 102 spilled
+// registers (the sampling instantiation ran at 36 us per decoder step against 13 without sampling); as a function the
+// spills around the call are paid by the one step in ten (per row) that takes it.
+struct SampleRow {
+  __amdgpu_buffer_rsrc_t rc, rh;
+  unsigned hoff, coff;          // byte offsets of my row's h / context inside their rings (slot of this step)
+  const float *wout, *bout;
+  int C, U, E;
+  int drop;
+  float keep;
+  unsigned long long seed, seed_off;
+  unsigned long long grow_u;    // batch row x U: my row's first element of the dropout stream
+  float *aux;
+  int *flag;
+  int *status;
+  unsigned long long timeout_ticks;
+  unsigned ry;                  // the second Philox word of (seed, offset + t, row): the uniform of the inverse CDF
+  int teacher;
+};
+__device__ __attribute__((noinline)) int sample_row(const SampleRow q) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int C = q.C, U = q.U, K = q.U + q.E;
+  float *xrow = q.aux, *lred = q.aux + K, *e_s = lred + NW * 64;
+  int *id_s = reinterpret_cast<int *>(e_s + 64);
+  {
+    // my row of [h_t (U) | ctx_t (E)], published in this step: K/4 pieces, <= 2 per thread
+    const int NPC = K / 4;
+    u32x4 v[2];
+    unsigned offs[2];
+    bool isc[2];
+    int qq[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      qq[j] = min(j * NT + tid, NPC - 1);
+      isc[j] = 4 * qq[j] >= U;
+      offs[j] = isc[j] ? q.coff + (unsigned)((4 * qq[j] - U) * 4) : q.hoff + (unsigned)(4 * qq[j] * 4);
+    }
+    unsigned long long t0 = 0;
+    unsigned n = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const u32x4 a = xld4(q.rc, isc[j] ? offs[j] : OOB), b = xld4(q.rh, isc[j] ? OOB : offs[j]);
+        v[j] = isc[j] ? a : b;
+        ok = ok && !has_sentinel(v[j]);
+      }
+      if (__all(ok)) break;
+      if (n == 0) t0 = wall_clock64();
+      if ((++n & 31u) != 0) continue;
+      __builtin_amdgcn_s_sleep(1);
+      if (__hip_atomic_load(q.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > q.timeout_ticks) {
+        if ((threadIdx.x & 63) == 0) {
+          q.flag[0] = 1;
+          __hip_atomic_store(q.status, 1 + 4 * (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        break;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (j * NT + tid < NPC) {
+        f32x4 f = __builtin_bit_cast(f32x4, v[j]);
+        if (q.drop && !isc[j]) {                   // the projection sees the DROPPED output
+          const float4 sc = dropout_scale4((q.grow_u + 4 * qq[j]) >> 2, q.keep, q.seed, q.seed_off);
+          f.x *= sc.x; f.y *= sc.y; f.z *= sc.z; f.w *= sc.w;
+        }
+        *reinterpret_cast<f32x4 *>(xrow + 4 * qq[j]) = f;
+      }
+  }
+  __syncthreads();
+  if (q.flag[0]) return q.teacher;
+  if (C % 4 == 0 && C <= 4 * (NT / 32)) {
+    // thread (class quad cq = tid / 32, k slot ks = tid % 32): 16-byte loads of the weight rows k = ks, ks + 32, ...,
+    // eight in flight; the 32 k slots of a class quad are the lanes of one half-wave: five shuffle steps add them
+    const int cq = tid >> 5, ks = tid & 31;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (4 * cq < C) {
+      const float *wp = q.wout + 4 * cq;
+#pragma unroll 8
+      for (int k = ks; k < K; k += 32) {
+        const float x = xrow[k];
+        const f32x4 wv = *reinterpret_cast<const f32x4 *>(wp + (size_t)k * C);
+        acc.x = fmaf(x, wv.x, acc.x); acc.y = fmaf(x, wv.y, acc.y); acc.z = fmaf(x, wv.z, acc.z); acc.w = fmaf(x, wv.w, acc.w);
+      }
+    }
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+      acc.x += __shfl_xor(acc.x, m); acc.y += __shfl_xor(acc.y, m); acc.z += __shfl_xor(acc.z, m); acc.w += __shfl_xor(acc.w, m);
+    }
+    // lred as [wave 0 .. NW - 1][64]: the totals go to "wave 0"'s row, the other rows read as zero below
+    for (int i = tid; i < NW * 64; i += NT) lred[i] = 0.f;
+    __syncthreads();
+    if (ks == 0 && 4 * cq < C) {
+      lred[4 * cq] = acc.x; lred[4 * cq + 1] = acc.y; lred[4 * cq + 2] = acc.z; lred[4 * cq + 3] = acc.w;
+    }
+  } else {
+    // lane = class, the waves split k; Wout is read from L2 (its rows are contiguous over the classes)
+    float part = 0.f;
+    if (lane < C) {
+      const int k0 = w * (K / NW);
+      const float *wp = q.wout + (size_t)k0 * C + lane;
+      for (int k = 0; k < K / NW; k += 4) {
+        const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xrow + k0 + k);
+        part = fmaf(x4.x, wp[(size_t)k * C], part);
+        part = fmaf(x4.y, wp[(size_t)(k + 1) * C], part);
+        part = fmaf(x4.z, wp[(size_t)(k + 2) * C], part);
+        part = fmaf(x4.w, wp[(size_t)(k + 3) * C], part);
+      }
+    }
+    lred[w * 64 + lane] = part;
+  }
+  __syncthreads();
+  if (w == 0) {
+    float l = -INFINITY;
+    if (lane < C) {
+      l = q.bout[lane];
+      for (int ww = 0; ww < NW; ++ww) l += lred[ww * 64 + lane];
+    }
+    const float m = wmax(l);
+    e_s[lane] = lane < C ? expf(l - m) : 0.f;
+    if (lane == 0) {                             // the sums in class order, as sample_ids_kernel adds them
+      float tot = 0.f;
+      for (int c = 0; c < C; ++c) tot += e_s[c];
+      const float target = u01(q.ry) * tot;
+      float acc = 0.f;
+      int pick = C - 1;
+      for (int c = 0; c < C; ++c) {
+        acc += e_s[c];
+        if (acc > target) { pick = c; break; }
+      }
+      id_s[0] = pick;
+    }
+  }
+  __syncthreads();
+  return id_s[0];
+}
+
 // NABU_PERSIST_DEBUG bit 2: wall-clock stamps of the phases of step L/2 in block 0 (status[16 + i], 10 ns ticks)
 #define SP_STAMP(i)                                                                \
   do {                                                                             \
@@ -764,88 +904,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
                                        make_uint2((unsigned)p.sseed, (unsigned)(p.sseed >> 32)));
         int id = p.ids[(size_t)(t + 1) * B + cbg];       // teacher forcing
         if (u01(rr.x) < p.sprob) {
-          const int C = p.C;
-          float *xrow = aux, *lred = aux + K, *e_s = lred + NW * 64;
-          int *id_s = reinterpret_cast<int *>(e_s + 64);
-          {
-            // my row of [h_t (U) | ctx_t (E)], published in this step (slot so): K/4 pieces, <= 2 per thread
-            const int NPC = K / 4;
-            u32x4 v[2];
-            unsigned offs[2];
-            bool isc[2];
-            int qq[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              qq[j] = min(j * NT + tid, NPC - 1);
-              isc[j] = 4 * qq[j] >= U;
-              offs[j] = isc[j] ? so * cb + (unsigned)((ci * E + 4 * qq[j] - U) * 4) : so * hb + (unsigned)((ci * U + 4 * qq[j]) * 4);
-            }
-            Spin g;
-            g.start();
-            for (;;) {
-              bool ok = true;
-#pragma unroll
-              for (int j = 0; j < 2; ++j) {
-                const u32x4 a = xld4(rc, isc[j] ? offs[j] : OOB), b = xld4(rh, isc[j] ? OOB : offs[j]);
-                v[j] = isc[j] ? a : b;
-                ok = ok && !has_sentinel(v[j]);
-              }
-              if (__all(ok)) break;
-              if (g.expired(p)) { SP_TIMEOUT(1); break; }
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              if (j * NT + tid < NPC) {
-                f32x4 f = __builtin_bit_cast(f32x4, v[j]);
-                if (drop && !isc[j]) {                   // the projection sees the DROPPED output
-                  const float4 sc = dropout_scale4(((size_t)cbg * U + 4 * qq[j]) >> 2, p.keep, p.seed, p.seed_offset + (unsigned long long)t);
-                  f.x *= sc.x; f.y *= sc.y; f.z *= sc.z; f.w *= sc.w;
-                }
-                *reinterpret_cast<f32x4 *>(xrow + 4 * qq[j]) = f;
-              }
-          }
-          __syncthreads();
+          SampleRow q;
+          q.rc = rc; q.rh = rh;
+          q.hoff = so * hb + (unsigned)(ci * U * 4); q.coff = so * cb + (unsigned)(ci * E * 4);
+          q.wout = p.wout; q.bout = p.bout; q.C = p.C; q.U = U; q.E = E;
+          q.drop = drop ? 1 : 0; q.keep = p.keep; q.seed = p.seed; q.seed_off = p.seed_offset + (unsigned long long)t;
+          q.grow_u = (unsigned long long)cbg * U;
+          q.aux = aux; q.flag = flag; q.status = p.status; q.timeout_ticks = p.timeout_ticks; q.ry = rr.y; q.teacher = id;
+          id = sample_row(q);
           if (flag[0]) return;
-          {
-            // lane = class, the waves split k; Wout is read from L2 (its rows are contiguous over the classes)
-            float part = 0.f;
-            if (lane < C) {
-              const int k0 = w * (K / NW);
-              const float *wp = p.wout + (size_t)k0 * C + lane;
-              for (int k = 0; k < K / NW; k += 4) {
-                const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xrow + k0 + k);
-                part = fmaf(x4.x, wp[(size_t)k * C], part);
-                part = fmaf(x4.y, wp[(size_t)(k + 1) * C], part);
-                part = fmaf(x4.z, wp[(size_t)(k + 2) * C], part);
-                part = fmaf(x4.w, wp[(size_t)(k + 3) * C], part);
-              }
-            }
-            lred[w * 64 + lane] = part;
-          }
-          __syncthreads();
-          if (w == 0) {
-            float l = -INFINITY;
-            if (lane < C) {
-              l = p.bout[lane];
-              for (int ww = 0; ww < NW; ++ww) l += lred[ww * 64 + lane];
-            }
-            const float m = wmax(l);
-            e_s[lane] = lane < C ? expf(l - m) : 0.f;
-            if (lane == 0) {                             // the sums in class order, as sample_ids_kernel adds them
-              float tot = 0.f;
-              for (int c = 0; c < C; ++c) tot += e_s[c];
-              const float target = u01(rr.y) * tot;
-              float acc = 0.f;
-              int pick = C - 1;
-              for (int c = 0; c < C; ++c) {
-                acc += e_s[c];
-                if (acc > target) { pick = c; break; }
-              }
-              id_s[0] = pick;
-            }
-          }
-          __syncthreads();
-          id = id_s[0];
         }
         if (tid == 0) {
           p.ids_w[(size_t)(t + 1) * B + cbg] = id;

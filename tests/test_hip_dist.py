@@ -86,6 +86,15 @@ def test_bench_two_rank_line_end_to_end_on_one_gpu():
     assert flat['scaling'] == 'weak' and flat['higher_is_better'] is True
     # which path every rank ran is part of the line (here: ranks share the device -> step-wise recurrence, no decoder)
     assert flat['ranks']['recurrence_persistent_per_rank'] == [0, 0] and flat['ranks']['decoder_persistent_per_rank'] == [-1, -1]
+    # the replicas hold bit-identical weights before the timed region and after its last step (checksum all-gather: bench.py
+    # raises on every rank otherwise), and the line says which collective library carried the exchange
+    rw = flat['ranks']['replica_weights']
+    assert rw['before_timed_region']['identical'] and rw['after_timed_region']['identical']
+    assert rw['before_timed_region']['checksum'] != rw['after_timed_region']['checksum']        # (training moved them)
+    lib = flat['ranks']['collective_library']
+    assert lib['backend'] == 'gloo' and 'nccl_algo_set' in lib and 'env' in lib and 'io_links_seen' in lib
+    # three repeats of the K timed steps in the same command, the headline being the first
+    assert len(flat['ms_per_step_repeats']) == 3 and flat['ms_per_step_repeats'][0] == flat['ms_per_step']
     buck = _two_rank_line(['--allreduce', 'bucketed'])
     assert buck['ranks']['allreduce'] == 'bucketed'
     assert buck['final_loss'] == flat['final_loss']
