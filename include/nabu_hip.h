@@ -284,6 +284,13 @@ int nabu_blstm_pk_bytes(const nabu_blstm_desc *d, size_t bytes[5]);
  * leave those out of the descriptor) */
 int nabu_blstm_emits_packed(const nabu_blstm_desc *d);
 
+/* RESERVE CONTRACT (since ABI version 2): nabu_blstm_fwd records, in host memory of THIS process, a fingerprint of the
+ * layout it wrote (shape, planes, flags, recurrent_precision, sizes), keyed by the reserve's address; nabu_blstm_bwd /
+ * _bwd_data / _bwd_weights compare it with the layout they derive and return NABU_EINVAL for a reserve that no forward
+ * call of this process wrote, that was written under another layout (descriptor or process default precision changed
+ * between the passes), or whose fingerprint has been displaced (the table keeps the 4096 most recently written
+ * reserves).  A backward call therefore needs the forward call of the SAME process on the SAME address first; a
+ * reserve copied elsewhere or produced by another process is rejected. */
 size_t nabu_blstm_reserve_bytes(const nabu_blstm_desc *d);
 size_t nabu_blstm_ws_bytes(const nabu_blstm_desc *d);
 int nabu_blstm_fwd(const nabu_blstm_desc *d, const float *x, const int32_t *len,

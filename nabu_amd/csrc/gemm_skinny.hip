@@ -346,14 +346,16 @@ __global__ __launch_bounds__(512) void rows16_kernel(Rows16Args a) {
   __shared__ float red[8][16][17];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 15, kq = lane >> 4;
   const int nt = blockIdx.x, n0 = 16 * nt;
-  const int em = min(tid >> 4, a.M - 1), en = tid & 15;       // the epilogue's (row, column) of threads < 256
+  const int mb = 16 * blockIdx.y;                               // row tile (gridDim.y tiles of 16 rows: M <= 64)
+  const int eml = tid >> 4, fml = tid >> 2;                     // tile-local rows of the epilogue threads
+  const int em = min(mb + eml, a.M - 1), en = tid & 15;         // the epilogue's (row, column) of threads < 256
   const SkinnyEpilogue &ep = a.ep;
   const int U = ep.U;
   // ---- loads: operands first, then what the epilogue reads (clamped addresses, masked later: no branch around a load)
   r16f4 bv[KG], av[KG];
   {
     const r16f4 *Bp = reinterpret_cast<const r16f4 *>(a.Wsw) + ((size_t)nt * (a.K / 16) + (size_t)w * KG) * 64 + lane;
-    const int row = min(fl, a.M - 1);
+    const int row = min(mb + fl, a.M - 1);
     const float *Ap = a.A + (size_t)row * a.lda + 4 * kq, *Ap2 = a.A2 + (size_t)row * a.lda2 - a.K1 + 4 * kq;
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(512) void rows16_kernel(Rows16Args a) {
     if (ep.dh2) e_dh2 = ep.dh2[(size_t)em * ep.ld_dh2 + n0 + en];
   }
   // kind 1 (forward cell): thread (row m = tid / 4, unit n0 / 4 + tid % 4) of the first wave
-  const int fm = min(tid >> 2, a.M - 1), fu = (n0 >> 2) + (tid & 3);
+  const int fm = min(mb + fml, a.M - 1), fu = (n0 >> 2) + (tid & 3);
   float f_b[4] = {0.f, 0.f, 0.f, 0.f}, f_e[4] = {0.f, 0.f, 0.f, 0.f}, f_cp = 0.f, f_hp = 0.f;
   int f_len = 0;
   if (FWD && ep.kind == 1 && tid < 64) {
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(512) void rows16_kernel(Rows16Args a) {
       zt[tid >> 4][en] = zs;
     }
     __syncthreads();
-    if (tid >= 64 || (tid >> 2) >= a.M) return;
+    if (tid >= 64 || mb + fml >= a.M) return;
     const size_t idx = (size_t)fm * U + fu, zo = (size_t)fm * 4 * U + fu;
     float dsc = 1.f;          // output dropout of the cell (the mask of dropout_rows on this step's h)
     if (ep.ho_new && ep.keep > 0.f && ep.keep < 1.f) {
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(512) void rows16_kernel(Rows16Args a) {
       ep.acts[zo] = ep.acts[zo + U] = ep.acts[zo + 2 * U] = ep.acts[zo + 3 * U] = 0.f;
       return;
     }
-    const float *zr = &zt[fm][4 * (tid & 3)];
+    const float *zr = &zt[fml][4 * (tid & 3)];
     const float zi = zr[0] + f_b[0] + f_e[0], zj = zr[1] + f_b[1] + f_e[1], zf = zr[2] + f_b[2] + f_e[2], zq = zr[3] + f_b[3] + f_e[3];
     const float i = sigmoidf_(zi), g = tanhf_(zj), fg = sigmoidf_(zf + 1.0f), o = sigmoidf_(zq);
     const float c = f_cp * fg + i * g;
@@ -438,10 +440,10 @@ __global__ __launch_bounds__(512) void rows16_kernel(Rows16Args a) {
     if (ep.ho_new) ep.ho_new[idx] = hn * dsc;
     return;
   }
-  if (tid >= 256 || (tid >> 4) >= a.M) return;
+  if (tid >= 256 || mb + eml >= a.M) return;
   float v = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) v += red[i][em][en];
+  for (int i = 0; i < 8; ++i) v += red[i][eml][en];
   if (beta != 0.f) v = fmaf(beta, cold, v);
   if (ep.kind == 0) { *cdst = v; return; }
   // kind 2: v = d h of unit n0 + en (the query projection's gradient added to the direct one): LSTM cell backward
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(512) void rows16_kernel(Rows16Args a) {
 
 bool rows16_ok(int M, int N, int K, int lda) {
   const int kg = K / 128;
-  return M >= 1 && M <= 16 && N % 16 == 0 && K % 128 == 0 && lda % 4 == 0 &&
+  return M >= 1 && M <= 64 && N % 16 == 0 && K % 128 == 0 && lda % 4 == 0 &&
          (kg == 1 || kg == 2 || kg == 3 || kg == 4 || kg == 6 || kg == 8 || kg == 12 || kg == 16);
 }
 // C[M, N] = A . W^T (+ beta C); ep: kind 0 (plain) or 2 (LSTM cell backward on the finished tile, as gemm_skinny_fused);
@@ -485,7 +487,7 @@ int rows16(int M, int N, int K, const float *A, int lda, const float *Wsw, float
   if (split) { a.C2 = split->C2; a.ldc2 = split->ldc2; a.split = split->split; a.beta2 = split->beta2; }
   if (ep) a.ep = *ep; else a.ep.kind = 0;
   if (a.ep.kind == 1) { a.C = nullptr; a.beta = 0.f; }      // the forward cell writes its state, not the product
-  const dim3 grid(N / 16), block(512);
+  const dim3 grid(N / 16, (M + 15) / 16), block(512);
   const bool fwd = a.ep.kind == 1 || A2 != nullptr;
 #define ROWS16_CASE(kg)                                                                    \
   case kg:                                                                                 \

@@ -345,7 +345,7 @@ static Layout make_layout(const nabu_blstm_desc *d) {
   L.persist_bytes = align_up(lstm_persist_ws_bytes(d->B, d->T, d->H), 256);
   L.persist_off = off; off += L.persist_bytes;
   // narrow input projected inside the forward kernel (lstm_persist.h): its plane copy of x
-  L.xws_bytes = align_up(lstm_persist_xws_bytes(d->B, d->T, d->D), 256);
+  L.xws_bytes = align_up(lstm_persist_xws_bytes(d->B, d->T, d->D, d->H), 256);
   L.xws_off = off; off += L.xws_bytes;
   L.bf16_pre = bf16_resident(d);
   L.bf16_fwd = bf16_resident_fwd(d);
@@ -480,7 +480,7 @@ struct ReserveTag {
   size_t reserve_bytes, res_dzT_off;
 };
 static std::mutex g_tag_mutex;
-static ReserveTag g_tags[256];
+static ReserveTag g_tags[4096];   // (least recently written is replaced: a reserve whose tag fell out is rejected, see nabu_hip.h)
 static uint64_t g_tag_serial = 0;
 static ReserveTag tag_of(const nabu_blstm_desc *d, const Layout &L, const void *reserve) {
   ReserveTag t = {};
@@ -507,7 +507,7 @@ static int tag_check(const nabu_blstm_desc *d, const Layout &L, const void *rese
   for (const ReserveTag &e : g_tags) {
     if (e.reserve != reserve || !e.serial) continue;
     if (e.B == want.B && e.T == want.T && e.D == want.D && e.H == want.H && e.planes == want.planes && e.flags == want.flags &&
-        e.pk_in == want.pk_in && e.pk_rec == want.pk_rec && e.pk_whole == want.pk_whole && e.bf16_pre == want.bf16_pre &&
+        e.rec == want.rec && e.pk_in == want.pk_in && e.pk_rec == want.pk_rec && e.pk_whole == want.pk_whole && e.bf16_pre == want.bf16_pre &&
         e.reserve_bytes == want.reserve_bytes && e.res_dzT_off == want.res_dzT_off)
       return 0;
     return fail(NABU_EINVAL, "%s: the reserve was written by nabu_blstm_fwd under another layout (B %d T %d D %d H %d, %d planes, "

@@ -29,7 +29,7 @@ int lstm_persist_fwd(int B, int T, int D, int H, int max_len, const int32_t *len
                      float *out, int *status, void *ws, size_t ws_bytes, hipStream_t stream, const float *x = nullptr,
                      const float *const bias[2] = nullptr, void *xws = nullptr, const EmitArgs *emit = nullptr);
 // xws: lstm_persist_xws_bytes(B, T, D) bytes of workspace for the fp16-plane kernels' copy of x (two fp16 planes per frame)
-size_t lstm_persist_xws_bytes(int B, int T, int D);
+size_t lstm_persist_xws_bytes(int B, int T, int D, int H);
 // x, bias given (only when lstm_persist_fuses_input says so: the fp16-plane kernels with D <= 64, one launch of <= 32 rows;
 // the exact-fp32 kernels with D = 40 on the 4-row geometry): gates[] need NOT hold
 // the input projection, the kernel computes x_t . Wx + b itself; it still leaves the activations there

@@ -976,7 +976,10 @@ bool lstm_persist_emits(int B, int T, int H, int max_len) {
   if (!env || max_len != T || !lstm_persist_supported(B, T, H) || !lstm_mx_supported(B, H)) return false;
   return B <= lstm_mx_chunk_rows() && !lstm_mxf_supported(B, H);
 }
-size_t lstm_persist_xws_bytes(int B, int T, int D) { return (D <= 64 && D % 8 == 0) ? lstm_mxh_xws_bytes(B, T) : 0; }
+// (sized from the ONE eligibility test, lstm_persist_fuses_input: no workspace where the projection is not taken)
+size_t lstm_persist_xws_bytes(int B, int T, int D, int H) {
+  return (lstm_mx_supported(B, H) && lstm_persist_fuses_input(B, T, D, H)) ? lstm_mxh_xws_bytes(B, T) : 0;
+}
 
 // narrow input (D = 40: 4 rows x D elements fit the 256 lanes of one prefetch), every launch of the forward pass on the
 // 4-row geometry: the kernel projects the input itself (no x . Wx GEMM in front of it)

@@ -2298,7 +2298,7 @@ static bool fwd_takes_persistent(const nabu_speller_desc *d, const SpWs &W) {
   // chain on sub-batches of 16 with its round-5 kernels (rows16_kernel, attn_fwd_loc_mfma_kernel) is faster than two
   // persistent launches (cfg5: 41.0 against 42.7 ms per training step).  NABU_SPELLER_PERSIST=2: the persistent kernel anyway.
   const char *env = getenv("NABU_SPELLER_PERSIST");
-  const bool chain_fast = d->kind == 1 && B > 32 && Bn <= 16 && E % 16 == 0 && (d->sample_prob == 0.f || (sample_step_ok(d->C) && env_int("NABU_SPELLER_CHAIN_SAMPLING", 1))) && rows16_ok(Bn, 4 * U, E + U, E) &&
+  const bool chain_fast = d->kind == 1 && B > 32 && Bn <= 64 && E % 16 == 0 && (d->sample_prob == 0.f || (sample_step_ok(d->C) && env_int("NABU_SPELLER_CHAIN_SAMPLING", 1))) && rows16_ok(Bn, 4 * U, E + U, E) &&
                           rows16_ok(Bn, U, U, U) && env_int("NABU_SPELLER_ROWS16", 1) && speller_persist_streams_values(pd);
   return !(chain_fast && !(env && atoi(env) == 2));
 }

@@ -31,6 +31,8 @@ CAPTURE = [None]
 # packed companions (include/nabu_hip.h, ABI version 3): the forward recurrent kernel writes the layer's output also as the
 # next layer's f16x3 operands and its own h^T operand.  NABU_PACKED_COMPANIONS=0: every call packs for itself as before.
 PACKED_COMPANIONS = [_os.environ.get('NABU_PACKED_COMPANIONS', '1') != '0']
+# NABU_CHECK_X_BOUND=1: every layer call measures max|x| (host round trip) and raises if it exceeds the bound it was promised
+CHECK_X_BOUND = [_os.environ.get('NABU_CHECK_X_BOUND', '0') == '1']
 
 
 def blstm(inputs, sequence_length, num_units, layer_norm=False, scope=None, out_stack=0):
@@ -58,6 +60,13 @@ def blstm(inputs, sequence_length, num_units, layer_norm=False, scope=None, out_
     plan = hip.BlstmPlan(B, T, D, H, min(lens.max(), T), LSTM_MODE[0], GEMM_PRECISION[0], x_bound=ops.value_bound(inputs),
                          fwd_only=not training, recurrent_precision=RECURRENT_PRECISION[0], out_stack=out_stack)
     x = inputs if inputs.is_contiguous() else inputs.contiguous()
+    if CHECK_X_BOUND[0] and ops.value_bound(inputs) > 0:
+        # debug mode (NABU_CHECK_X_BOUND=1): the recorded bound is a PROMISE (ops.set_value_bound) — an in-place change
+        # of a bounded tensor would leave it stale and the f16x3 packs would overflow to Inf without a diagnostic
+        worst = float(x.detach().cpu().numpy().__abs__().max())
+        if not worst <= ops.value_bound(inputs) * (1 + 1e-6):
+            raise RuntimeError('blstm input exceeds its recorded bound: max|x| = %g > %g (a tensor carrying a value bound '
+                               'was modified in place?)' % (worst, ops.value_bound(inputs)))
     out_pk = None
     if PACKED_COMPANIONS[0]:
         where = (vs.current_scope(), scope or 'BLSTM', B, T, D, H)

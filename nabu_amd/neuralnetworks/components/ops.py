@@ -13,6 +13,8 @@ from nabu_amd.autodiff import record, SeqLen
 _BOUNDS = {}
 
 
+# The bound is a promise about the tensor OBJECT: tensors that carry one must not be modified in place (a stale bound makes
+# the f16x3 packs overflow fp16 silently).  NABU_CHECK_X_BOUND=1 (layer.CHECK_X_BOUND) measures and asserts at every layer.
 def set_value_bound(tensor, bound):
     key = id(tensor)
     _BOUNDS[key] = (weakref.ref(tensor, lambda _r, k=key: _BOUNDS.pop(k, None)), float(bound))
