@@ -654,7 +654,7 @@ class HipWorkload(object):
         # WRITE_SIZE, separate runs of this command; summarised by tools/pmc_summary.py with the
         # gfx950 corrections of MI355X_MICROARCH.md).  null when this workload was not profiled.
         traffic = None
-        for name in ('r05_cfg2_pmc_traffic.json', 'r04b_cfg2_pmc_traffic.json', 'r04_cfg2_pmc_traffic.json', 'r03_cfg2_pmc_traffic.json'):
+        for name in ('r06_cfg2_pmc_traffic.json', 'r05_cfg2_pmc_traffic.json', 'r04b_cfg2_pmc_traffic.json', 'r04_cfg2_pmc_traffic.json', 'r03_cfg2_pmc_traffic.json'):
             pmc = os.path.join(ROOT, 'profiles', name)
             if persistent and args.workload == 'cfg2' and os.path.exists(pmc):
                 with open(pmc) as fid:
@@ -663,7 +663,7 @@ class HipWorkload(object):
         step_bytes_total = 2 * 2 * sum(self.layer_t) * step_bytes(B_, H_)
         step_s = dt / args.steps
         frac_step = step_bytes_total / step_s / (HBM_PEAK_GBS * 1e9)
-        kname = ('lstm_mxh_{fwd,bwd}_kernel (lstm_mx_* / lstm_persist_* where the fp16-plane kernels do not apply or are switched off)'
+        kname = ('lstm_mxh_{fwd,bwd}_kernel (lstm_mxf_* for 33-64 rows; lstm_persist_* where the fp16-plane kernels do not apply or are switched off)'
                  if persistent else 'lstm_step_{fwd,bwd}_kernel')
         roofline = {'bound': 'hbm', 'achieved': round(step_bytes_total / step_s / 1e9, 1), 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': round(frac_step, 4), 'traffic': traffic, 'kernel': kname,

@@ -1803,9 +1803,9 @@ static int attn_fwd_impl(const nabu_attn_desc *d, int step, const int32_t *dec_l
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool reg = d->kind == 1 && d->U <= 256 * RJ && d->F <= RF;
   auto kern = d->kind != 1 ? attn_fwd_kernel<0> : reg ? attn_fwd_kernel<2> : attn_fwd_kernel<1>;
-  // the sliced location-aware softmax form of the step chain: the matrix-pipe kernel (NABU_ATTN_FWD_MFMA=0: attn_fwd_kernel<2>)
-  const char *mfma_e = getenv("NABU_ATTN_FWD_MFMA");
-  if ((mfma_e ? atoi(mfma_e) : 1) && d->kind == 1 && reg && d->prob_fn == 0 && S > 1 && tickets && (d->Te + S - 1) / S <= 32 &&
+  // the sliced location-aware softmax form of the step chain: the matrix-pipe kernel wherever its geometry holds
+  // (attn_fwd_kernel<2> stays the general kernel: more frames per slice, U not a multiple of 16, sigmoid probabilities)
+  if (d->kind == 1 && reg && d->prob_fn == 0 && S > 1 && tickets && (d->Te + S - 1) / S <= 32 &&
       d->U % 16 == 0 && d->E / 4 <= AT / 2 && d->Te <= 1024 && d->K * d->F <= 8 * AT) {
     const int UT = (d->U / 16 + AT / 64 - 1) / (AT / 64);
     kern = UT <= 1 ? attn_fwd_loc_mfma_kernel<1> : UT == 2 ? attn_fwd_loc_mfma_kernel<2> : UT == 3 ? attn_fwd_loc_mfma_kernel<3>
@@ -1886,10 +1886,9 @@ static int attn_bwd_impl(const nabu_attn_desc *d, int step, const int32_t *dec_l
   const bool reg = d->kind == 1 && d->U <= 256 * RJ && d->F <= RF;
   auto kern = defer ? (d->kind != 1 ? attn_bwd_kernel<0, true> : reg ? attn_bwd_kernel<2, true> : attn_bwd_kernel<1, true>)
                     : (d->kind != 1 ? attn_bwd_kernel<0, false> : reg ? attn_bwd_kernel<2, false> : attn_bwd_kernel<1, false>);
-  // the matrix-pipe kernel of the deferred location-aware chain (NABU_ATTN_BWD_MFMA=0: attn_bwd_kernel<2, true>)
-  const char *mfma_e = getenv("NABU_ATTN_BWD_MFMA");      // (read per call, like every switch of this file)
-  const int mfma_env = mfma_e ? atoi(mfma_e) : 1;
-  if (defer && reg && mfma_env && cf_out && d->U % 16 == 0 && (d->Te + S - 1) / S <= 32 && d->Te <= 1024 && d->K * d->F <= 8 * AT &&
+  // the matrix-pipe kernel of the deferred location-aware chain wherever its geometry holds (attn_bwd_kernel<2, true>
+  // stays the general kernel)
+  if (defer && reg && cf_out && d->U % 16 == 0 && (d->Te + S - 1) / S <= 32 && d->Te <= 1024 && d->K * d->F <= 8 * AT &&
       d->E <= 16 * AT) {
     const int UT = (d->U / 16 + AT / 64 - 1) / (AT / 64);
     kern = UT <= 1 ? attn_bwd_loc_mfma_kernel<1> : UT == 2 ? attn_bwd_loc_mfma_kernel<2> : UT == 3 ? attn_bwd_loc_mfma_kernel<3>
@@ -1958,10 +1957,8 @@ static int attn_param_grads(const nabu_attn_desc *d, int S, int L, const int32_t
   const bool four = (per + NG - 1) / NG <= 4;
   auto kern = d->kind == 1 ? (four ? attn_param_grads_kernel<true, 4> : attn_param_grads_kernel<true, 8>)
                            : (four ? attn_param_grads_kernel<false, 4> : attn_param_grads_kernel<false, 8>);
-  // location-aware, U <= 512, <= 32 frames per slice: the matrix-pipe kernel (NABU_ATTN_GRADS_MFMA=0: the vector one)
-  const char *mfma_e = getenv("NABU_ATTN_GRADS_MFMA");
-  const int mfma_env = mfma_e ? atoi(mfma_e) : 1;
-  if (mfma_env && d->kind == 1 && d->U % 16 == 0 && d->U <= 512 && d->F <= 12 && per <= 32) {
+  // location-aware, U <= 512, <= 32 frames per slice: the matrix-pipe kernel (the vector kernel stays the general one)
+  if (d->kind == 1 && d->U % 16 == 0 && d->U <= 512 && d->F <= 12 && per <= 32) {
     kern = per <= 16 ? attn_param_grads_mfma_kernel<1> : attn_param_grads_mfma_kernel<2>;
     const size_t need = (size_t)PSB * (32 + 32 * d->F + 4) * sizeof(float);
     if (need > shm) shm = need;
@@ -2298,7 +2295,7 @@ static bool fwd_takes_persistent(const nabu_speller_desc *d, const SpWs &W) {
   // chain on sub-batches of 16 with its round-5 kernels (rows16_kernel, attn_fwd_loc_mfma_kernel) is faster than two
   // persistent launches (cfg5: 41.0 against 42.7 ms per training step).  NABU_SPELLER_PERSIST=2: the persistent kernel anyway.
   const char *env = getenv("NABU_SPELLER_PERSIST");
-  const bool chain_fast = d->kind == 1 && B > 32 && Bn <= 64 && E % 16 == 0 && (d->sample_prob == 0.f || (sample_step_ok(d->C) && env_int("NABU_SPELLER_CHAIN_SAMPLING", 1))) && rows16_ok(Bn, 4 * U, E + U, E) &&
+  const bool chain_fast = d->kind == 1 && B > 32 && Bn <= 64 && E % 16 == 0 && (d->sample_prob == 0.f || sample_step_ok(d->C)) && rows16_ok(Bn, 4 * U, E + U, E) &&
                           rows16_ok(Bn, U, U, U) && env_int("NABU_SPELLER_ROWS16", 1) && speller_persist_streams_values(pd);
   return !(chain_fast && !(env && atoi(env) == 2));
 }
@@ -2461,7 +2458,7 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
       if (sampling && t + 1 < L) {
         // ScheduledEmbeddingTrainingHelper: the step's logits decide the next input of selected rows
         float *lt = r + R.logits_tm + (size_t)t * B * C + (size_t)b0 * C;
-        if (sample_step_ok(C) && env_int("NABU_SPELLER_SAMPLE_STEP", 1)) {     // one launch, logits only for sampled rows
+        if (sample_step_ok(C)) {     // one launch, logits only for sampled rows
           SP_TRY(sample_step(Bn, C, U, E, htop, U, r + R.ctx + (size_t)(t + 1) * B * E + (size_t)b0 * E, E, p->out_kernel,
                              p->out_bias, d->sample_prob, d->sample_seed, d->sample_offset + (unsigned long long)t,
                              ids + (size_t)(t + 1) * B + b0, ids_used + (size_t)(t + 1) * B + b0, b0, ss.st[sub]));

@@ -3,12 +3,12 @@
 # gpurun_out/<tag>_prof/; the summaries that are judged are then copied into profiles/.
 # Counter passes are separate runs with --kernel-trace only (MI355X_MICROARCH.md, rocprofv3 PMC slots).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/${TAG}_prof
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-alt --no-gemm-roofline"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-alt --no-gemm-roofline --no-other-configs --repeats 1"
 stats() {   # name, args...
   local name=$1; shift
   rm -rf /tmp/p_$name
