@@ -705,6 +705,7 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d_in, const float *x, const
   const int by_kernel = emitted_by_kernel(d, L);
   const bool emit = by_kernel != 0;
   auto companions_by_pack_kernels = [&](int todo) -> int {
+    todo &= ((want_out && d->out_pk_rows) ? 1 : 0) | ((want_out && d->out_pk_cols) ? 2 : 0) | (L.hT_ext ? 4 : 0);
     if (!todo) return 0;
     uint32_t *am = reinterpret_cast<uint32_t *>(w + L.cmp_amax_off);
     const FillSeg fill = {am, L.cmp_amax_bytes / 4, CMP_AMAX_BITS};
