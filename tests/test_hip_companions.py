@@ -150,3 +150,30 @@ def test_all_three_companions_out_of_the_kernel_in_their_own_process():
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-k', 'bit_exactly or step_is_the_same'],
                        env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and ' passed' in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize('size', [32, 44])
+def test_older_descriptor_layouts_are_still_accepted(size):
+    """ABI version 3 grew nabu_blstm_desc; a caller compiled against version 1 (32 bytes: everything up to gemm_precision —
+    INTEGRATION.md's example binding) or version 2 (44 bytes: + x_bound, flags, recurrent_precision) passes its own size
+    and gets the same layer: the fields behind it read as 0"""
+    from nabu_amd import ops, _hip
+    B, T, D, H = 8, 24, 40, 128
+    lens, x, p = _case(B, T, D, H, np.full(B, T), seed=5)
+    ld = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    outs = []
+    for sz in (ctypes.sizeof(_hip.BlstmDesc), size):
+        plan = ops.BlstmPlan(B, T, D, H, T, ops.LSTM_AUTO)
+        plan.desc.size = sz
+        L = _hip.lib()
+        plan.reserve_bytes = L.nabu_blstm_reserve_bytes(ctypes.byref(plan.desc))
+        plan.ws_bytes = L.nabu_blstm_ws_bytes(ctypes.byref(plan.desc))
+        assert plan.reserve_bytes > 0
+        out = torch.full((B, T, 2 * H), float('nan'), device=DEV)
+        reserve = torch.empty(plan.reserve_bytes, dtype=torch.uint8, device=DEV)
+        ops.blstm_fwd(plan, x, ld, p['fw_kernel'], p['fw_bias'], p['bw_kernel'], p['bw_bias'], out, reserve)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    bad = ops.BlstmPlan(B, T, D, H, T, ops.LSTM_AUTO)
+    bad.desc.size = 40
+    assert _hip.lib().nabu_blstm_reserve_bytes(ctypes.byref(bad.desc)) == 0      # not a layout of any version
