@@ -242,22 +242,22 @@ __device__ __attribute__((noinline)) int sample_row(const SampleRow q) {
   }
   __syncthreads();
   if (q.flag[0]) return q.teacher;
-  if (C % 4 == 0 && C <= 4 * (NT / 32)) {
-    // thread (class quad cq = tid / 32, k slot ks = tid % 32): 16-byte loads of the weight rows k = ks, ks + 32, ...,
-    // eight in flight; the 32 k slots of a class quad are the lanes of one half-wave: five shuffle steps add them
-    const int cq = tid >> 5, ks = tid & 31;
+  if (C % 4 == 0 && C <= 4 * (NT / 16)) {
+    // thread (class quad cq = tid / 16, k slot ks = tid % 16): 16-byte loads of the weight rows k = ks, ks + 16, ...,
+    // eight in flight; the 16 k slots of a class quad are 16 consecutive lanes: four shuffle steps add them
+    const int cq = tid >> 4, ks = tid & 15;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (4 * cq < C) {
       const float *wp = q.wout + 4 * cq;
 #pragma unroll 8
-      for (int k = ks; k < K; k += 32) {
+      for (int k = ks; k < K; k += 16) {
         const float x = xrow[k];
         const f32x4 wv = *reinterpret_cast<const f32x4 *>(wp + (size_t)k * C);
         acc.x = fmaf(x, wv.x, acc.x); acc.y = fmaf(x, wv.y, acc.y); acc.z = fmaf(x, wv.z, acc.z); acc.w = fmaf(x, wv.w, acc.w);
       }
     }
 #pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) {
+    for (int m = 8; m >= 1; m >>= 1) {
       acc.x += __shfl_xor(acc.x, m); acc.y += __shfl_xor(acc.y, m); acc.z += __shfl_xor(acc.z, m); acc.w += __shfl_xor(acc.w, m);
     }
     // lred as [wave 0 .. NW - 1][64]: the totals go to "wave 0"'s row, the other rows read as zero below
