@@ -6,6 +6,8 @@
 // slower (it already needs all 256 ordinary registers: 1.31 -> 1.40 us), hence two files.
 #include "lstm_persist_mxh.h"
 
+#include <type_traits>
+
 namespace nabu {
 
 #ifndef MXH_TAG_MODE
@@ -115,7 +117,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   double db0 = 0.0, db1 = 0.0;
   float am0 = 0.f, am1 = 0.f;
   if (!unit_handshake(p, unit, slot, MXNU, P, flag)) return;
-  const bool coloc = flag[1] != 0;
   clock_stamp(p, 1, 0);
 
   // ring slot = [dest P][src P][8 rows][4 k quads] x 16 bytes
@@ -201,6 +202,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     fG = gf;
   };
 
+  // The step loop, compiled twice: co-located units (the normal case: plain stores) and units spread over several XCDs
+  // (write-through stores).  As a run-time flag the choice cost a taken branch around every publishing store (four per
+  // step: the wave sat ~50 ns of a step in branch bubbles).  Returns false when the launch is abandoned (a poll timed out).
+  auto steps = [&](auto CO) __attribute__((always_inline)) -> bool {
+  constexpr bool coloc = decltype(CO)::value;
   for (int s = p.max_len - 1; s >= 0; --s) {
     MXH_STAMP(1, 0);
     // (a) reduce-scatter input: the partial products of step s + 1 addressed to my units
@@ -300,7 +306,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     MXH_STAMP(1, 2);
     __syncthreads();                                            // the step's only barrier
-    if (flag[0]) return;
+    // (the abort flag is read WITH the product's operands and tested behind them: one LDS round trip, not two)
+    const int abort_now = *reinterpret_cast<volatile int *>(flag);
     MXH_STAMP(1, 3);
     if (s > 0) {
       // (c) partial dh of step s - 1: dz planes [16 slots x 64 columns] against W^T, tile t -> destination NT w + t,
@@ -311,6 +318,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int j = 0; j < 2; ++j) b1[j] = *reinterpret_cast<const u32x4 *>(dzb + (unsigned)n * L::DROWB + 64 * j + 16 * q);
       const float idz = invd[(s & 1) * 8 + (n & 7)];
+      asm volatile("" :: "v"(b1[0]), "v"(b1[1]), "v"(idz));    // (the operands are loaded before the test below)
+      if (abort_now) return false;
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         mxf32x4 acc[HT];
@@ -326,8 +335,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
             if (hf == 0) fetch_part(s - 1, 2 * j + g);     // one memory instruction behind every group of matrix instructions
             __builtin_amdgcn_sched_barrier(0);
+            if (hf == 0 && j == 0 && g == 0) MXH_STAMP(1, 10);
           }
         }
+        if (hf == 0) MXH_STAMP(1, 11); else MXH_STAMP(1, 12);
+#ifndef MXH_EXP_NOFOLD      // (timing experiment: the fold of the two plane halves left out — wrong sums)
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
           acc[t].x += mx_dpp<DPP_ROR8>(acc[t].x);
@@ -335,7 +347,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           acc[t].z += mx_dpp<DPP_ROR8>(acc[t].z);
           acc[t].w += mx_dpp<DPP_ROR8>(acc[t].w);
         }
-        if (hf == 0) MXH_STAMP(1, 4);
+#endif
+        if (hf == 0) MXH_STAMP(1, 4); else MXH_STAMP(1, 13);
         const int t0 = NT * w + hf * HT + (n < 8 ? 0 : HT / 2);
         const unsigned pbase = (unsigned)((it & 1) * slot_bytes + (size_t)t0 * block_bytes + (size_t)slot * piece_bytes +
                                           (size_t)(n & 7) * 64 + q * 16);
@@ -344,8 +357,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int t = 0; t < QT; ++t) {
           const mxf32x4 lo = acc[t], hi = acc[HT / 2 + t < HT ? HT / 2 + t : t];
           // descaled: 1 / (scale of output k) x 1 / (scale of the dz row), both powers of two
+#ifdef MXH_EXP_NODESCALE    // (timing experiment: no descale — wrong sums)
+          const mxf32x4 o = {(n < 8 ? lo.x : hi.x), (n < 8 ? lo.y : hi.y), (n < 8 ? lo.z : hi.z), (n < 8 ? lo.w : hi.w)};
+#else
           const mxf32x4 o = {(n < 8 ? lo.x : hi.x) * inv_sel[hf][t][0] * idz, (n < 8 ? lo.y : hi.y) * inv_sel[hf][t][1] * idz,
                              (n < 8 ? lo.z : hi.z) * inv_sel[hf][t][2] * idz, (n < 8 ? lo.w : hi.w) * inv_sel[hf][t][3] * idz};
+#endif
           const u32x4 ob = __builtin_bit_cast(u32x4, o);
 #if MXH_TAG_MODE == 1      // diagnostic: unbiased tagging (a wrong last bit moves the word up or down by its own bit 1)
           auto tg = [&](unsigned b) {
@@ -360,14 +377,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           // (HT = 1, H = 128: one tile per half, published by the lanes n < 8 only)
           xstore(ot, rs, ((HT >= 2 || n < 8) && !MXH_QVOL(q)) ? pbase + (unsigned)t * (unsigned)block_bytes : OOB, coloc);
         }
+        if (hf == 0) MXH_STAMP(1, 14);
       }
       MXH_STAMP(1, 9);
     }
+    else if (abort_now) return false;
     // (behind the publish: nothing waits for these)
     db0 += (double)d0; db1 += (double)d1;
     am0 = fmaxf(am0, fabsf(d0)); am1 = fmaxf(am1, fabsf(d1));
     MXH_STAMP(1, 5);
   }
+  return true;
+  };
+  if (!(flag[1] != 0 ? steps(std::true_type{}) : steps(std::false_type{}))) return;
   dz_stores();
   clock_stamp(p, 1, 1);
   // bias gradient / column maxima of my 64 gate columns over the unit's 8 rows
