@@ -518,7 +518,7 @@ class HipWorkload(object):
 
     # HIP events around the recurrent launches cost the stream ~6 us each (a queue barrier per record: 16 per cfg2
     # step): every PROFILE_EVERY-th step of the timed region carries them, the others run as a user's step does
-    PROFILE_EVERY = 4
+    PROFILE_EVERY = 8
 
     def step(self, i):
         if self.timing:
@@ -677,7 +677,7 @@ class HipWorkload(object):
                             'streamed per timestep model) over the measured step time — the step also pays for its '
                             'MFMA-bound dense products, so this is the whole-step figure the 0.40 target is stated on; '
                             'recurrent_kernels = the same bytes per launch over the launch duration from HIP events the '
-                            'library records around the recurrent launches of every 4th step of the timed region (an '
+                            'library records around the recurrent launches of every 8th step of the timed region (an '
                             'event record is a queue barrier, ~6 us: 16 of them per step would be paid by the metric); '
                             'traffic = HBM bytes '
                             'per recurrent launch from the rocprofv3 PMC passes under profiles/'}

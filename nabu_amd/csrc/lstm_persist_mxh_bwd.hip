@@ -289,7 +289,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       mb = max(mb, mx_dppu<DPP_XOR2>(mb));
       mb = max(mb, mx_dppu<DPP_HALF_MIRROR>(mb));
       mb = max(mb, mx_dppu<DPP_ROW_MIRROR>(mb));
-      mb = max(mb, (unsigned)__builtin_amdgcn_ds_swizzle((int)mb, 0x401F));
+      {   // the two 16-lane rows of my half-wave: v_permlane16_swap (gfx950) exchanges the odd rows of one copy with the even
+          // rows of the other — a vector-ALU instruction where the ds_swizzle before it was an LDS round trip on the chain
+        typedef unsigned mxu2 __attribute__((ext_vector_type(2)));
+        const mxu2 sw = __builtin_amdgcn_permlane16_swap(mb, mb, false, false);
+        mb = max(sw.x, sw.y);
+      }
       // scale / inverse straight from the exponent field (clamped to [15, 253]: both normal; an all-zero row takes the
       // smallest exponent, 0 * scale = 0)
       const unsigned ex = min(max(mb >> 23, 15u), 253u);
