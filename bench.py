@@ -37,7 +37,7 @@ One JSON line is printed by rank 0.  Extra objects:
   roofline_gemm— the dense products of a step at their real shapes, timed with events.
   cpu_baseline — oracle/cpu_baseline.py: the reference graph restated at TF op
                  granularity with PyTorch-CPU float32 ("port"), SURVEY.md 8(d)
-                 protocol (full T, 2 warm-ups + median of 5 steps).  The reference's own
+                 protocol at full T, as a bounded sample (cfg2: 1 warm-up + median of 3 complete steps).  The reference's own
                  TF-1.8 trainer cannot run here.
 """
 import argparse
@@ -68,7 +68,7 @@ CPU_CACHE = os.path.join(ROOT, 'gpurun_out', 'cpu_baseline_cache.json')
 def cpu_baseline():
     """PyTorch-CPU float32 at TF op granularity (one [B,in+H]x[in+H,4H] matmul per
     frame per direction over the FULL T, autograd backward, per-variable clip + Adam), cfg1 and cfg2:
-    2 warm-ups + median of 5 complete training steps each.  Thread counts: 8(d) names "all physical
+    cfg1: 2 warm-ups + median of 5 complete training steps; cfg2: 1 warm-up + median of 3 (a bounded sample).  Thread counts: 8(d) names "all physical
     cores"; for these small per-frame products that setting is an order of magnitude SLOWER than a
     handful of threads on a many-core host, so both are reported: `value` is cfg2 at the fastest
     thread count of a sweep on cfg1 (the CPU at its best), `all_physical_cores` holds cfg1 in full
@@ -84,8 +84,9 @@ def cpu_baseline():
     cores = min(sweep, key=sweep.get)
     c1 = cb.time_config('cfg1', 2, 5, threads=cores)
     c1f = cb.time_config('cfg1', 2, 5, fused=True, threads=cores)
-    # (a slower host: the timed loop stops after >= 2 steps once 7 minutes are used; `sample` says how many ran)
-    c2 = cb.time_config('cfg2', 2, 5, threads=cores, budget_s=420.0)
+    # a BOUNDED sample (round 6: 1 warm-up + median of 3 complete steps, ~2.5 minutes; rounds 1-5 ran SURVEY 8(d)'s 2 + 5 and
+    # spent 5 of the default run's 5.5 minutes here; a slower host stops after >= 2 steps once 3 minutes are used)
+    c2 = cb.time_config('cfg2', 1, 3, threads=cores, budget_s=180.0)
     allc = {'cores': phys}
     if phys != cores:
         a1 = cb.time_config('cfg1', 2, 5, threads=phys, budget_s=60.0)
