@@ -713,13 +713,16 @@ def run(args, server, wl):
     """W untimed warm-up steps, then EXACTLY K steps bracketed by device sync + barrier on both
     sides; the time is the MAX over ranks; rank 0 returns the JSON object (others None)."""
     rank, world = server.rank, server.world_size
+    replica = {}
+    # bit-identical replicas: checked behind the FIRST warm-up step (a 135 MB checksum pass right in front of the timed
+    # region would flush the caches the steps run out of: the first region then ran 0.5-1 % slower than its repeats) and
+    # after the last step of the command; a single process has nothing to compare with before it has trained
     for i in range(max(args.warmup, 1)):
         wl.step(i)
+        if i == 0 and world > 1 and hasattr(wl, 'replicas_identical'):     # (the first step builds the flat parameter buffer)
+            replica['before_timed_region'] = wl.replicas_identical('before')
     wl.check()
     wl.sync()
-    replica = {}
-    if hasattr(wl, 'replicas_identical'):
-        replica['before_timed_region'] = wl.replicas_identical('before')
     wl.start_timed_region()
     server.barrier()
     t0 = time.perf_counter()
@@ -730,8 +733,6 @@ def run(args, server, wl):
     dt_rank = time.perf_counter() - t0
     wl.end_timed_region()
     wl.check()
-    if hasattr(wl, 'replicas_identical'):
-        replica['after_timed_region'] = wl.replicas_identical('after')
     clocks = wl.effective_clock() if hasattr(wl, 'effective_clock') else None
     # the same K steps again (same bracket), repeats - 1 times: the headline stays the first region
     dt_repeats = []
@@ -746,6 +747,8 @@ def run(args, server, wl):
         dt_repeats.append(time.perf_counter() - t1)
     if dt_repeats:
         wl.check()
+    if hasattr(wl, 'replicas_identical'):
+        replica['after_timed_region'] = wl.replicas_identical('after')
     ar_ms = wl.allreduce_ms_per_step()
     ar_ranks = wl.gather(ar_ms if ar_ms is not None else 0.0)
     both = None
