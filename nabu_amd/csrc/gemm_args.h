@@ -126,7 +126,10 @@ int pk_amax_from_partials(int rows, int N, const float *part, int ld, uint32_t *
 // the same maxima AND the row maxima of dz as [BT, ...] (adz, rows_pad entries) out of the persistent backward kernel's
 // per-workgroup row maxima rowpart[nparts][BT] (bit patterns): one launch, no read of dz (either output may be null)
 int pk_amax_from_persist(int BT, int rows_pad, int T, int max_len, int nparts, const uint32_t *rowpart, uint32_t *adz,
-                         int crow, int N, const float *colpart, int ld, uint32_t *adzT, hipStream_t s);
+                         int crow, int N, const float *colpart, int ld, uint32_t *adzT, hipStream_t s,
+                         const float *sumpart = nullptr, float *db0 = nullptr, float *db1 = nullptr);
+// (sumpart: [crow, ld] partial column sums -> db0 | db1 [N / 2] each, summed in row order: colsum_pair's result from the
+//  launch that reads the maxima)
 // row / column maxima (nabu_pk_amax) of TWO sources of one shape in one launch: rows shared, columns per source;
 // cols_b (optional): a second array that receives the column maxima as well.  src1 = nullptr: one source.
 int pk_amax_pair(const float *src0, const float *src1, long long ld, int R, int C, uint32_t *rows, uint32_t *cols0,

@@ -700,10 +700,13 @@ __global__ void pk_colmax_kernel(int rows, int N, const float *src, int ld, unsi
 // f16x3 maxima of dz out of the persistent backward kernel's own bookkeeping, one launch, no read of dz:
 //   blocks [0, nb_rows): adz[r] = max over the nparts per-workgroup row maxima (bit patterns) of frame row r = b T + t
 //                        (frames t >= max_len were never visited: 0; rows >= BT up to rows_pad: 0)
-//   the others:          adzT[n] = bits of max_r |colpart[r][n]| (pk_colmax_kernel)
+//   the others:          adzT[n] = bits of max_r |colpart[r][n]| (pk_colmax_kernel); and, where asked for, the bias
+//                        gradients db0 | db1 [n] = sum_r sumpart[r][n] in row order (colsum_pair_kernel's sum: the
+//                        kernel's per-unit partial sums sit next to its maxima — one launch less per layer)
 __global__ __launch_bounds__(256) void pk_amax_persist_kernel(int nb_rows, int BT, int rows_pad, int T, int max_len, int nparts,
                                                               const unsigned *rowpart, unsigned *adz, int crow, int N,
-                                                              const float *colpart, int ld, unsigned *adzT) {
+                                                              const float *colpart, int ld, unsigned *adzT,
+                                                              const float *sumpart, float *db0, float *db1) {
   if ((int)blockIdx.x < nb_rows) {
     // 64 frame rows per block, the partial rows in four groups (one per wave) that meet in LDS
     __shared__ unsigned red[4][64];
@@ -724,6 +727,12 @@ __global__ __launch_bounds__(256) void pk_amax_persist_kernel(int nb_rows, int B
   float m = 0.f;
   for (int r = 0; r < crow; ++r) m = fmaxf(m, fabsf(colpart[(size_t)r * ld + n]));
   adzT[n] = __builtin_bit_cast(unsigned, m);
+  if (sumpart) {
+    float s = 0.f;
+    for (int r = 0; r < crow; ++r) s += sumpart[(size_t)r * ld + n];
+    if (n < N / 2) db0[n] = s;
+    else db1[n - N / 2] = s;
+  }
 }
 
 __global__ void pk_fill_u32_kernel(unsigned *dst, int n, unsigned v) {
@@ -925,11 +934,13 @@ int pk_amax_pair(const float *src0, const float *src1, long long ld, int R, int 
 }
 
 int pk_amax_from_persist(int BT, int rows_pad, int T, int max_len, int nparts, const uint32_t *rowpart, uint32_t *adz,
-                         int crow, int N, const float *colpart, int ld, uint32_t *adzT, hipStream_t s) {
+                         int crow, int N, const float *colpart, int ld, uint32_t *adzT, hipStream_t s,
+                         const float *sumpart, float *db0, float *db1) {
   const int nb_rows = adz ? (rows_pad + 63) / 64 : 0, nb_cols = adzT ? (N + 255) / 256 : 0;
+  if (sumpart && (!adzT || !db0 || !db1 || N % 2)) return fail(NABU_EINVAL, "pk_amax_from_persist: the column sums ride on the column maxima");
   if (nb_rows + nb_cols == 0) return 0;
   hipLaunchKernelGGL(pk_amax_persist_kernel, dim3(nb_rows + nb_cols), dim3(256), 0, s, nb_rows, BT, rows_pad, T, max_len, nparts,
-                     rowpart, adz, crow, N, colpart, ld, adzT);
+                     rowpart, adz, crow, N, colpart, ld, adzT, sumpart, db0, db1);
   NABU_LAUNCH_CHECK();
   return 0;
 }

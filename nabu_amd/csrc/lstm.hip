@@ -204,6 +204,7 @@ struct Layout {
   // the column maxima of x and the row maxima of Wx (the backward pass's x^T and Wx operands) are measured by the
   // forward pass in the same reads as its own and kept in the reserve (res_axT_off, res_aw2_off)
   size_t pk_ax, pk_aw, pk_adz, pk_ahT[2], pk_abwd_bytes, res_adzT_off, res_axT_off, res_aw2_off;
+  size_t res_ahT_off;        // 0: none.  The known row bound of h^T (|h| <= 1), written by the forward call's one fill
   // per-workgroup row maxima of dz written by the persistent backward kernel ([2 directions x H / 16][BT] bit patterns;
   // 0 bytes where the layer has no input gradient): the row scales of dZ as [BT, 8H] without a pass over dz
   size_t pk_rowmax, pk_rowmax_bytes;
@@ -321,7 +322,7 @@ static Layout make_layout(const nabu_blstm_desc *d) {
   L.cs_elems = B * T * H;
   L.reserve_bytes = (2 * L.gates_elems + 2 * L.cs_elems) * sizeof(float);
   L.res_dzT_off = L.res_dzT_bytes = 0;
-  L.res_adzT_off = L.res_axT_off = L.res_aw2_off = 0;
+  L.res_adzT_off = L.res_axT_off = L.res_aw2_off = L.res_ahT_off = 0;
   L.pk_rowmax = L.pk_rowmax_bytes = 0;
   L.fwd_only = (d->flags & NABU_BLSTM_FWD_ONLY) != 0;
   size_t off = 2048;  // ws[0..4): persistent kernels' status word (0 = ok), zeroed by the caller once;
@@ -381,6 +382,10 @@ static Layout make_layout(const nabu_blstm_desc *d) {
         L.res_axT_off = L.res_adzT_off + aG;
         L.res_aw2_off = L.res_axT_off + aD;
         L.reserve_bytes = L.res_aw2_off + aD;
+        if (L.pk_in && L.pk_rec) {     // (not the whole-kernel form: its leading rows are measured maxima of x)
+          L.res_ahT_off = L.reserve_bytes;
+          L.reserve_bytes += aW;
+        }
       }
       L.pk_ax = take(fwd, aBT); L.pk_aw = take(fwd, aG);
       L.pk_adz = take(bwd, aBT);
@@ -628,6 +633,8 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d_in, const float *x, const
 
   // narrow input (first layer): the persistent kernel projects its input itself (lstm_persist.hip, XK) — no product here
   const bool fuse_in = use_persistent(d) && lstm_persist_fuses_input(B, T, D, H);
+  lstm_persist_ring_cleared(nullptr, s);              // (no note from an earlier call that failed half-way)
+  bool ring_with_fill = use_persistent(d) && !fuse_in;   // the projection's fill also clears the exchange ring
   auto input_projection = [&]() -> int {
   // time-batched input projections (MFMA): gates_d = x·Wx_d + b_d
   if (L.pk_in) {
@@ -646,8 +653,15 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d_in, const float *x, const
       uint32_t *aw2 = L.fwd_only ? nullptr : reinterpret_cast<uint32_t *>(static_cast<char *>(reserve) + L.res_aw2_off);
       const unsigned xb = L.x_pk ? CMP_AMAX_BITS : bound_bits(d->x_bound);     // (a packed companion: scale 2^14)
       const int rpD = nabu_pk_rows_pad(D);
-      const FillSeg fill[4] = {{ax, (size_t)rpBT, xb}, {aw, (size_t)rpG, 0u}, {axT, axT ? (size_t)rpD : 0, xb}, {aw2, aw2 ? (size_t)rpD : 0, 0u}};
-      if (int e = multi_fill(fill, 4, s)) return e;
+      // (and the backward pass's row bound of h^T, |h| <= 1: a constant it would otherwise fill in a launch of its own)
+      uint32_t *ahT = L.res_ahT_off ? reinterpret_cast<uint32_t *>(static_cast<char *>(reserve) + L.res_ahT_off) : nullptr;
+      // and the recurrent launch's exchange ring (lstm_persist.h: lstm_persist_ring_seg) — nothing between here and that
+      // launch writes the persistent kernels' part of the workspace
+      FillSeg fill[6] = {{ax, (size_t)rpBT, xb}, {aw, (size_t)rpG, 0u}, {axT, axT ? (size_t)rpD : 0, xb}, {aw2, aw2 ? (size_t)rpD : 0, 0u},
+                         {ahT, ahT ? (size_t)nabu_pk_rows_pad(H) : 0, L.hT_ext ? CMP_AMAX_BITS : bound_bits(1.0f)}, {nullptr, 0, 0u}};
+      const bool with_ring = ring_with_fill && lstm_persist_ring_seg(true, B, T, H, w + L.persist_off, &fill[5]);
+      if (int e = multi_fill(fill, 6, s)) return e;
+      if (with_ring) lstm_persist_ring_cleared(&fill[5], s);
       if (!xb)
         if (int e = nabu_pk_amax(x, D, BT, D, ax, axT, stream)) return e;
       if (int e = pk_amax_pair(kern[0], kern[1], G, D, G, aw2, aw, aw + G, nullptr, s)) return e;
@@ -748,6 +762,8 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d_in, const float *x, const
       if (want_cmp) return companions_by_pack_kernels(7 & ~by_kernel);
       return 0;
     }
+    lstm_persist_ring_cleared(nullptr, s);
+    ring_with_fill = false;
     if (fuse_in)      // the step kernels read the projection from the gate buffers
       if (int e2 = input_projection()) return e2;
   }
@@ -791,6 +807,7 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
   if (d->mode == NABU_LSTM_PERSISTENT && !lstm_persist_supported(d->B, d->T, d->H))
     return fail(NABU_EUNSUP, "blstm_bwd: persistent kernel does not support B=%d H=%d", d->B, d->H);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  lstm_persist_ring_cleared(nullptr, s);
   const int B = d->B, T = d->T, D = d->D, H = d->H;
   const int max_len = d->max_len > 0 ? d->max_len : T;
   float *r = static_cast<float *>(reserve);
@@ -803,6 +820,7 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
 
   float *db_part = nullptr;   // persistent path: bias-gradient partials [db_rows][2][4H]
   int db_rows = 0;
+  bool db_done = false;       // the bias gradients were summed by the launch that read the maxima
   // f16x3 with an input gradient: the persistent kernel leaves every workgroup's row maxima of dz in the workspace
   uint32_t *rowmax = (L.pk_planes == 2 && L.pk_in && d_x && L.pk_rowmax_bytes)
                          ? reinterpret_cast<uint32_t *>(w + L.pk_off + L.pk_rowmax) : nullptr;
@@ -864,9 +882,11 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
         if (db_part && (!both || rowmax_done)) {
           // the persistent kernel kept them: the gate columns' maxima per unit next to its bias-gradient partials, the
           // frames' per workgroup in the workspace (only asked for where an input gradient follows) — no read of dz
+          // (the bias gradients — the sum of the same units' partial rows — come out of the same launch)
           if ((e = pk_amax_from_persist(M, rpBT, T, max_len, 2 * (H / 16), rowmax, both ? adz : nullptr, db_rows, 2 * G,
-                                        db_part + lstm_persist_db_floats(B, H), 2 * G, adzT, s)))
+                                        db_part + lstm_persist_db_floats(B, H), 2 * G, adzT, s, db_part, dbias[0], dbias[1])))
             return e;
+          db_done = true;
         } else {
           const FillSeg fill[2] = {{adz, both ? (size_t)rpBT : 0, 0u}, {adzT, (size_t)rpG, 0u}};
           if ((e = multi_fill(fill, 2, s))) return e;
@@ -914,7 +934,9 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
       // h^T: in the caller's hT_pk, written by the forward call (ABI version 3) — or packed here from `out`
       char *hTb[2] = {pk + L.pk_hT[0], pk + L.pk_hT[1]};
       if (L.hT_ext) { hTb[0] = static_cast<char *>(d->hT_pk); hTb[1] = hTb[0] + L.cmp_bytes[2] / 2; }
-      if (P == 2) {   // |h| <= 1 by construction (o · tanh c): one fill for both cells; the input features are measured
+      if (P == 2 && L.res_ahT_off) {   // |h| <= 1: the bound sits in the reserve since the forward call (both cells share it)
+        ahT[0] = ahT[1] = reinterpret_cast<uint32_t *>(static_cast<char *>(reserve) + L.res_ahT_off);
+      } else if (P == 2) {   // |h| <= 1 by construction (o · tanh c): one fill for both cells; the input features are measured
         const unsigned hb = L.hT_ext ? CMP_AMAX_BITS : bound_bits(1.0f);
         const FillSeg fill[4] = {{ahT[0], (size_t)r0, 0u}, {ahT[0] + r0, (size_t)(rpW - r0), hb},
                                  {ahT[1], (size_t)r0, 0u}, {ahT[1] + r0, (size_t)(rpW - r0), hb}};
@@ -977,7 +999,7 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
     // db = column sums of dz: the persistent kernel already summed them per unit (one launch adds the few partial
     // rows of both cells)
     if (db_part)
-      e = dir ? 0 : colsum_pair(db_rows, 4 * H, db_part, 2 * 4 * H, dbias[0], dbias[1], s);
+      e = (dir || db_done) ? 0 : colsum_pair(db_rows, 4 * H, db_part, 2 * 4 * H, dbias[0], dbias[1], s);
     else
       e = nabu_colsum_f32(M, 4 * H, gates[dir], 4 * H, 0.f, dbias[dir], w + L.gemm_off, L.gemm_bytes, stream);
     if (e) return e;

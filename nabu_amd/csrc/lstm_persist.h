@@ -50,4 +50,11 @@ bool lstm_persist_exact();
 // db_part + lstm_persist_db_floats(B, H): the largest |dz| of every gate column per unit (column maxima of dz = the
 // maximum over the rows; the row scales of the f16x3 weight-gradient products' dZ^T operand)
 size_t lstm_persist_db_floats(int B, int H);
+// One launch less in front of a forward recurrent launch: a caller that fills something anyway (lstm.hip: the maxima
+// of the input projection) adds the region lstm_persist_ring_seg names to that fill and says so with
+// lstm_persist_ring_cleared on the same host thread; the next launch on that workspace and stream then skips its own
+// reset.  false: not offered for this shape (several launches share the ring).
+struct FillSeg;
+bool lstm_persist_ring_seg(bool fwd, int B, int T, int H, void *ws, FillSeg *seg);
+void lstm_persist_ring_cleared(const FillSeg *seg, hipStream_t stream);
 }  // namespace nabu

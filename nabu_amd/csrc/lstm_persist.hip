@@ -701,7 +701,7 @@ int lstm_mx_chunk_rows();
 size_t lstm_mxh_ring_bytes(bool fwd, int H);
 int lstm_mxh_launch(bool fwd, int H, const PersistArgs &a, hipStream_t stream, bool dry);
 size_t lstm_mxh_xws_bytes(int B, int T);
-int lstm_mxh_prepare_x(int B, int T, int D, const float *x, void *ws, hipStream_t stream);
+int lstm_mxh_prepare_x(int B, int T, int D, const float *x, void *ws, hipStream_t stream, const FillSeg *also);
 // lstm_persist_mxf.hip: the same arithmetic with 32 hidden units per workgroup, two units of 8 rows per XCD: 33 .. 64 batch
 // rows at H = 512 in one launch (NABU_PERSIST_MXF=0: launches of <= 32 rows on the kernels above)
 bool lstm_mxf_supported(int B, int H);
@@ -821,9 +821,32 @@ static int run_chunk(bool fwd, int B, int T, int D, int H, int max_len, const in
 
 // exchange ring + XCC table back to 0xFF bytes: one small kernel (a hipMemsetAsync is its own kind of dispatch and
 // costs ~6 us of queue gap in front of every recurrent launch)
+// The caller of the forward pass may clear the ring in a fill of its own (it has one anyway: lstm.hip, the maxima of
+// the input projection): lstm_persist_ring_seg names the region the launch will want cleared, and
+// lstm_persist_ring_cleared says that it has been.  The note is consumed by the next reset on this host thread, whatever
+// that launch is, and honoured only if it names the same workspace, stream and at least as many bytes.
+static thread_local struct { void *ws; size_t bytes; hipStream_t stream; } g_ring_cleared = {nullptr, 0, nullptr};
 static int ring_reset(void *ws, size_t bytes, hipStream_t stream) {
+  const bool cleared = g_ring_cleared.ws == ws && g_ring_cleared.stream == stream && g_ring_cleared.bytes >= bytes;
+  g_ring_cleared.ws = nullptr;
+  if (cleared) return 0;
   const FillSeg seg = {ws, (bytes + 3) / 4, 0xFFFFFFFFu};
   return multi_fill(&seg, 1, stream);
+}
+bool lstm_persist_ring_seg(bool fwd, int B, int T, int H, void *ws, FillSeg *seg) {
+  if (!ws || !lstm_mx_supported(B, H)) return false;      // (the fp32 kernels' rings depend on the chunking: not offered)
+  if (chunk_rows(B, H, fwd, T) < B) return false;          // several launches share the ring: each clears it
+  size_t bytes;
+  if (lstm_mxf_supported(B, H)) bytes = TABLE_BYTES + lstm_mxf_ring_bytes(fwd, H);
+  else if (B <= lstm_mx_chunk_rows()) bytes = TABLE_BYTES + lstm_mxh_ring_bytes(fwd, H);
+  else return false;
+  *seg = FillSeg{ws, (bytes + 3) / 4, 0xFFFFFFFFu};
+  return true;
+}
+void lstm_persist_ring_cleared(const FillSeg *seg, hipStream_t stream) {
+  g_ring_cleared.ws = seg ? seg->ptr : nullptr;
+  g_ring_cleared.bytes = seg ? seg->words * 4 : 0;
+  g_ring_cleared.stream = stream;
 }
 
 static thread_local bool g_exact = false;
@@ -845,8 +868,12 @@ static int run(bool fwd, int B, int T, int D, int H, int max_len, const int32_t 
   bool kept = rowmax != nullptr;
   for (int pass = 0; pass < 2; ++pass) {     // pass 0 validates every chunk, pass 1 enqueues them
     shards = 0;
-    if (pass == 1 && fwd && x && lstm_mx_supported(B, H))
-      if (int e = lstm_mxh_prepare_x(B, T, D, x, xws, stream)) return e;
+    if (pass == 1 && fwd && x && lstm_mx_supported(B, H)) {
+      FillSeg ring;      // cleared by prepare_x's own fill
+      const bool with_ring = lstm_persist_ring_seg(true, B, T, H, ws, &ring);
+      if (int e = lstm_mxh_prepare_x(B, T, D, x, xws, stream, with_ring ? &ring : nullptr)) return e;
+      if (with_ring) lstm_persist_ring_cleared(&ring, stream);
+    }
     for (int b0 = 0; b0 < B; b0 += Bc) {
       RowMax rm = {rowmax ? rowmax + (size_t)b0 * T : nullptr, (unsigned)((size_t)B * T), false};
       const int nb = B - b0 < Bc ? B - b0 : Bc;

@@ -530,10 +530,10 @@ __global__ __launch_bounds__(256) void mxh_xplanes_kernel(int frames, int D, con
 }
 size_t lstm_mxh_xws_bytes(int B, int T) { return 1024 + (size_t)B * T * 256; }
 // x [B, T, D] -> ws (lstm_mxh_xws_bytes): three small launches (zero the maxima, measure, convert)
-int lstm_mxh_prepare_x(int B, int T, int D, const float *x, void *ws, hipStream_t stream) {
+int lstm_mxh_prepare_x(int B, int T, int D, const float *x, void *ws, hipStream_t stream, const FillSeg *also) {
   if (D > 64 || D % 8) return fail(NABU_EUNSUP, "persistent LSTM (mxh): in-kernel input projection takes D <= 64, D %% 8 == 0 (lstm_persist_fuses_input)");
-  const FillSeg seg = {ws, 256, 0u};
-  if (int e = multi_fill(&seg, 1, stream)) return e;
+  const FillSeg seg[2] = {{ws, 256, 0u}, also ? *also : FillSeg{nullptr, 0, 0u}};    // (also: the exchange ring)
+  if (int e = multi_fill(seg, 2, stream)) return e;
   if (int e = nabu_pk_amax(x, D, B * T, D, nullptr, static_cast<uint32_t *>(ws) + 16, stream)) return e;
   const size_t n = (size_t)B * T * 8;
   hipLaunchKernelGGL(mxh_xplanes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, B * T, D, x, static_cast<char *>(ws));
