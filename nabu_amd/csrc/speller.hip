@@ -2012,6 +2012,7 @@ struct SpLayout {
   size_t H[NABU_SPELLER_MAX_LAYERS], Cs[NABU_SPELLER_MAX_LAYERS], Ho[NABU_SPELLER_MAX_LAYERS],
       acts[NABU_SPELLER_MAX_LAYERS];
   size_t ctx, align, q, keys, logits_tm, ids, znorm, total;   // offsets in floats (ids: [L,B] int32)
+  size_t dscale, sdraw;    // persistent decoder (speller_persist.h): dropout scale factors [L,B,U], sampling draws [L,B,2]
 };
 
 static SpLayout sp_layout(const nabu_speller_desc *d) {
@@ -2032,6 +2033,8 @@ static SpLayout sp_layout(const nabu_speller_desc *d) {
   s.logits_tm = take(L * B * C);
   s.ids = take(L * B);
   s.znorm = take(L * B);
+  s.dscale = d->keep_prob < 1.f ? take(L * B * U) : 0;
+  s.sdraw = d->sample_prob > 0.f ? take(2 * L * B) : 0;
   s.total = o;
   return s;
 }
@@ -2373,6 +2376,8 @@ extern "C" int nabu_speller_fwd(const nabu_speller_desc *d, const float *values,
   pd.kind = d->kind; pd.K = d->K; pd.F = d->F;
   pd.keep_prob = d->keep_prob; pd.seed = d->seed; pd.seed_offset = d->seed_offset;     // nl == 1: offset + t*nl + n = offset + t
   pd.sample_prob = d->sample_prob; pd.sample_seed = d->sample_seed; pd.sample_offset = d->sample_offset;
+  pd.drop_scale = drop ? r + R.dscale : nullptr;
+  pd.sample_draws = d->sample_prob > 0.f ? reinterpret_cast<unsigned *>(r + R.sdraw) : nullptr;
   const bool persist = fwd_takes_persistent(d, W);
   if (persist)
     SP_TRY(speller_persist_fwd(pd, dec_len, enc_len, ids_used, w + W.kperm[0], p->lstm_bias[0], p->lstm_kernel[0],
@@ -2553,10 +2558,11 @@ extern "C" int nabu_speller_bwd(const nabu_speller_desc *d, const float *values,
   const bool fuse_shapes = epi_env_b && nl == 1 && fused_ok(Bn, U, U, U, 0, 0) && fused_ok(Bn, E + U, 4 * U, 4 * U, 0, 0) &&
                            (E + U) / 32 <= 1024;
   // the whole step loop as ONE persistent launch (speller_persist.hip), as in the forward pass (output dropout is
-  // applied inside it: the mask is recomputed from the Philox stream)
+  // applied inside it: the scale factors are drawn again from the Philox stream by a small launch in front of it)
   SpPersistDesc pd = {B, L, U, E, Te, C};
   pd.kind = d->kind; pd.K = d->K; pd.F = d->F;
   pd.keep_prob = d->keep_prob; pd.seed = d->seed; pd.seed_offset = d->seed_offset;
+  pd.drop_scale = drop ? const_cast<float *>(r + R.dscale) : nullptr;
   const bool persist = bwd_takes_persistent(d, W);
   // sub-batches of <= 16 utterances: both products of a step by rows16_kernel (no split-K hand-off between workgroups:
   // 13 -> 7 us per launch; its cell epilogue applies the output dropout's mask); NABU_SPELLER_ROWS16=0: gemm_skinny_fused

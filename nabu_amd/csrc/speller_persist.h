@@ -11,11 +11,14 @@ struct SpPersistDesc {
   // stream dropout_rows draws for (seed, seed_offset + t) over [B, U]; 1 = off
   float keep_prob = 1.f;
   unsigned long long seed = 0, seed_offset = 0;
+  float *drop_scale = nullptr;     // [L, B, U] scratch (keep_prob < 1): the scale factors 0 | 1 / keep of every step, WRITTEN
+                                   // by either pass in one small launch in front of its decoder kernel
   // scheduled sampling (rnn_decoder.py:59-66, ScheduledEmbeddingTrainingHelper): with probability sample_prob the
   // next input of a row is drawn from softmax(logits of this step) — the draws of nabu_sample_ids for
   // (sample_seed, sample_offset + t, batch row); 0 = teacher forcing
   float sample_prob = 0.f;
   unsigned long long sample_seed = 0, sample_offset = 0;
+  unsigned *sample_draws = nullptr;   // [L, B, 2] (sample_prob > 0): the two Philox words of every (step, row), written likewise
 };
 
 // shapes the persistent forward kernel takes (single LSTM layer, vanilla softmax attention, no dropout, no

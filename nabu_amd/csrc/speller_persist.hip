@@ -63,10 +63,10 @@ struct Args {
   int32_t *ids_w;                    // ... the inputs actually used (= ids), rows 1.. written here
   int C;
   float sprob;
-  unsigned long long sseed, soff;
+  const unsigned *sdraw;             // ... the Philox words (x: Bernoulli, y: inverse CDF) of (seed, offset + t, row) [L, Bt, 2]
   float *Ho;                         // dropped cell outputs (keep < 1), else unused
   float keep;                        // output dropout keep probability (1 = off)
-  unsigned long long seed, seed_offset;
+  const float *dscale;               // ... its scale factors (0 or 1 / keep) [L, Bt, U], written before the launch
   unsigned *table;
   char *xbuf;
   int *status;
@@ -178,10 +178,7 @@ struct SampleRow {
   unsigned hoff, coff;          // byte offsets of my row's h / context inside their rings (slot of this step)
   const float *wout, *bout;
   int C, U, E;
-  int drop;
-  float keep;
-  unsigned long long seed, seed_off;
-  unsigned long long grow_u;    // batch row x U: my row's first element of the dropout stream
+  const float *dscale;          // dropout scale factors of my row in this step [U] (nullptr: no dropout)
   float *aux;
   int *flag;
   int *status;
@@ -189,6 +186,12 @@ struct SampleRow {
   unsigned ry;                  // the second Philox word of (seed, offset + t, row): the uniform of the inverse CDF
   int teacher;
 };
+#ifndef SAMPLE_UNROLL
+// 16-byte weight loads in flight per thread.  Deliberately few: every register this function uses beyond the
+// call-clobbered set is one the CALLER (512 registers live, 384 of them weights) spills in its common path — cfg3 with
+// sample_prob 1e-6 over the plain step: +0.11 ms at 2, +0.4 at 8, +2.4 at 16 (79 / 117 / 228 spilled registers)
+#define SAMPLE_UNROLL 2
+#endif
 __device__ __attribute__((noinline)) int sample_row(const SampleRow q) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int C = q.C, U = q.U, K = q.U + q.E;
@@ -233,8 +236,8 @@ __device__ __attribute__((noinline)) int sample_row(const SampleRow q) {
     for (int j = 0; j < 2; ++j)
       if (j * NT + tid < NPC) {
         f32x4 f = __builtin_bit_cast(f32x4, v[j]);
-        if (q.drop && !isc[j]) {                   // the projection sees the DROPPED output
-          const float4 sc = dropout_scale4((q.grow_u + 4 * qq[j]) >> 2, q.keep, q.seed, q.seed_off);
+        if (q.dscale && !isc[j]) {                 // the projection sees the DROPPED output
+          const f32x4 sc = *reinterpret_cast<const f32x4 *>(q.dscale + 4 * qq[j]);
           f.x *= sc.x; f.y *= sc.y; f.z *= sc.z; f.w *= sc.w;
         }
         *reinterpret_cast<f32x4 *>(xrow + 4 * qq[j]) = f;
@@ -249,7 +252,7 @@ __device__ __attribute__((noinline)) int sample_row(const SampleRow q) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (4 * cq < C) {
       const float *wp = q.wout + 4 * cq;
-#pragma unroll 8
+#pragma unroll SAMPLE_UNROLL
       for (int k = ks; k < K; k += 16) {
         const float x = xrow[k];
         const f32x4 wv = *reinterpret_cast<const f32x4 *>(wp + (size_t)k * C);
@@ -314,6 +317,29 @@ __device__ __attribute__((noinline)) int sample_row(const SampleRow q) {
     if ((p.dbg & 4) && blockIdx.x == 0 && tid == 0 && t == L / 2)                  \
       p.status[16 + (i)] = (int)wall_clock64();                                    \
   } while (0)
+
+// The random numbers of a regularised forward call, drawn before it:
+//   dscale [L][B][U]: the output dropout's scale factors (0 or 1 / keep) — step t is the Philox stream dropout_rows draws
+//                     for (seed, seed_offset + t) over [B, U] (group = 4 consecutive elements);
+//   sdraw [L][B][2]:  words x, y of Philox((row, 0, offset + t), sample_seed) — sample_ids_kernel's Bernoulli and
+//                     inverse-CDF uniforms of step t
+__global__ __launch_bounds__(256) void speller_randoms_kernel(size_t groups, size_t draws, int B, int U, float keep,
+                                                              unsigned long long seed, unsigned long long seed_offset,
+                                                              float *dscale, unsigned long long sseed,
+                                                              unsigned long long soff, unsigned *sdraw) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < groups) {
+    const size_t per_step = (size_t)B * U / 4, t = i / per_step, g = i % per_step;
+    const float4 sc = dropout_scale4(g, keep, seed, seed_offset + t);
+    *reinterpret_cast<float4 *>(dscale + 4 * i) = sc;
+  } else if (i < groups + draws) {
+    const size_t j = i - groups, t = j / B, row = j % B;
+    const unsigned long long off = soff + t;
+    const uint4 rr = philox4x32_10(make_uint4((unsigned)row, 0u, (unsigned)off, (unsigned)(off >> 32)),
+                                   make_uint2((unsigned)sseed, (unsigned)(sseed >> 32)));
+    sdraw[2 * j] = rr.x; sdraw[2 * j + 1] = rr.y;
+  }
+}
 
 // KR = weight registers per lane >= (E+U)/4
 // LOC: location-aware attention (attention.py:186-292): the score also takes conv1d(previous alignments)·conv_proj;
@@ -465,6 +491,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
   for (int t = 0; t < L; ++t) {
     const unsigned so = (unsigned)(t % RING), sp = (unsigned)((t + RING - 1) % RING), sr = (unsigned)((t + RING - 2) % RING);
     SP_STAMP(0);
+    // scheduled sampling: was the input of this step — of the row my wave owns in the gate phase — sampled at the end
+    // of the previous one?  (the Bernoulli words were drawn before the launch: only a sampled row's wave has to wait for
+    // the word its utterance's first workgroup publishes, every other reads the teacher's label)
+    bool in_sampled = false;
+    if (samp && t > 0) {
+      const int ix = __builtin_amdgcn_readfirstlane(2 * ((t - 1) * B + p.b0 + unit * R + min(tid >> 6, R - 1)));
+      in_sampled = u01(p.sdraw[ix]) < p.sprob;
+    }
     // =========================== A: cell ===========================
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (t > 0) {
@@ -543,8 +577,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
       for (int ww = 0; ww < NW; ++ww) z += red0[(size_t)ww * red_stride + gcol * 4 + grow];
       float a = 0.f;
       int my_id = 0;
-      if (samp && t > 0) {
-        // the input of this step was decided at the end of the previous one (duty E): wave w = row w polls its word
+      if (in_sampled) {
+        // the input of this step was drawn at the end of the previous one (duty E): wave w = row w polls its word
         unsigned idw;
         Spin g;
         g.start();
@@ -568,12 +602,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
         h_state = ftanh(c_state) * go;
       }
       a_last = act ? a : 0.f;        // saved tensors of this step go to HBM under the NEXT step's product
-      if (drop && gate_thr && gg == 0) {   // what the query and the output projection see of h_t (the recurrence keeps h_t)
-        const size_t e = (size_t)gb * U + gunit;
-        const float4 sc = dropout_scale4(e >> 2, p.keep, p.seed, p.seed_offset + (unsigned long long)t);
-        const int j = (int)(e & 3);
-        ho_last = h_state * (j == 0 ? sc.x : j == 1 ? sc.y : j == 2 ? sc.z : sc.w);
-      }
+      if (drop && gate_thr && gg == 0)     // what the query and the output projection see of h_t (the recurrence keeps h_t)
+        ho_last = h_state * p.dscale[((size_t)t * B + gb) * U + gunit];
       const bool pub = gate_thr && gg == 0;
       xst1(fbits(h_state), rh, pub ? so * hb + (unsigned)((grow * U + gunit) * 4) : OOB, coloc);
       xst1(SENT, rh, (pub && t >= 2) ? sr * hb + (unsigned)((grow * U + gunit) * 4) : OOB, coloc);
@@ -585,6 +615,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
       const int NPC = R * U / 4;                       // <= 2 * NT (host check)
       const int q0 = min(tid, NPC - 1), q1 = min(NT + tid, NPC - 1);
       u32x4 v0, v1;
+      // the query is taken from the DROPPED output: the scale factors of my two pieces (written before the launch:
+      // the loads are on their way while the poll below waits)
+      f32x4 s0 = {1.f, 1.f, 1.f, 1.f}, s1 = s0;
+      if (drop) {
+        const float *ds = p.dscale + ((size_t)t * B + p.b0 + unit * R) * U;
+        s0 = *reinterpret_cast<const f32x4 *>(ds + (size_t)(4 * q0 / U) * U + 4 * q0 % U);
+        s1 = *reinterpret_cast<const f32x4 *>(ds + (size_t)(4 * q1 / U) * U + 4 * q1 % U);
+      }
       Spin g;
       g.start();
       for (;;) {
@@ -595,11 +633,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
       }
       f32x4 f0 = __builtin_bit_cast(f32x4, v0), f1 = __builtin_bit_cast(f32x4, v1);
       if (drop) {
-        // the query is taken from the DROPPED output: piece q = 4 consecutive units of row 4q / U = one Philox group
-        // of the [B, U] stream (the mask is a function of (seed, step, element), recomputed by whoever needs it)
-        const unsigned long long off = p.seed_offset + (unsigned long long)t;
-        const size_t e0 = (size_t)(p.b0 + unit * R + 4 * q0 / U) * U + 4 * q0 % U, e1 = (size_t)(p.b0 + unit * R + 4 * q1 / U) * U + 4 * q1 % U;
-        const float4 s0 = dropout_scale4(e0 >> 2, p.keep, p.seed, off), s1 = dropout_scale4(e1 >> 2, p.keep, p.seed, off);
         f0.x *= s0.x; f0.y *= s0.y; f0.z *= s0.z; f0.w *= s0.w;
         f1.x *= s1.x; f1.y *= s1.y; f1.z *= s1.z; f1.w *= s1.w;
       }
@@ -899,17 +932,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
     if (samp && t + 1 < L) {
       __syncthreads();                                   // parts / mz have been read: aux is free
       if (cs == 0) {
-        const unsigned long long off = p.soff + (unsigned long long)t;
-        const uint4 rr = philox4x32_10(make_uint4((unsigned)cbg, 0u, (unsigned)off, (unsigned)(off >> 32)),
-                                       make_uint2((unsigned)p.sseed, (unsigned)(p.sseed >> 32)));
+        // (the two Philox words of (seed, offset + t, row) were drawn before the launch: sdraw)
+        const uint2 rr = *reinterpret_cast<const uint2 *>(p.sdraw + 2 * ((size_t)t * B + cbg));
         int id = p.ids[(size_t)(t + 1) * B + cbg];       // teacher forcing
         if (u01(rr.x) < p.sprob) {
           SampleRow q;
           q.rc = rc; q.rh = rh;
           q.hoff = so * hb + (unsigned)(ci * U * 4); q.coff = so * cb + (unsigned)(ci * E * 4);
           q.wout = p.wout; q.bout = p.bout; q.C = p.C; q.U = U; q.E = E;
-          q.drop = drop ? 1 : 0; q.keep = p.keep; q.seed = p.seed; q.seed_off = p.seed_offset + (unsigned long long)t;
-          q.grow_u = (unsigned long long)cbg * U;
+          q.dscale = drop ? p.dscale + ((size_t)t * B + cbg) * U : nullptr;
           q.aux = aux; q.flag = flag; q.status = p.status; q.timeout_ticks = p.timeout_ticks; q.ry = rr.y; q.teacher = id;
           id = sample_row(q);
           if (flag[0]) return;
@@ -956,7 +987,7 @@ struct BArgs {
   const float *acts, *Cs, *q, *ctx, *align;     // saved by the forward pass (time-major)
   const float *dH;         // [L][B][U] d h_t of the output projection
   float keep;              // output dropout of the cell (1 = off): d h through the output = mask / keep * (dH + dq . Wq^T)
-  unsigned long long seed, seed_offset;
+  const float *dscale;     // ... mask / keep [L][B][U], drawn in front of the launch (speller_randoms_kernel)
   float *dCtx;             // [L][B][E] in: the output projection's share; out: the whole d context_t
   float *dq, *dz;          // [L][B][U], [L][B][4U] (gate-major): inputs of the weight-gradient products
   float *dkeys;            // [B][Te][U]
@@ -1530,12 +1561,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NW / 4, NW /
         const float gi = quad_bcast(a, 0), gj = quad_bcast(a, 1), gf = quad_bcast(a, 2), go = quad_bcast(a, 3);
         if (t < glen) {
           float dho = p.dH[sidx] + dhq;          // gradient of the cell OUTPUT (projection + query): through the dropout mask
-          if (DROP && p.keep < 1.f) {
-            const size_t e = (size_t)gb * U + gunit;
-            const float4 sc = dropout_scale4(e >> 2, p.keep, p.seed, p.seed_offset + (unsigned long long)t);
-            const int j = (int)(e & 3);
-            dho *= j == 0 ? sc.x : j == 1 ? sc.y : j == 2 ? sc.z : sc.w;
-          }
+          if (DROP && p.keep < 1.f) dho *= p.dscale[sidx];      // (the forward call's scale factors, [L, B, U])
           const float dh = dho + chs[grow * 16 + gu];          // + the recurrent carry (not dropped)
           const float cnew = p.Cs[sidx + (size_t)B * U], cprev = p.Cs[sidx];
           const float tc = ftanh(cnew);
@@ -1834,7 +1860,14 @@ int speller_persist_bwd(const SpPersistDesc &d, const int32_t *dec_len, const in
   a.dec_len = dec_len; a.enc_len = enc_len; a.kxhT = kxhT; a.wq = wq; a.v = v; a.keys = keys; a.values = values;
   a.acts = acts; a.Cs = Cs; a.q = q; a.ctx = ctx; a.align = align; a.dH = dH; a.dCtx = dCtx; a.dq = dq; a.dz = dz;
   a.dkeys = dkeys; a.dv_part = dv_part;
-  a.keep = d.keep_prob; a.seed = d.seed; a.seed_offset = d.seed_offset;
+  a.keep = d.keep_prob; a.dscale = d.drop_scale;
+  if (d.keep_prob < 1.f && !d.drop_scale) return fail(NABU_EINVAL, "persistent decoder (backward): dropout needs the drop_scale array");
+  if (d.keep_prob < 1.f) {     // the same draws as the forward call's (whatever kernels ran it)
+    const size_t groups = (size_t)d.L * d.B * d.U / 4;
+    hipLaunchKernelGGL(speller_randoms_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, groups, (size_t)0,
+                       d.B, d.U, d.keep_prob, d.seed, d.seed_offset, d.drop_scale, 0ull, 0ull, static_cast<unsigned *>(nullptr));
+    NABU_LAUNCH_CHECK();
+  }
   a.table = static_cast<unsigned *>(ws);
   a.xbuf = static_cast<char *>(ws) + TABLE_BYTES;
   a.status = status;
@@ -1891,10 +1924,11 @@ int speller_persist_fwd(const SpPersistDesc &d, const int32_t *dec_len, const in
   a.dec_len = dec_len; a.enc_len = enc_len; a.ids = ids;
   a.kperm = kperm; a.bias = bias; a.emb = emb; a.wq = wq; a.v = v; a.keys = keys; a.values = values;
   a.H = H; a.Cs = Cs; a.acts = acts; a.q = q; a.ctx = ctx; a.align = align;
-  a.Ho = Ho; a.keep = d.keep_prob; a.seed = d.seed; a.seed_offset = d.seed_offset;
-  if (d.keep_prob < 1.f && !Ho) return fail(NABU_EINVAL, "persistent decoder: dropout needs the Ho array");
+  a.Ho = Ho; a.keep = d.keep_prob; a.dscale = d.drop_scale;
+  if (d.keep_prob < 1.f && !(Ho && d.drop_scale)) return fail(NABU_EINVAL, "persistent decoder: dropout needs the Ho and drop_scale arrays");
   a.wout = out_kernel; a.bout = out_bias; a.ids_w = ids_used; a.C = d.C;
-  a.sprob = d.sample_prob; a.sseed = d.sample_seed; a.soff = d.sample_offset;
+  a.sprob = d.sample_prob; a.sdraw = d.sample_draws;
+  if (d.sample_prob > 0.f && !d.sample_draws) return fail(NABU_EINVAL, "persistent decoder: scheduled sampling needs the sample_draws array");
   if (d.sample_prob > 0.f && !(out_kernel && out_bias && ids_used == ids))
     return fail(NABU_EINVAL, "persistent decoder: scheduled sampling needs the output projection and a writable ids array");
   a.table = static_cast<unsigned *>(ws);
@@ -1913,6 +1947,14 @@ int speller_persist_fwd(const SpPersistDesc &d, const int32_t *dec_len, const in
     kern = loc ? (KW <= 64 ? speller_persist_fwd_kernel<64, true, true> : KW <= 192 ? speller_persist_fwd_kernel<192, true, true> : speller_persist_fwd_kernel<384, true, true>)
                : (KW <= 64 ? speller_persist_fwd_kernel<64, false, true> : KW <= 192 ? speller_persist_fwd_kernel<192, false, true> : speller_persist_fwd_kernel<384, false, true>);
   NABU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+  if (reg) {
+    // every random number of the call in one small launch in front of it (the Philox rounds cost the decoder kernels
+    // registers they do not have: 114 spilled in the hot loops with the generator inside)
+    const size_t groups = d.keep_prob < 1.f ? (size_t)d.L * d.B * d.U / 4 : 0, draws = d.sample_prob > 0.f ? (size_t)d.L * d.B : 0;
+    hipLaunchKernelGGL(speller_randoms_kernel, dim3((unsigned)((groups + draws + 255) / 256)), dim3(256), 0, stream, groups, draws,
+                       d.B, d.U, d.keep_prob, d.seed, d.seed_offset, d.drop_scale, d.sample_seed, d.sample_offset, d.sample_draws);
+    NABU_LAUNCH_CHECK();
+  }
   // 32 utterances per launch (4 per XCD): a batch of 64 runs as two launches on the stream
   for (int b0 = 0; b0 < d.B; b0 += NU * R) {
     a.b0 = b0;

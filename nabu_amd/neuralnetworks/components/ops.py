@@ -4,7 +4,7 @@ import weakref
 import numpy as np
 
 from nabu_amd import ops as hip
-from nabu_amd.autodiff import record, SeqLen
+from nabu_amd.autodiff import record, requires_grad, SeqLen
 
 
 # A-priori magnitude bounds of tensors on the path: id(tensor) -> (weak reference, bound).  layer.blstm records
@@ -125,7 +125,8 @@ def input_noise(x, stddev, rng_state):
     """inputs + tf.random_normal(shape, stddev) (listener.py:40-45)."""
     seed, offset = rng_state.next()
     y = hip.gaussian_noise(x, stddev, seed, offset)
-    record([x], [y], lambda dy: [dy])
+    if requires_grad(x):     # (raw features: the noisy copy depends on no parameter either — the first layer then skips
+        record([x], [y], lambda dy: [dy])   # its input gradient, two [B T, 8H] x [8H, D] products per step)
     return y
 
 
