@@ -186,6 +186,16 @@ def test_dropout_and_input_noise_paths_run_and_are_regenerable():
                                                     'encoder.dropout': 0.5, 'trainer.batch_size': 3})
     l0 = float(tr.step(tr.to_device(data.batch(0))).item())
     assert np.isfinite(l0)
+    # noise on raw features depends on no parameter: its output must not ask the first layer for an input gradient
+    # (two [B T, 8H] x [8H, D] products per step); on a tensor that does depend on one it is recorded
+    from nabu_amd.autodiff import Tape, record, requires_grad
+    from nabu_amd.neuralnetworks.components import ops as cops
+    with Tape():
+        raw = torch.randn(2, 8, 40, device='cuda')
+        assert not requires_grad(cops.input_noise(raw, 0.6, cops.RngState(1)))
+        dep = raw.clone()
+        record([raw], [dep], lambda g: [None])
+        assert requires_grad(cops.input_noise(dep, 0.6, cops.RngState(1)))
 
 
 def test_dnn_decoder_hidden_layers_match_oracle():
