@@ -32,6 +32,8 @@ def main():
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--fp32', type=int, default=1)
     ap.add_argument('--shapes', default='cfg2')
+    ap.add_argument('--data', default='randn', choices=['randn', 'ones', 'pow2', 'sparse'],
+                    help='operand values (the matrix pipe\'s power, hence its clock, depends on them): N(0,1); all 1; random signed powers of two (one mantissa bit pattern); N(0,1) with 90 %% zeros')
     a = ap.parse_args()
     shapes = {
         'cfg2': [  # (name, M, N, K)
@@ -46,8 +48,16 @@ def main():
     torch.manual_seed(0)
     tot = tot32 = totpack = 0.0
     for name, M, N, K in shapes:
-        A = torch.randn(M, K, device='cuda')
-        B = torch.randn(N, K, device='cuda')
+        def draw(r, c):
+            if a.data == 'ones':
+                return torch.ones(r, c, device='cuda')
+            x = torch.randn(r, c, device='cuda')
+            if a.data == 'pow2':
+                return torch.sign(x) * torch.exp2(torch.floor(torch.log2(x.abs() + 1e-6)))
+            if a.data == 'sparse':
+                return x * (torch.rand(r, c, device='cuda') < 0.1)
+            return x
+        A, B = draw(M, K), draw(N, K)
         pa, pb = ops.PackedOperand(M, K, a.planes, 'cuda'), ops.PackedOperand(N, K, a.planes, 'cuda')
         tp = timeit(lambda: (ops.pk_pack(pa, A), ops.pk_pack(pb, B)), 5)
         At = A.t().contiguous()
