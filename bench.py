@@ -524,6 +524,9 @@ class HipWorkload(object):
     def step(self, i):
         if self.timing:
             self.prof.enabled = i % self.PROFILE_EVERY == 0
+            # the same steps also bracket the decoder's two calls (recipes with a Speller) with events on the launch stream
+            from nabu_amd.neuralnetworks.models.ed_decoders import rnn_decoder
+            rnn_decoder.dynamic_decode.events = self.dec_events if self.prof.enabled else None
         self.loss = self.tr.step(self.batches[i % 2])
 
     def sync(self):
@@ -537,9 +540,12 @@ class HipWorkload(object):
     def start_timed_region(self):
         self.prof.collect()                                         # drop the warm-up records
         self.tr.allreduce_ms = []
+        self.dec_events = []
         self.timing = True
 
     def end_timed_region(self):
+        from nabu_amd.neuralnetworks.models.ed_decoders import rnn_decoder
+        rnn_decoder.dynamic_decode.events = None
         self.timing = False
         self.prof.enabled = False
         self.recs = self.prof.collect()
@@ -698,7 +704,40 @@ class HipWorkload(object):
                               else gemm_roofline_pk(B_, T_, D_, H_, 3) if self.precision == 'bf16x6'
                               else gemm_roofline_pk(B_, T_, D_, H_, 2) if self.precision == 'f16x3' else None),
             'final_loss': round(self.final_loss, 4),
+            'roofline_decoder': self.roofline_decoder(),
         }
+
+    def roofline_decoder(self):
+        '''The attention decoder against ITS roofline (recipes with a Speller; null otherwise): a decoder step reads the
+        keys [Te, U] and the values [Te, E] of every utterance once per pass — algorithmic bytes of the two calls
+        (nabu_speller_fwd / _bwd: all L steps each) over their duration from events on the launch stream (the step
+        chain's four streams fork from and join it inside the calls), every PROFILE_EVERY-th step of the timed region.'''
+        ev = getattr(self, 'dec_events', None)
+        if not ev:
+            return None
+        out = {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
+        tot_b = tot_ms = 0.0
+        for name in ('fwd', 'bwd'):
+            recs = [(sh, a.elapsed_time(b)) for kind, sh, a, b in ev if kind == name]
+            if not recs:
+                continue
+            sh = recs[0][0]
+            nbytes = 4.0 * sh['L'] * sh['B'] * sh['Te'] * (sh['U'] + sh['E'])
+            ms = sum(t for _, t in recs) / len(recs)
+            out[name] = {'ms_per_call': round(ms, 3), 'us_per_decoder_step': round(ms * 1e3 / sh['L'], 2),
+                         'achieved': round(nbytes / (ms * 1e-3) / 1e9, 1), 'frac': round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            tot_b += nbytes
+            tot_ms += ms
+        sh = ev[0][1]
+        out.update({'achieved': round(tot_b / (tot_ms * 1e-3) / 1e9, 1), 'frac': round(tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    'ms_per_step': round(tot_ms, 3), 'decoder_steps': sh['L'], 'utterances': sh['B'], 'frames': sh['Te'],
+                    'bytes_per_decoder_step_and_pass': int(4 * sh['B'] * sh['Te'] * (sh['U'] + sh['E'])),
+                    'calls_timed': len(ev),
+                    'note': 'keys [Te, U] + values [Te, E] of every utterance read once per decoder step and pass (SURVEY.md 8(d): '
+                            '(U+E)·Te·4 bytes per utterance and step) over the wall time of the two decoder calls; the persistent '
+                            'decoder (cfg3) keeps its slices of both in LDS for the whole call, so its HBM traffic is far below '
+                            'this figure — the fraction prices the step loop, not the memory system'})
+        return out
 
     def wants_cpu_baseline(self):
         return self.args.workload == 'cfg2'
@@ -918,6 +957,8 @@ def other_configs(args, server):
                      'recurrent_kernels': {'frac': rk['frac'], 'us_per_sequential_step': rk['us_per_sequential_step'],
                                            'ms_per_step': rk['ms_per_step']},
                      'effective_clock': wl.effective_clock()}
+            if d.get('roofline_decoder'):
+                entry['roofline_decoder'] = d['roofline_decoder']
             del wl
         except Exception as exc:          # noqa: BLE001 — one leg must not take the headline's line down
             entry = {'error': '%s: %s' % (type(exc).__name__, exc)}

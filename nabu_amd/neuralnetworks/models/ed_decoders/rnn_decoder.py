@@ -65,7 +65,7 @@ def cell_parameters(cell, E):
 
 
 def dynamic_decode(cell, encoded, encoded_seq_length, targets, target_seq_length, sample_prob,
-                   is_training):
+                   is_training):  # noqa: C901
     """Run the projected attention cell over the target sequence.
 
     encoded [B,Te,E] (rows >= length zero), targets [B,Lt] int32 (already holding EOS
@@ -106,21 +106,36 @@ def dynamic_decode(cell, encoded, encoded_seq_length, targets, target_seq_length
     reserve = torch.empty(reserve_bytes, dtype=torch.uint8, device=dev)
     ws = _hip.Workspace.get(ws_bytes, dev, 'speller')
     params = _ptrs(named, lstm, grad=False)
+    ev = dynamic_decode.events          # (bench.py: a list while a step's decoder calls are to be bracketed by events)
+    shape = dict(B=B, Te=Te, E=E, U=U, C=C, L=L)
+    if ev is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _hip.check(lib.nabu_speller_fwd(ctypes.byref(desc), _hip.ptr(values), _hip.ptr(elen.dev), _hip.ptr(ids),
                                     _hip.ptr(tlen.dev), ctypes.byref(params), _hip.ptr(logits),
                                     _hip.ptr(reserve), _hip.ptr(ws), ws_bytes, _hip.stream()),
                'nabu_speller_fwd')
+    if ev is not None:
+        e1.record()
+        ev.append(('fwd', shape, e0, e1))
 
     def backward(dlogits):
         grads = _ptrs(named, lstm, grad=True)
         p2 = _ptrs(named, lstm, grad=False)
         dvalues = torch.empty_like(values)
         w2 = _hip.Workspace.get(ws_bytes, dev, 'speller')
+        evb = dynamic_decode.events
+        if evb is not None:
+            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            b0.record()
         _hip.check(lib.nabu_speller_bwd(ctypes.byref(desc), _hip.ptr(values), _hip.ptr(elen.dev),
                                         _hip.ptr(ids), _hip.ptr(tlen.dev), ctypes.byref(p2),
                                         _hip.ptr(dlogits.contiguous()), _hip.ptr(reserve),
                                         ctypes.byref(grads), _hip.ptr(dvalues), _hip.ptr(w2), ws_bytes,
                                         _hip.stream()), 'nabu_speller_bwd')
+        if evb is not None:
+            b1.record()
+            evb.append(('bwd', shape, b0, b1))
         return [dvalues]
 
     record([encoded], [logits], backward)
@@ -129,6 +144,9 @@ def dynamic_decode(cell, encoded, encoded_seq_length, targets, target_seq_length
                                  lib.nabu_speller_uses_persistent(ctypes.byref(desc), 1))
     return logits, tlen
 
+
+
+dynamic_decode.events = None
 
 
 def beam_search(cell, encoded, encoded_seq_length, beam_width, max_steps, length_penalty=0.0,

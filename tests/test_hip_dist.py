@@ -117,3 +117,21 @@ def test_bench_two_rank_line_without_an_n1_run_and_both_exchanges():
     assert line['ranks']['allreduce'] == 'flat' and both['flat']['ms_per_step'] == line['ms_per_step']
     assert both['bucketed']['ms_per_step'] > 0 and len(both['bucketed']['exposed_allreduce_ms_per_step']) == 2
     assert [k for k, _ in both['bucketed']['bucket_schedule_last_step']][0] == 'decoder'
+
+
+def test_bench_cfg3_line_carries_the_decoder_roofline():
+    """python bench.py --workload cfg3: the line of a recipe with a Speller prices the decoder's two calls against
+    their own algorithmic bytes (roofline_decoder: keys + values per decoder step and pass over the calls' wall time)"""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--workload', 'cfg3', '--steps', '2', '--warmup', '1',
+                        '--repeats', '1', '--no-cpu-baseline', '--no-alt'], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    rd = line['roofline_decoder']
+    assert rd['bound'] == 'hbm' and rd['calls_timed'] == 2 and rd['utterances'] == 32 and rd['frames'] == 125
+    assert rd['bytes_per_decoder_step_and_pass'] == 4 * 32 * 125 * (512 + 1024)
+    for k in ('fwd', 'bwd'):
+        assert 0.0 < rd[k]['frac'] < 1.0 and rd[k]['ms_per_call'] > 0.1
+    assert abs(rd['ms_per_step'] - rd['fwd']['ms_per_call'] - rd['bwd']['ms_per_call']) < 0.01
+    assert line['ranks']['decoder_persistent_per_rank'] == [3]
