@@ -70,8 +70,11 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
   const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const unsigned hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
-    const unsigned hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+    // (one 32 x 32 -> 64 multiply per product — v_mad_u64_u32 — instead of a high and a low one: the multiplies run at
+    //  a quarter of the vector rate and are what a dropout pass is bound by)
+    const unsigned long long p0 = (unsigned long long)M0 * c.x, p1 = (unsigned long long)M1 * c.z;
+    const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
+    const unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
     c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
     k.x += 0x9E3779B9u;
     k.y += 0xBB67AE85u;

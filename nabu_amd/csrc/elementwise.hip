@@ -134,6 +134,13 @@ __global__ __launch_bounds__(256) void dropout_kernel(size_t n, const float *__r
                                              (unsigned)(offset >> 32)),
                                   make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
     const unsigned rr[4] = {r.x, r.y, r.z, r.w};
+    if (4 * il + 3 < n && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
+      // whole group, 16-byte aligned arrays: one load, one store
+      const float4 v = *reinterpret_cast<const float4 *>(x + 4 * il);
+      *reinterpret_cast<float4 *>(y + 4 * il) = make_float4(u01(rr[0]) < keep ? v.x * inv : 0.f, u01(rr[1]) < keep ? v.y * inv : 0.f,
+                                                            u01(rr[2]) < keep ? v.z * inv : 0.f, u01(rr[3]) < keep ? v.w * inv : 0.f);
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const size_t e = 4 * il + j;
