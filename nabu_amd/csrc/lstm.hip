@@ -572,14 +572,21 @@ static bool kernel_emits(const nabu_blstm_desc *d, const Layout &L) {
 // which companions the recurrent kernel writes itself: bit 0 rows, bit 1 transposed, bit 2 h^T.  Default 4: measured on
 // cfg2, the 2-byte stores of the transposed operand and the extra live state of the rows cost the forward kernel what the
 // pack kernels they replace cost; NABU_PERSIST_EMIT_MASK=7 writes all three from the kernel, 0 none
-static int emit_mask_env() {
+// (... and not from the launch that also projects its input (the first layer, XIN): there the h^T stores cost 0.09 ms
+// per cfg2 step against 0.05 for the pack they replace — per-launch events, LABNOTES.md section 9.  The switch, when set,
+// is taken literally.)
+static int emit_mask_env(bool *from_env = nullptr) {
   static int m = -1;
-  if (m < 0) { const char *e = getenv("NABU_PERSIST_EMIT_MASK"); m = e ? (atoi(e) & 7) : 4; }
+  static bool set = false;
+  if (m < 0) { const char *e = getenv("NABU_PERSIST_EMIT_MASK"); set = e != nullptr; m = e ? (atoi(e) & 7) : 4; }
+  if (from_env) *from_env = set;
   return m;
 }
 static int emitted_by_kernel(const nabu_blstm_desc *d, const Layout &L) {
   if (!kernel_emits(d, L)) return 0;
-  int m = emit_mask_env();
+  bool from_env = false;
+  int m = emit_mask_env(&from_env);
+  if (!from_env && lstm_persist_fuses_input(d->B, d->T, d->D, d->H)) m &= ~4;
   const bool want_out = (d->out_pk_rows || d->out_pk_cols) && L.cmp_bytes[3] != 0;
   if (!want_out || !d->out_pk_rows) m &= ~1;
   if (!want_out || !d->out_pk_cols) m &= ~2;
