@@ -518,12 +518,16 @@ class HipWorkload(object):
     units_per_step = property(lambda self: self.B)
 
     # HIP events around the recurrent launches cost the stream ~6 us each (a queue barrier per record: 16 per cfg2
-    # step): every PROFILE_EVERY-th step of the timed region carries them, the others run as a user's step does
-    PROFILE_EVERY = 8
+    # step): every PROFILE_EVERY-th step of the timed region carries them — counted from its THIRD step, whose first
+    # launch does not follow the idle bracket in front of the region — the others run as a user's step does
+    PROFILE_EVERY = 16
+
+    def profiled(self, i):
+        return (i - min(2, self.args.steps - 1)) % self.PROFILE_EVERY == 0
 
     def step(self, i):
         if self.timing:
-            self.prof.enabled = i % self.PROFILE_EVERY == 0
+            self.prof.enabled = self.profiled(i)
             # the same steps also bracket the decoder's two calls (recipes with a Speller) with events on the launch stream
             from nabu_amd.neuralnetworks.models.ed_decoders import rnn_decoder
             rnn_decoder.dynamic_decode.events = self.dec_events if self.prof.enabled else None
@@ -652,7 +656,7 @@ class HipWorkload(object):
         tot_ms = sum(r[4] for r in recs)
         tot_steps = sum(r[2] for r in recs)                   # timesteps covered (both directions each)
         tot_bytes = sum(2 * r[2] * step_bytes(r[1], r[3]) for r in recs)
-        prof_steps = max(len([i for i in range(args.steps) if i % self.PROFILE_EVERY == 0]), 1)
+        prof_steps = max(len([i for i in range(args.steps) if self.profiled(i)]), 1)
         launches = len(recs) if persistent else tot_steps
         per_launch_bytes = tot_bytes / max(launches, 1)
         per_launch_s = tot_ms * 1e-3 / max(launches, 1)
@@ -684,7 +688,7 @@ class HipWorkload(object):
                             'streamed per timestep model) over the measured step time — the step also pays for its '
                             'MFMA-bound dense products, so this is the whole-step figure the 0.40 target is stated on; '
                             'recurrent_kernels = the same bytes per launch over the launch duration from HIP events the '
-                            'library records around the recurrent launches of every 8th step of the timed region (an '
+                            'library records around the recurrent launches of every 16th step of the timed region, from its third (an '
                             'event record is a queue barrier, ~6 us: 16 of them per step would be paid by the metric); '
                             'traffic = HBM bytes '
                             'per recurrent launch from the rocprofv3 PMC passes under profiles/'}
