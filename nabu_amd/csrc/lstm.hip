@@ -204,6 +204,8 @@ struct Layout {
   // the column maxima of x and the row maxima of Wx (the backward pass's x^T and Wx operands) are measured by the
   // forward pass in the same reads as its own and kept in the reserve (res_axT_off, res_aw2_off)
   size_t pk_ax, pk_aw, pk_adz, pk_ahT[2], pk_abwd_bytes, res_adzT_off, res_axT_off, res_aw2_off;
+  size_t res_xT_off;         // 0: none.  x^T as a packed operand (the weight-gradient product's), written by the forward
+                             // call from the read of x that packs its own operand (one pass over x less per step)
   size_t res_ahT_off;        // 0: none.  The known row bound of h^T (|h| <= 1), written by the forward call's one fill
   // per-workgroup row maxima of dz written by the persistent backward kernel ([2 directions x H / 16][BT] bit patterns;
   // 0 bytes where the layer has no input gradient): the row scales of dZ as [BT, 8H] without a pass over dz
@@ -322,7 +324,7 @@ static Layout make_layout(const nabu_blstm_desc *d) {
   L.cs_elems = B * T * H;
   L.reserve_bytes = (2 * L.gates_elems + 2 * L.cs_elems) * sizeof(float);
   L.res_dzT_off = L.res_dzT_bytes = 0;
-  L.res_adzT_off = L.res_axT_off = L.res_aw2_off = L.res_ahT_off = 0;
+  L.res_adzT_off = L.res_axT_off = L.res_aw2_off = L.res_ahT_off = L.res_xT_off = 0;
   L.pk_rowmax = L.pk_rowmax_bytes = 0;
   L.fwd_only = (d->flags & NABU_BLSTM_FWD_ONLY) != 0;
   size_t off = 2048;  // ws[0..4): persistent kernels' status word (0 = ok), zeroed by the caller once;
@@ -372,6 +374,10 @@ static Layout make_layout(const nabu_blstm_desc *d) {
       L.res_dzT_off = align_up(L.reserve_bytes, 256);
       L.res_dzT_bytes = nabu_pk_bytes(2 * G, BT, P);
       L.reserve_bytes = L.res_dzT_off + L.res_dzT_bytes;
+      if (L.pk_in) {
+        L.res_xT_off = align_up(L.reserve_bytes, 256);
+        L.reserve_bytes = L.res_xT_off + nabu_pk_bytes((int)D, BT, P);
+      }
     }
     L.pk_abwd_bytes = 0;
     if (P == 2) {
@@ -675,8 +681,16 @@ extern "C" int nabu_blstm_fwd(const nabu_blstm_desc *d_in, const float *x, const
     }
     // the input operand: the producer layer's forward kernel wrote it (x_pk_rows) — or one pass over x here
     const void *xop = L.x_pk ? d->x_pk_rows : pk + L.pk_x;
-    if (!L.x_pk)
+    if (!L.x_pk && L.res_xT_off) {
+      // ... and x^T for the backward pass's weight-gradient product out of the same read (kept in the reserve)
+      const int rpDx = nabu_pk_rows_pad(D);
+      if (int e = pk_pack_both(P, x, D, BT, D, pk + L.pk_x, rpBT, 0, rpBT, nkb, static_cast<char *>(reserve) + L.res_xT_off, rpDx, 0,
+                               rpDx, nabu_pk_kblocks(BT, P), s, P == 2 ? ax : nullptr,
+                               P == 2 ? reinterpret_cast<uint32_t *>(static_cast<char *>(reserve) + L.res_axT_off) : nullptr))
+        return e;
+    } else if (!L.x_pk) {
       if (int e = pk_pack_any(P, 0, x, D, BT, D, pk + L.pk_x, rpBT, 0, 0, rpBT, nkb, 0, 0, ax, stream)) return e;
+    }
     {   // Wx^T of both cells: one launch
       PkPackReq rq[2];
       for (int dir = 0; dir < 2; ++dir)
@@ -923,8 +937,9 @@ static int blstm_bwd_parts(int parts, const nabu_blstm_desc *d, const float *x, 
     if ((parts & 2) && L.pk_in) {
       // x^T: the producer layer's forward kernel wrote it (x_pk_cols; its row maxima were set by this layer's forward
       // call) — or one transposing pass over x here
-      const void *xTop = L.x_pk ? d->x_pk_cols : pk + L.pk_xT;
-      if (!L.x_pk)
+      // (... or, since the forward call packs x anyway, from that call: res_xT_off)
+      const void *xTop = L.x_pk ? d->x_pk_cols : L.res_xT_off ? static_cast<const char *>(reserve) + L.res_xT_off : pk + L.pk_xT;
+      if (!L.x_pk && !L.res_xT_off)
         if ((e = pk_pack_any(P, 1, x, D, M, D, pk + L.pk_xT, rpD, 0, 0, rpD, nkbT, 0, 0, axT, stream))) return e;
       nabu_pk_gemm_desc g = pk_desc(P, D, 2 * G, nkbT, xTop, rpD, dzTp, rpG, dkern[0], G);
       g.C2[0] = dkern[1]; g.n_split = G;
